@@ -1,0 +1,194 @@
+/* mvsnet_hip.h -- C ABI of libmvsnet_hip.so (MI355X / gfx950 plane-sweep depth inference).
+ *
+ * The reference (ubiquity6/MVSNet) has NO plugin / operator / FFI interface: its seam is a set of
+ * Python functions building one TensorFlow graph.  This header is therefore the new
+ * drop-in boundary: one entry point per reference function on the hot path, cited below.  The
+ * Python host side (mvsnet_amd/model.py, same names and argument meaning as mvsnet/model.py) binds
+ * these through ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked [host];
+ *   - tensors are float32, channel-last, contiguous: images (H,W,C), volumes (D,H,W,C);
+ *   - functions enqueue kernels on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); they never allocate, never free, never synchronise;
+ *   - return value: 0 on success, a positive hipError_t on a HIP failure, a negative
+ *     MVS_E_* code on an argument error.  Nothing throws.
+ */
+#ifndef MVSNET_HIP_H_
+#define MVSNET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_ABI_VERSION 1
+
+#define MVS_E_BADARG   (-1)   /* null pointer / non-positive size                         */
+#define MVS_E_SHAPE    (-2)   /* shape not supported by this build (see function comment) */
+#define MVS_E_WORKSPACE (-3)  /* workspace too small                                      */
+
+/* Regulariser implementation selector (mvs_set_conv_impl): the MFMA path is the product;
+ * the scalar path is a slow, shape-generic HIP cross-check (never a CPU fallback). */
+#define MVS_CONV_IMPL_AUTO   0
+#define MVS_CONV_IMPL_SCALAR 1
+#define MVS_CONV_IMPL_MFMA   2
+
+int mvs_abi_version(void);
+/* Static description of a return code (never NULL). */
+const char* mvs_error_string(int code);
+int mvs_set_conv_impl(int impl);
+int mvs_get_conv_impl(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * R1/R1' + R2 prep: plane-induced homographies and their tf.contrib.image.transform 8-vectors.
+ * Replaces get_homographies (mvsnet/homography_warping.py:10-58), get_homographies_inv_depth
+ * (:60-106) and the coefficient algebra of tf_transform_homography (:216-250).
+ *   cams          (view_num,2,4,4)  reference layout, view 0 = reference view
+ *   inverse_depth 0: depth_d = depth_start + d*depth_interval          (depth_end ignored)
+ *                 1: depth_d = 1/linspace(1/depth_start, 1/depth_end, D) (depth_interval ignored)
+ *   homographies  (view_num-1, depth_num, 3, 3)   may be NULL
+ *   transforms    (view_num-1, depth_num, 8)      a0 a1 a2 b0 b1 b2 c0 c1, normalised by c2'
+ */
+int mvs_homography_transforms_f32(const float* cams, int view_num, int depth_num,
+                                  float depth_start, float depth_interval, float depth_end,
+                                  int inverse_depth, float* homographies, float* transforms,
+                                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * R2 + R3: fused projective bilinear warp (zero fill per tap) + cross-view variance.
+ * Replaces tf_transform_homography (mvsnet/homography_warping.py:251-252) and the cost loop of
+ * inference_mem (mvsnet/model.py:422-463) / inference (:315-334) / the GRU body (:680-693).
+ *   ref        (H,W,C)            reference-view feature map
+ *   src        (view_num-1,H,W,C) source-view feature maps
+ *   transforms (view_num-1,depth_total,8)
+ *   d_begin,d_count   planes [d_begin, d_begin+d_count) are produced (d_count = depth_total for the
+ *                     3D-CNN path, 1 per step for the recurrent path)
+ *   variant    0: cost = Q/N - S*S/(N*N)   (inference_mem, model.py:458-461)
+ *              1: cost = Q/N - (S/N)^2     (inference / GRU, model.py:330-332)
+ *   negate     1: writes -cost (the GRU consumes -cost, model.py:698)
+ *   border     0: zero fill per tap (reference behaviour)   1: clamp taps to the border
+ *              (the reference's dead homography_warping path, homography_warping.py:146-149)
+ *   cost       (d_count,H,W,C)
+ * C must be a multiple of 4.
+ */
+int mvs_cost_volume_f32(const float* ref, const float* src, const float* transforms,
+                        int view_num, int depth_total, int d_begin, int d_count,
+                        int H, int W, int C, int variant, int negate, int border,
+                        float* cost, void* stream);
+
+/* Stand-alone warp of one feature map by one transform (tf_transform_homography,
+ * mvsnet/homography_warping.py:211-253); used by the parity tests.  image/out (H,W,C). */
+int mvs_warp_f32(const float* image, const float* transform8, int H, int W, int C, int border,
+                 float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * R4: 3x3x3 convolution / transposed convolution with TensorFlow SAME padding, no bias, and the
+ * batch-statistics BatchNorm of the PRODUCER fused into the consumer's load:
+ *      in(v,c) = act(x(v,c)*x_scale[c] + x_shift[c]) [ + act(x2(v,c)*x2_scale[c] + x2_shift[c]) ]
+ * with act = ReLU when a scale pointer is given, identity (scale=1, shift=0) when it is NULL.
+ * Replaces Network.conv / conv_bn / deconv / deconv_bn / batch_normalization / add
+ * (mvsnet/cnn_wrapper/network.py:171-215,278-348,457-459,492-509).
+ *   x, x2     (D,H,W,Cin)        x2 may be NULL (no skip connection)
+ *   w         conv:   (3,3,3,Cin,Cout)  TensorFlow conv3d kernel layout
+ *             deconv: (3,3,3,Cout,Cin)  TensorFlow conv3d_transpose kernel layout
+ *   stride    conv: 1 or 2 (out = ceil(n/stride)); deconv: 2 (out = 2n)
+ *   y         raw (pre-BN) output, (Do,Ho,Wo,Cout)
+ *   stats     NULL, or (2,Cout) float64 accumulators [sum, sum of squares] over all output voxels;
+ *             must be zeroed by the caller before the launch (mvs_zero_f64)
+ */
+int mvs_conv3d_f32(const float* x, const float* x_scale, const float* x_shift,
+                   const float* x2, const float* x2_scale, const float* x2_shift,
+                   const float* w, int D, int H, int W, int Cin, int Cout, int stride,
+                   float* y, double* stats, void* stream);
+int mvs_deconv3d_f32(const float* x, const float* x_scale, const float* x_shift,
+                     const float* x2, const float* x2_scale, const float* x2_shift,
+                     const float* w, int D, int H, int W, int Cin, int Cout,
+                     float* y, double* stats, void* stream);
+
+/* BatchNorm (training-mode statistics, biased variance; network.py:496-506) folded to an affine:
+ *   mean = sum/count; var = sumsq/count - mean^2; scale = gamma/sqrt(var+eps); shift = beta-mean*scale
+ * stats (2,C) float64 as produced above; scale/shift (C). */
+int mvs_bn_finalize_f32(const double* stats, int C, double count, const float* gamma,
+                        const float* beta, float eps, float* scale, float* shift, void* stream);
+int mvs_zero_f64(double* p, size_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * R5: the whole RegNetUS0 3D U-Net (mvsnet/cnn_wrapper/mvsnetworks.py:122-158).
+ *   cost      (D,H,W,Cin) with D,H,W divisible by 8
+ *   weights   [host] array of 11 device pointers in the order
+ *             1_0, 2_0, 3_0, 0_1, 1_1, 2_1, 3_1, 4_0, 5_0, 6_0, 6_2   (TensorFlow layouts)
+ *   gammas, betas  [host] arrays of 10 device pointers (same order, no entry for 6_2)
+ *   base      base_filter (8 for network_mode 'normal'); Cin of the volume = cin
+ *   workspace device scratch of at least mvs_regnet_workspace_bytes() bytes
+ *   reg       (D,H,W) filtered cost volume (the squeezed 3dconv6_2 output)
+ */
+size_t mvs_regnet_workspace_bytes(int D, int H, int W, int cin, int base);
+int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int cin, int base,
+                       const float* const* weights, const float* const* gammas,
+                       const float* const* betas, float eps, void* workspace,
+                       size_t workspace_bytes, float* reg, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * R6 + R7: softmax(-reg) over depth, soft-argmin depth, 4-bucket probability map.
+ * Replaces mvsnet/model.py:471-498 and get_probability_map_slice (:45-144).
+ *   reg (D,H,W); depth, prob (H,W); depth samples as in mvs_homography_transforms_f32 with
+ *   depth_end = depth_start + (D-1)*depth_interval.
+ */
+int mvs_softargmin_prob_f32(const float* reg, int D, int H, int W, float depth_start,
+                            float depth_interval, int inverse_depth, float* depth, float* prob,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * R8: 3x3 SAME 2D convolution over the channel concatenation [xa | xb] with bias, used by the
+ * ConvGRU cell (mvsnet/convgru.py:89-93,107-111) and prob_conv (mvsnet/model.py:701-702).
+ *   xa (H,W,Ca), xb (H,W,Cb) (xb may be NULL with Cb = 0); w (3,3,Ca+Cb,Cout); bias (Cout)
+ *   y  (H,W,Cout)
+ *   stats  NULL or (groups,2) float64 [sum,sumsq] over (H,W, Cout/groups channels) per group,
+ *          zeroed by the caller: the LayerNorm moments of convgru.py:30-31 (groups = 2 for the
+ *          gate convolution: reset | update; 1 for the output convolution).
+ */
+int mvs_conv2d_cat_f32(const float* xa, int Ca, const float* xb, int Cb, const float* w,
+                       const float* bias, int H, int W, int Cout, float* y, double* stats,
+                       int groups, void* stream);
+
+/* ConvGRU element-wise stages (mvsnet/convgru.py:97-102,114-120); LayerNorm = tf.contrib.layers
+ * layer_norm: moments over (H,W,F), eps 1e-12, per-channel gamma/beta.
+ *   gates: g (H,W,2F) raw gate conv; stats (2,2) f64 -> r*h (H,W,F) and u (H,W,F)
+ *   blend: c (H,W,F) raw output conv; stats (1,2) f64; h updated in place:
+ *          h = u*h + (1-u)*tanh(LN(c))
+ */
+int mvs_gru_gates_f32(const float* g, const double* stats, const float* reset_gamma,
+                      const float* reset_beta, const float* update_gamma, const float* update_beta,
+                      const float* h, int H, int W, int F, float* rh, float* u, void* stream);
+int mvs_gru_blend_f32(const float* c, const double* stats, const float* out_gamma,
+                      const float* out_beta, const float* u, int H, int W, int F, float* h,
+                      void* stream);
+
+/* R9: winner-take-all update (mvsnet/model.py:703-731): prob = exp(reg); strict '<' keeps the first
+ * maximum.  All maps (H,W).  mvs_wta_finish: prob_out = max_prob / (exp_sum + 1e-7) (:749-751). */
+int mvs_wta_update_f32(const float* reg, float depth_value, int H, int W, float* max_prob,
+                       float* depth_image, float* exp_sum, void* stream);
+int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, int H, int W, float* prob_out,
+                       void* stream);
+
+/* R9 composed: the whole recurrent sweep of inference_winner_take_all (mvsnet/model.py:601-751)
+ * after the feature towers.
+ *   params [host] array of 32 device pointers: for cell i in 1..3:
+ *            gates_w, gates_b, reset_gamma, reset_beta, update_gamma, update_beta,
+ *            out_w, out_b, out_gamma, out_beta   (10 each), then prob_w, prob_b
+ *   depth_values [host] depth_num floats (depth of plane d, model.py:706-715)
+ *   filters (f1,f2,f3): ConvGRU filter counts (16,4,2 for 'normal')
+ */
+size_t mvs_gru_workspace_bytes(int H, int W, int C, int f1, int f2, int f3);
+int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms, int view_num,
+                    int depth_num, int H, int W, int C, int f1, int f2, int f3,
+                    const float* const* params, const float* depth_values, void* workspace,
+                    size_t workspace_bytes, float* depth_out, float* prob_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVSNET_HIP_H_ */

@@ -1,0 +1,110 @@
+"""ctypes binding of libmvsnet_hip.so (the C ABI declared in include/mvsnet_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call returns non-zero this
+module raises.  torch is used only to own device memory and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvsnet_hip.so")
+
+_f = C.c_float
+_i = C.c_int
+_p = C.c_void_p
+_sz = C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); must list every symbol include/mvsnet_hip.h declares
+SIGNATURES = {
+    "mvs_abi_version": (_i, []),
+    "mvs_error_string": (C.c_char_p, [_i]),
+    "mvs_set_conv_impl": (_i, [_i]),
+    "mvs_get_conv_impl": (_i, []),
+    "mvs_homography_transforms_f32": (_i, [_p, _i, _i, _f, _f, _f, _i, _p, _p, _p]),
+    "mvs_cost_volume_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "mvs_warp_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "mvs_conv3d_f32": (_i, [_p] * 7 + [_i] * 6 + [_p, _p, _p]),
+    "mvs_deconv3d_f32": (_i, [_p] * 7 + [_i] * 5 + [_p, _p, _p]),
+    "mvs_bn_finalize_f32": (_i, [_p, _i, C.c_double, _p, _p, _f, _p, _p, _p]),
+    "mvs_zero_f64": (_i, [_p, _sz, _p]),
+    "mvs_regnet_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "mvs_regnet_us0_f32": (_i, [_p, _i, _i, _i, _i, _i, _pp, _pp, _pp, _f, _p, _sz, _p, _p]),
+    "mvs_softargmin_prob_f32": (_i, [_p, _i, _i, _i, _f, _f, _i, _p, _p, _p]),
+    "mvs_conv2d_cat_f32": (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
+    "mvs_gru_gates_f32": (_i, [_p] * 7 + [_i, _i, _i, _p, _p, _p]),
+    "mvs_gru_blend_f32": (_i, [_p] * 5 + [_i, _i, _i, _p, _p]),
+    "mvs_wta_update_f32": (_i, [_p, _f, _i, _i, _p, _p, _p, _p]),
+    "mvs_wta_finish_f32": (_i, [_p, _p, _i, _i, _p, _p]),
+    "mvs_gru_workspace_bytes": (_sz, [_i] * 6),
+    "mvs_gru_wta_f32": (_i, [_p, _p, _p] + [_i] * 8 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
+}
+
+CONV_IMPL = {"auto": 0, "scalar": 1, "mfma": 2}
+
+_lib = None
+
+
+class MvsnetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads (once) and returns the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MvsnetHipError(
+                "libmvsnet_hip.so not found at %s -- build it with `python -m mvsnet_amd.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mvs_abi_version() != 1:
+            raise MvsnetHipError("libmvsnet_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().mvs_error_string(rc).decode()
+        raise MvsnetHipError("%s failed: %s (code %d)" % (what or "mvsnet_hip call", msg, rc))
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32/float64 CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MvsnetHipError("expected a device tensor (no CPU path exists)")
+    if not t.is_contiguous():
+        raise MvsnetHipError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def f32(t, name="tensor"):
+    if t.dtype != torch.float32:
+        raise MvsnetHipError("%s must be float32, got %s" % (name, t.dtype))
+    return t
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for k, t in enumerate(tensors):
+        arr[k] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def set_conv_impl(name: str):
+    check(load().mvs_set_conv_impl(CONV_IMPL[name]), "mvs_set_conv_impl")

@@ -1,0 +1,161 @@
+// Fused projective bilinear warp + cross-view variance -> (D,H,W,C) cost volume (R2 + R3).
+// Reference behaviour: tf.contrib.image.transform BILINEAR with zero fill per tap
+// (mvsnet/homography_warping.py:251-252) inside the cost loops of mvsnet/model.py:422-463
+// (inference_mem), :315-334 (inference) and :680-693 (GRU body).
+//
+// Roofline: HBM write of the volume (D*H*W*C*4 bytes) + one read of the N feature maps.
+// Layout: channel-last; one lane owns 4 consecutive channels (16 B) of one voxel, so the C/4
+// lanes of a voxel read each bilinear tap as one contiguous C*4-byte segment and the block's
+// stores are fully coalesced 16-B-per-lane rows of the volume.  Feature maps (N*H*W*C*4 bytes,
+// 13 MB at the metric config) stay resident in L2 / Infinity Cache across the D planes.
+#include "common.h"
+
+namespace {
+
+struct Tap4 { float4 v; };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ float4 fma4(float w, float4 a, float4 acc) {
+    acc.x += w * a.x; acc.y += w * a.y; acc.z += w * a.z; acc.w += w * a.w;
+    return acc;
+}
+
+// Bilinear sample of `img` (H,W,C) at the projective image of pixel (x,y); channels [c, c+4).
+template <int BORDER>
+__device__ __forceinline__ float4 warp_sample(const float* __restrict__ img, const float* __restrict__ t,
+                                              float xf, float yf, int H, int W, int C, int c) {
+    float proj = t[6] * xf + t[7] * yf + 1.0f;
+    float sx = (t[0] * xf + t[1] * yf + t[2]) / proj;
+    float sy = (t[3] * xf + t[4] * yf + t[5]) / proj;
+    float x0 = floorf(sx), y0 = floorf(sy);
+    float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BORDER == 0) {
+        // zero fill: each tap individually reads 0 outside [0,W)x[0,H)
+        bool okx0 = (x0 >= 0.0f) && (x0 < (float)W);
+        bool okx1 = (x1 >= 0.0f) && (x1 < (float)W);
+        bool oky0 = (y0 >= 0.0f) && (y0 < (float)H);
+        bool oky1 = (y1 >= 0.0f) && (y1 < (float)H);
+        int ix0 = okx0 ? (int)x0 : 0, ix1 = okx1 ? (int)x1 : 0;
+        int iy0 = oky0 ? (int)y0 : 0, iy1 = oky1 ? (int)y1 : 0;
+        float4 v00 = (okx0 && oky0) ? ld4(img + ((size_t)iy0 * W + ix0) * C + c) : z;
+        float4 v01 = (okx1 && oky0) ? ld4(img + ((size_t)iy0 * W + ix1) * C + c) : z;
+        float4 v10 = (okx0 && oky1) ? ld4(img + ((size_t)iy1 * W + ix0) * C + c) : z;
+        float4 v11 = (okx1 && oky1) ? ld4(img + ((size_t)iy1 * W + ix1) * C + c) : z;
+        float wx1 = x1 - sx, wx0 = sx - x0, wy1 = y1 - sy, wy0 = sy - y0;
+        float4 vf, vc, o;
+        vf.x = wx1 * v00.x + wx0 * v01.x; vf.y = wx1 * v00.y + wx0 * v01.y;
+        vf.z = wx1 * v00.z + wx0 * v01.z; vf.w = wx1 * v00.w + wx0 * v01.w;
+        vc.x = wx1 * v10.x + wx0 * v11.x; vc.y = wx1 * v10.y + wx0 * v11.y;
+        vc.z = wx1 * v10.z + wx0 * v11.z; vc.w = wx1 * v10.w + wx0 * v11.w;
+        o.x = wy1 * vf.x + wy0 * vc.x; o.y = wy1 * vf.y + wy0 * vc.y;
+        o.z = wy1 * vf.z + wy0 * vc.z; o.w = wy1 * vf.w + wy0 * vc.w;
+        return o;
+    } else {
+        // clamp-to-border variant (reference dead code, homography_warping.py:140-173)
+        float mx = (float)(W - 1), my = (float)(H - 1);
+        float cx0 = fminf(fmaxf(x0, 0.f), mx), cx1 = fminf(fmaxf(x1, 0.f), mx);
+        float cy0 = fminf(fmaxf(y0, 0.f), my), cy1 = fminf(fmaxf(y1, 0.f), my);
+        int ix0 = (int)cx0, ix1 = (int)cx1, iy0 = (int)cy0, iy1 = (int)cy1;
+        float4 v00 = ld4(img + ((size_t)iy0 * W + ix0) * C + c);
+        float4 v01 = ld4(img + ((size_t)iy0 * W + ix1) * C + c);
+        float4 v10 = ld4(img + ((size_t)iy1 * W + ix0) * C + c);
+        float4 v11 = ld4(img + ((size_t)iy1 * W + ix1) * C + c);
+        float wa = (cy1 - sy) * (cx1 - sx), wb = (cy1 - sy) * (sx - cx0);
+        float wc = (sy - cy0) * (cx1 - sx), wd = (sy - cy0) * (sx - cx0);
+        float4 o = z;
+        o = fma4(wa, v00, o); o = fma4(wb, v01, o); o = fma4(wc, v10, o); o = fma4(wd, v11, o);
+        return o;
+    }
+}
+
+// grid: x = ceil(H*W*(C/4) / 256), y = planes.  One lane = (pixel, 4 channels) of one plane.
+template <int BORDER>
+__global__ void __launch_bounds__(256)
+cost_volume_kernel(const float* __restrict__ ref, const float* __restrict__ src,
+                   const float* __restrict__ transforms, int n_src, int depth_total, int d_begin,
+                   int H, int W, int C, int variant, int negate, float* __restrict__ cost) {
+    const int cq = C >> 2;
+    const long long total = (long long)H * W * cq;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int dl = blockIdx.y;            // plane index inside the output
+    const int d = d_begin + dl;           // plane index inside the transform table
+    int c = (int)(idx % cq) * 4;
+    long long pix = idx / cq;
+    int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+    float xf = (float)x, yf = (float)y;
+
+    float4 r = ld4(ref + (size_t)pix * C + c);
+    float4 S = r;
+    float4 Q = make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w);
+    const size_t img_elems = (size_t)H * W * C;
+    for (int v = 0; v < n_src; ++v) {
+        const float* t = transforms + ((size_t)v * depth_total + d) * 8;   // block-uniform
+        float4 w = warp_sample<BORDER>(src + v * img_elems, t, xf, yf, H, W, C, c);
+        S.x += w.x; S.y += w.y; S.z += w.z; S.w += w.w;
+        Q.x += w.x * w.x; Q.y += w.y * w.y; Q.z += w.z * w.z; Q.w += w.w * w.w;
+    }
+    const float n = (float)(n_src + 1);
+    float4 o;
+    if (variant == 0) {          // inference_mem: Q/N - S*S/(N*N)      (model.py:458-461)
+        const float nn = n * n;
+        o.x = Q.x / n - (S.x * S.x) / nn; o.y = Q.y / n - (S.y * S.y) / nn;
+        o.z = Q.z / n - (S.z * S.z) / nn; o.w = Q.w / n - (S.w * S.w) / nn;
+    } else {                     // inference / GRU: Q/N - (S/N)^2      (model.py:330-332)
+        float ax = S.x / n, ay = S.y / n, az = S.z / n, aw = S.w / n;
+        o.x = Q.x / n - ax * ax; o.y = Q.y / n - ay * ay;
+        o.z = Q.z / n - az * az; o.w = Q.w / n - aw * aw;
+    }
+    if (negate) { o.x = -o.x; o.y = -o.y; o.z = -o.z; o.w = -o.w; }
+    *reinterpret_cast<float4*>(cost + ((size_t)dl * H * W + pix) * C + c) = o;
+}
+
+template <int BORDER>
+__global__ void __launch_bounds__(256)
+warp_kernel(const float* __restrict__ img, const float* __restrict__ t, int H, int W, int C,
+            float* __restrict__ out) {
+    const int cq = C >> 2;
+    const long long total = (long long)H * W * cq;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int c = (int)(idx % cq) * 4;
+    long long pix = idx / cq;
+    int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+    float4 w = warp_sample<BORDER>(img, t, (float)x, (float)y, H, W, C, c);
+    *reinterpret_cast<float4*>(out + (size_t)pix * C + c) = w;
+}
+
+}  // namespace
+
+extern "C" int mvs_cost_volume_f32(const float* ref, const float* src, const float* transforms,
+                                   int view_num, int depth_total, int d_begin, int d_count,
+                                   int H, int W, int C, int variant, int negate, int border,
+                                   float* cost, void* stream) {
+    MVS_CHECK_ARG(ref && src && transforms && cost);
+    MVS_CHECK_ARG(view_num >= 2 && depth_total >= 1 && d_begin >= 0 && d_count >= 1 &&
+                  d_begin + d_count <= depth_total && H > 0 && W > 0 && C > 0);
+    if (C % 4 != 0) return MVS_E_SHAPE;
+    long long total = (long long)H * W * (C / 4);
+    dim3 grid(mvs_cdiv(total, 256), d_count);
+    if (border == 0)
+        cost_volume_kernel<0><<<grid, 256, 0, mvs_stream(stream)>>>(
+            ref, src, transforms, view_num - 1, depth_total, d_begin, H, W, C, variant, negate, cost);
+    else
+        cost_volume_kernel<1><<<grid, 256, 0, mvs_stream(stream)>>>(
+            ref, src, transforms, view_num - 1, depth_total, d_begin, H, W, C, variant, negate, cost);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_warp_f32(const float* image, const float* transform8, int H, int W, int C,
+                            int border, float* out, void* stream) {
+    MVS_CHECK_ARG(image && transform8 && out && H > 0 && W > 0 && C > 0);
+    if (C % 4 != 0) return MVS_E_SHAPE;
+    long long total = (long long)H * W * (C / 4);
+    if (border == 0)
+        warp_kernel<0><<<mvs_cdiv(total, 256), 256, 0, mvs_stream(stream)>>>(image, transform8, H, W, C, out);
+    else
+        warp_kernel<1><<<mvs_cdiv(total, 256), 256, 0, mvs_stream(stream)>>>(image, transform8, H, W, C, out);
+    MVS_LAUNCH_RET();
+}

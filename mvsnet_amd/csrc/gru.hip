@@ -1,0 +1,286 @@
+// ConvGRU regulariser (R-MVSNet) and winner-take-all depth sweep (R8, R9, K10, K11).
+// Reference behaviour: ConvGRUCell.__call__ (mvsnet/convgru.py:82-122) with group_norm reducing
+// to tf.contrib.layers.layer_norm for every filter count on the path (convgru.py:24-31), and the
+// while_loop body / tail of inference_winner_take_all (mvsnet/model.py:676-751).
+//
+// v1 kernels: shape-generic VALU convolution over the channel concatenation [xa | xb] (no concat
+// is materialised), LayerNorm moments accumulated by the producing convolution, gate / blend
+// element-wise stages, WTA update.  The sweep keeps all state resident in HBM/L2; only the
+// current cost slice (H*W*C) exists, never the (D,H,W,C) volume.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_CO = 32;   // largest Cout on the path: gates of cell 1 = 2*16
+
+template <int CO>
+__global__ void __launch_bounds__(256)
+conv2d_cat_kernel(const float* __restrict__ xa, int Ca, const float* __restrict__ xb, int Cb,
+                  const float* __restrict__ w, const float* __restrict__ bias, int H, int W,
+                  float* __restrict__ y, double* __restrict__ stats, int groups) {
+    __shared__ float red[4][2][2];
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int HW = H * W;
+    const bool valid = pix < HW;
+    const int Ct = Ca + Cb;
+    float acc[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) acc[j] = bias ? bias[j] : 0.f;
+    if (valid) {
+        const int py = pix / W, px = pix - py * W;
+        for (int kh = 0; kh < 3; ++kh) {
+            int iy = py + kh - 1; if (iy < 0 || iy >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                int ix = px + kw - 1; if (ix < 0 || ix >= W) continue;
+                const size_t p = (size_t)iy * W + ix;
+                const float* wt = w + (size_t)(kh * 3 + kw) * Ct * CO;
+                for (int ci = 0; ci < Ca; ++ci) {
+                    float xv = xa[p * Ca + ci];
+#pragma unroll
+                    for (int j = 0; j < CO; ++j) acc[j] += xv * wt[(size_t)ci * CO + j];
+                }
+                for (int ci = 0; ci < Cb; ++ci) {
+                    float xv = xb[p * Cb + ci];
+#pragma unroll
+                    for (int j = 0; j < CO; ++j) acc[j] += xv * wt[(size_t)(Ca + ci) * CO + j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CO; ++j) y[(size_t)pix * CO + j] = acc[j];
+    }
+    if (stats) {
+        const int per = CO / groups;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int g = 0; g < groups; ++g) {
+            float s = 0.f, q = 0.f;
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < CO; ++j)
+                    if (j / per == g) { s += acc[j]; q += acc[j] * acc[j]; }
+            }
+            s = wave_sum(s); q = wave_sum(q);
+            if (lane == 0) { red[wv][g][0] = s; red[wv][g][1] = q; }
+        }
+        __syncthreads();
+        if (threadIdx.x < groups * 2) {
+            int g = threadIdx.x >> 1, k = threadIdx.x & 1;
+            double t = (double)red[0][g][k] + (double)red[1][g][k] + (double)red[2][g][k] + (double)red[3][g][k];
+            atomicAdd(&stats[g * 2 + k], t);
+        }
+    }
+}
+
+struct LN { float inv_r, mean_r; };
+
+// LayerNorm affine from accumulated moments: y = x*inv[c] + (beta[c] - mean*inv[c]),
+// inv[c] = gamma[c] / sqrt(var + 1e-12)   (tf.contrib.layers.layer_norm)
+__device__ __forceinline__ void ln_affine(const double* st, double n, float gamma, float beta,
+                                          float& a, float& b) {
+    double mean = st[0] / n;
+    double var = st[1] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    double inv = (double)gamma / sqrt(var + 1e-12);
+    a = (float)inv;
+    b = (float)((double)beta - mean * inv);
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+gru_gates_kernel(const float* __restrict__ g, const double* __restrict__ stats,
+                 const float* __restrict__ rg, const float* __restrict__ rb,
+                 const float* __restrict__ ug, const float* __restrict__ ub,
+                 const float* __restrict__ h, int HW, int F, float* __restrict__ rh,
+                 float* __restrict__ u) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)HW * F) return;
+    int f = (int)(i % F);
+    long long pix = i / F;
+    double n = (double)HW * F;
+    float a, b;
+    ln_affine(stats, n, rg[f], rb[f], a, b);
+    float r = sigmoidf(g[pix * 2 * F + f] * a + b);               // convgru.py:97,101
+    ln_affine(stats + 2, n, ug[f], ub[f], a, b);
+    float uu = sigmoidf(g[pix * 2 * F + F + f] * a + b);          // convgru.py:98,102
+    rh[i] = r * h[i];                                             // convgru.py:107
+    u[i] = uu;
+}
+
+__global__ void __launch_bounds__(256)
+gru_blend_kernel(const float* __restrict__ c, const double* __restrict__ stats,
+                 const float* __restrict__ og, const float* __restrict__ ob,
+                 const float* __restrict__ u, int HW, int F, float* __restrict__ h) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)HW * F) return;
+    int f = (int)(i % F);
+    float a, b;
+    ln_affine(stats, (double)HW * F, og[f], ob[f], a, b);
+    float yv = tanhf(c[i] * a + b);                               // convgru.py:114,117
+    float uu = u[i];
+    h[i] = uu * h[i] + (1.0f - uu) * yv;                          // convgru.py:120
+}
+
+__global__ void __launch_bounds__(256)
+wta_update_kernel(const float* __restrict__ reg, float depth_value, int HW,
+                  float* __restrict__ max_prob, float* __restrict__ depth_image,
+                  float* __restrict__ exp_sum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    float p = expf(reg[i]);                                       // model.py:703
+    float mp = max_prob[i];
+    if (mp < p) { max_prob[i] = p; depth_image[i] = depth_value; }  // :721-728 (strict <)
+    exp_sum[i] += p;                                              // :731
+}
+
+__global__ void __launch_bounds__(256)
+wta_finish_kernel(const float* __restrict__ max_prob, const float* __restrict__ exp_sum, int HW,
+                  float* __restrict__ prob) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < HW) prob[i] = max_prob[i] / (exp_sum[i] + 1e-7f);     // model.py:749-751
+}
+
+int launch_conv2d(const float* xa, int Ca, const float* xb, int Cb, const float* w,
+                  const float* bias, int H, int W, int Cout, float* y, double* stats, int groups,
+                  hipStream_t st) {
+    int grid = mvs_cdiv((long long)H * W, 256);
+#define MVS_C2D(CO) case CO: conv2d_cat_kernel<CO><<<grid, 256, 0, st>>>(xa, Ca, xb, Cb, w, bias, H, W, y, stats, groups); break;
+    switch (Cout) {
+        MVS_C2D(1) MVS_C2D(2) MVS_C2D(4) MVS_C2D(8) MVS_C2D(16) MVS_C2D(32)
+        default: return MVS_E_SHAPE;
+    }
+#undef MVS_C2D
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int mvs_conv2d_cat_f32(const float* xa, int Ca, const float* xb, int Cb, const float* w,
+                                  const float* bias, int H, int W, int Cout, float* y,
+                                  double* stats, int groups, void* stream) {
+    MVS_CHECK_ARG(xa && w && y && Ca > 0 && Cb >= 0 && H > 0 && W > 0 && Cout > 0);
+    MVS_CHECK_ARG(Cb == 0 || xb);
+    if (stats) { MVS_CHECK_ARG(groups == 1 || groups == 2); if (Cout % groups) return MVS_E_SHAPE; }
+    else groups = 1;
+    return launch_conv2d(xa, Ca, xb, Cb, w, bias, H, W, Cout, y, stats, groups, mvs_stream(stream));
+}
+
+extern "C" int mvs_gru_gates_f32(const float* g, const double* stats, const float* reset_gamma,
+                                 const float* reset_beta, const float* update_gamma,
+                                 const float* update_beta, const float* h, int H, int W, int F,
+                                 float* rh, float* u, void* stream) {
+    MVS_CHECK_ARG(g && stats && reset_gamma && reset_beta && update_gamma && update_beta && h && rh && u);
+    MVS_CHECK_ARG(H > 0 && W > 0 && F > 0);
+    long long n = (long long)H * W * F;
+    gru_gates_kernel<<<mvs_cdiv(n, 256), 256, 0, mvs_stream(stream)>>>(
+        g, stats, reset_gamma, reset_beta, update_gamma, update_beta, h, H * W, F, rh, u);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_gru_blend_f32(const float* c, const double* stats, const float* out_gamma,
+                                 const float* out_beta, const float* u, int H, int W, int F,
+                                 float* h, void* stream) {
+    MVS_CHECK_ARG(c && stats && out_gamma && out_beta && u && h && H > 0 && W > 0 && F > 0);
+    long long n = (long long)H * W * F;
+    gru_blend_kernel<<<mvs_cdiv(n, 256), 256, 0, mvs_stream(stream)>>>(c, stats, out_gamma, out_beta,
+                                                                     u, H * W, F, h);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_wta_update_f32(const float* reg, float depth_value, int H, int W,
+                                  float* max_prob, float* depth_image, float* exp_sum,
+                                  void* stream) {
+    MVS_CHECK_ARG(reg && max_prob && depth_image && exp_sum && H > 0 && W > 0);
+    wta_update_kernel<<<mvs_cdiv((long long)H * W, 256), 256, 0, mvs_stream(stream)>>>(
+        reg, depth_value, H * W, max_prob, depth_image, exp_sum);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, int H, int W,
+                                  float* prob_out, void* stream) {
+    MVS_CHECK_ARG(max_prob && exp_sum && prob_out && H > 0 && W > 0);
+    wta_finish_kernel<<<mvs_cdiv((long long)H * W, 256), 256, 0, mvs_stream(stream)>>>(
+        max_prob, exp_sum, H * W, prob_out);
+    MVS_LAUNCH_RET();
+}
+
+// ---- composed recurrent sweep -----------------------------------------------------------------
+
+namespace {
+struct GruWs {
+    float *x, *g, *c, *rh, *u, *h1, *h2, *h3, *reg, *max_prob, *exp_sum;
+    double* stats;     // 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
+    size_t bytes;
+};
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
+    size_t hw = (size_t)H * W, off = 0;
+    auto take = [&](size_t nfloat) { char* p = base ? base + off : nullptr; off += align256(nfloat * 4); return (float*)p; };
+    GruWs w;
+    int fmax = f1 > f2 ? (f1 > f3 ? f1 : f3) : (f2 > f3 ? f2 : f3);
+    w.x = take(hw * C); w.g = take(hw * 2 * fmax); w.c = take(hw * fmax); w.rh = take(hw * fmax);
+    w.u = take(hw * fmax); w.h1 = take(hw * f1); w.h2 = take(hw * f2); w.h3 = take(hw * f3);
+    w.reg = take(hw); w.max_prob = take(hw); w.exp_sum = take(hw);
+    w.stats = (double*)(base ? base + off : nullptr); off += align256(18 * 8);
+    w.bytes = off;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t mvs_gru_workspace_bytes(int H, int W, int C, int f1, int f2, int f3) {
+    return carve(nullptr, H, W, C, f1, f2, f3).bytes;
+}
+
+extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms,
+                               int view_num, int depth_num, int H, int W, int C, int f1, int f2,
+                               int f3, const float* const* params, const float* depth_values,
+                               void* workspace, size_t workspace_bytes, float* depth_out,
+                               float* prob_out, void* stream) {
+    MVS_CHECK_ARG(ref && src && transforms && params && depth_values && workspace && depth_out && prob_out);
+    MVS_CHECK_ARG(view_num >= 2 && depth_num >= 1 && H > 0 && W > 0 && C > 0 && f1 > 0 && f2 > 0 && f3 > 0);
+    GruWs ws = carve((char*)workspace, H, W, C, f1, f2, f3);
+    if (workspace_bytes < ws.bytes) return MVS_E_WORKSPACE;
+    hipStream_t st = mvs_stream(stream);
+    const size_t hw = (size_t)H * W;
+    hipError_t e;
+    // zero initial states and WTA accumulators (model.py:649-654, 737-739)
+    if ((e = hipMemsetAsync(ws.h1, 0, hw * f1 * 4, st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(ws.h2, 0, hw * f2 * 4, st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(ws.h3, 0, hw * f3 * 4, st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(ws.max_prob, 0, hw * 4, st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(ws.exp_sum, 0, hw * 4, st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(depth_out, 0, hw * 4, st)) != hipSuccess) return (int)e;
+
+    const int F[3] = {f1, f2, f3};
+    float* hs[3] = {ws.h1, ws.h2, ws.h3};
+    int rc;
+    for (int d = 0; d < depth_num; ++d) {
+        if ((e = hipMemsetAsync(ws.stats, 0, 18 * 8, st)) != hipSuccess) return (int)e;
+        // x = -variance cost of plane d (model.py:680-693,698)
+        rc = mvs_cost_volume_f32(ref, src, transforms, view_num, depth_num, d, 1, H, W, C,
+                                 /*variant*/ 1, /*negate*/ 1, /*border*/ 0, ws.x, stream);
+        if (rc) return rc;
+        const float* xin = ws.x;
+        int cin = C;
+        for (int k = 0; k < 3; ++k) {
+            const float* const* p = params + 10 * k;
+            double* sg = ws.stats + 6 * k;
+            double* so = sg + 4;
+            rc = launch_conv2d(xin, cin, hs[k], F[k], p[0], p[1], H, W, 2 * F[k], ws.g, sg, 2, st);
+            if (rc) return rc;
+            rc = mvs_gru_gates_f32(ws.g, sg, p[2], p[3], p[4], p[5], hs[k], H, W, F[k], ws.rh, ws.u, stream);
+            if (rc) return rc;
+            rc = launch_conv2d(xin, cin, ws.rh, F[k], p[6], p[7], H, W, F[k], ws.c, so, 1, st);
+            if (rc) return rc;
+            rc = mvs_gru_blend_f32(ws.c, so, p[8], p[9], ws.u, H, W, F[k], hs[k], stream);
+            if (rc) return rc;
+            xin = hs[k];
+            cin = F[k];
+        }
+        rc = launch_conv2d(ws.h3, f3, nullptr, 0, params[30], params[31], H, W, 1, ws.reg, nullptr, 1, st);
+        if (rc) return rc;
+        rc = mvs_wta_update_f32(ws.reg, depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum, stream);
+        if (rc) return rc;
+    }
+    return mvs_wta_finish_f32(ws.max_prob, ws.exp_sum, H, W, prob_out, stream);
+}

@@ -1,0 +1,97 @@
+"""UNetDS2GN 2D feature extractor on PyTorch-ROCm (north_star keeps it on torch).
+
+Restates mvsnet/cnn_wrapper/mvsnetworks.py:53-115 with the layer semantics of
+mvsnet/cnn_wrapper/network.py:217-276 (conv_gn: conv no-bias -> GroupNorm(G = C//8, eps 1e-5,
+gamma, beta) -> ReLU), :350-409 (deconv_gn: no ReLU) and :171-215 (plain conv for conv10_2),
+all with TensorFlow 'SAME' padding (asymmetric for stride 2).  It produces the hot path's input;
+it is plumbing, not a HIP target this round.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+# name, kind (cg = conv_gn+ReLU, dg = deconv_gn, c = plain conv), sources, kernel, cout multiple
+# of base_filter, stride.  Order is a valid topological order of mvsnetworks.py:60-115.
+UNET_LAYERS = (
+    ("2dconv1_0", "cg", ("data",), 3, 2, 2), ("2dconv2_0", "cg", ("2dconv1_0",), 3, 4, 2),
+    ("2dconv3_0", "cg", ("2dconv2_0",), 3, 8, 2), ("2dconv4_0", "cg", ("2dconv3_0",), 3, 16, 2),
+    ("2dconv0_1", "cg", ("data",), 3, 1, 1), ("2dconv0_2", "cg", ("2dconv0_1",), 3, 1, 1),
+    ("2dconv1_1", "cg", ("2dconv1_0",), 3, 2, 1), ("2dconv1_2", "cg", ("2dconv1_1",), 3, 2, 1),
+    ("2dconv2_1", "cg", ("2dconv2_0",), 3, 4, 1), ("2dconv2_2", "cg", ("2dconv2_1",), 3, 4, 1),
+    ("2dconv3_1", "cg", ("2dconv3_0",), 3, 8, 1), ("2dconv3_2", "cg", ("2dconv3_1",), 3, 8, 1),
+    ("2dconv4_1", "cg", ("2dconv4_0",), 3, 16, 1), ("2dconv4_2", "cg", ("2dconv4_1",), 3, 16, 1),
+    ("2dconv5_0", "dg", ("2dconv4_2",), 3, 8, 2),
+    ("2dconv5_1", "cg", ("2dconv5_0", "2dconv3_2"), 3, 8, 1), ("2dconv5_2", "cg", ("2dconv5_1",), 3, 8, 1),
+    ("2dconv6_0", "dg", ("2dconv5_2",), 3, 4, 2),
+    ("2dconv6_1", "cg", ("2dconv6_0", "2dconv2_2"), 3, 4, 1), ("2dconv6_2", "cg", ("2dconv6_1",), 3, 4, 1),
+    ("2dconv7_0", "dg", ("2dconv6_2",), 3, 2, 2),
+    ("2dconv7_1", "cg", ("2dconv7_0", "2dconv1_2"), 3, 2, 1), ("2dconv7_2", "cg", ("2dconv7_1",), 3, 2, 1),
+    ("2dconv8_0", "dg", ("2dconv7_2",), 3, 1, 2),
+    ("2dconv8_1", "cg", ("2dconv8_0", "2dconv0_2"), 3, 1, 1), ("2dconv8_2", "cg", ("2dconv8_1",), 3, 1, 1),
+    ("conv9_0", "cg", ("2dconv8_2",), 5, 2, 2), ("conv9_1", "cg", ("conv9_0",), 3, 2, 1),
+    ("conv9_2", "cg", ("conv9_1",), 3, 2, 1),
+    ("conv10_0", "cg", ("conv9_2",), 5, 4, 2), ("conv10_1", "cg", ("conv10_0",), 3, 4, 1),
+    ("conv10_2", "c", ("conv10_1",), 3, 4, 1),
+)
+
+
+def _same_pad(n, k, s):
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+class UNetDS2GN:
+    """Inference-only functional module.  ``params`` uses TensorFlow variable layouts
+    (numpy or torch): conv 'w' (k,k,Cin,Cout), transposed conv 'w' (k,k,Cout,Cin), 'gamma',
+    'beta' (Cout,)."""
+
+    def __init__(self, params, device="cuda", dtype=torch.float32):
+        self.device = torch.device(device)
+        self.layers = []
+        for name, kind, srcs, k, _mult, stride in UNET_LAYERS:
+            p = params[name]
+            w = torch.as_tensor(p["w"], dtype=dtype)
+            if kind == "dg":
+                w = w.permute(3, 2, 0, 1)      # (k,k,Cout,Cin) -> torch conv_transpose (Cin,Cout,k,k)
+            else:
+                w = w.permute(3, 2, 0, 1)      # (k,k,Cin,Cout) -> torch conv (Cout,Cin,k,k)
+            w = w.contiguous().to(self.device)
+            g = b = None
+            if kind != "c":
+                g = torch.as_tensor(p["gamma"], dtype=dtype).to(self.device)
+                b = torch.as_tensor(p["beta"], dtype=dtype).to(self.device)
+            self.layers.append((name, kind, srcs, k, stride, w, g, b))
+        self.out_channels = self.layers[-1][5].shape[0]
+
+    @torch.no_grad()
+    def __call__(self, images):
+        """images (V,H,W,3) channel-last float32 -> features (V,H/4,W/4,C) contiguous.
+        Each view is normalised independently (GroupNorm is per sample), so running the V
+        towers of mvsnet/model.py:392-406 as one batch is equivalent."""
+        x = images.to(self.device).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+        acts = {"data": x}
+        for name, kind, srcs, k, stride, w, g, b in self.layers:
+            x = acts[srcs[0]] if len(srcs) == 1 else torch.cat([acts[s] for s in srcs], dim=1)
+            if kind == "dg":
+                n_h, n_w = x.shape[2], x.shape[3]
+                y = F.conv_transpose2d(x, w, stride=stride)          # full length s*(n-1)+k
+                pb_h = _same_pad(n_h * stride, k, stride)[0]
+                pb_w = _same_pad(n_w * stride, k, stride)[0]
+                y = y[:, :, pb_h:pb_h + n_h * stride, pb_w:pb_w + n_w * stride]
+            else:
+                ph = _same_pad(x.shape[2], k, stride)
+                pw = _same_pad(x.shape[3], k, stride)
+                if ph[0] == ph[1] and pw[0] == pw[1]:
+                    y = F.conv2d(x, w, stride=stride, padding=(ph[0], pw[0]))
+                else:
+                    y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), w, stride=stride)
+            if kind != "c":
+                C = y.shape[1]
+                y = F.group_norm(y, max(1, C // 8), g, b, eps=1e-5)   # network.py:246-254
+                if kind == "cg":
+                    y = F.relu(y)
+            acts[name] = y
+        out = acts["conv10_2"]
+        return out.permute(0, 2, 3, 1).contiguous()

@@ -1,0 +1,379 @@
+"""Host-side mirror of mvsnet/model.py: depth inference by plane sweep on the HIP library.
+
+Public functions keep the reference's names, argument order and meaning
+(`inference_mem` model.py:374, `inference` :257, `inference_winner_take_all` :601,
+`get_probability_map` :20); the reference's hidden FLAGS inputs (view_num, batch_size, height,
+width) become explicit keyword arguments, and tensors are torch device
+tensors.  All arithmetic of the hot path runs in libmvsnet_hip.so; torch only owns memory,
+streams and the 2D feature extractor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .feature_net import UNetDS2GN
+from .homography_warping import homography_transforms
+from .synthetic import base_filter, gru_filters
+
+REGNET_ORDER = ("3dconv1_0", "3dconv2_0", "3dconv3_0", "3dconv0_1", "3dconv1_1", "3dconv2_1",
+                "3dconv3_1", "3dconv4_0", "3dconv5_0", "3dconv6_0", "3dconv6_2")
+GRU_CELL_KEYS = ("gates_w", "gates_b", "reset_gamma", "reset_beta", "update_gamma", "update_beta",
+                 "out_w", "out_b", "out_gamma", "out_beta")
+BN_EPSILON = 1e-5      # mvsnet/cnn_wrapper/network.py:55
+
+
+def _dev(a, device):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(device).contiguous()
+
+
+class RegNetWeights:
+    """RegNetUS0 parameters resident on the device, TensorFlow variable layouts
+    (conv (3,3,3,Cin,Cout), conv3d_transpose (3,3,3,Cout,Cin), BN gamma/beta)."""
+
+    def __init__(self, params: Dict[str, dict], device="cuda"):
+        self.device = torch.device(device)
+        self.w = [_dev(params[n]["w"], device) for n in REGNET_ORDER]
+        self.gamma = [_dev(params[n]["gamma"], device) for n in REGNET_ORDER[:-1]]
+        self.beta = [_dev(params[n]["beta"], device) for n in REGNET_ORDER[:-1]]
+        self.cin = int(self.w[0].shape[3])
+        self.base = int(self.w[3].shape[4])           # 3dconv0_1: Cin -> base_filter
+        self.w_ptrs = _lib.ptr_array(self.w)
+        self.g_ptrs = _lib.ptr_array(self.gamma)
+        self.b_ptrs = _lib.ptr_array(self.beta)
+
+
+class GRUWeights:
+    """ConvGRU x3 + prob_conv parameters on the device (convgru.py:82-122, model.py:701)."""
+
+    def __init__(self, params: Dict[str, dict], device="cuda"):
+        self.device = torch.device(device)
+        self.tensors = []
+        for cell in ("gru1", "gru2", "gru3"):
+            for k in GRU_CELL_KEYS:
+                self.tensors.append(_dev(params[cell][k], device))
+        self.tensors.append(_dev(params["prob_w"], device))
+        self.tensors.append(_dev(params["prob_b"], device))
+        self.filters = tuple(int(params[c]["out_b"].shape[0]) for c in ("gru1", "gru2", "gru3"))
+        self.cin = int(params["gru1"]["gates_w"].shape[2]) - self.filters[0]
+        self.ptrs = _lib.ptr_array(self.tensors)
+
+
+@dataclass
+class MVSNetWeights:
+    """Everything `inference_mem` / `inference_winner_take_all` need besides the inputs."""
+    network_mode: str = "normal"
+    unet: Optional[UNetDS2GN] = None
+    regnet: Optional[RegNetWeights] = None
+    gru: Optional[GRUWeights] = None
+
+    @classmethod
+    def from_numpy(cls, network_mode="normal", unet=None, regnet=None, gru=None, device="cuda"):
+        return cls(network_mode,
+                   UNetDS2GN(unet, device) if unet is not None else None,
+                   RegNetWeights(regnet, device) if regnet is not None else None,
+                   GRUWeights(gru, device) if gru is not None else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# single-op wrappers (each = one C-ABI call)
+# ------------------------------------------------------------------------------------------------
+
+
+def cost_volume(ref_feature, src_features, transforms, d_begin=0, d_count=None, variant="mem",
+                negate=False, border="zeros", out=None):
+    """Fused warp + variance (model.py:422-463 / :315-334).  ref (H,W,C), src (N-1,H,W,C),
+    transforms (N-1,D,8) -> (d_count,H,W,C)."""
+    lib = _lib.load()
+    ref = _lib.f32(ref_feature, "ref_feature")
+    src = _lib.f32(src_features, "src_features")
+    H, W, Cc = ref.shape
+    n_src, D = transforms.shape[0], transforms.shape[1]
+    if d_count is None:
+        d_count = D - d_begin
+    if out is None:
+        out = torch.empty((d_count, H, W, Cc), device=ref.device, dtype=torch.float32)
+    _lib.check(lib.mvs_cost_volume_f32(
+        _lib.ptr(ref), _lib.ptr(src), _lib.ptr(_lib.f32(transforms)), n_src + 1, D, d_begin,
+        d_count, H, W, Cc, 0 if variant == "mem" else 1, int(bool(negate)),
+        0 if border == "zeros" else 1, _lib.ptr(out), _lib.stream_ptr()), "mvs_cost_volume_f32")
+    return out
+
+
+def conv3d(x, w, stride=1, x_affine=None, skip=None, skip_affine=None, stats=None, transpose=False):
+    """One 3x3x3 SAME conv / transposed conv (network.py:171-215,300-329) with the producer's
+    BatchNorm+ReLU (and an optional additive skip) applied on load.  Returns raw output."""
+    lib = _lib.load()
+    D, H, W, Cin = x.shape
+    Cout = w.shape[3] if transpose else w.shape[4]
+    xs, xb = x_affine if x_affine is not None else (None, None)
+    ss, sb = skip_affine if skip_affine is not None else (None, None)
+    if transpose:
+        y = torch.empty((2 * D, 2 * H, 2 * W, Cout), device=x.device, dtype=torch.float32)
+        _lib.check(lib.mvs_deconv3d_f32(_lib.ptr(x), _lib.ptr(xs), _lib.ptr(xb), _lib.ptr(skip),
+                                        _lib.ptr(ss), _lib.ptr(sb), _lib.ptr(w), D, H, W, Cin, Cout,
+                                        _lib.ptr(y), _lib.ptr(stats), _lib.stream_ptr()),
+                   "mvs_deconv3d_f32")
+    else:
+        o = lambda n: -(-n // stride)
+        y = torch.empty((o(D), o(H), o(W), Cout), device=x.device, dtype=torch.float32)
+        _lib.check(lib.mvs_conv3d_f32(_lib.ptr(x), _lib.ptr(xs), _lib.ptr(xb), _lib.ptr(skip),
+                                      _lib.ptr(ss), _lib.ptr(sb), _lib.ptr(w), D, H, W, Cin, Cout,
+                                      stride, _lib.ptr(y), _lib.ptr(stats), _lib.stream_ptr()),
+                   "mvs_conv3d_f32")
+    return y
+
+
+def bn_finalize(stats, count, gamma, beta, eps=BN_EPSILON):
+    """(2,C) float64 sums -> per-channel (scale, shift) of training-mode BN (network.py:496-506)."""
+    lib = _lib.load()
+    Cn = gamma.shape[0]
+    scale = torch.empty(Cn, device=gamma.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    _lib.check(lib.mvs_bn_finalize_f32(_lib.ptr(stats), Cn, float(count), _lib.ptr(gamma),
+                                       _lib.ptr(beta), float(eps), _lib.ptr(scale), _lib.ptr(shift),
+                                       _lib.stream_ptr()), "mvs_bn_finalize_f32")
+    return scale, shift
+
+
+def regnet_us0(cost_volume_, weights: RegNetWeights, workspace=None, out=None):
+    """RegNetUS0 (mvsnetworks.py:122-158): (D,H,W,Cin) -> filtered cost volume (D,H,W)."""
+    lib = _lib.load()
+    D, H, W, Cin = cost_volume_.shape
+    if Cin != weights.cin:
+        raise _lib.MvsnetHipError("cost volume has %d channels, weights expect %d" % (Cin, weights.cin))
+    need = lib.mvs_regnet_workspace_bytes(D, H, W, Cin, weights.base)
+    if workspace is None:
+        workspace = torch.empty(need, device=cost_volume_.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((D, H, W), device=cost_volume_.device, dtype=torch.float32)
+    _lib.check(lib.mvs_regnet_us0_f32(
+        _lib.ptr(_lib.f32(cost_volume_)), D, H, W, Cin, weights.base, weights.w_ptrs, weights.g_ptrs,
+        weights.b_ptrs, BN_EPSILON, C.c_void_p(workspace.data_ptr()), workspace.numel(),
+        _lib.ptr(out), _lib.stream_ptr()), "mvs_regnet_us0_f32")
+    return out
+
+
+def softargmin_prob(filtered_cost_volume, depth_start, depth_interval, inverse_depth=False,
+                    depth_out=None, prob_out=None):
+    """model.py:471-498: softmax(-reg) over depth, soft-argmin and the 4-bucket probability."""
+    lib = _lib.load()
+    reg = _lib.f32(filtered_cost_volume)
+    D, H, W = reg.shape
+    if depth_out is None:
+        depth_out = torch.empty((H, W), device=reg.device, dtype=torch.float32)
+    if prob_out is None:
+        prob_out = torch.empty((H, W), device=reg.device, dtype=torch.float32)
+    _lib.check(lib.mvs_softargmin_prob_f32(_lib.ptr(reg), D, H, W, float(depth_start),
+                                           float(depth_interval), int(bool(inverse_depth)),
+                                           _lib.ptr(depth_out), _lib.ptr(prob_out),
+                                           _lib.stream_ptr()), "mvs_softargmin_prob_f32")
+    return depth_out, prob_out
+
+
+def get_probability_map(cv, depth_map, depth_start, depth_interval, inverse_depth=False,
+                        num_buckets=4):
+    """get_probability_map_slice (model.py:45-144) on an explicit probability volume
+    cv (D,H,W) and depth_map (H,W).  Small torch glue; the fused kernel above is what
+    inference_mem uses."""
+    D = cv.shape[0]
+    if inverse_depth:
+        end = depth_start + (D - 1.0) * depth_interval
+        inv_s, inv_e = 1.0 / depth_start, 1.0 / end
+        idx = (1.0 / depth_map - inv_e) / ((inv_s - inv_e) / (D - 1.0))
+        l0 = D - torch.ceil(idx).long() - 1
+        r0 = D - torch.floor(idx).long() - 1
+    else:
+        idx = (depth_map - depth_start) / depth_interval
+        l0 = torch.floor(idx).long()
+        r0 = torch.ceil(idx).long()
+    l0 = l0.clamp(0, D - 1); r0 = r0.clamp(0, D - 1)
+    l1 = (l0 - 1).clamp(0, D - 1); r1 = (r0 + 1).clamp(0, D - 1)
+    g = lambda i: torch.gather(cv, 0, i[None])[0]
+    out = g(l0) + g(r0)
+    if num_buckets == 4:
+        out = out + (g(l1) + g(r1))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# plans: pre-allocated buffers for one (D,H,W,C,N) problem; launch-only afterwards
+# ------------------------------------------------------------------------------------------------
+
+
+class DepthPlan:
+    """Owns every device buffer of one features->depth problem so that `run` only enqueues
+    kernels (no allocation, no synchronisation): usable under hipGraph capture and on several
+    streams (one plan per stream)."""
+
+    def __init__(self, view_num, depth_num, height, width, channels, weights: MVSNetWeights,
+                 regularization="3DCNN", device="cuda"):
+        lib = _lib.load()
+        self.N, self.D, self.H, self.W, self.C = view_num, depth_num, height, width, channels
+        self.weights = weights
+        self.regularization = regularization
+        dev = torch.device(device)
+        f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+        self.transforms = f(view_num - 1, depth_num, 8)
+        self.depth = f(height, width)
+        self.prob = f(height, width)
+        if regularization == "3DCNN":
+            self.cost = f(depth_num, height, width, channels)
+            self.reg = f(depth_num, height, width)
+            nbytes = lib.mvs_regnet_workspace_bytes(depth_num, height, width, channels, weights.regnet.base)
+            self.workspace = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        elif regularization == "GRU":
+            f1, f2, f3 = weights.gru.filters
+            nbytes = lib.mvs_gru_workspace_bytes(height, width, channels, f1, f2, f3)
+            self.workspace = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        else:
+            raise NotImplementedError(regularization)      # predictlib.py:97-98
+
+    def set_cameras(self, cams, depth_start, depth_interval, depth_end, inverse_depth):
+        lib = _lib.load()
+        _lib.check(lib.mvs_homography_transforms_f32(
+            _lib.ptr(_lib.f32(cams)), self.N, self.D, float(depth_start), float(depth_interval),
+            float(depth_end), int(bool(inverse_depth)), None, _lib.ptr(self.transforms),
+            _lib.stream_ptr()), "mvs_homography_transforms_f32")
+
+    def run_3dcnn(self, features, depth_start, depth_interval, inverse_depth=False, variant="mem"):
+        """features (N,H,W,C): cost volume -> RegNetUS0 -> soft-argmin.  Cameras must be set."""
+        cost_volume(features[0], features[1:], self.transforms, 0, self.D, variant, out=self.cost)
+        regnet_us0(self.cost, self.weights.regnet, self.workspace, self.reg)
+        softargmin_prob(self.reg, depth_start, depth_interval, inverse_depth, self.depth, self.prob)
+        return self.depth, self.prob
+
+    def run_gru(self, features, depth_values):
+        lib = _lib.load()
+        g = self.weights.gru
+        f1, f2, f3 = g.filters
+        dv = (C.c_float * self.D)(*[float(v) for v in depth_values])
+        _lib.check(lib.mvs_gru_wta_f32(
+            _lib.ptr(features[0]), _lib.ptr(features[1:]), _lib.ptr(self.transforms), self.N, self.D,
+            self.H, self.W, self.C, f1, f2, f3, g.ptrs, dv, C.c_void_p(self.workspace.data_ptr()),
+            self.workspace.numel(), _lib.ptr(self.depth), _lib.ptr(self.prob), _lib.stream_ptr()),
+            "mvs_gru_wta_f32")
+        return self.depth, self.prob
+
+
+_PLAN_CACHE: Dict[tuple, DepthPlan] = {}
+
+
+def _plan(view_num, D, H, W, Cc, weights, regularization, device):
+    key = (view_num, D, H, W, Cc, id(weights), regularization, str(device))
+    p = _PLAN_CACHE.get(key)
+    if p is None:
+        if len(_PLAN_CACHE) > 4:
+            _PLAN_CACHE.clear()
+        p = _PLAN_CACHE[key] = DepthPlan(view_num, D, H, W, Cc, weights, regularization, device)
+    return p
+
+
+def _scalar(x):
+    if torch.is_tensor(x):
+        x = x.reshape(-1)
+        if x.numel() != 1:
+            raise NotImplementedError("batch_size > 1 is not supported (one reference view per call)")
+        return float(x[0])
+    a = np.asarray(x, dtype=np.float32).reshape(-1)
+    if a.size != 1:
+        raise NotImplementedError("batch_size > 1 is not supported (one reference view per call)")
+    return float(a[0])
+
+
+def _features(images, cams, weights, features, view_num):
+    """Runs the UNetDS2GN towers (model.py:392-406) unless precomputed features are given."""
+    if features is None:
+        if images.dim() != 5 or images.shape[0] != 1:
+            raise NotImplementedError("images must be (1, view_num, H, W, 3); batch_size > 1 is not supported")
+        if weights.unet is None:
+            raise _lib.MvsnetHipError("weights.unet is required when features are not given")
+        features = weights.unet(images[0, :view_num])
+    elif features.dim() == 5:
+        features = features[0]
+    features = _lib.f32(features, "features")[:view_num].contiguous()
+    if cams.dim() == 5:
+        if cams.shape[0] != 1:
+            raise NotImplementedError("batch_size > 1 is not supported")
+        cams = cams[0]
+    cams = cams[:view_num].to(device=features.device, dtype=torch.float32).contiguous()
+    return features, cams
+
+
+def inference_mem(images, cams, depth_num, depth_start, depth_interval, network_mode="normal",
+                  is_master_gpu=True, training=True, trainable=True, inverse_depth=False, *,
+                  weights: MVSNetWeights, view_num=None, features=None, variant="mem"):
+    """mvsnet/model.py:374-502.  images (1,N,Himg,Wimg,3), cams (1,N,2,4,4), depth_start /
+    depth_interval scalars or shape-(1,) -> (depth_map (1,H,W,1), prob_map (1,H,W,1)).
+
+    `training` is accepted for signature parity; as in the reference's inference graph the
+    BatchNorm layers use the statistics of the current volume (SURVEY.md 3.1 note), so only
+    training=True semantics exist.  `features` (N,H,W,C) skips the 2D towers."""
+    if not training:
+        raise NotImplementedError("the reference inference graph runs BN with batch statistics "
+                                  "(training=True); moving averages are never used")
+    if weights.regnet is None:
+        raise _lib.MvsnetHipError("weights.regnet is required for the 3DCNN regulariser")
+    if view_num is None:
+        view_num = (features if features is not None else images).shape[-4]
+    start, interval = _scalar(depth_start), _scalar(depth_interval)
+    D = int(depth_num)
+    feats, cams_ = _features(images, cams, weights, features, view_num)
+    _, H, W, Cc = feats.shape
+    end = np.float32(start) + (np.float32(D) - np.float32(1)) * np.float32(interval)   # model.py:378-379
+    plan = _plan(view_num, D, H, W, Cc, weights, "3DCNN", feats.device)
+    plan.set_cameras(cams_, start, interval, float(end), inverse_depth)
+    depth, prob = plan.run_3dcnn(feats, start, interval, inverse_depth, variant)
+    return depth.reshape(1, H, W, 1).clone(), prob.reshape(1, H, W, 1).clone()
+
+
+def inference(images, cams, depth_num, depth_start, depth_interval, network_mode="normal",
+              is_master_gpu=True, trainable=True, inverse_depth=False, *, weights, view_num=None,
+              features=None):
+    """mvsnet/model.py:257-372 (the training-graph twin): identical to inference_mem except for
+    the rounding of the variance, cost = Q/N - (S/N)^2 (:330-332).  Forward only."""
+    return inference_mem(images, cams, depth_num, depth_start, depth_interval, network_mode,
+                         is_master_gpu, True, trainable, inverse_depth, weights=weights,
+                         view_num=view_num, features=features, variant="eager")
+
+
+def wta_depth_values(depth_num, depth_start, depth_end, inverse_depth=False):
+    """Depth of plane d inside the winner-take-all loop (model.py:605-607,706-715), float32."""
+    D = int(depth_num)
+    f = np.float32
+    d_idx = np.arange(D, dtype=np.float32)
+    start, end = f(depth_start), f(depth_end)
+    if inverse_depth:
+        inv_s, inv_e = f(1) / start, f(1) / end
+        inv_interval = (inv_s - inv_e) / (f(D) - f(1))
+        return (f(1) / (inv_s - d_idx * inv_interval)).astype(np.float32)
+    interval = (end - start) / (f(D) - f(1))
+    return (start + d_idx * interval).astype(np.float32)
+
+
+def inference_winner_take_all(images, cams, depth_num, depth_start, depth_end, network_mode="normal",
+                              is_master_gpu=True, reg_type="GRU", inverse_depth=False,
+                              training=True, trainable=True, *, weights: MVSNetWeights,
+                              view_num=None, features=None):
+    """mvsnet/model.py:601-751: ConvGRU-regularised sweep with winner-take-all depth.
+    -> (depth_map (1,H,W,1), prob_map (1,H,W,1))."""
+    if reg_type != "GRU":
+        raise NotImplementedError(reg_type)
+    if weights.gru is None:
+        raise _lib.MvsnetHipError("weights.gru is required for the GRU regulariser")
+    if view_num is None:
+        view_num = (features if features is not None else images).shape[-4]
+    start, end = _scalar(depth_start), _scalar(depth_end)
+    D = int(depth_num)
+    feats, cams_ = _features(images, cams, weights, features, view_num)
+    _, H, W, Cc = feats.shape
+    interval = float((np.float32(end) - np.float32(start)) / (np.float32(D) - np.float32(1)))  # :606-607
+    plan = _plan(view_num, D, H, W, Cc, weights, "GRU", feats.device)
+    plan.set_cameras(cams_, start, interval, end, inverse_depth)
+    depth, prob = plan.run_gru(feats, wta_depth_values(D, start, end, inverse_depth))
+    return depth.reshape(1, H, W, 1).clone(), prob.reshape(1, H, W, 1).clone()

@@ -1,0 +1,100 @@
+"""CPU tests: the C-ABI library builds, loads and exports every symbol include/mvsnet_hip.h
+declares (no compute calls without a GPU); PFM / camera formats are byte-compatible."""
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import mvsnet_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mvsnet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mvs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    from mvsnet_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 20
+    assert sorted(_lib.SIGNATURES) == syms          # binding table and header agree
+    lib = ctypes.CDLL(lib_built)
+    for s in syms:
+        assert hasattr(lib, s), s
+    h = _lib.load()
+    assert h.mvs_abi_version() == 1
+    assert h.mvs_error_string(0) == b"success"
+    assert b"bad argument" in h.mvs_error_string(-1)
+    assert h.mvs_regnet_workspace_bytes(8, 8, 8, 32, 8) > 0
+    assert h.mvs_set_conv_impl(7) == -1 and h.mvs_set_conv_impl(0) == 0
+    # argument validation happens before any HIP call, so it is testable without a GPU
+    assert h.mvs_softargmin_prob_f32(None, 8, 8, 8, 1.0, 1.0, 0, None, None, None) == -1
+    assert h.mvs_regnet_us0_f32(None, 8, 8, 8, 32, 8, None, None, None, 1e-5, None, 0, None, None) == -1
+
+
+def test_product_refuses_cpu_tensors(lib_built):
+    import torch
+    from mvsnet_amd import _lib
+    with pytest.raises(_lib.MvsnetHipError):
+        _lib.ptr(torch.zeros(4))
+
+
+def test_pfm_roundtrip_and_bytes(tmp_path):
+    from mvsnet_amd import preprocess as P
+    img = np.array([[1, 2], [3, 4]], np.float32)
+    exp = b"Pf\n2 2\n-1.000000\n" + np.array([3, 4, 1, 2], "<f4").tobytes()
+    assert P.pfm_encode(img) == exp == O.pfm_bytes(img)
+    rs = np.random.RandomState(0)
+    big = rs.standard_normal((13, 7)).astype(np.float32)
+    path = str(tmp_path / "x.pfm")
+    P.write_pfm(path, big)
+    assert open(path, "rb").read() == O.pfm_bytes(big)
+    assert np.array_equal(P.load_pfm(path), big)
+    assert np.array_equal(P.load_pfm(io.BytesIO(P.pfm_encode(big[:, :, None]))), big)
+    col = rs.standard_normal((4, 5, 3)).astype(np.float32)
+    assert np.array_equal(P.load_pfm(io.BytesIO(P.pfm_encode(col))), col)
+    with pytest.raises(Exception):
+        P.pfm_encode(big.astype(np.float64))
+    with pytest.raises(Exception):
+        P.load_pfm(io.BytesIO(b"P6\n1 1\n"))
+    # big-endian files (positive scale) are read too
+    be = b"Pf\n2 1\n1.000000\n" + np.array([5, 6], ">f4").tobytes()
+    assert np.array_equal(P.load_pfm(io.BytesIO(be)), np.array([[5, 6]], np.float32))
+
+
+def _cam_words(n_tail):
+    ext = " ".join(str(float(v)) for v in range(16))
+    intr = " ".join(str(float(v)) for v in range(100, 109))
+    tail = ["425.0", "2.5", "192", "935.0"][:n_tail]
+    return "extrinsic\n" + ext + "\n\nintrinsic\n" + intr + "\n\n" + " ".join(tail) + "\n"
+
+
+def test_load_cam_word_count_variants(tmp_path):
+    from mvsnet_amd import preprocess as P
+    c29 = P.load_cam(io.StringIO(_cam_words(2)), interval_scale=1.06, max_d=128)
+    assert np.array_equal(c29[0], np.arange(16.0).reshape(4, 4))
+    assert np.array_equal(c29[1][:3, :3], np.arange(100.0, 109).reshape(3, 3))
+    np.testing.assert_allclose(c29[1][3], [425, 2.65, 128, 425 + 2.65 * 128])
+    with pytest.raises(ValueError):
+        P.load_cam(io.StringIO(_cam_words(2)))
+    c30 = P.load_cam(io.StringIO(_cam_words(3)), interval_scale=2)
+    np.testing.assert_allclose(c30[1][3], [425, 5.0, 192, 425 + 5.0 * 192])
+    c31 = P.load_cam(io.StringIO(_cam_words(4)))
+    np.testing.assert_allclose(c31[1][3], [425, 2.5, 192, 935])
+    path = str(tmp_path / "cam.txt")
+    P.write_cam(path, c31)
+    back = P.load_cam(path)
+    assert np.array_equal(back, c31)
+    assert open(path).read().startswith("extrinsic\n0.0 1.0 2.0 3.0 \n")
+
+
+def test_png_quantisation():
+    from mvsnet_amd import preprocess as P
+    assert list(P.depth_to_uint16(np.array([-3.0, 12.7, 70000.0]))) == [0, 12, 65535]
+    assert list(P.confidence_to_uint16(np.array([0.0, 0.5, 1.5]))) == [0, 32767, 65535]

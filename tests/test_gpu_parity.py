@@ -1,0 +1,374 @@
+"""GPU parity tests: every HIP entry point against the CPU oracle on the same seeded inputs.
+
+All calls go through the C ABI (ctypes) of libmvsnet_hip.so.  Tolerances are stated per test;
+the north-star bar is 1e-3 relative L1 on the depth map, the kernels are held to ~1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mvsnet_oracle as O
+from mvsnet_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib(lib_built):
+    from mvsnet_amd import _lib as L
+    L.load()
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    yield
+
+
+def t(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(DEV)
+
+
+def n(x):
+    torch.cuda.synchronize()
+    return x.detach().cpu().numpy()
+
+
+def rel_l1(a, b):
+    return float(np.abs(a - b).sum() / np.abs(b).sum())
+
+
+# ---- R1 / R2 -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("inverse", [False, True])
+def test_homographies_match_oracle(inverse):
+    from mvsnet_amd.homography_warping import homography_transforms
+    w = S.make_workload("M")
+    cams = w.cams
+    D = w.depth_num
+    end = w.depth_start + (D - 1) * w.depth_interval
+    T, Hm = homography_transforms(t(cams), D, w.depth_start, w.depth_interval, end, inverse, True)
+    T, Hm = n(T), n(Hm)
+    for v in range(1, w.view_num):
+        if inverse:
+            Ho = O.get_homographies_inv_depth(cams[0], cams[v], D, w.depth_start, end, np.float64)
+        else:
+            Ho = O.get_homographies(cams[0], cams[v], D, w.depth_start, w.depth_interval, np.float64)
+        To = O.homography_to_transform8(Ho, np.float64)
+        # fp32 evaluation of a ~20-flop chain with entries up to ~1e2: absolute 1e-4 on pixel terms
+        np.testing.assert_allclose(Hm[v - 1], Ho, rtol=2e-5, atol=2e-4)
+        np.testing.assert_allclose(T[v - 1], To, rtol=2e-5, atol=2e-4)
+
+
+def test_identity_cameras_give_identity_transform():
+    from mvsnet_amd.homography_warping import homography_transforms
+    K = np.array([[128.0, 0, 64], [0, 128.0, 48], [0, 0, 1]])
+    c = np.zeros((2, 2, 4, 4), np.float32)
+    c[:, 0] = np.eye(4); c[:, 1, :3, :3] = K
+    T = n(homography_transforms(t(c), 4, 100.0, 10.0))
+    assert np.array_equal(T, np.broadcast_to(np.array([1, 0, 0, 0, 1, 0, 0, 0], np.float32), (1, 4, 8)))
+
+
+# ---- R2 warp KATs on the device ------------------------------------------------------------------------
+def test_warp_kats_shift_and_zero_fill():
+    from mvsnet_amd.homography_warping import transform_image
+    rs = np.random.RandomState(1)
+    img = rs.randint(-9, 10, size=(5, 12, 8)).astype(np.float32)
+    out = n(transform_image(t(img), t([1, 0, -4.0, 0, 1, 0, 0, 0])))
+    exp = np.zeros_like(img); exp[:, 4:] = img[:, :-4]
+    assert np.array_equal(out, exp)
+    out = n(transform_image(t(img), t([1, 0, -2.5, 0, 1, 0, 0, 0])))
+    exp = np.zeros_like(img)
+    exp[:, 3:] = 0.5 * img[:, :-3] + 0.5 * img[:, 1:-2]
+    exp[:, 2] = 0.5 * img[:, 0]
+    assert np.array_equal(out, exp)
+    out = n(transform_image(t(img), t([1, 0, 0, 0, 1, 0.5, 0, 0])))
+    exp = np.zeros_like(img); exp[:-1] = 0.5 * img[:-1] + 0.5 * img[1:]; exp[-1] = 0.5 * img[-1]
+    assert np.array_equal(out, exp)
+    assert np.array_equal(n(transform_image(t(img), t([1, 0, 0, 0, 1, 0, 0, 0]))), img)
+    # far outside: all taps zero
+    assert not n(transform_image(t(img), t([1, 0, 500.0, 0, 1, 0, 0, 0]))).any()
+
+
+@pytest.mark.parametrize("border", ["zeros", "clamp"])
+def test_warp_projective_matches_oracle(border):
+    from mvsnet_amd.homography_warping import tf_transform_homography
+    rs = np.random.RandomState(2)
+    img = rs.standard_normal((24, 40, 16)).astype(np.float32)
+    for k in range(4):
+        Hm = np.eye(3) + 0.03 * rs.standard_normal((3, 3))
+        Hm[2, :2] *= 0.01
+        Hm[:2, 2] += rs.uniform(-6, 6, 2)
+        got = n(tf_transform_homography(t(img), t(Hm), border))
+        if border == "zeros":
+            exp = O.tf_transform_homography(img, Hm, np.float64)
+        else:
+            exp = O.homography_warping_clamp(img, Hm, np.float64)
+        # a sample within 1e-5 px of an integer may pick the neighbouring tap pair: allow a few
+        bad = np.abs(got - exp) > 1e-4 * (1 + np.abs(exp))
+        assert bad.mean() < 1e-3, bad.mean()
+
+
+# ---- R3 cost volume ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["mem", "eager"])
+def test_cost_volume_matches_oracle(variant):
+    from mvsnet_amd.homography_warping import homography_transforms
+    from mvsnet_amd.model import cost_volume
+    w = S.make_workload("small")
+    feats, cams = w.features, w.cams
+    D = w.depth_num
+    T = homography_transforms(t(cams), D, w.depth_start, w.depth_interval)
+    got = n(cost_volume(t(feats[0]), t(feats[1:]), T, variant=variant))
+    To = n(T).astype(np.float64)
+    exp = np.empty_like(got, dtype=np.float64)
+    fn = O.variance_cost_mem if variant == "mem" else O.variance_cost_eager
+    for d in range(D):
+        warped = [O.image_projective_transform_bilinear(feats[v + 1], To[v, d], np.float64)
+                  for v in range(w.view_num - 1)]
+        exp[d] = fn(feats[0], warped, w.view_num, np.float64)
+    assert got.shape == (D, w.height, w.width, w.channels)
+    err = np.abs(got - exp)
+    assert (err > 1e-4).mean() < 1e-3          # tap flips at near-integer samples
+    assert rel_l1(got, exp) < 1e-5
+    # negated single plane (the GRU step input)
+    one = n(cost_volume(t(feats[0]), t(feats[1:]), T, d_begin=3, d_count=1, variant=variant, negate=True))
+    assert np.array_equal(one[0], -got[3])
+
+
+def test_cost_volume_identical_views_is_zero_and_padding_views():
+    from mvsnet_amd.model import cost_volume
+    rs = np.random.RandomState(3)
+    img = rs.randint(-4, 5, size=(8, 8, 32)).astype(np.float32)
+    T = np.broadcast_to(np.array([1, 0, 0, 0, 1, 0, 0, 0], np.float32), (3, 5, 8)).copy()
+    got = n(cost_volume(t(img), t(np.stack([img] * 3)), t(T)))
+    assert got.shape == (5, 8, 8, 32) and not got.any()
+
+
+# ---- R4 conv / deconv / BN -----------------------------------------------------------------------------
+CONV_CASES = [  # D,H,W,Cin,Cout,stride
+    (8, 8, 16, 32, 8, 1), (8, 8, 16, 32, 16, 2), (4, 8, 8, 16, 16, 1), (4, 4, 8, 16, 32, 2),
+    (4, 4, 4, 64, 64, 1), (8, 16, 16, 8, 1, 1), (6, 10, 12, 8, 8, 1), (6, 10, 12, 12, 6, 2),
+]
+
+
+@pytest.mark.parametrize("impl", ["scalar", "auto"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_matches_oracle(case, impl):
+    from mvsnet_amd import _lib as L
+    from mvsnet_amd.model import conv3d, bn_finalize
+    D, H, W, Cin, Cout, stride = case
+    rs = np.random.RandomState(sum(case))
+    x = rs.standard_normal((D, H, W, Cin)).astype(np.float32)
+    x2 = rs.standard_normal((D, H, W, Cin)).astype(np.float32)
+    wgt = (rs.standard_normal((3, 3, 3, Cin, Cout)) / np.sqrt(27 * Cin)).astype(np.float32)
+    sc = (1 + 0.3 * rs.standard_normal(Cin)).astype(np.float32); sh = (0.2 * rs.standard_normal(Cin)).astype(np.float32)
+    sc2 = (1 + 0.3 * rs.standard_normal(Cin)).astype(np.float32); sh2 = (0.2 * rs.standard_normal(Cin)).astype(np.float32)
+    L.set_conv_impl(impl)
+    try:
+        stats = torch.zeros((2, Cout), dtype=torch.float64, device=DEV)
+        y_plain = n(conv3d(t(x), t(wgt), stride))
+        y_fused = n(conv3d(t(x), t(wgt), stride, (t(sc), t(sh)), t(x2), (t(sc2), t(sh2)), stats))
+        st = n(stats)
+    finally:
+        L.set_conv_impl("auto")
+    e_plain = O.conv3d_same(x, wgt, stride, np.float64)
+    xin = np.maximum(x * sc + sh, 0).astype(np.float64) + np.maximum(x2 * sc2 + sh2, 0)
+    e_fused = O.conv3d_same(xin, wgt, stride, np.float64)
+    np.testing.assert_allclose(y_plain, e_plain, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(y_fused, e_fused, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(st[0], e_fused.reshape(-1, Cout).sum(0), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(st[1], (e_fused.reshape(-1, Cout) ** 2).sum(0), rtol=1e-4, atol=1e-3)
+    # BN finalise of those statistics against the oracle's batch-norm
+    gamma = (1 + 0.2 * rs.standard_normal(Cout)).astype(np.float32); beta = (0.1 * rs.standard_normal(Cout)).astype(np.float32)
+    scale, shift = bn_finalize(stats, e_fused.size // Cout, t(gamma), t(beta))
+    got = np.maximum(e_fused * n(scale) + n(shift), 0)
+    exp = O.batch_norm_train(e_fused, gamma, beta, 1e-5, True, np.float64)
+    np.testing.assert_allclose(got, exp, rtol=1e-4, atol=1e-5)
+
+
+DECONV_CASES = [(2, 2, 4, 64, 32), (4, 4, 8, 32, 16), (4, 8, 8, 16, 8), (3, 5, 6, 8, 4)]
+
+
+@pytest.mark.parametrize("impl", ["scalar", "auto"])
+@pytest.mark.parametrize("case", DECONV_CASES)
+def test_deconv3d_matches_oracle(case, impl):
+    from mvsnet_amd import _lib as L
+    from mvsnet_amd.model import conv3d
+    D, H, W, Cin, Cout = case
+    rs = np.random.RandomState(sum(case) + 7)
+    x = rs.standard_normal((D, H, W, Cin)).astype(np.float32)
+    x2 = rs.standard_normal((D, H, W, Cin)).astype(np.float32)
+    wgt = (rs.standard_normal((3, 3, 3, Cout, Cin)) / np.sqrt(27 * Cin)).astype(np.float32)
+    sc = (1 + 0.3 * rs.standard_normal(Cin)).astype(np.float32); sh = (0.2 * rs.standard_normal(Cin)).astype(np.float32)
+    L.set_conv_impl(impl)
+    try:
+        stats = torch.zeros((2, Cout), dtype=torch.float64, device=DEV)
+        y_plain = n(conv3d(t(x), t(wgt), transpose=True))
+        y_fused = n(conv3d(t(x), t(wgt), 2, (t(sc), t(sh)), t(x2), (t(sc), t(sh)), stats, transpose=True))
+        st = n(stats)
+    finally:
+        L.set_conv_impl("auto")
+    e_plain = O.conv3d_transpose_same(x, wgt, 2, np.float64)
+    xin = np.maximum(x * sc + sh, 0).astype(np.float64) + np.maximum(x2 * sc + sh, 0)
+    e_fused = O.conv3d_transpose_same(xin, wgt, 2, np.float64)
+    assert y_plain.shape == (2 * D, 2 * H, 2 * W, Cout)
+    np.testing.assert_allclose(y_plain, e_plain, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(y_fused, e_fused, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(st[0], e_fused.reshape(-1, Cout).sum(0), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(st[1], (e_fused.reshape(-1, Cout) ** 2).sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_conv_kat_pad_side_and_crop_on_device():
+    from mvsnet_amd.model import conv3d
+    x = np.arange(64 * 4, dtype=np.float32).reshape(4, 4, 4, 4)
+    w = np.zeros((3, 3, 3, 4, 4), np.float32); w[0, 0, 0] = np.eye(4)
+    y = n(conv3d(t(x), t(w), 2))
+    assert np.array_equal(y, x[::2, ::2, ::2])
+    w = np.zeros((3, 3, 3, 4, 4), np.float32); w[2, 2, 2] = np.eye(4)
+    y = n(conv3d(t(x), t(w), 2))
+    exp = np.zeros((2, 2, 2, 4), np.float32); exp[0, 0, 0] = x[2, 2, 2]
+    assert np.array_equal(y, exp)
+    wt = np.zeros((3, 3, 3, 4, 4), np.float32)
+    for k, v in enumerate([10, 20, 30]):
+        wt[k, 0, 0] = v * np.eye(4)
+    xin = np.zeros((2, 2, 2, 4), np.float32); xin[1, 1, 1, 2] = 1
+    y = n(conv3d(t(xin), t(wt), transpose=True))
+    exp = np.zeros((4, 4, 4, 4), np.float32); exp[2, 2, 2, 2] = 10; exp[3, 2, 2, 2] = 20
+    assert np.array_equal(y, exp)
+
+
+@pytest.mark.parametrize("mode,shape", [("normal", (8, 16, 16)), ("lite", (16, 8, 24)), ("semilite", (8, 8, 8))])
+def test_regnet_matches_oracle(mode, shape):
+    from mvsnet_amd.model import RegNetWeights, regnet_us0
+    D, H, W = shape
+    params = S.make_regnet_params(mode, seed=11, random_affine=True)
+    C = 4 * S.base_filter(mode)
+    rs = np.random.RandomState(12)
+    cost = np.abs(rs.standard_normal((D, H, W, C))).astype(np.float32)
+    got = n(regnet_us0(t(cost), RegNetWeights(params, DEV)))
+    exp = O.regnet_us0(cost, params, np.float64)
+    assert got.shape == (D, H, W)
+    assert rel_l1(got, exp) < 2e-5
+    np.testing.assert_allclose(got, exp, rtol=1e-3, atol=2e-4)
+
+
+# ---- R6 / R7 -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("inverse", [False, True])
+def test_softargmin_prob_matches_oracle(inverse):
+    from mvsnet_amd.model import softargmin_prob, get_probability_map
+    rs = np.random.RandomState(5)
+    D, H, W = 48, 20, 28
+    reg = (2.0 * rs.standard_normal((D, H, W))).astype(np.float32)
+    reg[7, 3, 4] = -60.0                       # near one-hot pixel
+    start, interval = 425.0, 2.65
+    depth, prob = softargmin_prob(t(reg), start, interval, inverse)
+    depth, prob = n(depth), n(prob)
+    ed, ep = O.softargmin_and_prob(reg, D, start, interval, inverse, np.float64)
+    np.testing.assert_allclose(depth, ed, rtol=2e-6)
+    # bucket indices flip when (depth-start)/interval is within rounding of an integer
+    bad = np.abs(prob - ep) > 1e-5
+    assert bad.mean() < 5e-3
+    P = O.softmax_neg(reg, np.float64)
+    pm = n(get_probability_map(t(P), t(ed), start, interval, inverse))
+    assert (np.abs(pm - ep) > 1e-5).mean() < 5e-3
+
+
+def test_softargmin_kats_on_device():
+    from mvsnet_amd.model import softargmin_prob
+    D, start, interval = 8, 100.0, 2.0
+    reg = np.zeros((D, 1, 64), np.float32)
+    depth, prob = softargmin_prob(t(reg), start, interval)
+    np.testing.assert_allclose(n(depth), 107.0, rtol=1e-6)
+    np.testing.assert_allclose(n(prob), 0.5, rtol=1e-6)
+    for k, expect in ((0, 3.0), (3, 2.0), (7, 3.0)):
+        reg = np.zeros((D, 1, 3), np.float32); reg[k] = -1000.0
+        depth, prob = softargmin_prob(t(reg), start, interval)
+        assert np.all(n(depth) == start + interval * k) and np.all(n(prob) == expect)
+
+
+# ---- R8 / R9 -------------------------------------------------------------------------------------------
+def test_convgru_cell_stages_match_oracle():
+    from mvsnet_amd import _lib as L
+    lib = L.load()
+    rs = np.random.RandomState(6)
+    H, W, Cin, F = 12, 20, 32, 16
+    p = S.make_gru_params("normal", seed=8, in_channels=Cin, random_affine=True)["gru1"]
+    x = rs.standard_normal((H, W, Cin)).astype(np.float32)
+    h = rs.standard_normal((H, W, F)).astype(np.float32)
+    dx, dh = t(x), t(h)
+    g = torch.empty((H, W, 2 * F), device=DEV); c = torch.empty((H, W, F), device=DEV)
+    rh = torch.empty((H, W, F), device=DEV); u = torch.empty((H, W, F), device=DEV)
+    st = torch.zeros(6, dtype=torch.float64, device=DEV)
+    P = {k: t(v) for k, v in p.items()}
+    sp = L.stream_ptr()
+    L.check(lib.mvs_conv2d_cat_f32(L.ptr(dx), Cin, L.ptr(dh), F, L.ptr(P["gates_w"]), L.ptr(P["gates_b"]),
+                                   H, W, 2 * F, L.ptr(g), L.ptr(st), 2, sp))
+    L.check(lib.mvs_gru_gates_f32(L.ptr(g), L.ptr(st), L.ptr(P["reset_gamma"]), L.ptr(P["reset_beta"]),
+                                  L.ptr(P["update_gamma"]), L.ptr(P["update_beta"]), L.ptr(dh), H, W, F,
+                                  L.ptr(rh), L.ptr(u), sp))
+    L.check(lib.mvs_conv2d_cat_f32(L.ptr(dx), Cin, L.ptr(rh), F, L.ptr(P["out_w"]), L.ptr(P["out_b"]),
+                                   H, W, F, L.ptr(c), L.ptr(st[4:]), 1, sp))
+    L.check(lib.mvs_gru_blend_f32(L.ptr(c), L.ptr(st[4:]), L.ptr(P["out_gamma"]), L.ptr(P["out_beta"]),
+                                  L.ptr(u), H, W, F, L.ptr(dh), sp))
+    exp = O.conv_gru_cell(x, h, p, np.float64)
+    np.testing.assert_allclose(n(dh), exp, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gru_wta_matches_oracle(inverse):
+    from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
+    w = S.make_workload("toy")
+    gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
+    depth, prob = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end,
+                                            inverse_depth=inverse, weights=weights, features=t(w.features))
+    ed, ep = O.inference_winner_take_all_from_features(w.features, w.cams, w.depth_num, w.depth_start,
+                                                       w.depth_end, gp, inverse, np.float64)
+    depth, prob = n(depth)[0, :, :, 0], n(prob)[0, :, :, 0]
+    # the arg-max plane may flip where two planes tie within rounding; everything else is exact
+    same = depth == ed.astype(np.float32)
+    assert same.mean() > 0.98
+    np.testing.assert_allclose(prob[same], ep[same], rtol=2e-4)
+
+
+# ---- R10 end to end -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,inverse", [("toy", False), ("toy", True), ("small", False)])
+def test_inference_mem_from_features_matches_oracle(name, inverse):
+    from mvsnet_amd.model import MVSNetWeights, inference_mem
+    w = S.make_workload(name)
+    rp = S.make_regnet_params("normal", seed=1, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", regnet=rp, device=DEV)
+    depth, prob = inference_mem(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_interval,
+                                inverse_depth=inverse, weights=weights, features=t(w.features))
+    ed, ep = O.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start,
+                                           w.depth_interval, rp, inverse, np.float64)
+    depth, prob = n(depth)[0, :, :, 0], n(prob)[0, :, :, 0]
+    abs_rel = float(np.mean(np.abs(depth - ed) / ed))
+    assert abs_rel < 1e-4, abs_rel              # north-star bar: 1e-3
+    assert (np.abs(prob - ep) > 1e-3).mean() < 0.02
+
+
+def test_feature_extractor_matches_oracle():
+    from mvsnet_amd.feature_net import UNetDS2GN
+    params = S.make_unet_params("normal", seed=3)
+    imgs = S.make_images(2, 32, 48, seed=0)
+    got = n(UNetDS2GN(params, DEV)(t(imgs)))
+    assert got.shape == (2, 8, 12, 32)
+    for v in range(2):
+        exp = O.unet_ds2gn(imgs[v], params, np.float64)
+        np.testing.assert_allclose(got[v], exp, rtol=2e-3, atol=2e-4)
+
+
+def test_inference_mem_from_images_runs_and_writes_outputs(tmp_path):
+    from mvsnet_amd.model import MVSNetWeights, inference_mem
+    from mvsnet_amd import preprocess as P
+    up = S.make_unet_params("normal", seed=3)
+    rp = S.make_regnet_params("normal", seed=1)
+    weights = MVSNetWeights.from_numpy("normal", unet=up, regnet=rp, device=DEV)
+    imgs = S.make_images(3, 64, 64, seed=1)
+    cams = S.make_cams(3, 16, 16, 8, interval=60.0)
+    depth, prob = inference_mem(t(imgs)[None], t(cams)[None], 8, cams[0, 1, 3, 0], cams[0, 1, 3, 1],
+                                weights=weights)
+    assert depth.shape == (1, 16, 16, 1) and prob.shape == (1, 16, 16, 1)
+    d = n(depth)[0, :, :, 0]
+    assert np.isfinite(d).all() and d.min() >= 425.0 and d.max() <= 425.0 + 7 * 60.0
+    path = str(tmp_path / "0_init.pfm")
+    P.write_pfm(path, d)
+    assert np.array_equal(P.load_pfm(path), d)
