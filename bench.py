@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py -- depth maps/sec of the plane-sweep hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one features->depth pass of the metric workload (BASELINE.json: N=5 views, D=192 planes,
+160x128 feature maps, C=32, 3D-CNN regulariser): homography transforms -> fused warp+variance
+cost volume -> RegNetUS0 -> soft-argmin + probability map, inputs (feature maps, cameras, weights)
+resident in HBM.  Reference views are independent, so ranks shard them with no
+data-path collective ("scaling": "weak"); value = depth maps of all ranks / max-over-ranks time.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def algorithmic_work(view_num, D, H, W, C, base=8):
+    """BASELINE.md section 2 / SURVEY 8d: bytes of the warp+variance kernel, FLOPs of RegNetUS0,
+    bytes of the soft-argmin kernel, per depth map."""
+    vox = D * H * W
+    warp_bytes = view_num * H * W * C * 4 + vox * C * 4
+    # MACs per full-resolution voxel (mvsnetworks.py:122-158), channels in units of base b, cin = C
+    b = base
+    mac = 27 * (C * b                      # 0_1   on V0
+                + C * 2 * b / 8            # 1_0   on V0/8
+                + 2 * b * 2 * b / 8        # 1_1
+                + 2 * b * 4 * b / 64       # 2_0
+                + 4 * b * 4 * b / 64       # 2_1
+                + 4 * b * 8 * b / 512      # 3_0
+                + 8 * b * 8 * b / 512      # 3_1
+                + 8 * b * 4 * b / 512      # 4_0 (27 taps per INPUT voxel of V0/512)
+                + 4 * b * 2 * b / 64       # 5_0
+                + 2 * b * b / 8            # 6_0
+                + b * 1)                   # 6_2
+    conv_flops = 2.0 * mac * vox
+    soft_bytes = vox * 4 + 2 * H * W * 4
+    return warp_bytes, conv_flops, soft_bytes
+
+
+def cpu_baseline(workload, rp, budget_s=20.0):
+    """CPU restatement (oracle/torch_restatement.py, fp32, all host cores) timed on a bounded
+    sample of the same workload: whole depth maps until ~budget_s have elapsed (at least one)."""
+    from oracle import torch_restatement as TR       # measurement only; never on the product path
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    w = workload
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        TR.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start, w.depth_interval, rp)
+        n_done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n_done >= 8:
+            break
+    return {"value": n_done / el, "unit": "depth maps/s", "cores": cores, "kind": "port",
+            "sample": "%d whole depth map(s) of workload %s (features->depth, torch-CPU fp32 restatement "
+                      "of the reference; TensorFlow reference not runnable offline) in %.1f s" % (n_done, w.name, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="M", help="M (metric), c1, c2, small, toy")
+    ap.add_argument("--network-mode", default="normal")
+    ap.add_argument("--conv-impl", default="auto", choices=["auto", "scalar", "mfma"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--with-images", action="store_true",
+                    help="also time images->depth (adds the PyTorch UNetDS2GN towers)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mvsnet_amd import _lib, synthetic as S
+    from mvsnet_amd.model import DepthPlan, MVSNetWeights
+    _lib.load()
+    _lib.set_conv_impl(args.conv_impl)
+
+    # each rank owns a different synthetic reference view (seed = rank): shard by ref view
+    w = S.make_workload(args.workload, args.network_mode, seed=rank)
+    rp = S.make_regnet_params(args.network_mode, seed=1)
+    weights = MVSNetWeights.from_numpy(args.network_mode, regnet=rp, device=dev)
+    feats = torch.as_tensor(w.features).to(dev)
+    cams = torch.as_tensor(w.cams).to(dev)
+    plan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", dev)
+    end = w.depth_end
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    marks = []
+
+    def step(record):
+        if record:
+            e = [ev() for _ in range(4)]
+            e[0].record()
+        plan.set_cameras(cams, w.depth_start, w.depth_interval, end, False)
+        from mvsnet_amd.model import cost_volume, regnet_us0, softargmin_prob
+        cost_volume(feats[0], feats[1:], plan.transforms, 0, plan.D, "mem", out=plan.cost)
+        if record:
+            e[1].record()
+        regnet_us0(plan.cost, weights.regnet, plan.workspace, plan.reg)
+        if record:
+            e[2].record()
+        softargmin_prob(plan.reg, w.depth_start, w.depth_interval, False, plan.depth, plan.prob)
+        if record:
+            e[3].record()
+            marks.append(e)
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-kernel device time from the events recorded inside the timed region
+    t_warp = np.mean([m[0].elapsed_time(m[1]) for m in marks]) * 1e-3     # includes the tiny homography kernel
+    t_conv = np.mean([m[1].elapsed_time(m[2]) for m in marks]) * 1e-3
+    t_soft = np.mean([m[2].elapsed_time(m[3]) for m in marks]) * 1e-3
+    warp_bytes, conv_flops, soft_bytes = algorithmic_work(w.view_num, w.depth_num, w.height, w.width,
+                                                         w.channels, S.base_filter(args.network_mode))
+    depth_np = plan.depth.cpu().numpy()
+
+    if rank == 0:
+        kernels = [
+            {"kernel": "warp+variance cost volume (cost_volume_kernel)", "bound": "hbm",
+             "achieved": warp_bytes / t_warp / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": warp_bytes / t_warp / 1e9 / HBM_PEAK_GBS, "ms": t_warp * 1e3,
+             "algorithmic_bytes": warp_bytes, "traffic": None},
+            {"kernel": "RegNetUS0 3D conv stack (11 conv launches + 10 BN finalises)", "bound": "mfma",
+             "achieved": conv_flops / t_conv / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": conv_flops / t_conv / 1e12 / MFMA_F32_PEAK_TFLOPS, "ms": t_conv * 1e3,
+             "algorithmic_flops": conv_flops, "peak_dtype": "fp32-input MFMA (dense)", "traffic": None},
+            {"kernel": "softmax+soft-argmin+prob (softargmin_prob_kernel)", "bound": "hbm",
+             "achieved": soft_bytes / t_soft / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": soft_bytes / t_soft / 1e9 / HBM_PEAK_GBS, "ms": t_soft * 1e3,
+             "algorithmic_bytes": soft_bytes, "traffic": None},
+        ]
+        dominant = max(kernels, key=lambda k: k["ms"])
+        out = {
+            "metric": "depth maps/sec (N=5, D=192, 160x128)" if args.workload == "M" else "depth maps/sec",
+            "value": world * args.steps / elapsed,
+            "unit": "depth maps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: features->depth, N=%d views, D=%d planes, %dx%d feature maps, C=%d, "
+                                   "3D-CNN regulariser (RegNetUS0), network_mode=%s; one reference view per "
+                                   "step per GPU, sharded by reference view" % (
+                                       w.name, w.view_num, w.depth_num, w.width, w.height, w.channels,
+                                       args.network_mode),
+                       "conv_impl": args.conv_impl},
+            "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
+            "roofline_kernels": kernels,
+            "depth_checksum": float(np.float64(depth_np).sum()),
+        }
+        out["roofline"]["kernel"] = dominant["kernel"]
+        if args.with_images:
+            up = S.make_unet_params(args.network_mode, seed=3)
+            from mvsnet_amd.feature_net import UNetDS2GN
+            net = UNetDS2GN(up, dev)
+            imgs = torch.as_tensor(S.make_images(w.view_num, 4 * w.height, 4 * w.width, seed=0)).to(dev)
+            for _ in range(3):
+                f = net(imgs)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                f = net(imgs)
+                plan.set_cameras(cams, w.depth_start, w.depth_interval, end, False)
+                plan.run_3dcnn(f, w.depth_start, w.depth_interval)
+            torch.cuda.synchronize()
+            out["images_to_depth_maps_per_s"] = args.steps / (time.perf_counter() - t1)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w, rp, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+"""Writes the golden fixtures tests/golden/toy_*.npz from the float64 CPU oracle.
+
+The reference (ubiquity6/MVSNet) holds no fixtures and cannot be executed here (TensorFlow 1.12 /
+python2 absent), so these vectors pin the build's own restatement, which is in turn pinned by the
+hand-computed KATs of tests/test_oracle_kat.py.  Inputs are regenerated from seeds
+(mvsnet_amd/synthetic.py); their SHA-256 is stored so RNG drift is detected.
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import mvsnet_oracle as O          # noqa: E402
+from mvsnet_amd import synthetic as S          # noqa: E402
+
+
+def main():
+    w = S.make_workload("toy")
+    sha = hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest()
+    rp = S.make_regnet_params("normal", seed=1, random_affine=True)
+    d, p = O.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start,
+                                         w.depth_interval, rp, False, np.float64)
+    np.savez_compressed(os.path.join(HERE, "toy_3dcnn.npz"), depth=d, prob=p, input_sha256=sha)
+    gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
+    d, p = O.inference_winner_take_all_from_features(w.features, w.cams, w.depth_num, w.depth_start,
+                                                     w.depth_end, gp, False, np.float64)
+    np.savez_compressed(os.path.join(HERE, "toy_gru.npz"), depth=d, prob=p, input_sha256=sha)
+    print("wrote golden fixtures; input sha256", sha)
+
+
+if __name__ == "__main__":
+    main()
