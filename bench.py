@@ -64,6 +64,13 @@ def cpu_baseline(workload, rp, budget_s=20.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:       # cgroup CPU quota (the GPU box gives one GPU's share of the host cores)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    cores = min(cores, int(os.environ.get("MVS_CPU_THREADS", "16")))   # 1-GPU share of the host
     torch.set_num_threads(cores)
     w = workload
     n_done, t0 = 0, time.perf_counter()

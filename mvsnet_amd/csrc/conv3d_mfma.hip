@@ -1,11 +1,340 @@
-// MFMA implicit-GEMM 3x3x3 convolution (placeholder until the tiled kernel lands).
+// fp32-MFMA implicit-GEMM 3x3x3 convolutions for gfx950 (R4/R5, K6a-d).
+//
+// Reference behaviour: tf.layers.conv3d / conv3d_transpose, SAME padding, no bias, NDHWC
+// (mvsnet/cnn_wrapper/network.py:203-215,300-329), with the producer's training-mode BatchNorm +
+// ReLU (+ additive skip) applied while the input is staged (network.py:457-459,492-509).
+//
+// Design ("input-stationary plane march"), written for CDNA4, not a translated CUDA tiling:
+//   * A workgroup (4 waves, one per SIMD) owns a TH x 16 (h x w) column of the volume and marches
+//     along depth.  Every input plane is staged into LDS exactly once (channel-last rows padded so
+//     that the 16-lane ds_read_b128 groups hit 16 distinct 16-B bank slots) and used once.
+//   * GEMM roles: rows (A operand) = (kd, cout) weight rows, columns (B operand) = 16 voxels along
+//     w, K = (kh, kw, ci).  One staged plane q therefore feeds the three output planes q+1, q, q-1
+//     (kd = 0, 1, 2) in the same sweep: 3x fewer LDS reads than an output-stationary loop, one
+//     slab (double buffered) instead of a 3-plane ring, and Cout = 8 fills 24 of 32 rows (75 %)
+//     instead of 8 of 16.
+//   * v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD): lane l supplies A[row l&15][k l>>4]
+//     and B[k l>>4][col l&15]; D regs r: row (l>>4)*4+r, col l&15.  K is ordered so that one
+//     ds_read_b128 per operand feeds 4 consecutive MFMAs (ci = 16s + 4*(l>>4) + j, j = 0..3).
+//   * The accumulator block that received kd = 0,1,2 on three successive planes is complete and is
+//     stored (coalesced 16-B lanes), with per-channel sum / sum-of-squares for the consumer's
+//     BatchNorm accumulated on the fly.  Blocks rotate through kd by re-basing the weight address
+//     per plane (loop unrolled by 3), never by moving registers.
+//   * Next plane's global loads are issued before the sweep and written to the other LDS buffer
+//     after it (one barrier per plane).
 #include "common.h"
+#include <type_traits>
 
-int mvs_conv3d_mfma(const float*, const float*, const float*, const float*, const float*,
-                    const float*, const float*, int, int, int, int, int, int, float*, double*,
-                    hipStream_t) {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const float* x; const float* xs; const float* xb;      // input + producer BN affine (or null)
+    const float* x2; const float* x2s; const float* x2b;   // optional additive skip input
+    const float* w;                                         // (3,3,3,Cin,CoutTotal)
+    float* y;                                               // (D,H,W,CoutTotal) raw output
+    double* stats;                                          // (2,CoutTotal) or null
+    int D, H, W, cout_total, planes_per_wg;
+};
+
+constexpr int TW = 16;          // voxels per MFMA column tile (along w)
+constexpr int PW = TW + 2;      // staged row width with halo
+
+template <int CIN> struct SlabGeom {
+    static constexpr int S = CIN + 8;             // floats per staged position: 16-B slots = 2 mod 4
+};
+
+// ------------------------------------------------------------------------------------------------
+// stride-1 convolution, input-stationary.  COUT = output channels handled by this workgroup (8|16).
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int TH, bool HAS_X2>
+__global__ void __launch_bounds__(256, 1)
+conv3d_s1_kernel(ConvArgs a) {
+    constexpr int S = SlabGeom<CIN>::S;
+    constexpr int NPOS = (TH + 2) * PW;
+    constexpr int CQ = CIN / 4;                    // float4 per position
+    constexpr int NF4 = NPOS * CQ;
+    constexpr int NIT = (NF4 + 255) / 256;
+    constexpr int V = TH / 4;                      // voxel tiles (rows of the h x w tile) per wave
+    constexpr int NROWS = 3 * COUT;                // (kd, co) weight rows
+    constexpr int MT = (NROWS + 15) / 16;          // 16-row MFMA tiles
+    constexpr int WROW = NROWS * 4;                // floats per (tap, ci-quad) weight group
+    constexpr int W_FLOATS = 9 * CQ * WROW;
+    constexpr int SLAB_FLOATS = NPOS * S;
+    static_assert(256 % CQ == 0, "channel quad per thread must be loop invariant");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;                              // [9 taps][CQ][3 kd][COUT][4]
+    float* slab = smem + W_FLOATS;                 // [2][NPOS][S]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+
+    const int tiles_w = (a.W + TW - 1) / TW;
+    const int tile_h = blockIdx.x / tiles_w, tile_w = blockIdx.x - tile_h * tiles_w;
+    const int h0 = tile_h * TH, w0 = tile_w * TW;
+    const int co_base = blockIdx.y * COUT;
+    const int d0 = blockIdx.z * a.planes_per_wg;
+    const int d1 = min(d0 + a.planes_per_wg, a.D);
+    const int T = d1 - d0 + 2;                     // input planes d0-1 .. d1
+
+    // ---- weights -> LDS, re-laid out as [tap][ci/4][kd][co][ci%4] ------------------------------
+    for (int i = tid; i < W_FLOATS; i += 256) {
+        int j = i & 3;
+        int r = (i >> 2) % NROWS;
+        int g = (i >> 2) / NROWS;                  // tap * CQ + ciq
+        int ciq = g % CQ, tap = g / CQ;
+        int kd = r / COUT, co = r - kd * COUT;
+        wl[i] = a.w[(((size_t)(kd * 9 + tap)) * CIN + ciq * 4 + j) * a.cout_total + co_base + co];
+    }
+
+    // ---- staging helpers ---------------------------------------------------------------------------
+    const int c4 = tid % CQ;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sc2 = sc, sh2 = sh;
+    const bool has_aff = a.xs != nullptr;
+    if (has_aff) { sc = *(const float4*)(a.xs + 4 * c4); sh = *(const float4*)(a.xb + 4 * c4); }
+    const bool has_aff2 = HAS_X2 && a.x2s != nullptr;
+    if (has_aff2) { sc2 = *(const float4*)(a.x2s + 4 * c4); sh2 = *(const float4*)(a.x2b + 4 * c4); }
+
+    float4 pre[NIT];
+    float4 pre2[HAS_X2 ? NIT : 1];
+
+    auto issue_loads = [&](int q) {
+        const bool plane_ok = (q >= 0) && (q < a.D);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            int f = tid + 256 * i;
+            int pos = f / CQ;
+            int r = pos / PW, c = pos - r * PW;
+            int gh = h0 - 1 + r, gw = w0 - 1 + c;
+            bool ok = plane_ok && (f < NF4) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+            size_t off = ((((size_t)q * a.H + gh) * a.W) + gw) * CIN + 4 * c4;
+            pre[i] = ok ? *(const float4*)(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (HAS_X2) pre2[i] = ok ? *(const float4*)(a.x2 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto xform = [&](float4 v, float4 s, float4 b, bool aff) {
+        if (aff) {
+            v.x = relu(v.x * s.x + b.x); v.y = relu(v.y * s.y + b.y);
+            v.z = relu(v.z * s.z + b.z); v.w = relu(v.w * s.w + b.w);
+        }
+        return v;
+    };
+    auto write_slab = [&](int q, float* buf) {
+        const bool plane_ok = (q >= 0) && (q < a.D);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            int f = tid + 256 * i;
+            if (f >= NF4) continue;
+            int pos = f / CQ;
+            int r = pos / PW, c = pos - r * PW;
+            int gh = h0 - 1 + r, gw = w0 - 1 + c;
+            bool ok = plane_ok && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {                               // SAME padding pads the NORMALISED input with 0
+                v = xform(pre[i], sc, sh, has_aff);
+                if (HAS_X2) {
+                    float4 v2 = xform(pre2[i], sc2, sh2, has_aff2);
+                    v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+                }
+            }
+            *(float4*)(buf + pos * S + 4 * c4) = v;
+        }
+    };
+
+    // ---- accumulators ------------------------------------------------------------------------------
+    f32x4 acc[MT][V];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[m][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // lane constants: B-operand base (floats) per voxel tile, A-operand row decomposition
+    int b_off[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) b_off[v] = ((V * wave + v) * PW + n) * S + 4 * kq;
+    // row m of tile mt -> block (mt*16+m)/COUT, channel (mt*16+m)%COUT
+    int row_blk[MT], row_co[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { int r = m * 16 + n; row_blk[m] = r / COUT; row_co[m] = r % COUT; }
+
+    // one plane sweep; P = plane counter mod 3 (static), block b carries kd = (P - b) mod 3
+    auto sweep = [&](auto Pc, const float* buf) {
+        constexpr int P = decltype(Pc)::value;
+        int a_off[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            int b = row_blk[m];
+            int kd = (b < 3) ? ((P - b + 3) % 3) : 0;      // pad blocks read harmless finite weights
+            a_off[m] = (kq * NROWS + kd * COUT + row_co[m]) * 4;
+        }
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int s = 0; s < CIN / 16; ++s) {
+                    f32x4 bv[V], av[MT];
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        bv[v] = *(const f32x4*)(buf + b_off[v] + (kh * PW + kw) * S + 16 * s);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        av[m] = *(const f32x4*)(wl + a_off[m] + ((kh * 3 + kw) * CQ + 4 * s) * WROW);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int v = 0; v < V; ++v)
+                                acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][j], bv[v][j], acc[m][v], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // store + zero the block that has just received kd = 2 (block (P+1)%3), output plane o
+    auto retire = [&](auto Pc, int o) {
+        constexpr int P = decltype(Pc)::value;
+        constexpr int B = (P + 1) % 3;
+        constexpr int mt = (B * COUT) / 16;                 // tile holding the block
+        constexpr int row0 = (B * COUT) % 16;               // first row of the block inside the tile
+        const bool plane_ok = (o >= d0) && (o < d1);
+        const int q4 = kq;                                  // lane group holds rows 4*q4 .. 4*q4+3
+        const bool mine = (4 * q4 >= row0) && (4 * q4 < row0 + COUT);
+        const int co = 4 * q4 - row0;                       // first of this lane's 4 channels
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if (mine) {
+                int h = h0 + V * wave + v, w = w0 + n;
+                if (plane_ok && h < a.H && w < a.W) {
+                    f32x4 r = acc[mt][v];
+                    float* dst = a.y + ((((size_t)o * a.H + h) * a.W) + w) * a.cout_total + co_base + co;
+                    *(float4*)dst = make_float4(r[0], r[1], r[2], r[3]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { st_s[k] += r[k]; st_q[k] += r[k] * r[k]; }
+                }
+                acc[mt][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+
+    // ---- plane march -------------------------------------------------------------------------------
+    issue_loads(d0 - 1);
+    write_slab(d0 - 1, slab);
+    __syncthreads();
+
+    auto plane = [&](auto Pc, int t) {
+        const int q = d0 - 1 + t;
+        float* cur = slab + (t & 1) * SLAB_FLOATS;
+        float* nxt = slab + ((t + 1) & 1) * SLAB_FLOATS;
+        const bool more = (t + 1 < T);
+        if (more) issue_loads(q + 1);
+        if (q >= 0 && q < a.D) sweep(Pc, cur);
+        retire(Pc, q - 1);
+        if (more) write_slab(q + 1, nxt);
+        __syncthreads();
+    };
+    for (int t = 0; t < T; t += 3) {
+        plane(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < T) plane(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < T) plane(std::integral_constant<int, 2>{}, t + 2);
+    }
+
+    // ---- BatchNorm statistics: lanes sharing a channel quad -> LDS -> one f64 atomic per channel -----
+    if (a.stats) {
+        // lane group kq holds channels (4*kq - row0(B)) of whichever block it served; across the three
+        // blocks a lane group always serves the same channel quad modulo the block layout below.
+        float (*red)[2][16] = reinterpret_cast<float (*)[2][16]>(slab);   // slabs are dead now
+        // channel of st_*[k]: for COUT=16 every block starts at row 0 of its tile: co = 4*kq + k.
+        // for COUT=8: blocks 0,2 start at row 0 (lane groups 0,1), block 1 at row 8 (groups 2,3):
+        // co = 4*(kq&1) + k in both cases.
+        float s[4], q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sv = st_s[k], qv = st_q[k];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+            if (COUT == 8) { sv += __shfl_xor(sv, 32, 64); qv += __shfl_xor(qv, 32, 64); }
+            s[k] = sv; q[k] = qv;
+        }
+        const int ngrp = COUT / 4;                           // distinct channel quads
+        if (n == 0 && kq < ngrp) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { red[wave][0][4 * kq + k] = s[k]; red[wave][1][4 * kq + k] = q[k]; }
+        }
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            int k = tid / COUT, c = tid - k * COUT;
+            double tsum = (double)red[0][k][c] + (double)red[1][k][c] + (double)red[2][k][c] + (double)red[3][k][c];
+            atomicAdd(&a.stats[(size_t)k * a.cout_total + co_base + c], tsum);
+        }
+    }
+}
+
+template <int CIN, int COUT, int TH>
+size_t s1_smem_bytes() {
+    return (size_t)(9 * (CIN / 4) * 3 * COUT * 4 + 2 * (TH + 2) * PW * SlabGeom<CIN>::S) * sizeof(float);
+}
+
+// planes per workgroup: enough workgroups to fill 256 CUs a few times, small halo overhead
+int pick_planes(int D, long long wgs_per_chunk) {
+    int best = D, best_cost = 1 << 30;
+    const int cands[] = {4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
+    for (int dr : cands) {
+        if (dr > D) dr = D;
+        long long chunks = (D + dr - 1) / dr;
+        long long wgs = wgs_per_chunk * chunks;
+        long long rounds = (wgs + 255) / 256;
+        int cost = (int)(rounds * (dr + 2));
+        if (cost < best_cost) { best_cost = cost; best = dr; }
+        if (dr == D) break;
+    }
+    return best;
+}
+
+template <int CIN, int COUT, int TH>
+int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
+    ConvArgs a = a0;
+    const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
+    const int groups = Cout / COUT;
+    a.planes_per_wg = pick_planes(a.D, (long long)tiles * groups);
+    dim3 grid(tiles, groups, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
+    size_t smem = s1_smem_bytes<CIN, COUT, TH>();
+    static bool attr_done = false;       // per template instantiation
+    if (!attr_done) {
+        hipError_t e;
+        if ((e = hipFuncSetAttribute((const void*)conv3d_s1_kernel<CIN, COUT, TH, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess) return (int)e;
+        if ((e = hipFuncSetAttribute((const void*)conv3d_s1_kernel<CIN, COUT, TH, false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    if (a.x2) conv3d_s1_kernel<CIN, COUT, TH, true><<<grid, 256, smem, st>>>(a);
+    else conv3d_s1_kernel<CIN, COUT, TH, false><<<grid, 256, smem, st>>>(a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int mvs_conv3d_mfma(const float* x, const float* xs, const float* xb, const float* x2,
+                    const float* x2s, const float* x2b, const float* w, int D, int H, int W,
+                    int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st) {
+    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0};
+    if (stride == 1) {
+        if (Cin == 32 && Cout == 8) return launch_s1<32, 8, 8>(a, Cout, st);
+        if (Cin == 16 && Cout % 16 == 0) return launch_s1<16, 16, 8>(a, Cout, st);
+        if (Cin == 32 && Cout % 16 == 0) return launch_s1<32, 16, 8>(a, Cout, st);
+        if (Cin == 64 && Cout % 8 == 0) return launch_s1<64, 8, 4>(a, Cout, st);
+        if (Cin == 16 && Cout == 8) return launch_s1<16, 8, 8>(a, Cout, st);
+    }
     return MVS_E_SHAPE;
 }
+
 int mvs_deconv3d_mfma(const float*, const float*, const float*, const float*, const float*,
                       const float*, const float*, int, int, int, int, int, float*, double*,
                       hipStream_t) {
