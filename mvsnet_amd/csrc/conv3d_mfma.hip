@@ -22,28 +22,12 @@
 //     per plane (loop unrolled by 3), never by moving registers.
 //   * Next plane's global loads are issued before the sweep and written to the other LDS buffer
 //     after it (one barrier per plane).
-#include "common.h"
-#include <type_traits>
+#include "conv_common.h"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvArgs {
-    const float* x; const float* xs; const float* xb;      // input + producer BN affine (or null)
-    const float* x2; const float* x2s; const float* x2b;   // optional additive skip input
-    const float* w;                                         // (3,3,3,Cin,CoutTotal)
-    float* y;                                               // (D,H,W,CoutTotal) raw output
-    double* stats;                                          // (2,CoutTotal) or null
-    int D, H, W, cout_total, planes_per_wg;
-};
-
-constexpr int TW = 16;          // voxels per MFMA column tile (along w)
+constexpr int TW = CONV_TW;
 constexpr int PW = TW + 2;      // staged row width with halo
-
-template <int CIN> struct SlabGeom {
-    static constexpr int S = CIN + 8;             // floats per staged position: 16-B slots = 2 mod 4
-};
 
 // ------------------------------------------------------------------------------------------------
 // stride-1 convolution, input-stationary.  COUT = output channels handled by this workgroup (8|16).
@@ -102,7 +86,7 @@ conv3d_s1_kernel(ConvArgs a) {
     float4 pre[NIT];
     float4 pre2[HAS_X2 ? NIT : 1];
 
-    auto issue_loads = [&](int q) {
+    auto issue_loads = [&](int q) __attribute__((always_inline)) {
         const bool plane_ok = (q >= 0) && (q < a.D);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -116,14 +100,7 @@ conv3d_s1_kernel(ConvArgs a) {
             if (HAS_X2) pre2[i] = ok ? *(const float4*)(a.x2 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto xform = [&](float4 v, float4 s, float4 b, bool aff) {
-        if (aff) {
-            v.x = relu(v.x * s.x + b.x); v.y = relu(v.y * s.y + b.y);
-            v.z = relu(v.z * s.z + b.z); v.w = relu(v.w * s.w + b.w);
-        }
-        return v;
-    };
-    auto write_slab = [&](int q, float* buf) {
+    auto write_slab = [&](int q, float* buf) __attribute__((always_inline)) {
         const bool plane_ok = (q >= 0) && (q < a.D);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -135,9 +112,9 @@ conv3d_s1_kernel(ConvArgs a) {
             bool ok = plane_ok && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {                               // SAME padding pads the NORMALISED input with 0
-                v = xform(pre[i], sc, sh, has_aff);
+                v = bn_relu4(pre[i], sc, sh, has_aff);
                 if (HAS_X2) {
-                    float4 v2 = xform(pre2[i], sc2, sh2, has_aff2);
+                    float4 v2 = bn_relu4(pre2[i], sc2, sh2, has_aff2);
                     v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
                 }
             }
@@ -163,7 +140,7 @@ conv3d_s1_kernel(ConvArgs a) {
     for (int m = 0; m < MT; ++m) { int r = m * 16 + n; row_blk[m] = r / COUT; row_co[m] = r % COUT; }
 
     // one plane sweep; P = plane counter mod 3 (static), block b carries kd = (P - b) mod 3
-    auto sweep = [&](auto Pc, const float* buf) {
+    auto sweep = [&](auto Pc, const float* buf) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
         int a_off[MT];
 #pragma unroll
@@ -198,7 +175,7 @@ conv3d_s1_kernel(ConvArgs a) {
     };
 
     // store + zero the block that has just received kd = 2 (block (P+1)%3), output plane o
-    auto retire = [&](auto Pc, int o) {
+    auto retire = [&](auto Pc, int o) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
         constexpr int B = (P + 1) % 3;
         constexpr int mt = (B * COUT) / 16;                 // tile holding the block
@@ -228,7 +205,7 @@ conv3d_s1_kernel(ConvArgs a) {
     write_slab(d0 - 1, slab);
     __syncthreads();
 
-    auto plane = [&](auto Pc, int t) {
+    auto plane = [&](auto Pc, int t) __attribute__((always_inline)) {
         const int q = d0 - 1 + t;
         float* cur = slab + (t & 1) * SLAB_FLOATS;
         float* nxt = slab + ((t + 1) & 1) * SLAB_FLOATS;
@@ -245,35 +222,10 @@ conv3d_s1_kernel(ConvArgs a) {
         if (t + 2 < T) plane(std::integral_constant<int, 2>{}, t + 2);
     }
 
-    // ---- BatchNorm statistics: lanes sharing a channel quad -> LDS -> one f64 atomic per channel -----
-    if (a.stats) {
-        // lane group kq holds channels (4*kq - row0(B)) of whichever block it served; across the three
-        // blocks a lane group always serves the same channel quad modulo the block layout below.
-        float (*red)[2][16] = reinterpret_cast<float (*)[2][16]>(slab);   // slabs are dead now
-        // channel of st_*[k]: for COUT=16 every block starts at row 0 of its tile: co = 4*kq + k.
-        // for COUT=8: blocks 0,2 start at row 0 (lane groups 0,1), block 1 at row 8 (groups 2,3):
-        // co = 4*(kq&1) + k in both cases.
-        float s[4], q[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float sv = st_s[k], qv = st_q[k];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
-            if (COUT == 8) { sv += __shfl_xor(sv, 32, 64); qv += __shfl_xor(qv, 32, 64); }
-            s[k] = sv; q[k] = qv;
-        }
-        const int ngrp = COUT / 4;                           // distinct channel quads
-        if (n == 0 && kq < ngrp) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { red[wave][0][4 * kq + k] = s[k]; red[wave][1][4 * kq + k] = q[k]; }
-        }
-        __syncthreads();
-        if (tid < 2 * COUT) {
-            int k = tid / COUT, c = tid - k * COUT;
-            double tsum = (double)red[0][k][c] + (double)red[1][k][c] + (double)red[2][k][c] + (double)red[3][k][c];
-            atomicAdd(&a.stats[(size_t)k * a.cout_total + co_base + c], tsum);
-        }
-    }
+    // ---- BatchNorm statistics ----------------------------------------------------------------------
+    // channel quad of st_*: COUT=16: blocks start at row 0 of their tile -> quad kq.  COUT=8: blocks
+    // 0,2 sit in lane groups 0,1 and block 1 in groups 2,3 -> quad kq&1, fold lanes l and l^32.
+    if (a.stats) stats_commit<COUT>(st_s, st_q, COUT == 8, slab, a.stats, a.cout_total, co_base);
 }
 
 template <int CIN, int COUT, int TH>
@@ -281,28 +233,12 @@ size_t s1_smem_bytes() {
     return (size_t)(9 * (CIN / 4) * 3 * COUT * 4 + 2 * (TH + 2) * PW * SlabGeom<CIN>::S) * sizeof(float);
 }
 
-// planes per workgroup: enough workgroups to fill 256 CUs a few times, small halo overhead
-int pick_planes(int D, long long wgs_per_chunk) {
-    int best = D, best_cost = 1 << 30;
-    const int cands[] = {4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
-    for (int dr : cands) {
-        if (dr > D) dr = D;
-        long long chunks = (D + dr - 1) / dr;
-        long long wgs = wgs_per_chunk * chunks;
-        long long rounds = (wgs + 255) / 256;
-        int cost = (int)(rounds * (dr + 2));
-        if (cost < best_cost) { best_cost = cost; best = dr; }
-        if (dr == D) break;
-    }
-    return best;
-}
-
 template <int CIN, int COUT, int TH>
 int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
     ConvArgs a = a0;
     const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
     const int groups = Cout / COUT;
-    a.planes_per_wg = pick_planes(a.D, (long long)tiles * groups);
+    a.planes_per_wg = conv_pick_planes(a.D, (long long)tiles * groups, 2);
     dim3 grid(tiles, groups, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
     size_t smem = s1_smem_bytes<CIN, COUT, TH>();
     static bool attr_done = false;       // per template instantiation
@@ -324,19 +260,24 @@ int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
 int mvs_conv3d_mfma(const float* x, const float* xs, const float* xb, const float* x2,
                     const float* x2s, const float* x2b, const float* w, int D, int H, int W,
                     int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0};
+    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0};
     if (stride == 1) {
+        if (Cout == 1) return mvs_conv3d_out_launch(a, Cin, st);
         if (Cin == 32 && Cout == 8) return launch_s1<32, 8, 8>(a, Cout, st);
         if (Cin == 16 && Cout % 16 == 0) return launch_s1<16, 16, 8>(a, Cout, st);
         if (Cin == 32 && Cout % 16 == 0) return launch_s1<32, 16, 8>(a, Cout, st);
         if (Cin == 64 && Cout % 8 == 0) return launch_s1<64, 8, 4>(a, Cout, st);
         if (Cin == 16 && Cout == 8) return launch_s1<16, 8, 8>(a, Cout, st);
+        return MVS_E_SHAPE;
     }
-    return MVS_E_SHAPE;
+    auto pad_before = [](int n) { int o = (n + 1) / 2; int t = (o - 1) * 2 + 3 - n; return t < 0 ? 0 : t / 2; };
+    a.pd = pad_before(D); a.ph = pad_before(H); a.pw = pad_before(W);
+    return mvs_conv3d_s2_mfma(a, Cin, Cout, st);
 }
 
-int mvs_deconv3d_mfma(const float*, const float*, const float*, const float*, const float*,
-                      const float*, const float*, int, int, int, int, int, float*, double*,
-                      hipStream_t) {
-    return MVS_E_SHAPE;
+int mvs_deconv3d_mfma(const float* x, const float* xs, const float* xb, const float* x2,
+                      const float* x2s, const float* x2b, const float* w, int D, int H, int W,
+                      int Cin, int Cout, float* y, double* stats, hipStream_t st) {
+    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0};
+    return mvs_deconv3d_mfma_launch(a, Cin, Cout, st);
 }

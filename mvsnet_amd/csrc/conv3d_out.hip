@@ -1,0 +1,141 @@
+// Output convolution 3dconv6_2: Cin (= base_filter) -> 1 channel, 3x3x3 SAME stride 1, no BN / ReLU /
+// bias (mvsnet/cnn_wrapper/mvsnetworks.py:156-158), consuming BN+ReLU(3dconv6_0) + BN+ReLU(3dconv0_1)
+// on load (the additive skip of :156-157).
+//
+// One output channel cannot fill an MFMA tile (1 of 16 rows), and the layer is HBM-bound anyway:
+// 216 MAC per voxel against 2 x Cin x 4 bytes read.  So: VALU kernel, same input-stationary plane
+// march as the MFMA kernels -- a workgroup owns an 8 x 32 (h x w) column, stages each normalised
+// input plane once in LDS (12-float positions: conflict-free 16-B reads for consecutive lanes) and
+// each thread adds the plane's 9 in-plane taps into the three output planes q+1, q, q-1.
+// Roofline: HBM, 2*Cin*4 + 4 bytes per voxel.
+#include "conv_common.h"
+
+namespace {
+
+constexpr int OTH = 8, OTW = 32;
+constexpr int OPW = OTW + 2;
+
+template <int CIN>
+__global__ void __launch_bounds__(256)
+conv3d_out_kernel(ConvArgs a) {
+    constexpr int S = CIN + 4;
+    constexpr int CQ = CIN / 4;
+    constexpr int NPOS = (OTH + 2) * OPW;
+    constexpr int NF4 = NPOS * CQ;
+    constexpr int NIT = (NF4 + 255) / 256;
+    static_assert(256 % CQ == 0, "channel quad per thread must be loop invariant");
+    __shared__ __attribute__((aligned(16))) float slab[2][NPOS * S];
+    __shared__ float wsh[27 * CIN];
+
+    const int tid = threadIdx.x;
+    const int row = tid >> 5, col = tid & 31;
+    const int tiles_w = (a.W + OTW - 1) / OTW;
+    const int tile_h = blockIdx.x / tiles_w, tile_w = blockIdx.x - tile_h * tiles_w;
+    const int h0 = tile_h * OTH, w0 = tile_w * OTW;
+    const int d0 = blockIdx.z * a.planes_per_wg;
+    const int d1 = min(d0 + a.planes_per_wg, a.D);
+    const int T = d1 - d0 + 2;
+
+    for (int i = tid; i < 27 * CIN; i += 256) wsh[i] = a.w[i];      // (3,3,3,Cin,1)
+
+    const int c4 = tid % CQ;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sc2 = sc, sh2 = sh;
+    const bool has_aff = a.xs != nullptr, has_x2 = a.x2 != nullptr;
+    if (has_aff) { sc = *(const float4*)(a.xs + 4 * c4); sh = *(const float4*)(a.xb + 4 * c4); }
+    const bool has_aff2 = has_x2 && a.x2s != nullptr;
+    if (has_aff2) { sc2 = *(const float4*)(a.x2s + 4 * c4); sh2 = *(const float4*)(a.x2b + 4 * c4); }
+
+    float4 pre[NIT], pre2[NIT];
+    auto issue_loads = [&](int q) __attribute__((always_inline)) {
+        const bool plane_ok = (q >= 0) && (q < a.D);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            int f = tid + 256 * i;
+            int pos = f / CQ;
+            int r = pos / OPW, c = pos - r * OPW;
+            int gh = h0 - 1 + r, gw = w0 - 1 + c;
+            bool ok = plane_ok && (f < NF4) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+            size_t off = ((((size_t)q * a.H + gh) * a.W) + gw) * CIN + 4 * c4;
+            pre[i] = ok ? *(const float4*)(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pre2[i] = (ok && has_x2) ? *(const float4*)(a.x2 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto write_slab = [&](int q, float* buf) __attribute__((always_inline)) {
+        const bool plane_ok = (q >= 0) && (q < a.D);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            int f = tid + 256 * i;
+            if (f >= NF4) continue;
+            int pos = f / CQ;
+            int r = pos / OPW, c = pos - r * OPW;
+            int gh = h0 - 1 + r, gw = w0 - 1 + c;
+            bool ok = plane_ok && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                v = bn_relu4(pre[i], sc, sh, has_aff);
+                if (has_x2) {
+                    float4 v2 = bn_relu4(pre2[i], sc2, sh2, has_aff2);
+                    v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+                }
+            }
+            *(float4*)(buf + pos * S + 4 * c4) = v;
+        }
+    };
+
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;      // kd = 0 (-> q+1), 1 (-> q), 2 (-> q-1)
+    const int base = (row * OPW + col) * S;
+
+    issue_loads(d0 - 1);
+    write_slab(d0 - 1, slab[0]);
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const int q = d0 - 1 + t;
+        const float* cur = slab[t & 1];
+        const bool more = (t + 1 < T);
+        if (more) issue_loads(q + 1);
+        if (q >= 0 && q < a.D) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int cq = 0; cq < CQ; ++cq) {
+                        float4 x = *(const float4*)(cur + base + (kh * OPW + kw) * S + 4 * cq);
+                        const float* w0p = wsh + ((0 * 9 + kh * 3 + kw) * CIN + 4 * cq);
+                        const float* w1p = wsh + ((1 * 9 + kh * 3 + kw) * CIN + 4 * cq);
+                        const float* w2p = wsh + ((2 * 9 + kh * 3 + kw) * CIN + 4 * cq);
+                        acc0 += x.x * w0p[0] + x.y * w0p[1] + x.z * w0p[2] + x.w * w0p[3];
+                        acc1 += x.x * w1p[0] + x.y * w1p[1] + x.z * w1p[2] + x.w * w1p[3];
+                        acc2 += x.x * w2p[0] + x.y * w2p[1] + x.z * w2p[2] + x.w * w2p[3];
+                    }
+        }
+        const int o = q - 1, h = h0 + row, w = w0 + col;
+        if (o >= d0 && o < d1 && h < a.H && w < a.W)
+            a.y[(((size_t)o * a.H + h) * a.W) + w] = acc2;
+        acc2 = acc1; acc1 = acc0; acc0 = 0.f;
+        if (more) write_slab(q + 1, slab[(t + 1) & 1]);
+        __syncthreads();
+    }
+}
+
+template <int CIN>
+int launch_out(const ConvArgs& a0, hipStream_t st) {
+    ConvArgs a = a0;
+    const int tiles = ((a.H + OTH - 1) / OTH) * ((a.W + OTW - 1) / OTW);
+    a.planes_per_wg = conv_pick_planes(a.D, tiles, 2);
+    dim3 grid(tiles, 1, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
+    conv3d_out_kernel<CIN><<<grid, 256, 0, st>>>(a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int mvs_conv3d_out_launch(const ConvArgs& a, int Cin, hipStream_t st) {
+    if (a.stats) return MVS_E_SHAPE;               // the output layer has no BatchNorm
+    if (Cin == 8) return launch_out<8>(a, st);
+    if (Cin == 4) return launch_out<4>(a, st);
+    if (Cin == 16) return launch_out<16>(a, st);
+    return MVS_E_SHAPE;
+}

@@ -1,0 +1,84 @@
+// Shared pieces of the fp32-MFMA 3D convolution kernels (conv3d_mfma.hip, conv3d_s2_mfma.hip,
+// deconv3d_mfma.hip, conv3d_out.hip).
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const float* x; const float* xs; const float* xb;      // input + producer BN affine (or null)
+    const float* x2; const float* x2s; const float* x2b;   // optional additive skip input
+    const float* w;                                         // TensorFlow kernel layout
+    float* y;                                               // raw (pre-BN) output
+    double* stats;                                          // (2,CoutTotal) float64 sums or null
+    int D, H, W, cout_total, planes_per_wg;
+    int pd, ph, pw;                                         // SAME pad_before per axis (stride 2)
+};
+
+constexpr int CONV_TW = 16;      // voxels per MFMA column tile (along w)
+
+// floats per staged position: channel count + 8 so that (bytes/16) = 2 mod 4, which makes the
+// 16-lane ds_read_b128 groups of a (col = lane&15, k-quad = lane>>4) access hit 16 distinct slots
+template <int CIN> struct SlabGeom { static constexpr int S = CIN + 8; };
+
+__device__ __forceinline__ float4 bn_relu4(float4 v, float4 s, float4 b, bool aff) {
+    if (aff) {
+        v.x = relu(v.x * s.x + b.x); v.y = relu(v.y * s.y + b.y);
+        v.z = relu(v.z * s.z + b.z); v.w = relu(v.w * s.w + b.w);
+    }
+    return v;
+}
+
+// Final reduction of per-lane BatchNorm partial sums.  Lane (kq = lane>>4, n = lane&15) holds the
+// sums of channels 4*cq .. 4*cq+3 (cq = channel-quad index given by the caller) over its voxels.
+// `red` is >= 4*2*16 floats of LDS that is dead by now; one f64 atomic per channel per workgroup.
+template <int COUT>
+__device__ __forceinline__ void stats_commit(const float (&st_s)[4], const float (&st_q)[4],
+                                             bool fold32, float* red_raw, double* stats,
+                                             int cout_total, int co_base) {
+    float (*red)[2][16] = reinterpret_cast<float (*)[2][16]>(red_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    float s[4], q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float sv = st_s[k], qv = st_q[k];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+        if (fold32) { sv += __shfl_xor(sv, 32, 64); qv += __shfl_xor(qv, 32, 64); }
+        s[k] = sv; q[k] = qv;
+    }
+    constexpr int ngrp = COUT / 4;
+    if (n == 0 && kq < ngrp) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[wave][0][4 * kq + k] = s[k]; red[wave][1][4 * kq + k] = q[k]; }
+    }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+        int k = tid / COUT, c = tid - k * COUT;
+        double t = (double)red[0][k][c] + (double)red[1][k][c] + (double)red[2][k][c] + (double)red[3][k][c];
+        atomicAdd(&stats[(size_t)k * cout_total + co_base + c], t);
+    }
+}
+
+// planes per workgroup: enough workgroups to fill the 256 CUs a few times at small halo overhead
+static inline int conv_pick_planes(int D, long long wgs_per_chunk, int halo) {
+    int best = D, best_cost = 1 << 30;
+    const int cands[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
+    for (int dr : cands) {
+        if (dr > D) dr = D;
+        long long chunks = (D + dr - 1) / dr;
+        long long wgs = wgs_per_chunk * chunks;
+        long long rounds = (wgs + 255) / 256;
+        int cost = (int)(rounds * (dr + halo));
+        if (cost < best_cost) { best_cost = cost; best = dr; }
+        if (dr == D) break;
+    }
+    return best;
+}
+
+// launchers implemented in the kernel files; MVS_E_SHAPE when the shape is outside their tiling
+int mvs_conv3d_s2_mfma(const ConvArgs& a, int Cin, int Cout, hipStream_t st);
+int mvs_deconv3d_mfma_launch(const ConvArgs& a, int Cin, int Cout, hipStream_t st);
+int mvs_conv3d_out_launch(const ConvArgs& a, int Cin, hipStream_t st);
