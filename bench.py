@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--conv-impl", default="auto", choices=["auto", "scalar", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MVS_BENCH_STREAMS", "1")),
+                    help="independent depth maps in flight per GPU (one plan + HIP stream each)")
     ap.add_argument("--with-images", action="store_true",
                     help="also time images->depth (adds the PyTorch UNetDS2GN towers)")
     args = ap.parse_args()
@@ -124,38 +126,45 @@ def main():
     weights = MVSNetWeights.from_numpy(args.network_mode, regnet=rp, device=dev)
     feats = torch.as_tensor(w.features).to(dev)
     cams = torch.as_tensor(w.cams).to(dev)
-    plan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", dev)
+    n_streams = max(1, args.streams)
+    plans = [DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", dev)
+             for _ in range(n_streams)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    plan = plans[0]
     end = w.depth_end
+    from mvsnet_amd.model import cost_volume, regnet_us0, softargmin_prob
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     marks = []
 
-    def step(record):
-        if record:
-            e = [ev() for _ in range(4)]
-            e[0].record()
-        plan.set_cameras(cams, w.depth_start, w.depth_interval, end, False)
-        from mvsnet_amd.model import cost_volume, regnet_us0, softargmin_prob
-        cost_volume(feats[0], feats[1:], plan.transforms, 0, plan.D, "mem", out=plan.cost)
-        if record:
-            e[1].record()
-        regnet_us0(plan.cost, weights.regnet, plan.workspace, plan.reg)
-        if record:
-            e[2].record()
-        softargmin_prob(plan.reg, w.depth_start, w.depth_interval, False, plan.depth, plan.prob)
-        if record:
-            e[3].record()
-            marks.append(e)
+    def step(i, record):
+        plan = plans[i % n_streams]
+        with torch.cuda.stream(streams[i % n_streams]):
+            if record:
+                e = [ev() for _ in range(4)]
+                e[0].record()
+            plan.set_cameras(cams, w.depth_start, w.depth_interval, end, False)
+            cost_volume(feats[0], feats[1:], plan.transforms, 0, plan.D, "mem", out=plan.cost)
+            if record:
+                e[1].record()
+            regnet_us0(plan.cost, weights.regnet, plan.workspace, plan.reg)
+            if record:
+                e[2].record()
+            softargmin_prob(plan.reg, w.depth_start, w.depth_interval, False, plan.depth, plan.prob)
+            if record:
+                e[3].record()
+                marks.append(e)
 
-    for _ in range(args.warmup):
-        step(False)
+    torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i, False)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        step(i, True)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -203,7 +212,7 @@ def main():
                                    "step per GPU, sharded by reference view" % (
                                        w.name, w.view_num, w.depth_num, w.width, w.height, w.channels,
                                        args.network_mode),
-                       "conv_impl": args.conv_impl},
+                       "conv_impl": args.conv_impl, "streams_per_gpu": n_streams},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
             "roofline_kernels": kernels,
             "depth_checksum": float(np.float64(depth_np).sum()),

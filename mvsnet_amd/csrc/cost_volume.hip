@@ -112,6 +112,106 @@ cost_volume_kernel(const float* __restrict__ ref, const float* __restrict__ src,
     *reinterpret_cast<float4*>(cost + ((size_t)dl * H * W + pix) * C + c) = o;
 }
 
+// Depth-sweep variant (the 3D-CNN path): one lane = (pixel, 4 channels) sweeping DC consecutive
+// planes.  Along depth a pixel's sample point slides along its epipolar line by a fraction of a
+// pixel per plane (that is how plane-sweep depth intervals are chosen), so its 2x2 tap
+// neighbourhood is kept in registers and re-fetched only when floor(sx) or floor(sy) changes:
+// tap traffic to L1/L2 drops from 16 x 16 B per voxel-lane to a few, the kernel becomes bound by
+// the coalesced HBM write of the volume.  Zero fill per tap exactly as warp_sample<0>.
+template <int NSRC>
+__global__ void __launch_bounds__(256)
+cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict__ src,
+                         const float* __restrict__ transforms, int depth_total, int d_begin,
+                         int d_count, int planes_per_block, int H, int W, int C, int variant,
+                         int negate, float* __restrict__ cost) {
+    const int cq = C >> 2;
+    const long long total = (long long)H * W * cq;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int dl0 = blockIdx.y * planes_per_block;
+    const int dl1 = min(dl0 + planes_per_block, d_count);
+    const int c = (int)(idx % cq) * 4;
+    const long long pix = idx / cq;
+    const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+    const float xf = (float)x, yf = (float)y;
+    const size_t img_elems = (size_t)H * W * C;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const float4 r = ld4(ref + (size_t)pix * C + c);
+    const float4 r2 = make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w);
+    float cx0[NSRC], cy0[NSRC];
+    float4 t00[NSRC], t01[NSRC], t10[NSRC], t11[NSRC];
+#pragma unroll
+    for (int v = 0; v < NSRC; ++v) { cx0[v] = -3.0e38f; cy0[v] = -3.0e38f; t00[v] = t01[v] = t10[v] = t11[v] = z4; }
+    // One IEEE division each, hoisted out of the sweep: the per-plane scalings become multiplies
+    // (differs from Q/N, S*S/(N*N) by at most 1 ulp; the single-pass E[x^2]-E[x]^2 form is kept).
+    const float n = (float)(NSRC + 1);
+    const float inv_n = 1.0f / n, inv_nn = 1.0f / (n * n);
+
+    for (int dl = dl0; dl < dl1; ++dl) {
+        const int d = d_begin + dl;
+        float4 S = r, Q = r2;
+#pragma unroll
+        for (int v = 0; v < NSRC; ++v) {
+            const float* t = transforms + ((size_t)v * depth_total + d) * 8;     // block-uniform
+            const float* img = src + v * img_elems;
+            float proj = t[6] * xf + t[7] * yf + 1.0f;
+            float inv = __builtin_amdgcn_rcpf(proj);            // v_rcp_f32: 1 ulp, exact for proj = 1
+            float sx = (t[0] * xf + t[1] * yf + t[2]) * inv;
+            float sy = (t[3] * xf + t[4] * yf + t[5]) * inv;
+            float x0 = floorf(sx), y0 = floorf(sy);
+            float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+            if (x0 != cx0[v] || y0 != cy0[v]) {
+                bool okx0 = (x0 >= 0.0f) && (x0 < (float)W);
+                bool okx1 = (x1 >= 0.0f) && (x1 < (float)W);
+                bool oky0 = (y0 >= 0.0f) && (y0 < (float)H);
+                bool oky1 = (y1 >= 0.0f) && (y1 < (float)H);
+                int ix0 = okx0 ? (int)x0 : 0, ix1 = okx1 ? (int)x1 : 0;
+                int iy0 = oky0 ? (int)y0 : 0, iy1 = oky1 ? (int)y1 : 0;
+                if (y0 == cy0[v] && x0 == cx0[v] + 1.0f) {      // slid one pixel right: keep a column
+                    t00[v] = t01[v]; t10[v] = t11[v];
+                } else {
+                    t00[v] = (okx0 && oky0) ? ld4(img + ((size_t)iy0 * W + ix0) * C + c) : z4;
+                    t10[v] = (okx0 && oky1) ? ld4(img + ((size_t)iy1 * W + ix0) * C + c) : z4;
+                }
+                t01[v] = (okx1 && oky0) ? ld4(img + ((size_t)iy0 * W + ix1) * C + c) : z4;
+                t11[v] = (okx1 && oky1) ? ld4(img + ((size_t)iy1 * W + ix1) * C + c) : z4;
+                cx0[v] = x0; cy0[v] = y0;
+            }
+            float wx1 = x1 - sx, wx0 = sx - x0, wy1 = y1 - sy, wy0 = sy - y0;
+            float4 w;
+            w.x = wy1 * (wx1 * t00[v].x + wx0 * t01[v].x) + wy0 * (wx1 * t10[v].x + wx0 * t11[v].x);
+            w.y = wy1 * (wx1 * t00[v].y + wx0 * t01[v].y) + wy0 * (wx1 * t10[v].y + wx0 * t11[v].y);
+            w.z = wy1 * (wx1 * t00[v].z + wx0 * t01[v].z) + wy0 * (wx1 * t10[v].z + wx0 * t11[v].z);
+            w.w = wy1 * (wx1 * t00[v].w + wx0 * t01[v].w) + wy0 * (wx1 * t10[v].w + wx0 * t11[v].w);
+            S.x += w.x; S.y += w.y; S.z += w.z; S.w += w.w;
+            Q.x += w.x * w.x; Q.y += w.y * w.y; Q.z += w.z * w.z; Q.w += w.w * w.w;
+        }
+        float4 o;
+        if (variant == 0) {
+            o.x = Q.x * inv_n - (S.x * S.x) * inv_nn; o.y = Q.y * inv_n - (S.y * S.y) * inv_nn;
+            o.z = Q.z * inv_n - (S.z * S.z) * inv_nn; o.w = Q.w * inv_n - (S.w * S.w) * inv_nn;
+        } else {
+            float ax = S.x * inv_n, ay = S.y * inv_n, az = S.z * inv_n, aw = S.w * inv_n;
+            o.x = Q.x * inv_n - ax * ax; o.y = Q.y * inv_n - ay * ay;
+            o.z = Q.z * inv_n - az * az; o.w = Q.w * inv_n - aw * aw;
+        }
+        if (negate) { o.x = -o.x; o.y = -o.y; o.z = -o.z; o.w = -o.w; }
+        *reinterpret_cast<float4*>(cost + ((size_t)dl * H * W + pix) * C + c) = o;
+    }
+}
+
+template <int NSRC>
+void launch_sweep(const float* ref, const float* src, const float* transforms, int depth_total,
+                  int d_begin, int d_count, int H, int W, int C, int variant, int negate,
+                  float* cost, hipStream_t st) {
+    const int ppb = 16;
+    long long total = (long long)H * W * (C / 4);
+    dim3 grid(mvs_cdiv(total, 256), mvs_cdiv(d_count, ppb));
+    cost_volume_sweep_kernel<NSRC><<<grid, 256, 0, st>>>(ref, src, transforms, depth_total, d_begin,
+                                                         d_count, ppb, H, W, C, variant, negate, cost);
+}
+
 template <int BORDER>
 __global__ void __launch_bounds__(256)
 warp_kernel(const float* __restrict__ img, const float* __restrict__ t, int H, int W, int C,
@@ -139,6 +239,15 @@ extern "C" int mvs_cost_volume_f32(const float* ref, const float* src, const flo
     if (C % 4 != 0) return MVS_E_SHAPE;
     long long total = (long long)H * W * (C / 4);
     dim3 grid(mvs_cdiv(total, 256), d_count);
+    if (border == 0 && d_count >= 4 && view_num <= 8) {      // depth sweep with register tap reuse
+        hipStream_t st = mvs_stream(stream);
+#define MVS_SWEEP(NS) case NS: launch_sweep<NS>(ref, src, transforms, depth_total, d_begin, d_count, H, W, C, variant, negate, cost, st); break;
+        switch (view_num - 1) {
+            MVS_SWEEP(1) MVS_SWEEP(2) MVS_SWEEP(3) MVS_SWEEP(4) MVS_SWEEP(5) MVS_SWEEP(6) MVS_SWEEP(7)
+        }
+#undef MVS_SWEEP
+        MVS_LAUNCH_RET();
+    }
     if (border == 0)
         cost_volume_kernel<0><<<grid, 256, 0, mvs_stream(stream)>>>(
             ref, src, transforms, view_num - 1, depth_total, d_begin, H, W, C, variant, negate, cost);

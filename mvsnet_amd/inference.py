@@ -1,0 +1,124 @@
+"""Entry point mirroring `python -m mvsnet.inference` (mvsnet/inference.py:83-145):
+
+    python -m mvsnet_amd.inference --input_dir <session> [--output_dir ...] --view_num 5 --max_d 192 \
+        --width 640 --height 512 --regularization 3DCNN [--weights weights.npz]
+
+One process per GPU; under torch.distributed.run the clusters (reference views) of the session are
+sharded round-robin across ranks with no collective on the data path.  Without
+--weights the networks are randomly initialised (no checkpoint exists offline; TF-checkpoint import
+is SURVEY 8f row f5), which exercises the full pipeline and output formats.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import time
+
+import numpy as np
+
+logger = logging.getLogger("mvsnet_amd.inference")
+
+
+def build_weights(config, device, weights_path=None):
+    from . import synthetic as S
+    from .model import MVSNetWeights
+    if weights_path:
+        z = np.load(weights_path, allow_pickle=True)
+        unet, regnet, gru = z["unet"].item(), z["regnet"].item(), z["gru"].item()
+    else:
+        unet = S.make_unet_params(config.network_mode, seed=3)
+        regnet = S.make_regnet_params(config.network_mode, seed=1)
+        gru = S.make_gru_params(config.network_mode, seed=2,
+                                in_channels=4 * S.base_filter(config.network_mode))
+    return MVSNetWeights.from_numpy(config.network_mode, unet=unet, regnet=regnet, gru=gru, device=device)
+
+
+def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwargs):
+    """mvsnet/inference.py:83-119.  Returns the number of depth maps this rank wrote."""
+    import torch
+    from . import predictlib as pl
+    from . import shard as sh
+    from .mvs_data_generation import ClusterGenerator
+
+    config = config or pl.InferenceConfig()
+    for k, v in kwargs.items():                       # predictlib.init_inference: kwargs -> flags
+        if not hasattr(config, k):
+            raise AttributeError("unknown flag %s" % k)
+        setattr(config, k, v)
+    rank, local_rank, world = sh.rank_world()
+    if device is None:
+        device = torch.device("cuda", local_rank)
+    output_dir = pl.setup_output_dir(input_dir, config.output_dir)
+    gen = ClusterGenerator(input_dir, config.view_num, config.width, config.height, config.max_d,
+                           config.interval_scale, config.base_image_size, mode="inference",
+                           output_scale=config.sample_scale,
+                           max_clusters_per_session=config.max_clusters_per_session)
+    clusters = sorted(gen.clusters, key=lambda c: (c.session_dir, c.ref_index))
+    mine = sh.shard(clusters, rank, world)
+    if weights is None:
+        weights = build_weights(config, device)
+    done = 0
+    for c in mine:
+        start = time.time()
+        try:
+            out_images, in_images, out_cams, full_cams, index = gen.prepare(c)
+        except Exception as e:                        # skip-and-log per reference view
+            logger.warning("skipping cluster %s/%d: %s", c.session_dir, c.ref_index, e)
+            continue
+        images = torch.as_tensor(in_images, dtype=torch.float32, device=device)[None]
+        cams = torch.as_tensor(out_cams, dtype=torch.float32, device=device)[None]
+        depth_start = float(out_cams[0, 1, 3, 0])     # predictlib.set_shapes :190-197
+        depth_interval = float(out_cams[0, 1, 3, 1])
+        depth_num = int(out_cams[0, 1, 3, 2])
+        depth_end = float(out_cams[0, 1, 3, 3])
+        d, p, _ = pl.get_depth_and_prob_map(images, cams, depth_start, depth_interval, config, weights,
+                                            depth_num=depth_num, depth_end=depth_end)
+        pl.write_output_slice(output_dir, d.cpu().numpy(), p.cpu().numpy(), out_images[0], out_cams[0],
+                              index, config.visualize)
+        done += 1
+        logger.info("Depth inference %d/%d finished. (%.3f sec/step)", done, len(mine), time.time() - start)
+    return done
+
+
+def main(argv=None):
+    from . import predictlib as pl
+    from . import shard as sh
+    ap = argparse.ArgumentParser(description=__doc__)
+    cfg = pl.InferenceConfig()
+    for name, default in vars(cfg).items():
+        if isinstance(default, bool):
+            ap.add_argument("--" + name, type=lambda s: s.lower() in ("1", "true", "yes"), default=default)
+        else:
+            ap.add_argument("--" + name, type=type(default) if default is not None else str, default=default)
+    ap.add_argument("--weights", default=None, help=".npz with 'unet', 'regnet', 'gru' parameter dicts")
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=os.environ.get("LOG_LEVEL", "INFO"))
+    weights_path = args.weights
+    for name in vars(cfg):
+        setattr(cfg, name, getattr(args, name))
+    if cfg.input_dir is None:
+        ap.error("--input_dir is required")
+    dist = sh.init_process_group()
+    # a single session, or a folder of sessions (inference.py:121-141)
+    if os.path.isfile(os.path.join(cfg.input_dir, "covisibility.json")):
+        dirs = [cfg.input_dir]
+    else:
+        dirs = [os.path.join(cfg.input_dir, f) for f in sorted(os.listdir(cfg.input_dir))
+                if not f.startswith(".") and not f.endswith(".txt")]
+    import torch
+    rank, local_rank, world = sh.rank_world()
+    device = torch.device("cuda", local_rank)
+    weights = build_weights(cfg, device, weights_path)
+    total = 0
+    for d in dirs:
+        total += compute_depth_maps(d, cfg, weights, device)
+    counts = sh.gather_counts(dist, total, device=device if dist is not None else "cpu")
+    if rank == 0:
+        logger.info("all dense finished: %d depth maps (%s per rank)", int(sum(counts)), counts)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

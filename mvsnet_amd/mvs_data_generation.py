@@ -1,0 +1,206 @@
+"""Host-side input pipeline: session directories -> (images, cams) batches for the hot path.
+
+Restates the inference branch of the reference's data model without cv2 / imageio / TensorFlow:
+  * session format: covisibility.json, images/<i>.jpg, cameras/<i>.json
+    (mvsnet/mvs_data_generation/cluster_generator.py:140-156, mvs_cluster.py:63-127)
+  * per cluster: load -> scale-to-cover -> centre-crop -> per-image standardise -> cams scaled to
+    the feature resolution (cluster_generator.py:234-286, mvs_data_generation/utils.py:33-153).
+Pure numpy + Pillow; this is plumbing outside the HIP hot path.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+
+import numpy as np
+
+
+def center_image(img):
+    """mvs_data_generation/utils.py:33-38: per-image, per-channel standardisation."""
+    img = img.astype(np.float32)
+    var = np.var(img, axis=(0, 1), keepdims=True)
+    mean = np.mean(img, axis=(0, 1), keepdims=True)
+    return (img - mean) / (np.sqrt(var) + 0.00000001)
+
+
+def scale_camera(cam, scale=1):
+    """mvs_data_generation/utils.py:61-71: focal lengths and principal point times scale."""
+    new_cam = np.copy(cam)
+    new_cam[1][0][0] = cam[1][0][0] * scale
+    new_cam[1][1][1] = cam[1][1][1] * scale
+    new_cam[1][0][2] = cam[1][0][2] * scale
+    new_cam[1][1][2] = cam[1][1][2] * scale
+    return new_cam
+
+
+def scale_image(image, scale=1, interpolation="linear"):
+    """cv2.resize(image, None, fx=scale, fy=scale, INTER_LINEAR | INTER_NEAREST)
+    (mvs_data_generation/utils.py:81-86) restated: output size = round(n*scale), sample position
+    src = (dst + 0.5)/scale - 0.5 with edge replication (linear) or floor(dst/scale) (nearest).
+    uint8 inputs are interpolated in float and rounded (cv2 uses 11-bit fixed point: results may
+    differ by one grey level on rare pixels)."""
+    img = np.asarray(image)
+    h, w = img.shape[:2]
+    nh, nw = int(round(h * scale)), int(round(w * scale))
+    if interpolation == "nearest":
+        ys = np.minimum((np.arange(nh) / scale).astype(np.int64), h - 1)
+        xs = np.minimum((np.arange(nw) / scale).astype(np.int64), w - 1)
+        return img[ys][:, xs]
+    inv = 1.0 / scale
+
+    def taps(n_out, n_in):
+        s = (np.arange(n_out, dtype=np.float64) + 0.5) * inv - 0.5
+        i0 = np.floor(s).astype(np.int64)
+        f = s - i0
+        lo = np.clip(i0, 0, n_in - 1)
+        hi = np.clip(i0 + 1, 0, n_in - 1)
+        return lo, hi, f
+
+    y0, y1, fy = taps(nh, h)
+    x0, x1, fx = taps(nw, w)
+    src = img.astype(np.float64)
+    if src.ndim == 2:
+        src = src[..., None]
+    top = src[y0][:, x0] * (1 - fx)[None, :, None] + src[y0][:, x1] * fx[None, :, None]
+    bot = src[y1][:, x0] * (1 - fx)[None, :, None] + src[y1][:, x1] * fx[None, :, None]
+    out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
+    if img.ndim == 2:
+        out = out[..., 0]
+    if img.dtype == np.uint8:
+        return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+    return out.astype(img.dtype)
+
+
+def scale_mvs_input(images, cams, scale=1):
+    """mvs_data_generation/utils.py:103-116 (without the GT-depth branch)."""
+    return [scale_image(i, scale) for i in images], [scale_camera(c, scale) for c in cams]
+
+
+def crop_mvs_input(images, cams, width, height, base_image_size):
+    """mvs_data_generation/utils.py:119-153: centre-crop to at most (height, width), otherwise
+    round the size UP to a multiple of base_image_size (as the reference does), shifting the
+    principal point."""
+    images, cams = list(images), [np.copy(c) for c in cams]
+    for view in range(len(images)):
+        h, w = images[view].shape[0:2]
+        new_h = height if h > height else int(math.ceil(h / base_image_size) * base_image_size)
+        new_w = width if w > width else int(math.ceil(w / base_image_size) * base_image_size)
+        start_h = int(math.ceil((h - new_h) / 2))
+        start_w = int(math.ceil((w - new_w) / 2))
+        images[view] = images[view][start_h:start_h + new_h, start_w:start_w + new_w]
+        cams[view][1][0][2] = cams[view][1][0][2] - start_w
+        cams[view][1][1][2] = cams[view][1][1][2] - start_h
+    return images, cams
+
+
+class Cluster:
+    """One reference view and its covisible source views (mvs_cluster.py:27-207)."""
+
+    def __init__(self, session_dir, ref_index, views, min_depth, max_depth, view_num,
+                 image_width=1024, image_height=768, depth_num=256, interval_scale=1.0):
+        self.session_dir = session_dir
+        self.ref_index = int(ref_index)
+        self.views = views
+        self.min_depth, self.max_depth = min_depth, max_depth
+        self.view_num = view_num
+        self.image_width, self.image_height = image_width, image_height
+        self.depth_num, self.interval_scale = depth_num, interval_scale
+        indices = [int(self.ref_index)] + [int(v) for v in views]
+        indices += [int(self.ref_index)] * max(0, view_num - len(indices))   # pad with the reference
+        self.indices = indices[:view_num]                                    # mvs_cluster.py:128-140
+        self.rescale = 1.0
+
+    def image_path(self, index):
+        return os.path.join(self.session_dir, "images", "{}.jpg".format(index))
+
+    def camera_path(self, index):
+        return os.path.join(self.session_dir, "cameras", "{}.json".format(index))
+
+    def load_image(self, index):
+        """RGB decode then RGB->BGR, as mvs_cluster.py:72-76."""
+        from PIL import Image
+        rgb = np.asarray(Image.open(self.image_path(index)).convert("RGB"))
+        return np.ascontiguousarray(rgb[:, :, ::-1])
+
+    def load_camera(self, index):
+        """(2,4,4): pose (translation metres -> mm), intrinsics, (min, interval, num, max)
+        (mvs_cluster.py:91-127)."""
+        with open(self.camera_path(index)) as f:
+            data = json.load(f)
+        interval = ((self.max_depth - self.min_depth) / (self.depth_num - 1)) * self.interval_scale
+        cam = np.zeros((2, 4, 4))
+        for i in range(4):
+            for j in range(4):
+                cam[0, i, j] = data["pose"]["matrix"]["{},{}".format(i, j)]
+        cam[0, 0:3, 3] *= 1000
+        intr = data["intrinsics"]
+        cam[1, 0, 0], cam[1, 1, 1] = intr["fx"], intr["fy"]
+        cam[1, 0, 2], cam[1, 1, 2], cam[1, 2, 2] = intr["px"], intr["py"], 1.0
+        cam[1, 3, 0], cam[1, 3, 1] = self.min_depth, interval
+        cam[1, 3, 2], cam[1, 3, 3] = self.depth_num, self.max_depth
+        return cam
+
+    def images(self):
+        imgs = [self.load_image(i) for i in self.indices]
+        h_scale = max(float(self.image_height) / im.shape[0] for im in imgs)
+        w_scale = max(float(self.image_width) / im.shape[1] for im in imgs)
+        self.rescale = max(h_scale, w_scale)                                 # mvs_cluster.py:178-192
+        return imgs
+
+    def cameras(self):
+        return [self.load_camera(i) for i in self.indices]
+
+
+class ClusterGenerator:
+    """Inference-mode iterator of cluster_generator.py:27-286: yields
+    (output_images, input_images, output_cams, full_cams, image_index) once per cluster."""
+
+    def __init__(self, data_dir, view_num=3, image_width=1024, image_height=768, depth_num=256,
+                 interval_scale=1, base_image_size=1, include_empty=False, mode="inference",
+                 output_scale=0.25, max_clusters_per_session=None):
+        if mode != "inference":
+            raise NotImplementedError("only the inference branch is built (SURVEY 8f)")
+        self.data_dir = data_dir
+        self.view_num = view_num
+        self.image_width, self.image_height = image_width, image_height
+        self.depth_num, self.interval_scale = depth_num, interval_scale
+        self.base_image_size = base_image_size
+        self.include_empty = include_empty
+        self.output_scale = output_scale
+        self.max_clusters_per_session = max_clusters_per_session
+        self.clusters = []
+        self.load_clusters(data_dir, self.clusters)
+
+    def load_clusters(self, session_dir, clusters):
+        with open(os.path.join(session_dir, "covisibility.json")) as f:
+            data = json.load(f)
+        added = 0
+        max_clusters = len(data) if self.max_clusters_per_session is None else self.max_clusters_per_session
+        for d in data:
+            if not self.include_empty and not data[d]["views"]:
+                continue
+            if added < max_clusters:
+                clusters.append(Cluster(session_dir, int(d), data[d]["views"], data[d]["min_depth"],
+                                        data[d]["max_depth"], self.view_num, self.image_width,
+                                        self.image_height, self.depth_num, self.interval_scale))
+                added += 1
+
+    def prepare(self, c: Cluster):
+        images = c.images()
+        cams = c.cameras()
+        images, cams = scale_mvs_input(images, cams, scale=c.rescale)
+        cropped_images, cropped_cams = crop_mvs_input(images, cams, self.image_width, self.image_height,
+                                                      self.base_image_size)
+        full_cams = np.stack(cropped_cams, axis=0)
+        input_images = np.stack([center_image(i) for i in cropped_images], axis=0)
+        output_images, output_cams = scale_mvs_input(cropped_images, cropped_cams, scale=self.output_scale)
+        return (np.stack(output_images, axis=0), input_images, np.stack(output_cams, axis=0),
+                full_cams, c.ref_index)
+
+    def __len__(self):
+        return len(self.clusters)
+
+    def __iter__(self):
+        for c in self.clusters:
+            yield self.prepare(c)

@@ -1,0 +1,156 @@
+"""CPU tests of the host logic around the hot path: session loader, output
+writers, and the world_size-2 sharding path over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_session(path, n_images=4, h=48, w=64, seed=0):
+    """A tiny on-disk session in the reference's format (covisibility.json, images/, cameras/)."""
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    os.makedirs(os.path.join(path, "images"))
+    os.makedirs(os.path.join(path, "cameras"))
+    covis = {}
+    for i in range(n_images):
+        img = rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(path, "images", "%d.jpg" % i), quality=95)
+        pose = np.eye(4)
+        pose[0, 3] = 0.05 * i                                   # metres
+        cam = {"pose": {"matrix": {"%d,%d" % (r, c): float(pose[r, c]) for r in range(4) for c in range(4)}},
+               "intrinsics": {"fx": 60.0, "fy": 60.0, "px": w / 2.0, "py": h / 2.0}}
+        with open(os.path.join(path, "cameras", "%d.json" % i), "w") as f:
+            json.dump(cam, f)
+        views = [j for j in range(n_images) if j != i][:2] if i != 3 else []
+        covis[str(i)] = {"views": views, "min_depth": 400.0, "max_depth": 900.0}
+    with open(os.path.join(path, "covisibility.json"), "w") as f:
+        json.dump(covis, f)
+    return path
+
+
+def test_scale_image_kats():
+    from mvsnet_amd.mvs_data_generation import scale_image
+    ramp = np.arange(8, dtype=np.float32)[None, :].repeat(4, 0)           # value = x
+    half = scale_image(ramp, 0.5)                                          # src = 2*dst + 0.5
+    assert half.shape == (2, 4)
+    np.testing.assert_allclose(half[0], [0.5, 2.5, 4.5, 6.5])
+    dbl = scale_image(ramp, 2.0)                                           # src = dst/2 - 0.25, edges clamp
+    assert dbl.shape == (8, 16)
+    np.testing.assert_allclose(dbl[0, :4], [0.0, 0.25, 0.75, 1.25])
+    np.testing.assert_allclose(dbl[0, -1], 7.0)
+    u8 = scale_image((ramp * 30).astype(np.uint8), 0.5)
+    assert u8.dtype == np.uint8 and list(u8[0]) == [15, 75, 135, 195]
+    near = scale_image(ramp, 0.5, "nearest")
+    assert list(near[0]) == [0, 2, 4, 6]
+    col = scale_image(np.zeros((6, 10, 3), np.uint8), 0.25)
+    assert col.shape == (2, 2, 3)                                          # round(1.5) = 2, round(2.5) = 2
+
+
+def test_crop_center_and_camera_scaling():
+    from mvsnet_amd import mvs_data_generation as G
+    img = np.arange(10 * 12 * 3, dtype=np.float32).reshape(10, 12, 3)
+    cam = np.zeros((2, 4, 4)); cam[1, 0, 0] = cam[1, 1, 1] = 100; cam[1, 0, 2] = 6; cam[1, 1, 2] = 5
+    imgs, cams = G.crop_mvs_input([img], [cam], width=8, height=8, base_image_size=8)
+    assert imgs[0].shape == (8, 8, 3)
+    assert np.array_equal(imgs[0], img[1:9, 2:10])
+    assert cams[0][1, 0, 2] == 4 and cams[0][1, 1, 2] == 4
+    c2 = G.scale_camera(cam, 0.25)
+    assert c2[1, 0, 0] == 25 and c2[1, 0, 2] == 1.5 and c2[1, 1, 2] == 1.25
+    z = G.center_image(img)
+    np.testing.assert_allclose(z.mean(axis=(0, 1)), 0, atol=1e-5)
+    np.testing.assert_allclose(z.std(axis=(0, 1)), 1, atol=1e-5)
+
+
+def test_cluster_generator_on_synthetic_session(tmp_path):
+    from mvsnet_amd.mvs_data_generation import ClusterGenerator
+    sess = make_session(str(tmp_path / "sess"))
+    gen = ClusterGenerator(sess, view_num=3, image_width=32, image_height=32, depth_num=8,
+                           interval_scale=1.0, base_image_size=8, output_scale=0.25)
+    assert len(gen) == 3                                   # image 3 has no covisible views -> skipped
+    items = list(gen)
+    out_images, in_images, out_cams, full_cams, idx = items[0]
+    assert idx == 0
+    assert in_images.shape == (3, 32, 32, 3) and in_images.dtype == np.float32
+    assert out_images.shape == (3, 8, 8, 3)
+    assert out_cams.shape == (3, 2, 4, 4) and full_cams.shape == (3, 2, 4, 4)
+    # rescale = max(32/48, 32/64) = 2/3 -> 32 x 43 -> centre crop 32 x 32; intrinsics follow
+    np.testing.assert_allclose(full_cams[0, 1, 0, 0], 60.0 * 2 / 3)
+    np.testing.assert_allclose(out_cams[0, 1, 0, 0], 60.0 * 2 / 3 * 0.25)
+    np.testing.assert_allclose(out_cams[0, 1, 3], [400.0, 500.0 / 7, 8, 900.0])
+    np.testing.assert_allclose(out_cams[1, 0, 0, 3], 50.0)                # metres -> mm
+    # a cluster with one covisible view is padded with copies of the reference
+    c = gen.clusters[0]
+    c2 = type(c)(c.session_dir, 0, [2], 400.0, 900.0, 3)
+    assert c2.indices == [0, 2, 0]
+
+
+def test_write_output_slice_files(tmp_path):
+    from mvsnet_amd import predictlib as pl, preprocess as pp
+    depth = np.linspace(425, 900, 12, dtype=np.float32).reshape(1, 3, 4, 1)
+    prob = np.linspace(0, 1, 12, dtype=np.float32).reshape(1, 3, 4, 1)
+    img = np.zeros((3, 4, 3), np.float32); img[..., 0] = 255            # blue in BGR
+    cam = np.zeros((2, 4, 4)); cam[0] = np.eye(4); cam[1, :3, :3] = np.eye(3)
+    out = pl.setup_output_dir(str(tmp_path), None)
+    assert out == os.path.join(str(tmp_path), "depths_mvsnet")
+    pl.write_output_slice(out, depth, prob, img, cam, np.array([7]))
+    names = sorted(os.listdir(out))
+    assert names == ["7.jpg", "7.txt", "7_depth.png", "7_init.pfm", "7_prob.pfm", "7_prob.png"]
+    assert np.array_equal(pp.load_pfm(os.path.join(out, "7_init.pfm")), depth[0, :, :, 0])
+    from PIL import Image
+    d16 = np.asarray(Image.open(os.path.join(out, "7_depth.png")))
+    assert d16.dtype == np.uint16 and d16[0, 0] == 425 and d16[-1, -1] == 900
+    p16 = np.asarray(Image.open(os.path.join(out, "7_prob.png")))
+    assert p16[0, 0] == 0 and p16[-1, -1] == 65535
+    rgb = np.asarray(Image.open(os.path.join(out, "7.jpg")))
+    assert rgb[0, 0, 2] > 200 and rgb[0, 0, 0] < 50                      # written as RGB
+
+
+def test_shard_indices_cover_everything_once():
+    from mvsnet_amd.shard import shard_indices
+    for n in (0, 1, 7, 1078):
+        for world in (1, 2, 3, 8):
+            parts = [shard_indices(n, r, world) for r in range(world)]
+            flat = sorted(i for p in parts for i in p)
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    with pytest.raises(ValueError):
+        shard_indices(4, 2, 2)
+
+
+_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+from mvsnet_amd import shard as sh
+dist = sh.init_process_group("gloo")
+rank, local, world = sh.rank_world()
+items = list(range(11))
+mine = sh.shard(items, rank, world)
+counts = sh.gather_counts(dist, len(mine))
+import torch
+t = torch.zeros(11, dtype=torch.int64); t[mine] = 1
+dist.all_reduce(t)                      # test-only check that the shards tile the list
+dist.barrier()
+if rank == 0:
+    print(json.dumps({"counts": counts, "cover": t.tolist(), "world": world}))
+dist.destroy_process_group()
+"""
+
+
+def test_world_size_2_sharding_over_gloo(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER % {"root": ROOT}], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert res["world"] == 2 and res["counts"] == [6.0, 5.0]
+    assert res["cover"] == [1] * 11

@@ -129,7 +129,7 @@ def test_cost_volume_matches_oracle(variant):
     assert rel_l1(got, exp) < 1e-5
     # negated single plane (the GRU step input)
     one = n(cost_volume(t(feats[0]), t(feats[1:]), T, d_begin=3, d_count=1, variant=variant, negate=True))
-    assert np.array_equal(one[0], -got[3])
+    np.testing.assert_allclose(one[0], -got[3], rtol=1e-4, atol=5e-5)   # per-plane kernel vs depth sweep (fp32 cancellation noise)
 
 
 def test_cost_volume_identical_views_is_zero_and_padding_views():

@@ -1,0 +1,102 @@
+"""GPU tests at the outer boundary: session directory -> .pfm outputs, full-size properties of
+the metric workload, plan re-use under hipGraph capture."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mvsnet_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def t(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(DEV)
+
+
+@pytest.mark.parametrize("regularization", ["3DCNN", "GRU"])
+def test_compute_depth_maps_on_session_dir(tmp_path, lib_built, regularization):
+    from tests.test_data_and_sharding import make_session
+    from mvsnet_amd.inference import compute_depth_maps
+    from mvsnet_amd import predictlib as pl, preprocess as pp
+    sess = make_session(str(tmp_path / "sess"), n_images=4, h=96, w=128)
+    cfg = pl.InferenceConfig(view_num=3, max_d=8, width=64, height=64, base_image_size=8,
+                             regularization=regularization, max_clusters_per_session=2)
+    n = compute_depth_maps(sess, cfg)
+    assert n == 2
+    out = os.path.join(sess, "depths_mvsnet")
+    for idx in (0, 1):
+        d = pp.load_pfm(os.path.join(out, "%d_init.pfm" % idx))
+        p = pp.load_pfm(os.path.join(out, "%d_prob.pfm" % idx))
+        assert d.shape == (16, 16) and p.shape == (16, 16)
+        assert np.isfinite(d).all() and d.min() >= 400.0 - 1e-3 and d.max() <= 900.0 + 1e-3
+        assert np.isfinite(p).all() and p.min() >= 0.0
+        for suffix in ("_depth.png", "_prob.png", ".jpg", ".txt"):
+            assert os.path.exists(os.path.join(out, "%d%s" % (idx, suffix)))
+        cam = pp.load_cam(os.path.join(out, "%d.txt" % idx))
+        assert cam[1, 3, 2] == 8
+
+
+def test_metric_workload_properties_and_mfma_vs_scalar(lib_built):
+    """Full-size (N=5, D=192, 160x128) checks that do not need the oracle: the depth map stays
+    inside the swept range, probabilities are finite, the MFMA and scalar regularisers agree, and
+    identical source views give a cost volume of exactly zero."""
+    from mvsnet_amd import _lib as L
+    from mvsnet_amd.model import MVSNetWeights, DepthPlan, cost_volume
+    w = S.make_workload("M")
+    rp = S.make_regnet_params("normal", seed=1)
+    weights = MVSNetWeights.from_numpy("normal", regnet=rp, device=DEV)
+    feats, cams = t(w.features), t(w.cams)
+    plan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", DEV)
+    plan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
+    d1, p1 = plan.run_3dcnn(feats, w.depth_start, w.depth_interval)
+    d1, p1 = d1.clone(), p1.clone()
+    cost_sum = float(plan.cost.double().sum())
+    assert np.isfinite(cost_sum) and float(plan.cost.min()) > -1e-3       # variance >= 0 up to rounding
+    assert float(d1.min()) >= w.depth_start and float(d1.max()) <= w.depth_end
+    assert torch.isfinite(p1).all() and float(p1.min()) >= 0
+    L.set_conv_impl("scalar")
+    try:
+        d2, p2 = plan.run_3dcnn(feats, w.depth_start, w.depth_interval)
+        d2 = d2.clone()
+    finally:
+        L.set_conv_impl("auto")
+    rel = float(((d1 - d2).abs() / d2).mean())
+    assert rel < 1e-4, rel
+    # identical views through an identity transform: exact zeros at full size
+    same = feats[:1].expand(5, -1, -1, -1).contiguous()
+    ident = torch.zeros((4, w.depth_num, 8), device=DEV); ident[..., 0] = 1; ident[..., 4] = 1
+    cz = cost_volume(same[0], same[1:], ident)
+    assert float(cz.abs().max()) < 1e-5
+
+
+def test_plan_runs_under_hipgraph_capture(lib_built):
+    """The C ABI never allocates or synchronises, so a whole features->depth pass can be captured
+    into a hipGraph and replayed."""
+    from mvsnet_amd.model import MVSNetWeights, DepthPlan
+    w = S.make_workload("small")
+    rp = S.make_regnet_params("normal", seed=1)
+    weights = MVSNetWeights.from_numpy("normal", regnet=rp, device=DEV)
+    feats, cams = t(w.features), t(w.cams)
+    plan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", DEV)
+
+    def run():
+        plan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
+        plan.run_3dcnn(feats, w.depth_start, w.depth_interval)
+    run()
+    torch.cuda.synchronize()
+    eager = plan.depth.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            run()
+    plan.depth.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(plan.depth, eager, rtol=1e-6, atol=1e-4)
