@@ -32,10 +32,19 @@ constexpr int PW = TW + 2;      // staged row width with halo
 // ------------------------------------------------------------------------------------------------
 // stride-1 convolution, input-stationary.  COUT = output channels handled by this workgroup (8|16).
 // ------------------------------------------------------------------------------------------------
+// Per-instance geometry.  The big full-resolution layer (32 -> 8) trades the conflict-free slab
+// pitch (Cin+8) for Cin+4 (2-way conflicts on the B reads, LDS is ~12 % busy) so that two
+// workgroups fit in a CU's 160 KB LDS: two waves per SIMD hide each other's LDS / barrier stalls.
+template <int CIN, int COUT, int TH> struct S1Geom {
+    static constexpr bool TWO_PER_CU = (CIN == 32 && COUT == 8 && TH == 8);
+    static constexpr int S = TWO_PER_CU ? CIN + 4 : SlabGeom<CIN>::S;
+    static constexpr int WGS_PER_CU = TWO_PER_CU ? 2 : 1;
+};
+
 template <int CIN, int COUT, int TH, bool HAS_X2>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, (S1Geom<CIN, COUT, TH>::WGS_PER_CU))
 conv3d_s1_kernel(ConvArgs a) {
-    constexpr int S = SlabGeom<CIN>::S;
+    constexpr int S = S1Geom<CIN, COUT, TH>::S;
     constexpr int NPOS = (TH + 2) * PW;
     constexpr int CQ = CIN / 4;                    // float4 per position
     constexpr int NF4 = NPOS * CQ;
@@ -78,10 +87,12 @@ conv3d_s1_kernel(ConvArgs a) {
     const int c4 = tid % CQ;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 sc2 = sc, sh2 = sh;
-    const bool has_aff = a.xs != nullptr;
-    if (has_aff) { sc = *(const float4*)(a.xs + 4 * c4); sh = *(const float4*)(a.xb + 4 * c4); }
-    const bool has_aff2 = HAS_X2 && a.x2s != nullptr;
-    if (has_aff2) { sc2 = *(const float4*)(a.x2s + 4 * c4); sh2 = *(const float4*)(a.x2b + 4 * c4); }
+    const bool has_aff = a.xs != nullptr || a.bn.stats != nullptr;
+    if (a.xs) { sc = *(const float4*)(a.xs + 4 * c4); sh = *(const float4*)(a.xb + 4 * c4); }
+    else if (a.bn.stats) bn_affine4(a.bn, 4 * c4, sc, sh);
+    const bool has_aff2 = HAS_X2 && (a.x2s != nullptr || a.bn2.stats != nullptr);
+    if (HAS_X2 && a.x2s) { sc2 = *(const float4*)(a.x2s + 4 * c4); sh2 = *(const float4*)(a.x2b + 4 * c4); }
+    else if (HAS_X2 && a.bn2.stats) bn_affine4(a.bn2, 4 * c4, sc2, sh2);
 
     float4 pre[NIT];
     float4 pre2[HAS_X2 ? NIT : 1];
@@ -149,27 +160,35 @@ conv3d_s1_kernel(ConvArgs a) {
             int kd = (b < 3) ? ((P - b + 3) % 3) : 0;      // pad blocks read harmless finite weights
             a_off[m] = (kq * NROWS + kd * COUT + row_co[m]) * 4;
         }
-#pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh) {
+        // Operand groups g = (kh, kw, s): one ds_read_b128 per operand tile feeds 4 k-steps.  The
+        // reads of group g+1 are issued before the MFMAs of group g (register double buffer), so a
+        // lone wave per SIMD never waits on LDS latency with an idle matrix pipe.
+        constexpr int NG = 9 * (CIN / 16);
+        constexpr int NR = V + MT;                 // LDS reads per group
+        constexpr int NM = 4 * MT * V;             // MFMAs per group
+        f32x4 bv[2][V], av[2][MT];
+        // read r of group g: r < V -> B tile r, else A tile r - V
+        auto load_one = [&](int g, int r, f32x4 (&b)[V], f32x4 (&aop)[MT]) __attribute__((always_inline)) {
+            const int tap = g / (CIN / 16), s = g % (CIN / 16);
+            const int kh = tap / 3, kw = tap % 3;
+            if (r < V) b[r] = *(const f32x4*)(buf + b_off[r] + (kh * PW + kw) * S + 16 * s);
+            else aop[r - V] = *(const f32x4*)(wl + a_off[r - V] + (tap * CQ + 4 * s) * WROW);
+        };
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
+        for (int r = 0; r < NR; ++r) load_one(0, r, bv[0], av[0]);
 #pragma unroll
-                for (int s = 0; s < CIN / 16; ++s) {
-                    f32x4 bv[V], av[MT];
+        for (int g = 0; g < NG; ++g) {
+            // NR slices: one read of the next group, then NM/NR MFMAs of this group; the
+            // sched_barrier keeps hipcc from sinking the read down to its first use
 #pragma unroll
-                    for (int v = 0; v < V; ++v)
-                        bv[v] = *(const f32x4*)(buf + b_off[v] + (kh * PW + kw) * S + 16 * s);
+            for (int r = 0; r < NR; ++r) {
+                if (g + 1 < NG) load_one(g + 1, r, bv[(g + 1) & 1], av[(g + 1) & 1]);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        av[m] = *(const f32x4*)(wl + a_off[m] + ((kh * 3 + kw) * CQ + 4 * s) * WROW);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-#pragma unroll
-                            for (int v = 0; v < V; ++v)
-                                acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][j], bv[v][j], acc[m][v], 0, 0, 0);
+                for (int i = (r * NM) / NR; i < ((r + 1) * NM) / NR; ++i) {
+                    const int j = i / (MT * V), m = (i / V) % MT, v = i % V;
+                    acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][j], bv[g & 1][v][j], acc[m][v], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -230,7 +249,7 @@ conv3d_s1_kernel(ConvArgs a) {
 
 template <int CIN, int COUT, int TH>
 size_t s1_smem_bytes() {
-    return (size_t)(9 * (CIN / 4) * 3 * COUT * 4 + 2 * (TH + 2) * PW * SlabGeom<CIN>::S) * sizeof(float);
+    return (size_t)(9 * (CIN / 4) * 3 * COUT * 4 + 2 * (TH + 2) * PW * S1Geom<CIN, COUT, TH>::S) * sizeof(float);
 }
 
 template <int CIN, int COUT, int TH>
@@ -238,7 +257,7 @@ int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
     ConvArgs a = a0;
     const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
     const int groups = Cout / COUT;
-    a.planes_per_wg = conv_pick_planes(a.D, (long long)tiles * groups, 2);
+    a.planes_per_wg = conv_pick_planes(a.D, (long long)tiles * groups, 2, 256 * S1Geom<CIN, COUT, TH>::WGS_PER_CU);
     dim3 grid(tiles, groups, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
     size_t smem = s1_smem_bytes<CIN, COUT, TH>();
     static bool attr_done = false;       // per template instantiation
@@ -257,10 +276,7 @@ int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
 
 }  // namespace
 
-int mvs_conv3d_mfma(const float* x, const float* xs, const float* xb, const float* x2,
-                    const float* x2s, const float* x2b, const float* w, int D, int H, int W,
-                    int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0};
+static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t st) {
     if (stride == 1) {
         if (Cout == 1) return mvs_conv3d_out_launch(a, Cin, st);
         if (Cin == 32 && Cout == 8) return launch_s1<32, 8, 8>(a, Cout, st);
@@ -271,13 +287,35 @@ int mvs_conv3d_mfma(const float* x, const float* xs, const float* xb, const floa
         return MVS_E_SHAPE;
     }
     auto pad_before = [](int n) { int o = (n + 1) / 2; int t = (o - 1) * 2 + 3 - n; return t < 0 ? 0 : t / 2; };
-    a.pd = pad_before(D); a.ph = pad_before(H); a.pw = pad_before(W);
+    a.pd = pad_before(a.D); a.ph = pad_before(a.H); a.pw = pad_before(a.W);
     return mvs_conv3d_s2_mfma(a, Cin, Cout, st);
+}
+
+int mvs_conv3d_mfma(const float* x, const float* xs, const float* xb, const float* x2,
+                    const float* x2s, const float* x2b, const float* w, int D, int H, int W,
+                    int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st) {
+    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, {}, {}};
+    return conv_dispatch(a, Cin, Cout, stride, st);
 }
 
 int mvs_deconv3d_mfma(const float* x, const float* xs, const float* xb, const float* x2,
                       const float* x2s, const float* x2b, const float* w, int D, int H, int W,
                       int Cin, int Cout, float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0};
+    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, {}, {}};
+    return mvs_deconv3d_mfma_launch(a, Cin, Cout, st);
+}
+
+// Variants taking the producers' raw BatchNorm sums (regnet.hip): no bn_finalize launch in between.
+int mvs_conv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
+                       const float* w, int D, int H, int W, int Cin, int Cout, int stride, float* y,
+                       double* stats, hipStream_t st) {
+    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2};
+    return conv_dispatch(a, Cin, Cout, stride, st);
+}
+
+int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
+                         const float* w, int D, int H, int W, int Cin, int Cout, float* y,
+                         double* stats, hipStream_t st) {
+    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2};
     return mvs_deconv3d_mfma_launch(a, Cin, Cout, st);
 }

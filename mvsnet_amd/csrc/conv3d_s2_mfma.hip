@@ -64,10 +64,12 @@ conv3d_s2_kernel(ConvArgs a) {
     const int c4 = tid % CQ;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 sc2 = sc, sh2 = sh;
-    const bool has_aff = a.xs != nullptr;
-    if (has_aff) { sc = *(const float4*)(a.xs + 4 * c4); sh = *(const float4*)(a.xb + 4 * c4); }
-    const bool has_aff2 = HAS_X2 && a.x2s != nullptr;
-    if (has_aff2) { sc2 = *(const float4*)(a.x2s + 4 * c4); sh2 = *(const float4*)(a.x2b + 4 * c4); }
+    const bool has_aff = a.xs != nullptr || a.bn.stats != nullptr;
+    if (a.xs) { sc = *(const float4*)(a.xs + 4 * c4); sh = *(const float4*)(a.xb + 4 * c4); }
+    else if (a.bn.stats) bn_affine4(a.bn, 4 * c4, sc, sh);
+    const bool has_aff2 = HAS_X2 && (a.x2s != nullptr || a.bn2.stats != nullptr);
+    if (HAS_X2 && a.x2s) { sc2 = *(const float4*)(a.x2s + 4 * c4); sh2 = *(const float4*)(a.x2b + 4 * c4); }
+    else if (HAS_X2 && a.bn2.stats) bn_affine4(a.bn2, 4 * c4, sc2, sh2);
 
     float4 pre[NIT];
     float4 pre2[HAS_X2 ? NIT : 1];

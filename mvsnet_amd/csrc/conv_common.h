@@ -6,6 +6,29 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Producer BatchNorm given as raw float64 sums: the consumer folds them into (scale, shift) itself
+// (same arithmetic as bn_finalize_kernel), which removes one launch per layer.
+struct BnSrc {
+    const double* stats;      // (2,C) [sum, sum of squares] or null
+    const float* gamma; const float* beta;
+    double count; float eps; int C;
+};
+
+__device__ __forceinline__ void bn_affine4(const BnSrc& b, int c0, float4& sc, float4& sh) {
+    float s[4], t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double mean = b.stats[c0 + k] / b.count;
+        double var = b.stats[b.C + c0 + k] / b.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        double inv = (double)b.gamma[c0 + k] / sqrt(var + (double)b.eps);
+        s[k] = (float)inv;
+        t[k] = (float)((double)b.beta[c0 + k] - mean * inv);
+    }
+    sc = make_float4(s[0], s[1], s[2], s[3]);
+    sh = make_float4(t[0], t[1], t[2], t[3]);
+}
+
 struct ConvArgs {
     const float* x; const float* xs; const float* xb;      // input + producer BN affine (or null)
     const float* x2; const float* x2s; const float* x2b;   // optional additive skip input
@@ -14,6 +37,7 @@ struct ConvArgs {
     double* stats;                                          // (2,CoutTotal) float64 sums or null
     int D, H, W, cout_total, planes_per_wg;
     int pd, ph, pw;                                         // SAME pad_before per axis (stride 2)
+    BnSrc bn, bn2;                                          // alternative to xs/xb, x2s/x2b (stats given)
 };
 
 constexpr int CONV_TW = 16;      // voxels per MFMA column tile (along w)
@@ -63,14 +87,14 @@ __device__ __forceinline__ void stats_commit(const float (&st_s)[4], const float
 }
 
 // planes per workgroup: enough workgroups to fill the 256 CUs a few times at small halo overhead
-static inline int conv_pick_planes(int D, long long wgs_per_chunk, int halo) {
+static inline int conv_pick_planes(int D, long long wgs_per_chunk, int halo, int slots = 256) {
     int best = D, best_cost = 1 << 30;
     const int cands[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
     for (int dr : cands) {
         if (dr > D) dr = D;
         long long chunks = (D + dr - 1) / dr;
         long long wgs = wgs_per_chunk * chunks;
-        long long rounds = (wgs + 255) / 256;
+        long long rounds = (wgs + slots - 1) / slots;
         int cost = (int)(rounds * (dr + halo));
         if (cost < best_cost) { best_cost = cost; best = dr; }
         if (dr == D) break;

@@ -1,7 +1,7 @@
 // Host-side composition: conv dispatch (scalar vs MFMA), the RegNetUS0 3D U-Net launch sequence
 // (mvsnet/cnn_wrapper/mvsnetworks.py:122-158) and library bookkeeping entry points.
 // No kernels here; every launch goes to the caller's stream and nothing allocates or syncs.
-#include "common.h"
+#include "conv_common.h"
 
 // scalar path (conv3d_scalar.hip)
 int mvs_conv3d_scalar(const float*, const float*, const float*, const float*, const float*,
@@ -17,6 +17,13 @@ int mvs_conv3d_mfma(const float*, const float*, const float*, const float*, cons
 int mvs_deconv3d_mfma(const float*, const float*, const float*, const float*, const float*,
                       const float*, const float*, int, int, int, int, int, float*, double*,
                       hipStream_t);
+// same, taking the producers' raw BatchNorm sums instead of a finalised (scale, shift)
+int mvs_conv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
+                       const float* w, int D, int H, int W, int Cin, int Cout, int stride, float* y,
+                       double* stats, hipStream_t st);
+int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
+                         const float* w, int D, int H, int W, int Cin, int Cout, float* y,
+                         double* stats, hipStream_t st);
 
 static int g_conv_impl = MVS_CONV_IMPL_AUTO;
 
@@ -127,36 +134,56 @@ extern "C" int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int ci
     const double v0 = (double)D * H * W, v1 = v0 / 8, v2 = v1 / 8, v3 = v2 / 8;
     int rc;
     if ((rc = mvs_zero_f64(ws.stats, (size_t)N_BN * 2 * cmax, stream))) return rc;
+    hipStream_t hs = mvs_stream(stream);
+    const int ch[N_BN] = {2 * b, 4 * b, 8 * b, b, 2 * b, 4 * b, 8 * b, 4 * b, 2 * b, b};
+    const double cnt[N_BN] = {v1, v2, v3, v0, v1, v2, v3, v2, v1, v0};
     auto st = [&](int i) { return ws.stats + (size_t)i * 2 * cmax; };
-    auto fin = [&](int i, int C, double cnt) {
-        return mvs_bn_finalize_f32(st(i), C, cnt, gammas[i], betas[i], eps, ws.scale[i], ws.shift[i], stream);
+    bool finalised[N_BN] = {false};
+    auto bn_of = [&](int i) {      // producer i's raw BatchNorm sums (i < 0: raw input, no BN)
+        BnSrc s{nullptr, nullptr, nullptr, 1.0, eps, 0};
+        if (i >= 0) s = BnSrc{st(i), gammas[i], betas[i], cnt[i], eps, ch[i]};
+        return s;
+    };
+    auto ensure_final = [&](int i) -> int {
+        if (i < 0 || finalised[i]) return 0;
+        finalised[i] = true;
+        return mvs_bn_finalize_f32(st(i), ch[i], cnt[i], gammas[i], betas[i], eps, ws.scale[i], ws.shift[i], stream);
+    };
+    // one layer: in = BN+ReLU(producer p1) [+ BN+ReLU(producer p2)], out = layer `out` (or reg)
+    auto layer = [&](bool deconv, int p1, int p2, int out, int d, int h, int w, int ci, int co,
+                     int stride) -> int {
+        const float* x = p1 >= 0 ? ws.y[p1] : cost;
+        const float* x2 = p2 >= 0 ? ws.y[p2] : nullptr;
+        float* y = out == L62 ? reg : ws.y[out];
+        double* so = out == L62 ? nullptr : st(out);
+        if (g_conv_impl != MVS_CONV_IMPL_SCALAR) {
+            int r = deconv ? mvs_deconv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], d, h, w, ci, co, y, so, hs)
+                           : mvs_conv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], d, h, w, ci, co, stride, y, so, hs);
+            if (r != MVS_E_SHAPE || g_conv_impl == MVS_CONV_IMPL_MFMA) return r;
+        }
+        int r;
+        if ((r = ensure_final(p1)) || (r = ensure_final(p2))) return r;
+        const float* s1 = p1 >= 0 ? ws.scale[p1] : nullptr; const float* t1 = p1 >= 0 ? ws.shift[p1] : nullptr;
+        const float* s2 = p2 >= 0 ? ws.scale[p2] : nullptr; const float* t2 = p2 >= 0 ? ws.shift[p2] : nullptr;
+        return deconv ? mvs_deconv3d_scalar(x, s1, t1, x2, s2, t2, weights[out], d, h, w, ci, co, y, so, hs)
+                      : mvs_conv3d_scalar(x, s1, t1, x2, s2, t2, weights[out], d, h, w, ci, co, stride, y, so, hs);
     };
 #define RUN(call) do { if ((rc = (call))) return rc; } while (0)
     // encoder on the raw cost volume (mvsnetworks.py:130-136)
-    RUN(mvs_conv3d_f32(cost, 0, 0, 0, 0, 0, weights[L10], D, H, W, cin, 2 * b, 2, ws.y[L10], st(L10), stream));
-    RUN(fin(L10, 2 * b, v1));
-    RUN(mvs_conv3d_f32(cost, 0, 0, 0, 0, 0, weights[L01], D, H, W, cin, b, 1, ws.y[L01], st(L01), stream));
-    RUN(fin(L01, b, v0));
-    RUN(mvs_conv3d_f32(ws.y[L10], ws.scale[L10], ws.shift[L10], 0, 0, 0, weights[L20], D1, H1, W1, 2 * b, 4 * b, 2, ws.y[L20], st(L20), stream));
-    RUN(fin(L20, 4 * b, v2));
-    RUN(mvs_conv3d_f32(ws.y[L20], ws.scale[L20], ws.shift[L20], 0, 0, 0, weights[L30], D2, H2, W2, 4 * b, 8 * b, 2, ws.y[L30], st(L30), stream));
-    RUN(fin(L30, 8 * b, v3));
+    RUN(layer(false, -1, -1, L10, D, H, W, cin, 2 * b, 2));
+    RUN(layer(false, -1, -1, L01, D, H, W, cin, b, 1));
+    RUN(layer(false, L10, -1, L20, D1, H1, W1, 2 * b, 4 * b, 2));
+    RUN(layer(false, L20, -1, L30, D2, H2, W2, 4 * b, 8 * b, 2));
     // same-resolution branches (mvsnetworks.py:138-145)
-    RUN(mvs_conv3d_f32(ws.y[L10], ws.scale[L10], ws.shift[L10], 0, 0, 0, weights[L11], D1, H1, W1, 2 * b, 2 * b, 1, ws.y[L11], st(L11), stream));
-    RUN(fin(L11, 2 * b, v1));
-    RUN(mvs_conv3d_f32(ws.y[L20], ws.scale[L20], ws.shift[L20], 0, 0, 0, weights[L21], D2, H2, W2, 4 * b, 4 * b, 1, ws.y[L21], st(L21), stream));
-    RUN(fin(L21, 4 * b, v2));
-    RUN(mvs_conv3d_f32(ws.y[L30], ws.scale[L30], ws.shift[L30], 0, 0, 0, weights[L31], D3, H3, W3, 8 * b, 8 * b, 1, ws.y[L31], st(L31), stream));
-    RUN(fin(L31, 8 * b, v3));
+    RUN(layer(false, L10, -1, L11, D1, H1, W1, 2 * b, 2 * b, 1));
+    RUN(layer(false, L20, -1, L21, D2, H2, W2, 4 * b, 4 * b, 1));
+    RUN(layer(false, L30, -1, L31, D3, H3, W3, 8 * b, 8 * b, 1));
     // decoder with additive skips (mvsnetworks.py:146-157)
-    RUN(mvs_deconv3d_f32(ws.y[L31], ws.scale[L31], ws.shift[L31], 0, 0, 0, weights[L40], D3, H3, W3, 8 * b, 4 * b, ws.y[L40], st(L40), stream));
-    RUN(fin(L40, 4 * b, v2));
-    RUN(mvs_deconv3d_f32(ws.y[L40], ws.scale[L40], ws.shift[L40], ws.y[L21], ws.scale[L21], ws.shift[L21], weights[L50], D2, H2, W2, 4 * b, 2 * b, ws.y[L50], st(L50), stream));
-    RUN(fin(L50, 2 * b, v1));
-    RUN(mvs_deconv3d_f32(ws.y[L50], ws.scale[L50], ws.shift[L50], ws.y[L11], ws.scale[L11], ws.shift[L11], weights[L60], D1, H1, W1, 2 * b, b, ws.y[L60], st(L60), stream));
-    RUN(fin(L60, b, v0));
+    RUN(layer(true, L31, -1, L40, D3, H3, W3, 8 * b, 4 * b, 2));
+    RUN(layer(true, L40, L21, L50, D2, H2, W2, 4 * b, 2 * b, 2));
+    RUN(layer(true, L50, L11, L60, D1, H1, W1, 2 * b, b, 2));
     // output conv, no BN / ReLU / bias (mvsnetworks.py:158)
-    RUN(mvs_conv3d_f32(ws.y[L60], ws.scale[L60], ws.shift[L60], ws.y[L01], ws.scale[L01], ws.shift[L01], weights[L62], D, H, W, b, 1, 1, reg, nullptr, stream));
+    RUN(layer(false, L60, L01, L62, D, H, W, b, 1, 1));
 #undef RUN
     return 0;
 }
