@@ -12,7 +12,7 @@
 
 namespace {
 
-struct Tap4 { float4 v; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -148,56 +148,87 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
     const float n = (float)(NSRC + 1);
     const float inv_n = 1.0f / n, inv_nn = 1.0f / (n * n);
 
-    for (int dl = dl0; dl < dl1; ++dl) {
-        const int d = d_begin + dl;
-        float4 S = r, Q = r2;
+    // The C/4 lanes of a pixel share their sample coordinates: lane `sub` evaluates the projective
+    // map for plane (batch + sub) of every view, and the pixel's lanes then fetch plane p's (sx, sy)
+    // from lane `base + p` with ds_bpermute.  The ~30 VALU instructions of the coordinate math are
+    // thereby paid once per lg planes instead of once per plane (the kernel is VALU-bound).
+    const int lg = cq;                                   // lanes per pixel: power of two (checked by the host)
+    const int sub = threadIdx.x & (lg - 1);
+    const int base_lane = (threadIdx.x & 63) - sub;
+
+    for (int dlb = dl0; dlb < dl1; dlb += lg) {
+        float msx[NSRC], msy[NSRC];
+        {
+            const int dmy = d_begin + min(dlb + sub, dl1 - 1);
 #pragma unroll
-        for (int v = 0; v < NSRC; ++v) {
-            const float* t = transforms + ((size_t)v * depth_total + d) * 8;     // block-uniform
-            const float* img = src + v * img_elems;
-            float proj = t[6] * xf + t[7] * yf + 1.0f;
-            float inv = __builtin_amdgcn_rcpf(proj);            // v_rcp_f32: 1 ulp, exact for proj = 1
-            float sx = (t[0] * xf + t[1] * yf + t[2]) * inv;
-            float sy = (t[3] * xf + t[4] * yf + t[5]) * inv;
-            float x0 = floorf(sx), y0 = floorf(sy);
-            float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
-            if (x0 != cx0[v] || y0 != cy0[v]) {
-                bool okx0 = (x0 >= 0.0f) && (x0 < (float)W);
-                bool okx1 = (x1 >= 0.0f) && (x1 < (float)W);
-                bool oky0 = (y0 >= 0.0f) && (y0 < (float)H);
-                bool oky1 = (y1 >= 0.0f) && (y1 < (float)H);
-                int ix0 = okx0 ? (int)x0 : 0, ix1 = okx1 ? (int)x1 : 0;
-                int iy0 = oky0 ? (int)y0 : 0, iy1 = oky1 ? (int)y1 : 0;
-                if (y0 == cy0[v] && x0 == cx0[v] + 1.0f) {      // slid one pixel right: keep a column
-                    t00[v] = t01[v]; t10[v] = t11[v];
-                } else {
-                    t00[v] = (okx0 && oky0) ? ld4(img + ((size_t)iy0 * W + ix0) * C + c) : z4;
-                    t10[v] = (okx0 && oky1) ? ld4(img + ((size_t)iy1 * W + ix0) * C + c) : z4;
-                }
-                t01[v] = (okx1 && oky0) ? ld4(img + ((size_t)iy0 * W + ix1) * C + c) : z4;
-                t11[v] = (okx1 && oky1) ? ld4(img + ((size_t)iy1 * W + ix1) * C + c) : z4;
-                cx0[v] = x0; cy0[v] = y0;
+            for (int v = 0; v < NSRC; ++v) {
+                const float* t = transforms + ((size_t)v * depth_total + dmy) * 8;
+                const float4 ta = ld4(t), tb = ld4(t + 4);
+                float proj = tb.z * xf + tb.w * yf + 1.0f;
+                float inv = __builtin_amdgcn_rcpf(proj);        // v_rcp_f32: 1 ulp, exact for proj = 1
+                msx[v] = (ta.x * xf + ta.y * yf + ta.z) * inv;
+                msy[v] = (ta.w * xf + tb.x * yf + tb.y) * inv;
             }
-            float wx1 = x1 - sx, wx0 = sx - x0, wy1 = y1 - sy, wy0 = sy - y0;
-            float4 w;
-            w.x = wy1 * (wx1 * t00[v].x + wx0 * t01[v].x) + wy0 * (wx1 * t10[v].x + wx0 * t11[v].x);
-            w.y = wy1 * (wx1 * t00[v].y + wx0 * t01[v].y) + wy0 * (wx1 * t10[v].y + wx0 * t11[v].y);
-            w.z = wy1 * (wx1 * t00[v].z + wx0 * t01[v].z) + wy0 * (wx1 * t10[v].z + wx0 * t11[v].z);
-            w.w = wy1 * (wx1 * t00[v].w + wx0 * t01[v].w) + wy0 * (wx1 * t10[v].w + wx0 * t11[v].w);
-            S.x += w.x; S.y += w.y; S.z += w.z; S.w += w.w;
-            Q.x += w.x * w.x; Q.y += w.y * w.y; Q.z += w.z * w.z; Q.w += w.w * w.w;
         }
-        float4 o;
-        if (variant == 0) {
-            o.x = Q.x * inv_n - (S.x * S.x) * inv_nn; o.y = Q.y * inv_n - (S.y * S.y) * inv_nn;
-            o.z = Q.z * inv_n - (S.z * S.z) * inv_nn; o.w = Q.w * inv_n - (S.w * S.w) * inv_nn;
-        } else {
-            float ax = S.x * inv_n, ay = S.y * inv_n, az = S.z * inv_n, aw = S.w * inv_n;
-            o.x = Q.x * inv_n - ax * ax; o.y = Q.y * inv_n - ay * ay;
-            o.z = Q.z * inv_n - az * az; o.w = Q.w * inv_n - aw * aw;
+        const int np = min(lg, dl1 - dlb);
+        for (int p = 0; p < np; ++p) {
+            const int dl = dlb + p;
+            const int srcl = base_lane + p;
+            // phase A: fetch this plane's sample points, refill the tap cache where floor() moved.
+            // Taps are loaded from CLAMPED addresses; the zero fill is applied through the weights
+            // below (w * finite = 0 exactly), so the only divergent region is four loads per view and
+            // every view's loads are in flight before the first one is consumed.
+            float sxs[NSRC], sys_[NSRC], x0s[NSRC], y0s[NSRC];
+#pragma unroll
+            for (int v = 0; v < NSRC; ++v) {
+                const float* img = src + v * img_elems;
+                float sx = __shfl(msx[v], srcl, 64);
+                float sy = __shfl(msy[v], srcl, 64);
+                float x0 = floorf(sx), y0 = floorf(sy);
+                sxs[v] = sx; sys_[v] = sy; x0s[v] = x0; y0s[v] = y0;
+                if (x0 != cx0[v] || y0 != cy0[v]) {
+                    int ix0 = (int)x0, iy0 = (int)y0;                     // v_cvt saturates, NaN -> 0
+                    int jx0 = min(max(ix0, 0), W - 1), jx1 = min(max(ix0 + 1, 0), W - 1);
+                    int jy0 = min(max(iy0, 0), H - 1), jy1 = min(max(iy0 + 1, 0), H - 1);
+                    // 32-bit offsets: one feature map is far below 2^31 elements (checked by the host)
+                    const int r0 = jy0 * W, r1 = jy1 * W;
+                    t00[v] = ld4(img + ((r0 + jx0) * C + c)); t01[v] = ld4(img + ((r0 + jx1) * C + c));
+                    t10[v] = ld4(img + ((r1 + jx0) * C + c)); t11[v] = ld4(img + ((r1 + jx1) * C + c));
+                    cx0[v] = x0; cy0[v] = y0;
+                }
+            }
+            // phase B: bilinear blend + running sums, two channels per packed instruction
+            f32x2 S0 = (f32x2){r.x, r.y}, S1 = (f32x2){r.z, r.w};
+            f32x2 Q0 = (f32x2){r2.x, r2.y}, Q1 = (f32x2){r2.z, r2.w};
+            const float wmax = (float)(W - 1), hmax = (float)(H - 1);
+#pragma unroll
+            for (int v = 0; v < NSRC; ++v) {
+                const float sx = sxs[v], sy = sys_[v], x0 = x0s[v], y0 = y0s[v];
+                // per-tap zero fill folded into the separable weights (tap (y,x) is dropped iff its
+                // row or its column is outside the image, exactly as reading 0 for it)
+                float wx1 = (x0 >= 0.0f && x0 <= wmax) ? (x0 + 1.0f) - sx : 0.0f;
+                float wx0 = (x0 >= -1.0f && x0 <= wmax - 1.0f) ? sx - x0 : 0.0f;
+                float wy1 = (y0 >= 0.0f && y0 <= hmax) ? (y0 + 1.0f) - sy : 0.0f;
+                float wy0 = (y0 >= -1.0f && y0 <= hmax - 1.0f) ? sy - y0 : 0.0f;
+                f32x2 a0 = (f32x2){t00[v].x, t00[v].y}, a1 = (f32x2){t00[v].z, t00[v].w};
+                f32x2 b0 = (f32x2){t01[v].x, t01[v].y}, b1 = (f32x2){t01[v].z, t01[v].w};
+                f32x2 c0 = (f32x2){t10[v].x, t10[v].y}, c1 = (f32x2){t10[v].z, t10[v].w};
+                f32x2 e0 = (f32x2){t11[v].x, t11[v].y}, e1 = (f32x2){t11[v].z, t11[v].w};
+                f32x2 w0 = wy1 * (wx1 * a0 + wx0 * b0) + wy0 * (wx1 * c0 + wx0 * e0);
+                f32x2 w1 = wy1 * (wx1 * a1 + wx0 * b1) + wy0 * (wx1 * c1 + wx0 * e1);
+                S0 += w0; S1 += w1;
+                Q0 += w0 * w0; Q1 += w1 * w1;
+            }
+            f32x2 o0, o1;
+            if (variant == 0) {
+                o0 = Q0 * inv_n - (S0 * S0) * inv_nn; o1 = Q1 * inv_n - (S1 * S1) * inv_nn;
+            } else {
+                f32x2 m0 = S0 * inv_n, m1 = S1 * inv_n;
+                o0 = Q0 * inv_n - m0 * m0; o1 = Q1 * inv_n - m1 * m1;
+            }
+            if (negate) { o0 = -o0; o1 = -o1; }
+            *reinterpret_cast<float4*>(cost + ((size_t)dl * H * W + pix) * C + c) = make_float4(o0[0], o0[1], o1[0], o1[1]);
         }
-        if (negate) { o.x = -o.x; o.y = -o.y; o.z = -o.z; o.w = -o.w; }
-        *reinterpret_cast<float4*>(cost + ((size_t)dl * H * W + pix) * C + c) = o;
     }
 }
 
@@ -239,7 +270,9 @@ extern "C" int mvs_cost_volume_f32(const float* ref, const float* src, const flo
     if (C % 4 != 0) return MVS_E_SHAPE;
     long long total = (long long)H * W * (C / 4);
     dim3 grid(mvs_cdiv(total, 256), d_count);
-    if (border == 0 && d_count >= 4 && view_num <= 8) {      // depth sweep with register tap reuse
+    const int cq_ = C / 4;
+    const bool cq_pow2 = cq_ <= 16 && (cq_ & (cq_ - 1)) == 0;     // lanes of a pixel stay inside one wave
+    if (border == 0 && d_count >= 4 && view_num <= 8 && cq_pow2 && (long long)H * W * C < (1LL << 30)) {      // depth sweep with register tap reuse
         hipStream_t st = mvs_stream(stream);
 #define MVS_SWEEP(NS) case NS: launch_sweep<NS>(ref, src, transforms, depth_total, d_begin, d_count, H, W, C, variant, negate, cost, st); break;
         switch (view_num - 1) {
