@@ -55,6 +55,30 @@ def algorithmic_work(view_num, D, H, W, C, base=8):
     return warp_bytes, conv_flops, soft_bytes
 
 
+def pmc_traffic():
+    """HBM bytes per depth map from the committed rocprofv3 PMC summary (profiles/rNN_pmc.json,
+    produced by profiles/collect_rNN.sh in separate --pmc passes; FETCH_SIZE x2 as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, WRITE_SIZE exact).
+    Returns {"warp": bytes, "conv": bytes, "soft": bytes} or {} when no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return {}
+    data = json.load(open(files[-1]))
+    out = {"warp": 0.0, "conv": 0.0, "soft": 0.0, "source": os.path.basename(files[-1])}
+    for name, d in data.items():
+        if "hbm_write_bytes" not in d:
+            continue
+        b = (d["hbm_read_bytes_corrected_x2"] + d["hbm_write_bytes"]) * d.get("launches_per_depth_map", 1.0)
+        if "cost_volume" in name:
+            out["warp"] += b
+        elif "conv3d" in name or "deconv3d" in name:
+            out["conv"] += b
+        elif "softargmin" in name:
+            out["soft"] += b
+    return out
+
+
 def cpu_baseline(workload, rp, budget_s=20.0):
     """CPU restatement (oracle/torch_restatement.py, fp32, all host cores) timed on a bounded
     sample of the same workload: whole depth maps until ~budget_s have elapsed (at least one)."""
@@ -184,19 +208,21 @@ def main():
     depth_np = plan.depth.cpu().numpy()
 
     if rank == 0:
+        tr = pmc_traffic()
         kernels = [
             {"kernel": "warp+variance cost volume (cost_volume_kernel)", "bound": "hbm",
              "achieved": warp_bytes / t_warp / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": warp_bytes / t_warp / 1e9 / HBM_PEAK_GBS, "ms": t_warp * 1e3,
-             "algorithmic_bytes": warp_bytes, "traffic": None},
+             "algorithmic_bytes": warp_bytes, "traffic": tr.get("warp") or None},
             {"kernel": "RegNetUS0 3D conv stack (11 conv launches + 10 BN finalises)", "bound": "mfma",
              "achieved": conv_flops / t_conv / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
              "frac": conv_flops / t_conv / 1e12 / MFMA_F32_PEAK_TFLOPS, "ms": t_conv * 1e3,
-             "algorithmic_flops": conv_flops, "peak_dtype": "fp32-input MFMA (dense)", "traffic": None},
+             "algorithmic_flops": conv_flops, "peak_dtype": "fp32-input MFMA (dense)",
+             "traffic": tr.get("conv") or None},
             {"kernel": "softmax+soft-argmin+prob (softargmin_prob_kernel)", "bound": "hbm",
              "achieved": soft_bytes / t_soft / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": soft_bytes / t_soft / 1e9 / HBM_PEAK_GBS, "ms": t_soft * 1e3,
-             "algorithmic_bytes": soft_bytes, "traffic": None},
+             "algorithmic_bytes": soft_bytes, "traffic": tr.get("soft") or None},
         ]
         dominant = max(kernels, key=lambda k: k["ms"])
         out = {
@@ -218,6 +244,7 @@ def main():
             "depth_checksum": float(np.float64(depth_np).sum()),
         }
         out["roofline"]["kernel"] = dominant["kernel"]
+        out["roofline"]["traffic_source"] = tr.get("source")
         if args.with_images:
             up = S.make_unet_params(args.network_mode, seed=3)
             from mvsnet_amd.feature_net import UNetDS2GN

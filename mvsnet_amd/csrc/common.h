@@ -26,3 +26,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 __device__ __forceinline__ float relu(float v) { return v > 0.f ? v : 0.f; }
+
+// XCD-aware block remap (MI355X: 8 XCDs with private 4 MiB L2s, workgroups dealt round-robin over
+// them, so blocks b and b+8 share an L2).  Gives each XCD a contiguous run of the index space so that
+// neighbouring tiles (shared halos, overlapping warp footprints) hit the same L2.  Speed only; the
+// identity is used when the count is not a multiple of 8.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
+    return (nb & 7) ? bid : (bid & 7) * (nb >> 3) + (bid >> 3);
+}

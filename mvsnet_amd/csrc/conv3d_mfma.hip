@@ -66,7 +66,8 @@ conv3d_s1_kernel(ConvArgs a) {
     const int n = lane & 15, kq = lane >> 4;
 
     const int tiles_w = (a.W + TW - 1) / TW;
-    const int tile_h = blockIdx.x / tiles_w, tile_w = blockIdx.x - tile_h * tiles_w;
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_h = bid / tiles_w, tile_w = bid - tile_h * tiles_w;
     const int h0 = tile_h * TH, w0 = tile_w * TW;
     const int co_base = blockIdx.y * COUT;
     const int d0 = blockIdx.z * a.planes_per_wg;

@@ -30,7 +30,8 @@ conv3d_out_kernel(ConvArgs a) {
     const int tid = threadIdx.x;
     const int row = tid >> 5, col = tid & 31;
     const int tiles_w = (a.W + OTW - 1) / OTW;
-    const int tile_h = blockIdx.x / tiles_w, tile_w = blockIdx.x - tile_h * tiles_w;
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_h = bid / tiles_w, tile_w = bid - tile_h * tiles_w;
     const int h0 = tile_h * OTH, w0 = tile_w * OTW;
     const int d0 = blockIdx.z * a.planes_per_wg;
     const int d1 = min(d0 + a.planes_per_wg, a.D);

@@ -43,7 +43,8 @@ conv3d_s2_kernel(ConvArgs a) {
 
     const int Do = (a.D + 1) / 2, Ho = (a.H + 1) / 2, Wo = (a.W + 1) / 2;
     const int tiles_w = (Wo + TW - 1) / TW;
-    const int tile_h = blockIdx.x / tiles_w, tile_w = blockIdx.x - tile_h * tiles_w;
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_h = bid / tiles_w, tile_w = bid - tile_h * tiles_w;
     const int oh0 = tile_h * TOH, ow0 = tile_w * TW;
     const int co_base = blockIdx.y * COUT;
     const int od0 = blockIdx.z * a.planes_per_wg;

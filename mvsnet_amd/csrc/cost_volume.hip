@@ -126,7 +126,7 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
                          int negate, float* __restrict__ cost) {
     const int cq = C >> 2;
     const long long total = (long long)H * W * cq;
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long idx = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int dl0 = blockIdx.y * planes_per_block;
     const int dl1 = min(dl0 + planes_per_block, d_count);
