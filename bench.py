@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--conv-impl", default="auto", choices=["auto", "scalar", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MVS_BENCH_STREAMS", "1")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MVS_BENCH_STREAMS", "2")),
                     help="independent depth maps in flight per GPU (one plan + HIP stream each)")
     ap.add_argument("--with-images", action="store_true",
                     help="also time images->depth (adds the PyTorch UNetDS2GN towers)")

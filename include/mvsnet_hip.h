@@ -126,6 +126,17 @@ int mvs_zero_f64(double* p, size_t n, void* stream);
  *   reg       (D,H,W) filtered cost volume (the squeezed 3dconv6_2 output)
  */
 size_t mvs_regnet_workspace_bytes(int D, int H, int W, int cin, int base);
+/* Optional one-off weight pre-layout: re-orders the 10 MFMA layers' kernels into the order the
+ * kernels keep them in LDS, so that a workgroup uploads its weights with coalesced 16-byte lanes.
+ * `prepared` holds mvs_regnet_prepared_floats() floats; pass it to mvs_regnet_us0_prepared_f32
+ * together with the original weights (still used by layers outside the MFMA tiling). */
+size_t mvs_regnet_prepared_floats(int cin, int base);
+int mvs_regnet_prepare_f32(const float* const* weights, int cin, int base, float* prepared,
+                           void* stream);
+int mvs_regnet_us0_prepared_f32(const float* cost, int D, int H, int W, int cin, int base,
+                                const float* const* weights, const float* prepared,
+                                const float* const* gammas, const float* const* betas, float eps,
+                                void* workspace, size_t workspace_bytes, float* reg, void* stream);
 int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int cin, int base,
                        const float* const* weights, const float* const* gammas,
                        const float* const* betas, float eps, void* workspace,

@@ -36,9 +36,11 @@ constexpr int PW = TW + 2;      // staged row width with halo
 // pitch (Cin+8) for Cin+4 (2-way conflicts on the B reads, LDS is ~12 % busy) so that two
 // workgroups fit in a CU's 160 KB LDS: two waves per SIMD hide each other's LDS / barrier stalls.
 template <int CIN, int COUT, int TH> struct S1Geom {
-    static constexpr bool TWO_PER_CU = (CIN == 32 && COUT == 8 && TH == 8);
-    static constexpr int S = TWO_PER_CU ? CIN + 4 : SlabGeom<CIN>::S;
-    static constexpr int WGS_PER_CU = TWO_PER_CU ? 2 : 1;
+    static constexpr bool TIGHT = (CIN == 32 && COUT == 8 && TH == 8);
+    static constexpr int S = TIGHT ? CIN + 4 : SlabGeom<CIN>::S;
+    // LDS bytes = weights + two slabs; two workgroups per CU whenever that fits in 160 KB
+    static constexpr int LDS_BYTES = (9 * (CIN / 4) * 3 * COUT * 4 + 2 * (TH + 2) * (CONV_TW + 2) * S) * 4;
+    static constexpr int WGS_PER_CU = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;
 };
 
 template <int CIN, int COUT, int TH, bool HAS_X2>
@@ -75,7 +77,8 @@ conv3d_s1_kernel(ConvArgs a) {
     const int T = d1 - d0 + 2;                     // input planes d0-1 .. d1
 
     // ---- weights -> LDS, re-laid out as [tap][ci/4][kd][co][ci%4] ------------------------------
-    for (int i = tid; i < W_FLOATS; i += 256) {
+    if (a.wprep) load_prepared_weights(wl, a.wprep, W_FLOATS);
+    else for (int i = tid; i < W_FLOATS; i += 256) {
         int j = i & 3;
         int r = (i >> 2) % NROWS;
         int g = (i >> 2) / NROWS;                  // tap * CQ + ciq
@@ -258,7 +261,7 @@ int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
     ConvArgs a = a0;
     const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
     const int groups = Cout / COUT;
-    a.planes_per_wg = conv_pick_planes(a.D, (long long)tiles * groups, 2, 256 * S1Geom<CIN, COUT, TH>::WGS_PER_CU);
+    a.planes_per_wg = conv_pick_planes(a.D, (long long)tiles * groups, 2);
     dim3 grid(tiles, groups, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
     size_t smem = s1_smem_bytes<CIN, COUT, TH>();
     static bool attr_done = false;       // per template instantiation
@@ -295,28 +298,64 @@ static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t
 int mvs_conv3d_mfma(const float* x, const float* xs, const float* xb, const float* x2,
                     const float* x2s, const float* x2b, const float* w, int D, int H, int W,
                     int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, {}, {}};
+    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, {}, {}, nullptr};
     return conv_dispatch(a, Cin, Cout, stride, st);
 }
 
 int mvs_deconv3d_mfma(const float* x, const float* xs, const float* xb, const float* x2,
                       const float* x2s, const float* x2b, const float* w, int D, int H, int W,
                       int Cin, int Cout, float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, {}, {}};
+    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, {}, {}, nullptr};
     return mvs_deconv3d_mfma_launch(a, Cin, Cout, st);
 }
 
 // Variants taking the producers' raw BatchNorm sums (regnet.hip): no bn_finalize launch in between.
 int mvs_conv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
-                       const float* w, int D, int H, int W, int Cin, int Cout, int stride, float* y,
-                       double* stats, hipStream_t st) {
-    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2};
+                       const float* w, const float* wprep, int D, int H, int W, int Cin, int Cout,
+                       int stride, float* y, double* stats, hipStream_t st) {
+    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep};
     return conv_dispatch(a, Cin, Cout, stride, st);
 }
 
 int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
-                         const float* w, int D, int H, int W, int Cin, int Cout, float* y,
-                         double* stats, hipStream_t st) {
-    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2};
+                         const float* w, const float* wprep, int D, int H, int W, int Cin, int Cout,
+                         float* y, double* stats, hipStream_t st) {
+    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep};
     return mvs_deconv3d_mfma_launch(a, Cin, Cout, st);
+}
+
+// ---- weight pre-layout (run once per weight set, mvs_regnet_prepare_f32) ---------------------------
+namespace {
+// conv:   out[g][tap9][ci/4][kd][co][ci%4] <- w[(kd*9+tap)][ci][g*G+co]       (TensorFlow (3,3,3,Cin,Cout))
+// deconv: out[g][tap27][ci/4][co][ci%4]    <- w[tap][g*G+co][ci]              (TensorFlow (3,3,3,Cout,Cin))
+__global__ void weight_layout_kernel(const float* __restrict__ w, int kind, int Cin, int Cout, int G,
+                                     float* __restrict__ out) {
+    const int total = 27 * Cin * Cout;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int per_group = 27 * Cin * G;
+    const int g = i / per_group;
+    int r = i - g * per_group;
+    const int j = r & 3; r >>= 2;
+    const int CQ = Cin / 4;
+    if (kind == 2) {
+        const int co = r % G; r /= G;
+        const int ciq = r % CQ, tap = r / CQ;
+        out[i] = w[((size_t)tap * Cout + g * G + co) * Cin + ciq * 4 + j];
+    } else {
+        const int rows = 3 * G;
+        const int row = r % rows; r /= rows;
+        const int ciq = r % CQ, tap = r / CQ;
+        const int kd = row / G, co = row - kd * G;
+        out[i] = w[((size_t)(kd * 9 + tap) * Cin + ciq * 4 + j) * Cout + g * G + co];
+    }
+}
+}  // namespace
+
+int mvs_conv_weight_layout(const float* w, int kind, int Cin, int Cout, float* out, hipStream_t st) {
+    const int G = conv_coutg(kind, Cin, Cout);
+    if (G == 0 || (Cin % 4)) return MVS_E_SHAPE;
+    const int total = 27 * Cin * Cout;
+    weight_layout_kernel<<<mvs_cdiv(total, 256), 256, 0, st>>>(w, kind, Cin, Cout, G, out);
+    return (int)hipGetLastError();
 }

@@ -16,7 +16,7 @@ constexpr int OTH = 8, OTW = 32;
 constexpr int OPW = OTW + 2;
 
 template <int CIN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)     // 3 workgroups per CU: HBM-latency bound, needs waves in flight
 conv3d_out_kernel(ConvArgs a) {
     constexpr int S = CIN + 4;
     constexpr int CQ = CIN / 4;
@@ -128,7 +128,7 @@ template <int CIN>
 int launch_out(const ConvArgs& a0, hipStream_t st) {
     ConvArgs a = a0;
     const int tiles = ((a.H + OTH - 1) / OTH) * ((a.W + OTW - 1) / OTW);
-    a.planes_per_wg = conv_pick_planes(a.D, tiles, 2);
+    a.planes_per_wg = conv_pick_planes(a.D, tiles, 2, 768);
     dim3 grid(tiles, 1, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
     conv3d_out_kernel<CIN><<<grid, 256, 0, st>>>(a);
     return (int)hipGetLastError();

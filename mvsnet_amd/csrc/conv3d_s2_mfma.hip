@@ -53,7 +53,8 @@ conv3d_s2_kernel(ConvArgs a) {
     const int q0 = 2 * od0 - a.pd;
     const int ih0 = 2 * oh0 - a.ph, iw0 = 2 * ow0 - a.pw;
 
-    for (int i = tid; i < W_FLOATS; i += 256) {
+    if (a.wprep) load_prepared_weights(wl, a.wprep, W_FLOATS);
+    else for (int i = tid; i < W_FLOATS; i += 256) {
         int j = i & 3;
         int r = (i >> 2) % NROWS;
         int g = (i >> 2) / NROWS;

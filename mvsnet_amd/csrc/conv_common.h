@@ -38,6 +38,7 @@ struct ConvArgs {
     int D, H, W, cout_total, planes_per_wg;
     int pd, ph, pw;                                         // SAME pad_before per axis (stride 2)
     BnSrc bn, bn2;                                          // alternative to xs/xb, x2s/x2b (stats given)
+    const float* wprep;                                     // weights already in the kernel's LDS order, or null
 };
 
 constexpr int CONV_TW = 16;      // voxels per MFMA column tile (along w)
@@ -86,20 +87,46 @@ __device__ __forceinline__ void stats_commit(const float (&st_s)[4], const float
     }
 }
 
-// planes per workgroup: enough workgroups to fill the 256 CUs a few times at small halo overhead
+// Planes per workgroup.  The MFMA kernels are compute-bound, so a CU's throughput does not grow with
+// the number of resident workgroups: time ~ ceil(workgroups / 256 CUs) * (planes + halo planes + a
+// start-up cost of about one plane for the weight upload).  Exhaustive over the chunk length.
+// `slots` > 256 is for latency-bound kernels whose co-resident workgroups do overlap.
 static inline int conv_pick_planes(int D, long long wgs_per_chunk, int halo, int slots = 256) {
-    int best = D, best_cost = 1 << 30;
-    const int cands[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
-    for (int dr : cands) {
-        if (dr > D) dr = D;
+    int best = D;
+    long long best_cost = 1LL << 60;
+    for (int dr = 1; dr <= D; ++dr) {
         long long chunks = (D + dr - 1) / dr;
         long long wgs = wgs_per_chunk * chunks;
         long long rounds = (wgs + slots - 1) / slots;
-        int cost = (int)(rounds * (dr + halo));
+        long long cost = rounds * (dr + halo + 1);
         if (cost < best_cost) { best_cost = cost; best = dr; }
-        if (dr == D) break;
     }
     return best;
+}
+
+// Output channels per workgroup chosen by the dispatchers; the weight pre-layout uses the same rule.
+// kind: 0 = conv stride 1, 1 = conv stride 2, 2 = transposed conv.  0 = shape not covered by MFMA.
+static inline int conv_coutg(int kind, int Cin, int Cout) {
+    if (kind == 0) {
+        if (Cin == 32 && Cout == 8) return 8;
+        if (Cin == 16 && Cout % 16 == 0) return 16;
+        if (Cin == 32 && Cout % 16 == 0) return 16;
+        if (Cin == 64 && Cout % 8 == 0) return 8;
+        if (Cin == 16 && Cout == 8) return 8;
+        return 0;
+    }
+    if (kind == 1) return (Cout % 16 == 0 && (Cin == 32 || Cin == 16)) ? 16 : 0;
+    if (Cin == 16 && Cout == 8) return 8;
+    if (Cin == 32 && Cout % 16 == 0) return 16;
+    if (Cin == 64 && Cout % 8 == 0) return 8;
+    if (Cin == 16 && Cout % 16 == 0) return 16;
+    return 0;
+}
+
+// Copies a workgroup's pre-laid-out weights (mvs_regnet_prepare_f32) into LDS: coalesced 16-B lanes.
+__device__ __forceinline__ void load_prepared_weights(float* wl, const float* wprep, int w_floats) {
+    const float4* s4 = reinterpret_cast<const float4*>(wprep + (size_t)blockIdx.y * w_floats);
+    for (int i = threadIdx.x; i < w_floats / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = s4[i];
 }
 
 // launchers implemented in the kernel files; MVS_E_SHAPE when the shape is outside their tiling

@@ -17,8 +17,13 @@ namespace {
 constexpr int TW = CONV_TW;
 constexpr int PW = TW + 1;              // staged row width (one halo column on the left)
 
+template <int CIN, int COUT, int TH> struct DeconvGeom {
+    static constexpr int LDS_BYTES = (27 * CIN * COUT + 2 * (TH + 1) * (CONV_TW + 1) * SlabGeom<CIN>::S) * 4;
+    static constexpr int WGS_PER_CU = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;
+};
+
 template <int CIN, int COUT, int TH, bool HAS_X2>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, (DeconvGeom<CIN, COUT, TH>::WGS_PER_CU))
 deconv3d_kernel(ConvArgs a) {
     constexpr int S = SlabGeom<CIN>::S;
     constexpr int NPOS = (TH + 1) * PW;
@@ -50,7 +55,8 @@ deconv3d_kernel(ConvArgs a) {
     const int Ho = 2 * a.H, Wo = 2 * a.W;
 
     // weights (kd,kh,kw,Cout,Cin) -> LDS [tap][ci/4][co][ci%4]
-    for (int i = tid; i < W_FLOATS; i += 256) {
+    if (a.wprep) load_prepared_weights(wl, a.wprep, W_FLOATS);
+    else for (int i = tid; i < W_FLOATS; i += 256) {
         int j = i & 3;
         int co = (i >> 2) % COUT;
         int g = (i >> 2) / COUT;

@@ -19,11 +19,12 @@ int mvs_deconv3d_mfma(const float*, const float*, const float*, const float*, co
                       hipStream_t);
 // same, taking the producers' raw BatchNorm sums instead of a finalised (scale, shift)
 int mvs_conv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
-                       const float* w, int D, int H, int W, int Cin, int Cout, int stride, float* y,
-                       double* stats, hipStream_t st);
+                       const float* w, const float* wprep, int D, int H, int W, int Cin, int Cout,
+                       int stride, float* y, double* stats, hipStream_t st);
 int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
-                         const float* w, int D, int H, int W, int Cin, int Cout, float* y,
-                         double* stats, hipStream_t st);
+                         const float* w, const float* wprep, int D, int H, int W, int Cin, int Cout,
+                         float* y, double* stats, hipStream_t st);
+int mvs_conv_weight_layout(const float* w, int kind, int Cin, int Cout, float* out, hipStream_t st);
 
 static int g_conv_impl = MVS_CONV_IMPL_AUTO;
 
@@ -119,10 +120,47 @@ extern "C" size_t mvs_regnet_workspace_bytes(int D, int H, int W, int cin, int b
     return carve(nullptr, D, H, W, cin, base).bytes;
 }
 
-extern "C" int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int cin, int base,
-                                  const float* const* weights, const float* const* gammas,
-                                  const float* const* betas, float eps, void* workspace,
-                                  size_t workspace_bytes, float* reg, void* stream) {
+namespace {
+// layer table (order of the weights array) and offsets of the pre-laid-out weights
+struct PrepLayout { int kind[11]; int ci[11]; int co[11]; size_t off[11]; bool ok[11]; size_t total; };
+PrepLayout prep_layout(int cin, int b) {
+    PrepLayout L;
+    const int kind[11] = {1, 1, 1, 0, 0, 0, 0, 2, 2, 2, 0};
+    const int ci[11] = {cin, 2 * b, 4 * b, cin, 2 * b, 4 * b, 8 * b, 8 * b, 4 * b, 2 * b, b};
+    const int co[11] = {2 * b, 4 * b, 8 * b, b, 2 * b, 4 * b, 8 * b, 4 * b, 2 * b, b, 1};
+    size_t off = 0;
+    for (int i = 0; i < 11; ++i) {
+        L.kind[i] = kind[i]; L.ci[i] = ci[i]; L.co[i] = co[i]; L.off[i] = off;
+        L.ok[i] = (i != L62) && (ci[i] % 4 == 0) && conv_coutg(kind[i], ci[i], co[i]) != 0;
+        off += (size_t)27 * ci[i] * co[i];
+    }
+    L.total = off;
+    return L;
+}
+}  // namespace
+
+extern "C" size_t mvs_regnet_prepared_floats(int cin, int base) {
+    if (cin <= 0 || base <= 0) return 0;
+    return prep_layout(cin, base).total;
+}
+
+extern "C" int mvs_regnet_prepare_f32(const float* const* weights, int cin, int base, float* prepared,
+                                      void* stream) {
+    MVS_CHECK_ARG(weights && prepared && cin > 0 && base > 0);
+    PrepLayout L = prep_layout(cin, base);
+    for (int i = 0; i < 11; ++i) {
+        if (!L.ok[i]) continue;
+        int rc = mvs_conv_weight_layout(weights[i], L.kind[i], L.ci[i], L.co[i], prepared + L.off[i], mvs_stream(stream));
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
+                      const float* const* weights, const float* prepared, const float* const* gammas,
+                      const float* const* betas, float eps, void* workspace, size_t workspace_bytes,
+                      float* reg, void* stream) {
+    const PrepLayout lay = prep_layout(cin, base);
     MVS_CHECK_ARG(cost && weights && gammas && betas && workspace && reg);
     MVS_CHECK_ARG(D > 0 && H > 0 && W > 0 && cin > 0 && base > 0);
     if ((D % 8) || (H % 8) || (W % 8)) return MVS_E_SHAPE;
@@ -157,8 +195,9 @@ extern "C" int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int ci
         float* y = out == L62 ? reg : ws.y[out];
         double* so = out == L62 ? nullptr : st(out);
         if (g_conv_impl != MVS_CONV_IMPL_SCALAR) {
-            int r = deconv ? mvs_deconv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], d, h, w, ci, co, y, so, hs)
-                           : mvs_conv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], d, h, w, ci, co, stride, y, so, hs);
+            const float* wp = (prepared && lay.ok[out]) ? prepared + lay.off[out] : nullptr;
+            int r = deconv ? mvs_deconv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, d, h, w, ci, co, y, so, hs)
+                           : mvs_conv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, d, h, w, ci, co, stride, y, so, hs);
             if (r != MVS_E_SHAPE || g_conv_impl == MVS_CONV_IMPL_MFMA) return r;
         }
         int r;
@@ -186,4 +225,22 @@ extern "C" int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int ci
     RUN(layer(false, L60, L01, L62, D, H, W, b, 1, 1));
 #undef RUN
     return 0;
+}
+
+extern "C" int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int cin, int base,
+                                  const float* const* weights, const float* const* gammas,
+                                  const float* const* betas, float eps, void* workspace,
+                                  size_t workspace_bytes, float* reg, void* stream) {
+    return regnet_run(cost, D, H, W, cin, base, weights, nullptr, gammas, betas, eps, workspace,
+                      workspace_bytes, reg, stream);
+}
+
+extern "C" int mvs_regnet_us0_prepared_f32(const float* cost, int D, int H, int W, int cin, int base,
+                                           const float* const* weights, const float* prepared,
+                                           const float* const* gammas, const float* const* betas,
+                                           float eps, void* workspace, size_t workspace_bytes,
+                                           float* reg, void* stream) {
+    MVS_CHECK_ARG(prepared);
+    return regnet_run(cost, D, H, W, cin, base, weights, prepared, gammas, betas, eps, workspace,
+                      workspace_bytes, reg, stream);
 }

@@ -46,6 +46,13 @@ class RegNetWeights:
         self.w_ptrs = _lib.ptr_array(self.w)
         self.g_ptrs = _lib.ptr_array(self.gamma)
         self.b_ptrs = _lib.ptr_array(self.beta)
+        # one-off re-layout of the kernels into the MFMA kernels' LDS order
+        lib = _lib.load()
+        n = lib.mvs_regnet_prepared_floats(self.cin, self.base)
+        self.prepared = torch.empty(max(n, 1), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mvs_regnet_prepare_f32(self.w_ptrs, self.cin, self.base, _lib.ptr(self.prepared),
+                                                  _lib.stream_ptr()), "mvs_regnet_prepare_f32")
 
 
 class GRUWeights:
@@ -152,10 +159,11 @@ def regnet_us0(cost_volume_, weights: RegNetWeights, workspace=None, out=None):
         workspace = torch.empty(need, device=cost_volume_.device, dtype=torch.uint8)
     if out is None:
         out = torch.empty((D, H, W), device=cost_volume_.device, dtype=torch.float32)
-    _lib.check(lib.mvs_regnet_us0_f32(
-        _lib.ptr(_lib.f32(cost_volume_)), D, H, W, Cin, weights.base, weights.w_ptrs, weights.g_ptrs,
-        weights.b_ptrs, BN_EPSILON, C.c_void_p(workspace.data_ptr()), workspace.numel(),
-        _lib.ptr(out), _lib.stream_ptr()), "mvs_regnet_us0_f32")
+    _lib.check(lib.mvs_regnet_us0_prepared_f32(
+        _lib.ptr(_lib.f32(cost_volume_)), D, H, W, Cin, weights.base, weights.w_ptrs,
+        _lib.ptr(weights.prepared), weights.g_ptrs, weights.b_ptrs, BN_EPSILON,
+        C.c_void_p(workspace.data_ptr()), workspace.numel(), _lib.ptr(out), _lib.stream_ptr()),
+        "mvs_regnet_us0_prepared_f32")
     return out
 
 
