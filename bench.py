@@ -119,8 +119,10 @@ def main():
     ap.add_argument("--conv-impl", default="auto", choices=["auto", "scalar", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MVS_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MVS_BENCH_STREAMS", "1")),
                     help="independent depth maps in flight per GPU (one plan + HIP stream each)")
+    ap.add_argument("--regularization", default="3DCNN", choices=["3DCNN", "GRU"],
+                    help="GRU = R-MVSNet recurrent sweep (config 3); reported as an extra, not the metric")
     ap.add_argument("--with-images", action="store_true",
                     help="also time images->depth (adds the PyTorch UNetDS2GN towers)")
     args = ap.parse_args()
@@ -150,6 +152,29 @@ def main():
     weights = MVSNetWeights.from_numpy(args.network_mode, regnet=rp, device=dev)
     feats = torch.as_tensor(w.features).to(dev)
     cams = torch.as_tensor(w.cams).to(dev)
+    if args.regularization == "GRU":
+        gp = S.make_gru_params(args.network_mode, seed=2, in_channels=w.channels)
+        gw = MVSNetWeights.from_numpy(args.network_mode, gru=gp, device=dev)
+        gplan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, gw, "GRU", dev)
+        from mvsnet_amd.model import wta_depth_values
+        dv = wta_depth_values(w.depth_num, w.depth_start, w.depth_end, False)
+        gplan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
+        for _ in range(args.warmup):
+            gplan.run_gru(feats, dv)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gplan.run_gru(feats, dv)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        flops = 2.0 * 23238 * w.depth_num * w.height * w.width
+        print(json.dumps({"metric": "depth maps/sec (GRU regulariser)", "value": args.steps / el,
+                          "unit": "depth maps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": el / args.steps * 1e3, "ms_per_plane": el / args.steps / w.depth_num * 1e3,
+                          "achieved_tflops": flops * args.steps / el / 1e12, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "%s: GRU sweep, N=%d, D=%d, %dx%d" % (
+                              w.name, w.view_num, w.depth_num, w.width, w.height)}}), flush=True)
+        return
     n_streams = max(1, args.streams)
     plans = [DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", dev)
              for _ in range(n_streams)]
@@ -214,7 +239,7 @@ def main():
              "achieved": warp_bytes / t_warp / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": warp_bytes / t_warp / 1e9 / HBM_PEAK_GBS, "ms": t_warp * 1e3,
              "algorithmic_bytes": warp_bytes, "traffic": tr.get("warp") or None},
-            {"kernel": "RegNetUS0 3D conv stack (11 conv launches + 10 BN finalises)", "bound": "mfma",
+            {"kernel": "RegNetUS0 3D conv stack (11 conv launches, BatchNorm folded into the consumers)", "bound": "mfma",
              "achieved": conv_flops / t_conv / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
              "frac": conv_flops / t_conv / 1e12 / MFMA_F32_PEAK_TFLOPS, "ms": t_conv * 1e3,
              "algorithmic_flops": conv_flops, "peak_dtype": "fp32-input MFMA (dense)",
