@@ -9,6 +9,15 @@
 // current cost slice (H*W*C) exists, never the (D,H,W,C) volume.
 #include "common.h"
 
+// cell-1 MFMA convolutions (gru_mfma.hip); MVS_E_SHAPE outside their tiling
+int mvs_gru_weight_layout(const float* w, int CT, int COUT, float* out, hipStream_t st);
+int mvs_gru1_gates_mfma(const float* x, const float* h, const float* wprep, const float* bias, int H,
+                        int W, int CA, int F, float* g, double* stats, hipStream_t st);
+int mvs_gru1_out_mfma(const float* x, const float* h, const float* g, const double* g_stats,
+                      const float* r_gamma, const float* r_beta, const float* wprep,
+                      const float* bias, int H, int W, int CA, int F, float* c, double* stats,
+                      hipStream_t st);
+
 namespace {
 
 constexpr int MAX_CO = 32;   // largest Cout on the path: gates of cell 1 = 2*16
@@ -140,6 +149,55 @@ wta_finish_kernel(const float* __restrict__ max_prob, const float* __restrict__ 
     if (i < HW) prob[i] = max_prob[i] / (exp_sum[i] + 1e-7f);     // model.py:749-751
 }
 
+// blend with the update gate evaluated in place: h = u*h + (1-u)*tanh(LN(c)), u = sigmoid(LN(g_u))
+// (convgru.py:98,102,114-120); g holds the raw gate convolution (reset | update).
+__global__ void __launch_bounds__(256)
+gru_blend_fused_kernel(const float* __restrict__ c, const double* __restrict__ stats_c,
+                       const float* __restrict__ og, const float* __restrict__ ob,
+                       const float* __restrict__ g, const double* __restrict__ stats_u,
+                       const float* __restrict__ ug, const float* __restrict__ ub, int HW, int F,
+                       float* __restrict__ h) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)HW * F) return;
+    int f = (int)(i % F);
+    long long pix = i / F;
+    const double n = (double)HW * F;
+    float a, b;
+    ln_affine(stats_u, n, ug[f], ub[f], a, b);
+    float uu = sigmoidf(g[pix * 2 * F + F + f] * a + b);
+    ln_affine(stats_c, n, og[f], ob[f], a, b);
+    float yv = tanhf(c[i] * a + b);
+    h[i] = uu * h[i] + (1.0f - uu) * yv;
+}
+
+// prob_conv (3x3, F3 -> 1, bias) + exp + winner-take-all update in one pass
+// (model.py:701-703, 721-731); strict '<' keeps the first maximum.
+template <int F3>
+__global__ void __launch_bounds__(256)
+prob_wta_kernel(const float* __restrict__ h3, const float* __restrict__ w, const float* __restrict__ bias,
+                float depth_value, int H, int W, float* __restrict__ max_prob,
+                float* __restrict__ depth_image, float* __restrict__ exp_sum) {
+    int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= H * W) return;
+    int py = pix / W, px = pix - py * W;
+    float acc = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        int iy = py + kh - 1; if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            int ix = px + kw - 1; if (ix < 0 || ix >= W) continue;
+            const float* p = h3 + ((size_t)iy * W + ix) * F3;
+#pragma unroll
+            for (int ci = 0; ci < F3; ++ci) acc += p[ci] * w[(kh * 3 + kw) * F3 + ci];
+        }
+    }
+    float pr = expf(acc);
+    float mp = max_prob[pix];
+    if (mp < pr) { max_prob[pix] = pr; depth_image[pix] = depth_value; }
+    exp_sum[pix] += pr;
+}
+
 int launch_conv2d(const float* xa, int Ca, const float* xb, int Cb, const float* w,
                   const float* bias, int H, int W, int Cout, float* y, double* stats, int groups,
                   hipStream_t st) {
@@ -208,7 +266,7 @@ extern "C" int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, i
 
 namespace {
 struct GruWs {
-    float *x, *g, *c, *rh, *u, *h1, *h2, *h3, *reg, *max_prob, *exp_sum;
+    float *x, *g, *c, *rh, *u, *h1, *h2, *h3, *reg, *max_prob, *exp_sum, *wprep_g, *wprep_o;
     double* stats;     // 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
     size_t bytes;
 };
@@ -221,6 +279,7 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     w.x = take(hw * C); w.g = take(hw * 2 * fmax); w.c = take(hw * fmax); w.rh = take(hw * fmax);
     w.u = take(hw * fmax); w.h1 = take(hw * f1); w.h2 = take(hw * f2); w.h3 = take(hw * f3);
     w.reg = take(hw); w.max_prob = take(hw); w.exp_sum = take(hw);
+    w.wprep_g = take((size_t)9 * (C + f1) * 2 * f1); w.wprep_o = take((size_t)9 * (C + f1) * f1);
     w.stats = (double*)(base ? base + off : nullptr); off += align256(18 * 8);
     w.bytes = off;
     return w;
@@ -254,6 +313,13 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     const int F[3] = {f1, f2, f3};
     float* hs[3] = {ws.h1, ws.h2, ws.h3};
     int rc;
+    // cell 1 (90 % of the MACs) runs on the fp32-MFMA kernels when its shape fits their tiling
+    bool mfma1 = (mvs_get_conv_impl() != MVS_CONV_IMPL_SCALAR) && C == 32 && f1 == 16;
+    if (mfma1) {
+        if ((rc = mvs_gru_weight_layout(params[0], C + f1, 2 * f1, ws.wprep_g, st))) return rc;
+        if ((rc = mvs_gru_weight_layout(params[6], C + f1, f1, ws.wprep_o, st))) return rc;
+    }
+    const long long hw_ll = (long long)H * W;
     for (int d = 0; d < depth_num; ++d) {
         if ((e = hipMemsetAsync(ws.stats, 0, 18 * 8, st)) != hipSuccess) return (int)e;
         // x = -variance cost of plane d (model.py:680-693,698)
@@ -266,21 +332,36 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
             const float* const* p = params + 10 * k;
             double* sg = ws.stats + 6 * k;
             double* so = sg + 4;
-            rc = launch_conv2d(xin, cin, hs[k], F[k], p[0], p[1], H, W, 2 * F[k], ws.g, sg, 2, st);
-            if (rc) return rc;
-            rc = mvs_gru_gates_f32(ws.g, sg, p[2], p[3], p[4], p[5], hs[k], H, W, F[k], ws.rh, ws.u, stream);
-            if (rc) return rc;
-            rc = launch_conv2d(xin, cin, ws.rh, F[k], p[6], p[7], H, W, F[k], ws.c, so, 1, st);
-            if (rc) return rc;
-            rc = mvs_gru_blend_f32(ws.c, so, p[8], p[9], ws.u, H, W, F[k], hs[k], stream);
-            if (rc) return rc;
+            if (k == 0 && mfma1) {
+                if ((rc = mvs_gru1_gates_mfma(xin, hs[0], ws.wprep_g, p[1], H, W, C, f1, ws.g, sg, st))) return rc;
+                if ((rc = mvs_gru1_out_mfma(xin, hs[0], ws.g, sg, p[2], p[3], ws.wprep_o, p[7], H, W, C, f1, ws.c, so, st))) return rc;
+            } else {
+                rc = launch_conv2d(xin, cin, hs[k], F[k], p[0], p[1], H, W, 2 * F[k], ws.g, sg, 2, st);
+                if (rc) return rc;
+                rc = mvs_gru_gates_f32(ws.g, sg, p[2], p[3], p[4], p[5], hs[k], H, W, F[k], ws.rh, ws.u, stream);
+                if (rc) return rc;
+                rc = launch_conv2d(xin, cin, ws.rh, F[k], p[6], p[7], H, W, F[k], ws.c, so, 1, st);
+                if (rc) return rc;
+            }
+            gru_blend_fused_kernel<<<mvs_cdiv(hw_ll * F[k], 256), 256, 0, st>>>(
+                ws.c, so, p[8], p[9], ws.g, sg + 2, p[4], p[5], H * W, F[k], hs[k]);
+            if ((rc = (int)hipGetLastError())) return rc;
             xin = hs[k];
             cin = F[k];
         }
-        rc = launch_conv2d(ws.h3, f3, nullptr, 0, params[30], params[31], H, W, 1, ws.reg, nullptr, 1, st);
-        if (rc) return rc;
-        rc = mvs_wta_update_f32(ws.reg, depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum, stream);
-        if (rc) return rc;
+        // prob_conv + exp + winner-take-all update (model.py:701-731)
+        const int grid = mvs_cdiv(hw_ll, 256);
+        switch (f3) {
+            case 1: prob_wta_kernel<1><<<grid, 256, 0, st>>>(ws.h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+            case 2: prob_wta_kernel<2><<<grid, 256, 0, st>>>(ws.h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+            case 4: prob_wta_kernel<4><<<grid, 256, 0, st>>>(ws.h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+            default:
+                rc = launch_conv2d(ws.h3, f3, nullptr, 0, params[30], params[31], H, W, 1, ws.reg, nullptr, 1, st);
+                if (rc) return rc;
+                rc = mvs_wta_update_f32(ws.reg, depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum, stream);
+                if (rc) return rc;
+        }
+        if ((rc = (int)hipGetLastError())) return rc;
     }
     return mvs_wta_finish_f32(ws.max_prob, ws.exp_sum, H, W, prob_out, stream);
 }
