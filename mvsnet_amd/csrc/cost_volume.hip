@@ -236,7 +236,7 @@ template <int NSRC>
 void launch_sweep(const float* ref, const float* src, const float* transforms, int depth_total,
                   int d_begin, int d_count, int H, int W, int C, int variant, int negate,
                   float* cost, hipStream_t st) {
-    const int ppb = 16;
+    const int ppb = d_count < 16 ? d_count : 16;
     long long total = (long long)H * W * (C / 4);
     dim3 grid(mvs_cdiv(total, 256), mvs_cdiv(d_count, ppb));
     cost_volume_sweep_kernel<NSRC><<<grid, 256, 0, st>>>(ref, src, transforms, depth_total, d_begin,
@@ -272,7 +272,7 @@ extern "C" int mvs_cost_volume_f32(const float* ref, const float* src, const flo
     dim3 grid(mvs_cdiv(total, 256), d_count);
     const int cq_ = C / 4;
     const bool cq_pow2 = cq_ <= 16 && (cq_ & (cq_ - 1)) == 0;     // lanes of a pixel stay inside one wave
-    if (border == 0 && d_count >= 4 && view_num <= 8 && cq_pow2 && (long long)H * W * C < (1LL << 30)) {      // depth sweep with register tap reuse
+    if (border == 0 && view_num <= 8 && cq_pow2 && (long long)H * W * C < (1LL << 30)) {      // depth sweep with register tap reuse
         hipStream_t st = mvs_stream(stream);
 #define MVS_SWEEP(NS) case NS: launch_sweep<NS>(ref, src, transforms, depth_total, d_begin, d_count, H, W, C, variant, negate, cost, st); break;
         switch (view_num - 1) {

@@ -149,6 +149,120 @@ wta_finish_kernel(const float* __restrict__ max_prob, const float* __restrict__ 
     if (i < HW) prob[i] = max_prob[i] / (exp_sum[i] + 1e-7f);     // model.py:749-751
 }
 
+template <int N>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&o)[N]) {
+    if constexpr (N % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) { float4 t = *(const float4*)(p + 4 * i); o[4*i] = t.x; o[4*i+1] = t.y; o[4*i+2] = t.z; o[4*i+3] = t.w; }
+    } else if constexpr (N % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) { float2 t = *(const float2*)(p + 2 * i); o[2*i] = t.x; o[2*i+1] = t.y; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = p[i];
+    }
+}
+
+// Small-channel 3x3 convolution over [xa | xb] for ConvGRU cells 2 and 3 (20 -> 8/4, 6 -> 4/2
+// channels): vector loads of whole pixels, weights broadcast from LDS.  MODE 1 folds the reset gate
+// into the read of xb: xb = sigmoid(LayerNorm(g_r)) * h (convgru.py:97,101,107).
+template <int CA, int CB, int CO, int MODE>
+__global__ void __launch_bounds__(256)
+conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                    const float* __restrict__ g, const double* __restrict__ g_stats,
+                    const float* __restrict__ r_gamma, const float* __restrict__ r_beta,
+                    const float* __restrict__ w, const float* __restrict__ bias, int H, int W,
+                    float* __restrict__ y, double* __restrict__ stats, int groups) {
+    constexpr int CT = CA + CB;
+    __shared__ __attribute__((aligned(16))) float wsh[9 * CT * CO];
+    __shared__ float red[4][2][2];
+    for (int i = threadIdx.x; i < 9 * CT * CO; i += 256) wsh[i] = w[i];
+    float ra[CB], rb[CB];
+    if (MODE == 1) {
+        const double cnt = (double)H * W * CB;
+        double mean = g_stats[0] / cnt;
+        double var = g_stats[1] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+#pragma unroll
+        for (int f = 0; f < CB; ++f) {
+            double inv = (double)r_gamma[f] / sqrt(var + 1e-12);
+            ra[f] = (float)inv; rb[f] = (float)((double)r_beta[f] - mean * inv);
+        }
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = pix < H * W;
+    float acc[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) acc[j] = bias ? bias[j] : 0.f;
+    if (valid) {
+        const int py = pix / W, px = pix - py * W;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = py + kh - 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = px + kw - 1;
+                if (ix < 0 || ix >= W) continue;
+                const size_t p = (size_t)iy * W + ix;
+                float va[CA], vb[CB];
+                load_vec<CA>(xa + p * CA, va);
+                load_vec<CB>(xb + p * CB, vb);
+                if (MODE == 1) {
+                    float gr[CB];
+                    load_vec<CB>(g + p * 2 * CB, gr);
+#pragma unroll
+                    for (int f = 0; f < CB; ++f) vb[f] *= 1.0f / (1.0f + expf(-(gr[f] * ra[f] + rb[f])));
+                }
+                const float* wt = wsh + (kh * 3 + kw) * CT * CO;
+#pragma unroll
+                for (int ci = 0; ci < CA; ++ci)
+#pragma unroll
+                    for (int j = 0; j < CO; ++j) acc[j] += va[ci] * wt[ci * CO + j];
+#pragma unroll
+                for (int ci = 0; ci < CB; ++ci)
+#pragma unroll
+                    for (int j = 0; j < CO; ++j) acc[j] += vb[ci] * wt[(CA + ci) * CO + j];
+            }
+        }
+        float* dst = y + (size_t)pix * CO;
+#pragma unroll
+        for (int j = 0; j < CO; ++j) dst[j] = acc[j];
+    }
+    if (stats) {
+        const int per = CO / groups;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int gi = 0; gi < groups; ++gi) {
+            float sv = 0.f, qv = 0.f;
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < CO; ++j)
+                    if (j / per == gi) { sv += acc[j]; qv += acc[j] * acc[j]; }
+            }
+            sv = wave_sum(sv); qv = wave_sum(qv);
+            if (lane == 0) { red[wv][gi][0] = sv; red[wv][gi][1] = qv; }
+        }
+        __syncthreads();
+        if (threadIdx.x < groups * 2) {
+            int gi = threadIdx.x >> 1, k = threadIdx.x & 1;
+            double t = (double)red[0][gi][k] + (double)red[1][gi][k] + (double)red[2][gi][k] + (double)red[3][gi][k];
+            atomicAdd(&stats[gi * 2 + k], t);
+        }
+    }
+}
+
+// cells 2 / 3: gate conv then candidate conv (reset gate folded in); false if the shape has no instance
+template <int CA, int F>
+bool launch_small_cell(const float* xin, float* h, const float* const* p, int H, int W, float* g, float* c,
+                       double* sg, double* so, hipStream_t st) {
+    const int grid = mvs_cdiv((long long)H * W, 256);
+    conv2d_small_kernel<CA, F, 2 * F, 0><<<grid, 256, 0, st>>>(xin, h, nullptr, nullptr, nullptr, nullptr,
+                                                               p[0], p[1], H, W, g, sg, 2);
+    conv2d_small_kernel<CA, F, F, 1><<<grid, 256, 0, st>>>(xin, h, g, sg, p[2], p[3], p[6], p[7], H, W, c, so, 1);
+    return true;
+}
+
 // blend with the update gate evaluated in place: h = u*h + (1-u)*tanh(LN(c)), u = sigmoid(LN(g_u))
 // (convgru.py:98,102,114-120); g holds the raw gate convolution (reset | update).
 __global__ void __launch_bounds__(256)
@@ -335,6 +449,10 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
             if (k == 0 && mfma1) {
                 if ((rc = mvs_gru1_gates_mfma(xin, hs[0], ws.wprep_g, p[1], H, W, C, f1, ws.g, sg, st))) return rc;
                 if ((rc = mvs_gru1_out_mfma(xin, hs[0], ws.g, sg, p[2], p[3], ws.wprep_o, p[7], H, W, C, f1, ws.c, so, st))) return rc;
+            } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hs[k], p, H, W, ws.g, ws.c, sg, so, st)) {
+            } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hs[k], p, H, W, ws.g, ws.c, sg, so, st)) {
+            } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hs[k], p, H, W, ws.g, ws.c, sg, so, st)) {
+            } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hs[k], p, H, W, ws.g, ws.c, sg, so, st)) {
             } else {
                 rc = launch_conv2d(xin, cin, hs[k], F[k], p[0], p[1], H, W, 2 * F[k], ws.g, sg, 2, st);
                 if (rc) return rc;

@@ -153,26 +153,29 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[m][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh) {
+        {   // software-pipelined sweep (see conv3d_mfma.hip): group g+1's LDS reads are interleaved
+            // with group g's MFMAs; a lone wave per SIMD never idles the matrix pipe on LDS latency
+            constexpr int NG = 9 * (CT / 16), NR = V + MT, NM = 4 * MT * V;
+            f32x4 bv[2][V], av[2][MT];
+            auto load_one = [&](int g, int r, f32x4 (&b)[V], f32x4 (&aop)[MT]) __attribute__((always_inline)) {
+                const int tap = g / (CT / 16), s = g % (CT / 16);
+                const int kh = tap / 3, kw = tap % 3;
+                if (r < V) b[r] = *(const f32x4*)(cur + b_off[r] + (kh * PW2 + kw) * S + 16 * s);
+                else aop[r - V] = *(const f32x4*)(wl + a_off + (r - V) * 64 + (tap * CQ + 4 * s) * WROW);
+            };
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
+            for (int r = 0; r < NR; ++r) load_one(0, r, bv[0], av[0]);
 #pragma unroll
-                for (int s = 0; s < CT / 16; ++s) {
-                    f32x4 bv[V], av[MT];
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v)
-                        bv[v] = *(const f32x4*)(cur + b_off[v] + (kh * PW2 + kw) * S + 16 * s);
+                for (int r = 0; r < NR; ++r) {
+                    if (g + 1 < NG) load_one(g + 1, r, bv[(g + 1) & 1], av[(g + 1) & 1]);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        av[m] = *(const f32x4*)(wl + a_off + m * 64 + ((kh * 3 + kw) * CQ + 4 * s) * WROW);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-#pragma unroll
-                            for (int v = 0; v < V; ++v)
-                                acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][j], bv[v][j], acc[m][v], 0, 0, 0);
+                    for (int i = (r * NM) / NR; i < ((r + 1) * NM) / NR; ++i) {
+                        const int j = i / (MT * V), m = (i / V) % MT, v = i % V;
+                        acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][j], bv[g & 1][v][j], acc[m][v], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
