@@ -76,39 +76,46 @@ deconv3d_kernel(ConvArgs a) {
 
     float4 pre[NIT];
     float4 pre2[HAS_X2 ? NIT : 1];
+    // Per-thread staging map, identical for every plane: element offset inside one input plane
+    // (-1 = outside the volume -> SAME padding zero) and float offset inside the LDS slab (-1 = none).
+    int goff[NIT], loff[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        int f = tid + 256 * i;
+        int pos = f / CQ;
+        int r = pos / PW, c = pos - r * PW;
+        int gh = h0 - 1 + r, gw = w0 - 1 + c;
+        bool inb = (f < NF4) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        goff[i] = inb ? (gh * a.W + gw) * CIN + 4 * c4 : -1;
+        loff[i] = (f < NF4) ? (pos) * S + 4 * c4 : -1;
+    }
+    const size_t plane_elems = (size_t)a.H * a.W * CIN;
+
     auto issue_loads = [&](int q) __attribute__((always_inline)) {
         const bool plane_ok = (q >= 0) && (q < a.D);
+        const float* px = a.x + (size_t)(plane_ok ? q : 0) * plane_elems;
+        const float* px2 = HAS_X2 ? a.x2 + (size_t)(plane_ok ? q : 0) * plane_elems : nullptr;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            int f = tid + 256 * i;
-            int pos = f / CQ;
-            int r = pos / PW, c = pos - r * PW;
-            int gh = h0 - 1 + r, gw = w0 - 1 + c;
-            bool ok = plane_ok && (f < NF4) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-            size_t off = ((((size_t)q * a.H + gh) * a.W) + gw) * CIN + 4 * c4;
-            pre[i] = ok ? *(const float4*)(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (HAS_X2) pre2[i] = ok ? *(const float4*)(a.x2 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = plane_ok && goff[i] >= 0;
+            pre[i] = ok ? *(const float4*)(px + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (HAS_X2) pre2[i] = ok ? *(const float4*)(px2 + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto write_slab = [&](int q, float* buf) __attribute__((always_inline)) {
         const bool plane_ok = (q >= 0) && (q < a.D);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            int f = tid + 256 * i;
-            if (f >= NF4) continue;
-            int pos = f / CQ;
-            int r = pos / PW, c = pos - r * PW;
-            int gh = h0 - 1 + r, gw = w0 - 1 + c;
-            bool ok = plane_ok && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+            if (loff[i] < 0) continue;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
+            if (plane_ok && goff[i] >= 0) {             // SAME padding pads the NORMALISED input with 0
                 v = bn_relu4(pre[i], sc, sh, has_aff);
                 if (HAS_X2) {
                     float4 v2 = bn_relu4(pre2[i], sc2, sh2, has_aff2);
                     v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
                 }
             }
-            *(float4*)(buf + pos * S + 4 * c4) = v;
+            *(float4*)(buf + loff[i]) = v;
         }
     };
 
