@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="M", help="M (metric), c1, c2, small, toy")
     ap.add_argument("--network-mode", default="normal")
-    ap.add_argument("--conv-impl", default="auto", choices=["auto", "scalar", "mfma"])
+    ap.add_argument("--conv-impl", default="auto", choices=["auto", "scalar", "mfma", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MVS_BENCH_STREAMS", "1")),
@@ -257,7 +257,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.conv_impl != "bf16x3" else "bf16x3 (fp32 operands split into two bf16, fp32 accumulate; opt-in)",
+            "data": "synthetic",
             "config": {"workload": "%s: features->depth, N=%d views, D=%d planes, %dx%d feature maps, C=%d, "
                                    "3D-CNN regulariser (RegNetUS0), network_mode=%s; one reference view per "
                                    "step per GPU, sharded by reference view" % (

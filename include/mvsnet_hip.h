@@ -35,6 +35,9 @@ extern "C" {
 #define MVS_CONV_IMPL_AUTO   0
 #define MVS_CONV_IMPL_SCALAR 1
 #define MVS_CONV_IMPL_MFMA   2
+/* opt-in: stride-1 MFMA layers evaluate fp32 products as three bf16 MFMAs (x = hi + lo split,
+ * fp32 accumulate, ~1.5e-5 relative error per product); only through mvs_regnet_us0_prepared_f32 */
+#define MVS_CONV_IMPL_BF16X3 3
 
 int mvs_abi_version(void);
 /* Static description of a return code (never NULL). */

@@ -47,7 +47,7 @@ SIGNATURES = {
     "mvs_gru_wta_f32": (_i, [_p, _p, _p] + [_i] * 8 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
 }
 
-CONV_IMPL = {"auto": 0, "scalar": 1, "mfma": 2}
+CONV_IMPL = {"auto": 0, "scalar": 1, "mfma": 2, "bf16x3": 3}
 
 _lib = None
 

@@ -290,6 +290,7 @@ int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
 static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t st) {
     if (stride == 1) {
         if (Cout == 1) return mvs_conv3d_out_launch(a, Cin, st);
+        if (a.wprep_bf && mvs_conv3d_bf16x3_supported(Cin, Cout)) return mvs_conv3d_s1_bf16x3(a, Cin, Cout, st);
         if (Cin == 32 && Cout == 8) return launch_s1<32, 8, 8>(a, Cout, st);
         if (Cin == 16 && Cout % 16 == 0) return launch_s1<16, 16, 8>(a, Cout, st);
         if (Cin == 32 && Cout % 16 == 0) return launch_s1<32, 16, 8>(a, Cout, st);
@@ -305,29 +306,29 @@ static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t
 int mvs_conv3d_mfma(const float* x, const float* xs, const float* xb, const float* x2,
                     const float* x2s, const float* x2b, const float* w, int D, int H, int W,
                     int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, {}, {}, nullptr};
+    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, {}, {}, nullptr, nullptr};
     return conv_dispatch(a, Cin, Cout, stride, st);
 }
 
 int mvs_deconv3d_mfma(const float* x, const float* xs, const float* xb, const float* x2,
                       const float* x2s, const float* x2b, const float* w, int D, int H, int W,
                       int Cin, int Cout, float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, {}, {}, nullptr};
+    ConvArgs a{x, xs, xb, x2, x2s, x2b, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, {}, {}, nullptr, nullptr};
     return mvs_deconv3d_mfma_launch(a, Cin, Cout, st);
 }
 
 // Variants taking the producers' raw BatchNorm sums (regnet.hip): no bn_finalize launch in between.
 int mvs_conv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
-                       const float* w, const float* wprep, int D, int H, int W, int Cin, int Cout,
-                       int stride, float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep};
+                       const float* w, const float* wprep, const unsigned short* wprep_bf, int D, int H,
+                       int W, int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st) {
+    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep, wprep_bf};
     return conv_dispatch(a, Cin, Cout, stride, st);
 }
 
 int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
                          const float* w, const float* wprep, int D, int H, int W, int Cin, int Cout,
                          float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep};
+    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep, nullptr};
     return mvs_deconv3d_mfma_launch(a, Cin, Cout, st);
 }
 

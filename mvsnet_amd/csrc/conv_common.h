@@ -39,6 +39,7 @@ struct ConvArgs {
     int pd, ph, pw;                                         // SAME pad_before per axis (stride 2)
     BnSrc bn, bn2;                                          // alternative to xs/xb, x2s/x2b (stats given)
     const float* wprep;                                     // weights already in the kernel's LDS order, or null
+    const unsigned short* wprep_bf;                         // bf16 hi|lo split weights (opt-in bf16x3 path), or null
 };
 
 constexpr int CONV_TW = 16;      // voxels per MFMA column tile (along w)
@@ -133,3 +134,7 @@ __device__ __forceinline__ void load_prepared_weights(float* wl, const float* wp
 int mvs_conv3d_s2_mfma(const ConvArgs& a, int Cin, int Cout, hipStream_t st);
 int mvs_deconv3d_mfma_launch(const ConvArgs& a, int Cin, int Cout, hipStream_t st);
 int mvs_conv3d_out_launch(const ConvArgs& a, int Cin, hipStream_t st);
+// opt-in split-precision stride-1 path (conv3d_bf16x3.hip)
+bool mvs_conv3d_bf16x3_supported(int Cin, int Cout);
+int mvs_conv3d_s1_bf16x3(const ConvArgs& a, int Cin, int Cout, hipStream_t st);
+int mvs_conv_weight_split(const float* w, int Cin, int Cout, unsigned short* out, hipStream_t st);

@@ -19,8 +19,8 @@ int mvs_deconv3d_mfma(const float*, const float*, const float*, const float*, co
                       hipStream_t);
 // same, taking the producers' raw BatchNorm sums instead of a finalised (scale, shift)
 int mvs_conv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
-                       const float* w, const float* wprep, int D, int H, int W, int Cin, int Cout,
-                       int stride, float* y, double* stats, hipStream_t st);
+                       const float* w, const float* wprep, const unsigned short* wprep_bf, int D, int H,
+                       int W, int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st);
 int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
                          const float* w, const float* wprep, int D, int H, int W, int Cin, int Cout,
                          float* y, double* stats, hipStream_t st);
@@ -40,7 +40,7 @@ extern "C" const char* mvs_error_string(int code) {
 }
 
 extern "C" int mvs_set_conv_impl(int impl) {
-    if (impl < MVS_CONV_IMPL_AUTO || impl > MVS_CONV_IMPL_MFMA) return MVS_E_BADARG;
+    if (impl < MVS_CONV_IMPL_AUTO || impl > MVS_CONV_IMPL_BF16X3) return MVS_E_BADARG;
     g_conv_impl = impl;
     return 0;
 }
@@ -122,7 +122,7 @@ extern "C" size_t mvs_regnet_workspace_bytes(int D, int H, int W, int cin, int b
 
 namespace {
 // layer table (order of the weights array) and offsets of the pre-laid-out weights
-struct PrepLayout { int kind[11]; int ci[11]; int co[11]; size_t off[11]; bool ok[11]; size_t total; };
+struct PrepLayout { int kind[11]; int ci[11]; int co[11]; size_t off[11]; bool ok[11]; bool bf[11]; size_t total; };
 PrepLayout prep_layout(int cin, int b) {
     PrepLayout L;
     const int kind[11] = {1, 1, 1, 0, 0, 0, 0, 2, 2, 2, 0};
@@ -132,6 +132,7 @@ PrepLayout prep_layout(int cin, int b) {
     for (int i = 0; i < 11; ++i) {
         L.kind[i] = kind[i]; L.ci[i] = ci[i]; L.co[i] = co[i]; L.off[i] = off;
         L.ok[i] = (i != L62) && (ci[i] % 4 == 0) && conv_coutg(kind[i], ci[i], co[i]) != 0;
+        L.bf[i] = L.ok[i] && kind[i] == 0 && mvs_conv3d_bf16x3_supported(ci[i], co[i]);
         off += (size_t)27 * ci[i] * co[i];
     }
     L.total = off;
@@ -141,7 +142,7 @@ PrepLayout prep_layout(int cin, int b) {
 
 extern "C" size_t mvs_regnet_prepared_floats(int cin, int base) {
     if (cin <= 0 || base <= 0) return 0;
-    return prep_layout(cin, base).total;
+    return 2 * prep_layout(cin, base).total;      // fp32 layouts, then bf16 hi|lo layouts
 }
 
 extern "C" int mvs_regnet_prepare_f32(const float* const* weights, int cin, int base, float* prepared,
@@ -152,6 +153,11 @@ extern "C" int mvs_regnet_prepare_f32(const float* const* weights, int cin, int 
         if (!L.ok[i]) continue;
         int rc = mvs_conv_weight_layout(weights[i], L.kind[i], L.ci[i], L.co[i], prepared + L.off[i], mvs_stream(stream));
         if (rc) return rc;
+        if (L.bf[i]) {
+            rc = mvs_conv_weight_split(weights[i], L.ci[i], L.co[i],
+                                       reinterpret_cast<unsigned short*>(prepared + L.total + L.off[i]), mvs_stream(stream));
+            if (rc) return rc;
+        }
     }
     return 0;
 }
@@ -196,9 +202,12 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
         double* so = out == L62 ? nullptr : st(out);
         if (g_conv_impl != MVS_CONV_IMPL_SCALAR) {
             const float* wp = (prepared && lay.ok[out]) ? prepared + lay.off[out] : nullptr;
+            // opt-in split-precision path: bf16 hi|lo weights live behind the fp32 layouts
+            const unsigned short* wbf = (prepared && g_conv_impl == MVS_CONV_IMPL_BF16X3 && lay.bf[out])
+                ? reinterpret_cast<const unsigned short*>(prepared + lay.total + lay.off[out]) : nullptr;
             int r = deconv ? mvs_deconv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, d, h, w, ci, co, y, so, hs)
-                           : mvs_conv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, d, h, w, ci, co, stride, y, so, hs);
-            if (r != MVS_E_SHAPE || g_conv_impl == MVS_CONV_IMPL_MFMA) return r;
+                           : mvs_conv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, wbf, d, h, w, ci, co, stride, y, so, hs);
+            if (r != MVS_E_SHAPE || g_conv_impl == MVS_CONV_IMPL_MFMA || g_conv_impl == MVS_CONV_IMPL_BF16X3) return r;
         }
         int r;
         if ((r = ensure_final(p1)) || (r = ensure_final(p2))) return r;
