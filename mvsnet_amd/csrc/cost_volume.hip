@@ -16,6 +16,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <typename R>
+__device__ __forceinline__ float4 ldb(R rsrc, int byte_off) {      // buffer_load_dwordx4 ... offen
+    u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
 __device__ __forceinline__ float4 fma4(float w, float4 a, float4 acc) {
     acc.x += w * a.x; acc.y += w * a.y; acc.z += w * a.z; acc.w += w * a.w;
     return acc;
@@ -118,42 +125,50 @@ cost_volume_kernel(const float* __restrict__ ref, const float* __restrict__ src,
 // neighbourhood is kept in registers and re-fetched only when floor(sx) or floor(sy) changes:
 // tap traffic to L1/L2 drops from 16 x 16 B per voxel-lane to a few, the kernel becomes bound by
 // the coalesced HBM write of the volume.  Zero fill per tap exactly as warp_sample<0>.
-template <int NSRC>
+template <int NSRC, int Q>       // Q float4 per lane: 4*Q channels per lane, C/(4*Q) lanes per pixel
 __global__ void __launch_bounds__(256)
 cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict__ src,
                          const float* __restrict__ transforms, int depth_total, int d_begin,
                          int d_count, int planes_per_block, int H, int W, int C, int variant,
                          int negate, float* __restrict__ cost) {
-    const int cq = C >> 2;
-    const long long total = (long long)H * W * cq;
+    const int lg = C / (4 * Q);                           // lanes per pixel: power of two (host-checked)
+    const long long total = (long long)H * W * lg;
     long long idx = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int dl0 = blockIdx.y * planes_per_block;
     const int dl1 = min(dl0 + planes_per_block, d_count);
-    const int c = (int)(idx % cq) * 4;
-    const long long pix = idx / cq;
+    const int sub = threadIdx.x & (lg - 1);
+    const int c = sub * 4 * Q;                            // first channel of this lane
+    const long long pix = idx / lg;
     const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
     const float xf = (float)x, yf = (float)y;
-    const size_t img_elems = (size_t)H * W * C;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const float4 r = ld4(ref + (size_t)pix * C + c);
-    const float4 r2 = make_float4(r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w);
-    float cx0[NSRC], cy0[NSRC];
-    float4 t00[NSRC], t01[NSRC], t10[NSRC], t11[NSRC];
+    f32x2 rr[2 * Q], rq[2 * Q];                           // reference feature and its square, channel pairs
 #pragma unroll
-    for (int v = 0; v < NSRC; ++v) { cx0[v] = -3.0e38f; cy0[v] = -3.0e38f; t00[v] = t01[v] = t10[v] = t11[v] = z4; }
+    for (int k = 0; k < Q; ++k) {
+        const float4 r = ld4(ref + (size_t)pix * C + c + 4 * k);
+        rr[2 * k] = (f32x2){r.x, r.y}; rr[2 * k + 1] = (f32x2){r.z, r.w};
+        rq[2 * k] = rr[2 * k] * rr[2 * k]; rq[2 * k + 1] = rr[2 * k + 1] * rr[2 * k + 1];
+    }
+    float cx0[NSRC], cy0[NSRC], mx0[NSRC], mx1[NSRC], my0[NSRC], my1[NSRC];
+    float4 t00[NSRC][Q], t01[NSRC][Q], t10[NSRC][Q], t11[NSRC][Q];
+    const auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, NSRC * H * W * C * 4, 0x00020000);
+    const int pix_bytes = C * 4, row_bytes = W * C * 4, img_bytes = H * W * C * 4, lane_bytes = c * 4;
+#pragma unroll
+    for (int v = 0; v < NSRC; ++v) {
+        cx0[v] = -3.0e38f; cy0[v] = -3.0e38f; mx0[v] = mx1[v] = my0[v] = my1[v] = 0.f;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) t00[v][k] = t01[v][k] = t10[v][k] = t11[v][k] = z4;
+    }
     // One IEEE division each, hoisted out of the sweep: the per-plane scalings become multiplies
     // (differs from Q/N, S*S/(N*N) by at most 1 ulp; the single-pass E[x^2]-E[x]^2 form is kept).
     const float n = (float)(NSRC + 1);
     const float inv_n = 1.0f / n, inv_nn = 1.0f / (n * n);
 
-    // The C/4 lanes of a pixel share their sample coordinates: lane `sub` evaluates the projective
-    // map for plane (batch + sub) of every view, and the pixel's lanes then fetch plane p's (sx, sy)
-    // from lane `base + p` with ds_bpermute.  The ~30 VALU instructions of the coordinate math are
-    // thereby paid once per lg planes instead of once per plane (the kernel is VALU-bound).
-    const int lg = cq;                                   // lanes per pixel: power of two (checked by the host)
-    const int sub = threadIdx.x & (lg - 1);
+    // The lanes of a pixel share their sample coordinates: lane `sub` evaluates the projective map for
+    // plane (batch + sub) of every view, and the pixel's lanes then fetch plane p's (sx, sy) from lane
+    // `base + p` with ds_bpermute: the coordinate math is paid once per lg planes (kernel is VALU-bound).
     const int base_lane = (threadIdx.x & 63) - sub;
 
     for (int dlb = dl0; dlb < dl1; dlb += lg) {
@@ -175,59 +190,71 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
             const int dl = dlb + p;
             const int srcl = base_lane + p;
             // phase A: fetch this plane's sample points, refill the tap cache where floor() moved.
-            // Taps are loaded from CLAMPED addresses; the zero fill is applied through the weights
-            // below (w * finite = 0 exactly), so the only divergent region is four loads per view and
-            // every view's loads are in flight before the first one is consumed.
-            float sxs[NSRC], sys_[NSRC], x0s[NSRC], y0s[NSRC];
+            // Taps come from CLAMPED addresses (32-bit buffer offsets); the per-tap zero fill is applied
+            // through 0/1 factors on the separable weights (w * finite = 0 exactly), refreshed together
+            // with the taps.  Every view's loads are in flight before the first one is consumed.
+            float sxs[NSRC], sys_[NSRC];
 #pragma unroll
             for (int v = 0; v < NSRC; ++v) {
-                const float* img = src + v * img_elems;
                 float sx = __shfl(msx[v], srcl, 64);
                 float sy = __shfl(msy[v], srcl, 64);
                 float x0 = floorf(sx), y0 = floorf(sy);
-                sxs[v] = sx; sys_[v] = sy; x0s[v] = x0; y0s[v] = y0;
+                sxs[v] = sx; sys_[v] = sy;
                 if (x0 != cx0[v] || y0 != cy0[v]) {
                     int ix0 = (int)x0, iy0 = (int)y0;                     // v_cvt saturates, NaN -> 0
                     int jx0 = min(max(ix0, 0), W - 1), jx1 = min(max(ix0 + 1, 0), W - 1);
                     int jy0 = min(max(iy0, 0), H - 1), jy1 = min(max(iy0 + 1, 0), H - 1);
-                    // 32-bit offsets: one feature map is far below 2^31 elements (checked by the host)
-                    const int r0 = jy0 * W, r1 = jy1 * W;
-                    t00[v] = ld4(img + ((r0 + jx0) * C + c)); t01[v] = ld4(img + ((r0 + jx1) * C + c));
-                    t10[v] = ld4(img + ((r1 + jx0) * C + c)); t11[v] = ld4(img + ((r1 + jx1) * C + c));
+                    const int r0 = v * img_bytes + jy0 * row_bytes + lane_bytes;
+                    const int r1 = v * img_bytes + jy1 * row_bytes + lane_bytes;
+#pragma unroll
+                    for (int k = 0; k < Q; ++k) {
+                        t00[v][k] = ldb(srsrc, r0 + jx0 * pix_bytes + 16 * k); t01[v][k] = ldb(srsrc, r0 + jx1 * pix_bytes + 16 * k);
+                        t10[v][k] = ldb(srsrc, r1 + jx0 * pix_bytes + 16 * k); t11[v][k] = ldb(srsrc, r1 + jx1 * pix_bytes + 16 * k);
+                    }
+                    mx1[v] = (ix0 >= 0 && ix0 < W) ? 1.0f : 0.0f;
+                    mx0[v] = (ix0 + 1 >= 0 && ix0 + 1 < W) ? 1.0f : 0.0f;
+                    my1[v] = (iy0 >= 0 && iy0 < H) ? 1.0f : 0.0f;
+                    my0[v] = (iy0 + 1 >= 0 && iy0 + 1 < H) ? 1.0f : 0.0f;
                     cx0[v] = x0; cy0[v] = y0;
                 }
             }
             // phase B: bilinear blend + running sums, two channels per packed instruction
-            f32x2 S0 = (f32x2){r.x, r.y}, S1 = (f32x2){r.z, r.w};
-            f32x2 Q0 = (f32x2){r2.x, r2.y}, Q1 = (f32x2){r2.z, r2.w};
-            const float wmax = (float)(W - 1), hmax = (float)(H - 1);
+            f32x2 S[2 * Q], Qs[2 * Q];
+#pragma unroll
+            for (int k = 0; k < 2 * Q; ++k) { S[k] = rr[k]; Qs[k] = rq[k]; }
 #pragma unroll
             for (int v = 0; v < NSRC; ++v) {
-                const float sx = sxs[v], sy = sys_[v], x0 = x0s[v], y0 = y0s[v];
-                // per-tap zero fill folded into the separable weights (tap (y,x) is dropped iff its
-                // row or its column is outside the image, exactly as reading 0 for it)
-                float wx1 = (x0 >= 0.0f && x0 <= wmax) ? (x0 + 1.0f) - sx : 0.0f;
-                float wx0 = (x0 >= -1.0f && x0 <= wmax - 1.0f) ? sx - x0 : 0.0f;
-                float wy1 = (y0 >= 0.0f && y0 <= hmax) ? (y0 + 1.0f) - sy : 0.0f;
-                float wy0 = (y0 >= -1.0f && y0 <= hmax - 1.0f) ? sy - y0 : 0.0f;
-                f32x2 a0 = (f32x2){t00[v].x, t00[v].y}, a1 = (f32x2){t00[v].z, t00[v].w};
-                f32x2 b0 = (f32x2){t01[v].x, t01[v].y}, b1 = (f32x2){t01[v].z, t01[v].w};
-                f32x2 c0 = (f32x2){t10[v].x, t10[v].y}, c1 = (f32x2){t10[v].z, t10[v].w};
-                f32x2 e0 = (f32x2){t11[v].x, t11[v].y}, e1 = (f32x2){t11[v].z, t11[v].w};
-                f32x2 w0 = wy1 * (wx1 * a0 + wx0 * b0) + wy0 * (wx1 * c0 + wx0 * e0);
-                f32x2 w1 = wy1 * (wx1 * a1 + wx0 * b1) + wy0 * (wx1 * c1 + wx0 * e1);
-                S0 += w0; S1 += w1;
-                Q0 += w0 * w0; Q1 += w1 * w1;
+                const float sx = sxs[v], sy = sys_[v], x0 = cx0[v], y0 = cy0[v];
+                float wx1 = mx1[v] * ((x0 + 1.0f) - sx);
+                float wx0 = mx0[v] * (sx - x0);
+                float wy1 = my1[v] * ((y0 + 1.0f) - sy);
+                float wy0 = my0[v] * (sy - y0);
+#pragma unroll
+                for (int k = 0; k < Q; ++k) {
+                    f32x2 a0 = (f32x2){t00[v][k].x, t00[v][k].y}, a1 = (f32x2){t00[v][k].z, t00[v][k].w};
+                    f32x2 b0 = (f32x2){t01[v][k].x, t01[v][k].y}, b1 = (f32x2){t01[v][k].z, t01[v][k].w};
+                    f32x2 c0 = (f32x2){t10[v][k].x, t10[v][k].y}, c1 = (f32x2){t10[v][k].z, t10[v][k].w};
+                    f32x2 e0 = (f32x2){t11[v][k].x, t11[v][k].y}, e1 = (f32x2){t11[v][k].z, t11[v][k].w};
+                    f32x2 w0 = wy1 * (wx1 * a0 + wx0 * b0) + wy0 * (wx1 * c0 + wx0 * e0);
+                    f32x2 w1 = wy1 * (wx1 * a1 + wx0 * b1) + wy0 * (wx1 * c1 + wx0 * e1);
+                    S[2 * k] += w0; S[2 * k + 1] += w1;
+                    Qs[2 * k] += w0 * w0; Qs[2 * k + 1] += w1 * w1;
+                }
             }
-            f32x2 o0, o1;
-            if (variant == 0) {
-                o0 = Q0 * inv_n - (S0 * S0) * inv_nn; o1 = Q1 * inv_n - (S1 * S1) * inv_nn;
-            } else {
-                f32x2 m0 = S0 * inv_n, m1 = S1 * inv_n;
-                o0 = Q0 * inv_n - m0 * m0; o1 = Q1 * inv_n - m1 * m1;
+            float* dst = cost + ((size_t)dl * H * W + pix) * C + c;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                f32x2 o0, o1;
+                if (variant == 0) {
+                    o0 = Qs[2 * k] * inv_n - (S[2 * k] * S[2 * k]) * inv_nn;
+                    o1 = Qs[2 * k + 1] * inv_n - (S[2 * k + 1] * S[2 * k + 1]) * inv_nn;
+                } else {
+                    f32x2 m0 = S[2 * k] * inv_n, m1 = S[2 * k + 1] * inv_n;
+                    o0 = Qs[2 * k] * inv_n - m0 * m0; o1 = Qs[2 * k + 1] * inv_n - m1 * m1;
+                }
+                if (negate) { o0 = -o0; o1 = -o1; }
+                *reinterpret_cast<float4*>(dst + 4 * k) = make_float4(o0[0], o0[1], o1[0], o1[1]);
             }
-            if (negate) { o0 = -o0; o1 = -o1; }
-            *reinterpret_cast<float4*>(cost + ((size_t)dl * H * W + pix) * C + c) = make_float4(o0[0], o0[1], o1[0], o1[1]);
         }
     }
 }
@@ -237,10 +264,18 @@ void launch_sweep(const float* ref, const float* src, const float* transforms, i
                   int d_begin, int d_count, int H, int W, int C, int variant, int negate,
                   float* cost, hipStream_t st) {
     const int ppb = d_count < 16 ? d_count : 16;
-    long long total = (long long)H * W * (C / 4);
+    // Q = 2 (8 channels per lane) halves the per-lane bookkeeping per channel but needs 236 VGPRs
+    // (2 waves/SIMD instead of 3): measured 0.258 ms vs 0.243 ms at the metric config, so it stays off.
+    const bool wide = false;
+    const int lg = wide ? C / 8 : C / 4;
+    long long total = (long long)H * W * lg;
     dim3 grid(mvs_cdiv(total, 256), mvs_cdiv(d_count, ppb));
-    cost_volume_sweep_kernel<NSRC><<<grid, 256, 0, st>>>(ref, src, transforms, depth_total, d_begin,
-                                                         d_count, ppb, H, W, C, variant, negate, cost);
+    if (wide)
+        cost_volume_sweep_kernel<NSRC, 2><<<grid, 256, 0, st>>>(ref, src, transforms, depth_total, d_begin,
+                                                                d_count, ppb, H, W, C, variant, negate, cost);
+    else
+        cost_volume_sweep_kernel<NSRC, 1><<<grid, 256, 0, st>>>(ref, src, transforms, depth_total, d_begin,
+                                                                d_count, ppb, H, W, C, variant, negate, cost);
 }
 
 template <int BORDER>
