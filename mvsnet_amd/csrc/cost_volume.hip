@@ -151,13 +151,13 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
         rr[2 * k] = (f32x2){r.x, r.y}; rr[2 * k + 1] = (f32x2){r.z, r.w};
         rq[2 * k] = rr[2 * k] * rr[2 * k]; rq[2 * k + 1] = rr[2 * k + 1] * rr[2 * k + 1];
     }
-    float cx0[NSRC], cy0[NSRC], mx0[NSRC], mx1[NSRC], my0[NSRC], my1[NSRC];
+    int c00[NSRC], c11[NSRC];                             // cached tap identity (byte offsets of taps 00 / 11)
     float4 t00[NSRC][Q], t01[NSRC][Q], t10[NSRC][Q], t11[NSRC][Q];
     const auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, NSRC * H * W * C * 4, 0x00020000);
     const int pix_bytes = C * 4, row_bytes = W * C * 4, img_bytes = H * W * C * 4, lane_bytes = c * 4;
 #pragma unroll
     for (int v = 0; v < NSRC; ++v) {
-        cx0[v] = -3.0e38f; cy0[v] = -3.0e38f; mx0[v] = mx1[v] = my0[v] = my1[v] = 0.f;
+        c00[v] = -1; c11[v] = -1;
 #pragma unroll
         for (int k = 0; k < Q; ++k) t00[v][k] = t01[v][k] = t10[v][k] = t11[v][k] = z4;
     }
@@ -166,13 +166,16 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
     const float n = (float)(NSRC + 1);
     const float inv_n = 1.0f / n, inv_nn = 1.0f / (n * n);
 
-    // The lanes of a pixel share their sample coordinates: lane `sub` evaluates the projective map for
-    // plane (batch + sub) of every view, and the pixel's lanes then fetch plane p's (sx, sy) from lane
-    // `base + p` with ds_bpermute: the coordinate math is paid once per lg planes (kernel is VALU-bound).
+    // Plane-vectorised bookkeeping.  The kernel is VALU-bound and everything except the blend itself
+    // is identical for the lg lanes of a pixel, so lane `sub` does ALL the per-view bookkeeping of
+    // plane (batch + sub): projective map, floor, clamped tap offsets, zero-fill-masked weights.
+    // While sweeping plane p every lane fetches those 8 numbers per view from lane (base + p) with
+    // ds_bpermute (the LDS crossbar is otherwise idle here) and only pays for the loads and the blend.
     const int base_lane = (threadIdx.x & 63) - sub;
 
     for (int dlb = dl0; dlb < dl1; dlb += lg) {
-        float msx[NSRC], msy[NSRC];
+        int mo[NSRC][4];                                  // my plane: tap byte offsets 00, 01, 10, 11
+        float mw[NSRC][4];                                //           weights wx1, wx0, wy1, wy0 (masked)
         {
             const int dmy = d_begin + min(dlb + sub, dl1 - 1);
 #pragma unroll
@@ -181,41 +184,43 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
                 const float4 ta = ld4(t), tb = ld4(t + 4);
                 float proj = tb.z * xf + tb.w * yf + 1.0f;
                 float inv = __builtin_amdgcn_rcpf(proj);        // v_rcp_f32: 1 ulp, exact for proj = 1
-                msx[v] = (ta.x * xf + ta.y * yf + ta.z) * inv;
-                msy[v] = (ta.w * xf + tb.x * yf + tb.y) * inv;
+                float sx = (ta.x * xf + ta.y * yf + ta.z) * inv;
+                float sy = (ta.w * xf + tb.x * yf + tb.y) * inv;
+                float x0 = floorf(sx), y0 = floorf(sy);
+                int ix0 = (int)x0, iy0 = (int)y0;                // v_cvt saturates, NaN -> 0
+                int jx0 = min(max(ix0, 0), W - 1), jx1 = min(max(ix0 + 1, 0), W - 1);
+                int jy0 = min(max(iy0, 0), H - 1), jy1 = min(max(iy0 + 1, 0), H - 1);
+                const int r0 = v * img_bytes + jy0 * row_bytes, r1 = v * img_bytes + jy1 * row_bytes;
+                mo[v][0] = r0 + jx0 * pix_bytes; mo[v][1] = r0 + jx1 * pix_bytes;
+                mo[v][2] = r1 + jx0 * pix_bytes; mo[v][3] = r1 + jx1 * pix_bytes;
+                // per-tap zero fill folded into the separable weights: a tap is dropped iff its row or
+                // its column is outside the image, exactly as reading 0 for it (w * finite = 0)
+                mw[v][0] = (ix0 >= 0 && ix0 < W) ? (x0 + 1.0f) - sx : 0.0f;
+                mw[v][1] = (ix0 + 1 >= 0 && ix0 + 1 < W) ? sx - x0 : 0.0f;
+                mw[v][2] = (iy0 >= 0 && iy0 < H) ? (y0 + 1.0f) - sy : 0.0f;
+                mw[v][3] = (iy0 + 1 >= 0 && iy0 + 1 < H) ? sy - y0 : 0.0f;
             }
         }
         const int np = min(lg, dl1 - dlb);
         for (int p = 0; p < np; ++p) {
             const int dl = dlb + p;
             const int srcl = base_lane + p;
-            // phase A: fetch this plane's sample points, refill the tap cache where floor() moved.
-            // Taps come from CLAMPED addresses (32-bit buffer offsets); the per-tap zero fill is applied
-            // through 0/1 factors on the separable weights (w * finite = 0 exactly), refreshed together
-            // with the taps.  Every view's loads are in flight before the first one is consumed.
-            float sxs[NSRC], sys_[NSRC];
+            // phase A: this plane's tap offsets; refill the register tap cache where they moved.
+            // All views' loads are issued before the first one is consumed.
+            float wts[NSRC][4];
 #pragma unroll
             for (int v = 0; v < NSRC; ++v) {
-                float sx = __shfl(msx[v], srcl, 64);
-                float sy = __shfl(msy[v], srcl, 64);
-                float x0 = floorf(sx), y0 = floorf(sy);
-                sxs[v] = sx; sys_[v] = sy;
-                if (x0 != cx0[v] || y0 != cy0[v]) {
-                    int ix0 = (int)x0, iy0 = (int)y0;                     // v_cvt saturates, NaN -> 0
-                    int jx0 = min(max(ix0, 0), W - 1), jx1 = min(max(ix0 + 1, 0), W - 1);
-                    int jy0 = min(max(iy0, 0), H - 1), jy1 = min(max(iy0 + 1, 0), H - 1);
-                    const int r0 = v * img_bytes + jy0 * row_bytes + lane_bytes;
-                    const int r1 = v * img_bytes + jy1 * row_bytes + lane_bytes;
+                const int o00 = __shfl(mo[v][0], srcl, 64), o11 = __shfl(mo[v][3], srcl, 64);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wts[v][k] = __shfl(mw[v][k], srcl, 64);
+                if (o00 != c00[v] || o11 != c11[v]) {
+                    const int o01 = __shfl(mo[v][1], srcl, 64), o10 = __shfl(mo[v][2], srcl, 64);
 #pragma unroll
                     for (int k = 0; k < Q; ++k) {
-                        t00[v][k] = ldb(srsrc, r0 + jx0 * pix_bytes + 16 * k); t01[v][k] = ldb(srsrc, r0 + jx1 * pix_bytes + 16 * k);
-                        t10[v][k] = ldb(srsrc, r1 + jx0 * pix_bytes + 16 * k); t11[v][k] = ldb(srsrc, r1 + jx1 * pix_bytes + 16 * k);
+                        t00[v][k] = ldb(srsrc, o00 + lane_bytes + 16 * k); t01[v][k] = ldb(srsrc, o01 + lane_bytes + 16 * k);
+                        t10[v][k] = ldb(srsrc, o10 + lane_bytes + 16 * k); t11[v][k] = ldb(srsrc, o11 + lane_bytes + 16 * k);
                     }
-                    mx1[v] = (ix0 >= 0 && ix0 < W) ? 1.0f : 0.0f;
-                    mx0[v] = (ix0 + 1 >= 0 && ix0 + 1 < W) ? 1.0f : 0.0f;
-                    my1[v] = (iy0 >= 0 && iy0 < H) ? 1.0f : 0.0f;
-                    my0[v] = (iy0 + 1 >= 0 && iy0 + 1 < H) ? 1.0f : 0.0f;
-                    cx0[v] = x0; cy0[v] = y0;
+                    c00[v] = o00; c11[v] = o11;
                 }
             }
             // phase B: bilinear blend + running sums, two channels per packed instruction
@@ -224,11 +229,7 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
             for (int k = 0; k < 2 * Q; ++k) { S[k] = rr[k]; Qs[k] = rq[k]; }
 #pragma unroll
             for (int v = 0; v < NSRC; ++v) {
-                const float sx = sxs[v], sy = sys_[v], x0 = cx0[v], y0 = cy0[v];
-                float wx1 = mx1[v] * ((x0 + 1.0f) - sx);
-                float wx0 = mx0[v] * (sx - x0);
-                float wy1 = my1[v] * ((y0 + 1.0f) - sy);
-                float wy0 = my0[v] * (sy - y0);
+                const float wx1 = wts[v][0], wx0 = wts[v][1], wy1 = wts[v][2], wy0 = wts[v][3];
 #pragma unroll
                 for (int k = 0; k < Q; ++k) {
                     f32x2 a0 = (f32x2){t00[v][k].x, t00[v][k].y}, a1 = (f32x2){t00[v][k].z, t00[v][k].w};
