@@ -39,7 +39,7 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
     import torch
     from . import predictlib as pl
     from . import shard as sh
-    from .mvs_data_generation import ClusterGenerator
+    from .mvs_data_generation import make_generator
 
     config = config or pl.InferenceConfig()
     for k, v in kwargs.items():                       # predictlib.init_inference: kwargs -> flags
@@ -50,7 +50,7 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
     if device is None:
         device = torch.device("cuda", local_rank)
     output_dir = pl.setup_output_dir(input_dir, config.output_dir)
-    gen = ClusterGenerator(input_dir, config.view_num, config.width, config.height, config.max_d,
+    gen = make_generator(input_dir, config.view_num, config.width, config.height, config.max_d,
                            config.interval_scale, config.base_image_size, mode="inference",
                            output_scale=config.sample_scale,
                            max_clusters_per_session=config.max_clusters_per_session)
@@ -58,6 +58,11 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
     mine = sh.shard(clusters, rank, world)
     if weights is None:
         weights = build_weights(config, device)
+    # Per-image feature cache: the reference re-runs the UNetDS2GN tower on
+    # every source image of every cluster (model.py:392-406); an image's features only depend on
+    # the image and on the (rescale, crop) it received, so they are computed once per session and
+    # re-used by all the reference views that list the image as a source.
+    feature_cache = {}
     done = 0
     for c in mine:
         start = time.time()
@@ -66,14 +71,26 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
         except Exception as e:                        # skip-and-log per reference view
             logger.warning("skipping cluster %s/%d: %s", c.session_dir, c.ref_index, e)
             continue
-        images = torch.as_tensor(in_images, dtype=torch.float32, device=device)[None]
+        ids = getattr(c, "indices", None) or [p for p in getattr(c, "paths", [])[0::2]]
+        feats = []
+        for v in range(config.view_num):
+            key = (ids[v], round(float(c.rescale), 9), in_images[v].shape) if v < len(ids) else None
+            f = feature_cache.get(key) if key is not None else None
+            if f is None:
+                f = weights.unet(torch.as_tensor(in_images[v:v + 1], dtype=torch.float32, device=device))[0]
+                if key is not None:
+                    if len(feature_cache) >= 256:
+                        feature_cache.pop(next(iter(feature_cache)))
+                    feature_cache[key] = f
+            feats.append(f)
+        features = torch.stack(feats).contiguous()
         cams = torch.as_tensor(out_cams, dtype=torch.float32, device=device)[None]
         depth_start = float(out_cams[0, 1, 3, 0])     # predictlib.set_shapes :190-197
         depth_interval = float(out_cams[0, 1, 3, 1])
         depth_num = int(out_cams[0, 1, 3, 2])
         depth_end = float(out_cams[0, 1, 3, 3])
-        d, p, _ = pl.get_depth_and_prob_map(images, cams, depth_start, depth_interval, config, weights,
-                                            depth_num=depth_num, depth_end=depth_end)
+        d, p, _ = pl.get_depth_and_prob_map(None, cams, depth_start, depth_interval, config, weights,
+                                            depth_num=depth_num, depth_end=depth_end, features=features)
         pl.write_output_slice(output_dir, d.cpu().numpy(), p.cpu().numpy(), out_images[0], out_cams[0],
                               index, config.visualize)
         done += 1
@@ -101,7 +118,8 @@ def main(argv=None):
         ap.error("--input_dir is required")
     dist = sh.init_process_group()
     # a single session, or a folder of sessions (inference.py:121-141)
-    if os.path.isfile(os.path.join(cfg.input_dir, "covisibility.json")):
+    if os.path.isfile(os.path.join(cfg.input_dir, "covisibility.json")) or \
+            os.path.isfile(os.path.join(cfg.input_dir, "pair.txt")):
         dirs = [cfg.input_dir]
     else:
         dirs = [os.path.join(cfg.input_dir, f) for f in sorted(os.listdir(cfg.input_dir))

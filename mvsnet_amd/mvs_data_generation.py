@@ -204,3 +204,81 @@ class ClusterGenerator:
     def __iter__(self):
         for c in self.clusters:
             yield self.prepare(c)
+
+
+# ------------------------------------------------------------------------------------------------
+# upstream MVSNet project folders (README.md:165-215): images/%08d.jpg, cams/%08d_cam.txt, pair.txt
+# ------------------------------------------------------------------------------------------------
+
+
+def gen_pipeline_mvs_list(dense_folder, view_num):
+    """mvsnet/preprocess.py:547-579: [[ref_image, ref_cam, view_image, view_cam, ...], ...] from pair.txt
+    (the 10 best source views per reference image, best first; at most view_num - 1 are used)."""
+    image_folder = os.path.join(dense_folder, "images")
+    cam_folder = os.path.join(dense_folder, "cams")
+    words = open(os.path.join(dense_folder, "pair.txt")).read().split()
+    mvs_list, pos = [], 1
+    for _ in range(int(words[0])):
+        ref_index = int(words[pos]); pos += 1
+        paths = [os.path.join(image_folder, "%08d.jpg" % ref_index),
+                 os.path.join(cam_folder, "%08d_cam.txt" % ref_index)]
+        all_view_num = int(words[pos]); pos += 1
+        for view in range(min(view_num - 1, all_view_num)):
+            view_index = int(words[pos + 2 * view])
+            paths += [os.path.join(image_folder, "%08d.jpg" % view_index),
+                      os.path.join(cam_folder, "%08d_cam.txt" % view_index)]
+        pos += 2 * all_view_num
+        mvs_list.append((ref_index, paths))
+    return mvs_list
+
+
+class PairCluster:
+    """One reference view of an upstream-format project folder; duck-types Cluster."""
+
+    def __init__(self, dense_folder, ref_index, paths, view_num, image_width, image_height, depth_num,
+                 interval_scale):
+        self.session_dir = dense_folder
+        self.ref_index = int(ref_index)
+        self.paths = list(paths)
+        while len(self.paths) < 2 * view_num:           # pad missing views with the reference
+            self.paths += self.paths[:2]
+        self.view_num = view_num
+        self.image_width, self.image_height = image_width, image_height
+        self.depth_num, self.interval_scale = depth_num, interval_scale
+        self.rescale = 1.0
+
+    def images(self):
+        from PIL import Image
+        imgs = []
+        for v in range(self.view_num):
+            rgb = np.asarray(Image.open(self.paths[2 * v]).convert("RGB"))
+            imgs.append(np.ascontiguousarray(rgb[:, :, ::-1]))          # BGR, as cv2.imread upstream
+        h_scale = max(float(self.image_height) / im.shape[0] for im in imgs)
+        w_scale = max(float(self.image_width) / im.shape[1] for im in imgs)
+        self.rescale = max(h_scale, w_scale)
+        return imgs
+
+    def cameras(self):
+        from .preprocess import load_cam
+        return [load_cam(self.paths[2 * v + 1], self.interval_scale, self.depth_num)
+                for v in range(self.view_num)]
+
+
+class PairClusterGenerator(ClusterGenerator):
+    """ClusterGenerator over an upstream MVSNet project folder (pair.txt)."""
+
+    def load_clusters(self, session_dir, clusters):
+        for ref_index, paths in gen_pipeline_mvs_list(session_dir, self.view_num):
+            if self.max_clusters_per_session is not None and len(clusters) >= self.max_clusters_per_session:
+                break
+            clusters.append(PairCluster(session_dir, ref_index, paths, self.view_num, self.image_width,
+                                        self.image_height, self.depth_num, self.interval_scale))
+
+
+def make_generator(data_dir, *args, **kwargs):
+    """Session format (covisibility.json) or upstream format (pair.txt), whichever the folder holds."""
+    if os.path.isfile(os.path.join(data_dir, "covisibility.json")):
+        return ClusterGenerator(data_dir, *args, **kwargs)
+    if os.path.isfile(os.path.join(data_dir, "pair.txt")):
+        return PairClusterGenerator(data_dir, *args, **kwargs)
+    raise FileNotFoundError("%s holds neither covisibility.json nor pair.txt" % data_dir)

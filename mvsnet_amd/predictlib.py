@@ -45,10 +45,11 @@ def setup_output_dir(input_dir, output_dir):
 
 
 def get_depth_and_prob_map(full_images, scaled_cams, depth_start, depth_interval, config, weights,
-                           depth_num=None, depth_end=None):
+                           depth_num=None, depth_end=None, features=None):
     """predictlib.py:79-99.  Returns (depth_map, prob_map, None).  The reference's GRU branch
     raises NameError as shipped (undefined depth_num / depth_end, predictlib.py:95-96); here they
-    are explicit arguments (default: config.max_d and start + (D-1)*interval)."""
+    are explicit arguments (default: config.max_d and start + (D-1)*interval).  `features`
+    (N,H/4,W/4,C) skips the 2D towers (used by the per-image feature cache of inference.py)."""
     from .model import inference_mem, inference_winner_take_all
     D = int(depth_num if depth_num is not None else config.max_d)
     if config.regularization == "3DCNN":
@@ -56,14 +57,14 @@ def get_depth_and_prob_map(full_images, scaled_cams, depth_start, depth_interval
             raise NotImplementedError("depth refinement is outside the hot path (SURVEY 8f row f3)")
         d, p = inference_mem(full_images, scaled_cams, D, depth_start, depth_interval,
                              config.network_mode, inverse_depth=config.inverse_depth,
-                             weights=weights, view_num=config.view_num)
+                             weights=weights, view_num=config.view_num, features=features)
     elif config.regularization == "GRU":
         if depth_end is None:
             depth_end = float(depth_start) + (D - 1) * float(depth_interval)
         d, p = inference_winner_take_all(full_images, scaled_cams, D, depth_start, depth_end,
                                          network_mode=config.network_mode, reg_type="GRU",
                                          inverse_depth=config.inverse_depth, weights=weights,
-                                         view_num=config.view_num)
+                                         view_num=config.view_num, features=features)
     else:
         raise NotImplementedError(config.regularization)          # predictlib.py:97-98
     return d, p, None

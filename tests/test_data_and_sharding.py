@@ -154,3 +154,40 @@ def test_world_size_2_sharding_over_gloo(tmp_path):
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["world"] == 2 and res["counts"] == [6.0, 5.0]
     assert res["cover"] == [1] * 11
+
+
+def make_pair_project(path, n_images=3, h=48, w=64, seed=1):
+    """A tiny project folder in the upstream MVSNet format (images/, cams/, pair.txt)."""
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    os.makedirs(os.path.join(path, "images")); os.makedirs(os.path.join(path, "cams"))
+    for i in range(n_images):
+        Image.fromarray(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)).save(
+            os.path.join(path, "images", "%08d.jpg" % i), quality=95)
+        ext = np.eye(4); ext[0, 3] = -30.0 * i
+        K = np.array([[60.0, 0, w / 2.0], [0, 60.0, h / 2.0], [0, 0, 1.0]])
+        with open(os.path.join(path, "cams", "%08d_cam.txt" % i), "w") as f:
+            f.write("extrinsic\n" + "\n".join(" ".join(str(v) for v in row) for row in ext) + "\n\n")
+            f.write("intrinsic\n" + "\n".join(" ".join(str(v) for v in row) for row in K) + "\n\n")
+            f.write("425.0 2.5\n")
+    with open(os.path.join(path, "pair.txt"), "w") as f:
+        f.write("%d\n" % n_images)
+        for i in range(n_images):
+            others = [j for j in range(n_images) if j != i]
+            f.write("%d\n%d %s\n" % (i, len(others), " ".join("%d %.1f" % (j, 100.0 - j) for j in others)))
+    return path
+
+
+def test_upstream_pair_txt_project(tmp_path):
+    from mvsnet_amd.mvs_data_generation import make_generator, gen_pipeline_mvs_list, PairClusterGenerator
+    proj = make_pair_project(str(tmp_path / "proj"))
+    lst = gen_pipeline_mvs_list(proj, view_num=3)
+    assert [r for r, _ in lst] == [0, 1, 2]
+    assert lst[0][1][0].endswith("images/00000000.jpg") and lst[0][1][3].endswith("cams/00000001_cam.txt")
+    gen = make_generator(proj, 5, 32, 32, 16, 1.06, 8, output_scale=0.25)
+    assert isinstance(gen, PairClusterGenerator) and len(gen) == 3
+    out_images, in_images, out_cams, full_cams, idx = next(iter(gen))
+    assert idx == 0 and in_images.shape == (5, 32, 32, 3)               # 2 sources + 2 reference pads
+    assert np.array_equal(in_images[3], in_images[0]) and np.array_equal(out_cams[4], out_cams[0])
+    np.testing.assert_allclose(out_cams[0, 1, 3], [425.0, 2.65, 16, 425.0 + 2.65 * 16])   # 29-word cams + max_d
+    np.testing.assert_allclose(out_cams[1, 0, 0, 3], -30.0)
