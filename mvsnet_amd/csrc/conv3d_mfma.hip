@@ -23,6 +23,7 @@
 //   * Next plane's global loads are issued before the sweep and written to the other LDS buffer
 //     after it (one barrier per plane).
 #include "conv_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -287,10 +288,14 @@ int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
 
 }  // namespace
 
+// test hook: MVS_GENERIC_C8=1 keeps the 32 -> 8 layer on the generic kernel (A/B timing, parity)
+static const bool g_generic_c8 = getenv("MVS_GENERIC_C8") != nullptr;
+
 static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t st) {
     if (stride == 1) {
         if (Cout == 1) return mvs_conv3d_out_launch(a, Cin, st);
         if (a.wprep_bf && mvs_conv3d_bf16x3_supported(Cin, Cout)) return mvs_conv3d_s1_bf16x3(a, Cin, Cout, st);
+        if (Cin == 32 && Cout == 8 && !a.x2 && !g_generic_c8) return mvs_conv3d_c8_launch(a, st);
         if (Cin == 32 && Cout == 8) return launch_s1<32, 8, 8>(a, Cout, st);
         if (Cin == 16 && Cout % 16 == 0) return launch_s1<16, 16, 8>(a, Cout, st);
         if (Cin == 32 && Cout % 16 == 0) return launch_s1<32, 16, 8>(a, Cout, st);
