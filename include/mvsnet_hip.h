@@ -111,6 +111,17 @@ int mvs_deconv3d_f32(const float* x, const float* x_scale, const float* x_shift,
                      const float* w, int D, int H, int W, int Cin, int Cout,
                      float* y, double* stats, void* stream);
 
+/* The two consumers of the cost volume in ONE pass over it: y1 = conv3d(x, w1, stride 1) and
+ * y2 = conv3d(x, w2, stride 2), i.e. 3dconv0_1 and 3dconv1_0 of RegNetUS0
+ * (mvsnet/cnn_wrapper/mvsnetworks.py:130-134), each with the semantics of mvs_conv3d_f32 (raw input,
+ * no producer BatchNorm).  Only the shape of that layer pair is implemented: Cin = 32, Cout1 = 8,
+ * Cout2 = 16, even D, H, W; anything else returns MVS_E_SHAPE (call mvs_conv3d_f32 twice instead).
+ *   x (D,H,W,32)   w1 (3,3,3,32,8)   w2 (3,3,3,32,16)   y1 (D,H,W,8)   y2 (D/2,H/2,W/2,16)
+ *   stats1 / stats2: NULL or zeroed (2,8) / (2,16) float64 accumulators as in mvs_conv3d_f32 */
+int mvs_conv3d_pair_f32(const float* x, const float* w1, const float* w2, int D, int H, int W,
+                        int Cin, int Cout1, int Cout2, float* y1, double* stats1,
+                        float* y2, double* stats2, void* stream);
+
 /* BatchNorm (training-mode statistics, biased variance; network.py:496-506) folded to an affine:
  *   mean = sum/count; var = sumsq/count - mean^2; scale = gamma/sqrt(var+eps); shift = beta-mean*scale
  * stats (2,C) float64 as produced above; scale/shift (C). */

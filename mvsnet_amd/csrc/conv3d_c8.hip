@@ -1,22 +1,29 @@
-// fp32-MFMA 3x3x3 stride-1 convolution specialised for the full-resolution 32 -> 8 layer (3dconv0_1,
-// mvsnet/cnn_wrapper/mvsnetworks.py:134; tf.layers.conv3d SAME, network.py:203-215): 60 % of the
-// regulariser's FLOPs run through this one kernel.
+// fp32-MFMA kernel for the two consumers of the cost volume: the full-resolution 32 -> 8 stride-1
+// convolution (3dconv0_1) and, fused into the same pass, the 32 -> 16 stride-2 convolution
+// (3dconv1_0) (mvsnet/cnn_wrapper/mvsnetworks.py:130-134; tf.layers.conv3d SAME, network.py:203-215).
+// 3dconv0_1 alone is 60 % of the regulariser's FLOPs, and both layers read the same 503 MB volume:
+// fused, the volume is staged through LDS once instead of being streamed from HBM twice.
 //
 // Same input-stationary plane march as conv3d_mfma.hip (a workgroup owns an 8 x 16 (h x w) column,
 // stages every input plane into LDS once, and each staged plane feeds the output planes q+1, q, q-1
-// through the (kd, cout) weight rows), with two changes that only pay at Cout = 8:
+// through the (kd, cout) weight rows), with three changes:
 //
-//   * Row packing.  (kd, cout) is 24 rows = 1.5 MFMA row tiles; the generic kernel pads the third
-//     8-row block to a full tile (75 % useful).  Here a wave owns two adjacent output rows r, r+1
-//     and the third block of BOTH rows shares one tile: against the staged row r-1+i (i = 0..3)
-//     tile rows 0-7 carry the weights of kh = i (output row r) and rows 8-15 those of kh = i-1
-//     (output row r+1) -- the same B operand is tap kh = i of row r and tap kh = i-1 of row r+1.
-//     Per (kw, ci-group) that is 6 + 4 = 10 MFMA tiles instead of 12 (90 % useful rows).
+//   * Row packing (stride-1 part).  (kd, cout) is 24 rows = 1.5 MFMA row tiles; the generic kernel
+//     pads the third 8-row block to a full tile (75 % useful).  Here a wave owns two adjacent output
+//     rows r, r+1 and the third block of BOTH rows shares one tile: against the staged row r-1+i
+//     (i = 0..3) tile rows 0-7 carry the weights of kh = i (output row r) and rows 8-15 those of
+//     kh = i-1 (output row r+1) -- the same B operand is tap kh = i of row r and tap kh = i-1 of
+//     row r+1.  Per (kw, ci-group) that is 6 + 4 = 10 MFMA tiles instead of 12 (90 % useful rows).
 //   * XOR-swizzled slab.  Positions are stored at a 128-B pitch (no padding) with the 16-B channel
-//     slot XORed by (pos >> 1) & 7: the (col = lane&15, k-quad = lane>>4) ds_read_b128 groups stay
+//     slot XORed by (column >> 1) & 7: the (col = lane&15, k-quad = lane>>4) ds_read_b128 groups stay
 //     bank-conflict free and the slab shrinks by 11 %, which keeps two workgroups per CU.
+//   * Stride-2 part.  The workgroup's slab covers a 4 x 8 patch of stride-2 outputs (two 16-voxel
+//     column tiles).  Its 55 KB of weights do not fit in LDS next to the slab, so K = (kh, kw, ci)
+//     is split four ways by ci: wave w keeps the A fragments of ci 8w..8w+7 for all 27 taps x 16
+//     couts in 54 registers, accumulates its quarter of every output, and the four partial tiles
+//     are summed through 6 KB of LDS when an output plane completes (every second input plane).
 //
-// Operand reads of (kw, ci-group) g+1 are issued between the MFMAs of g (register double buffer).
+// Operand reads of the next (kw, ci-group, row) step are issued between the MFMAs of the current one.
 #include "conv_common.h"
 
 namespace {
@@ -25,6 +32,7 @@ constexpr int TW = CONV_TW;
 constexpr int TH = 8;
 constexpr int PW = TW + 2;
 constexpr int CIN = 32, COUT = 8, CQ = CIN / 4;
+constexpr int COUT2 = 16;                      // stride-2 layer
 constexpr int NPOS = (TH + 2) * PW;            // 180 staged positions
 constexpr int NF4 = NPOS * CQ;                 // 1440 float4
 constexpr int NIT = (NF4 + 255) / 256;         // 6
@@ -32,17 +40,32 @@ constexpr int NROWS = 3 * COUT;                // 24
 constexpr int WROW = NROWS * 4;                // floats per (tap, ci-quad)
 constexpr int W_FLOATS = 9 * CQ * WROW;        // 6912
 constexpr int SP = CIN;                        // slab pitch (floats), swizzled
+constexpr int ROWP = PW * SP;                  // floats per staged row
 constexpr int SLAB_FLOATS = NPOS * SP;         // 5760
 constexpr int KH_FLOATS = 3 * CQ * WROW;       // weight floats per kh
+constexpr int RED_FLOATS = 3 * 2 * 64 * 4;     // partial stride-2 tiles of waves 1..3
 constexpr int LDS_FLOATS = 2 * SLAB_FLOATS + W_FLOATS + 4;
 
-__device__ __forceinline__ int slab_off(int pos, int slot) { return pos * SP + ((slot ^ ((pos >> 1) & 7)) << 2); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// float offset of 16-B channel slot `slot` at staged (row, col)
+__device__ __forceinline__ int slab_off(int row, int col, int slot) {
+    return (row * PW + col) * SP + ((slot ^ ((col >> 1) & 7)) << 2);
+}
+
+struct FuseArgs {
+    const float* w2;      // stride-2 weights, TensorFlow layout (3,3,3,32,16)
+    float* y2;            // (D/2, H/2, W/2, 16) raw output
+    double* stats2;       // (2,16) float64 sums or null
+};
+
+template <bool FUSE>
 __global__ void __launch_bounds__(256, 2)
-conv3d_c8_kernel(ConvArgs a) {
+conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* slab = smem;                            // [2][NPOS][SP]
     float* wl = smem + 2 * SLAB_FLOATS;            // [9 taps][CQ][3 kd][8 co][4], then 4 zeros
+    float* red = wl + W_FLOATS + 4;                // FUSE: [3 waves][2 tiles][64 lanes][4]
     constexpr int ZOFF = W_FLOATS;
 
     const int tid = threadIdx.x;
@@ -85,7 +108,7 @@ conv3d_c8_kernel(ConvArgs a) {
         int gh = h0 - 1 + r, gw = w0 - 1 + c;
         bool inb = (f < NF4) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
         goff[i] = inb ? (gh * a.W + gw) * CIN + 4 * c4 : -1;
-        loff[i] = (f < NF4) ? slab_off(pos, c4) : -1;
+        loff[i] = (f < NF4) ? slab_off(r, c, c4) : -1;
     }
     const size_t plane_elems = (size_t)a.H * a.W * CIN;
 
@@ -109,19 +132,17 @@ conv3d_c8_kernel(ConvArgs a) {
         }
     };
 
-    // ---- accumulators: [0],[1] = blocks 0|1 (rows 0-7 | 8-15) of output rows r, r+1; [2] = block 2
-    // of row r (rows 0-7) and of row r+1 (rows 8-15).  Block b carries kd = (P - b) mod 3.
+    // ---- stride-1 accumulators: [0],[1] = blocks 0|1 (rows 0-7 | 8-15) of output rows r, r+1;
+    // [2] = block 2 of row r (rows 0-7) and of row r+1 (rows 8-15).  Block b carries kd = (P-b) mod 3.
     f32x4 acc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // B operand: staged row 2*wave + i (i = 0..3), column n + kw, channel slot kq (s = 0; s = 1 is ^16)
-    int boff[4][3];
+    // B operand: staged row 2*wave + i (i = 0..3, an immediate), column n + kw, slot kq (s = 1 is ^16)
+    int bcol[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) boff[i][kw] = slab_off((2 * wave + i) * PW + n + kw, kq);
+    for (int kw = 0; kw < 3; ++kw) bcol[kw] = slab_off(2 * wave, n + kw, kq);
     const int hi = n >> 3;                         // 0: tile rows 0-7, 1: rows 8-15
     const int a_lane = (kq * NROWS + (n & 7)) * 4;
 
@@ -130,38 +151,40 @@ conv3d_c8_kernel(ConvArgs a) {
         constexpr int KD_B0 = P % 3, KD_B1 = (P + 2) % 3, KD_B2 = (P + 1) % 3;
         const int a0 = a_lane + (hi ? KD_B1 : KD_B0) * COUT * 4;          // blocks 0|1
         const int ap = a_lane + KD_B2 * COUT * 4 - hi * KH_FLOATS;        // block 2: kh = i - hi
-        f32x4 bv[2][4], av[2][3], pv[2][4];
-        // read r of group g = (kw, s): b0 a0 p0 b1 a1 p1 b2 a2 p2 b3 p3
-        auto load_one = [&](int g, int r, f32x4 (&b)[4], f32x4 (&a0v)[3], f32x4 (&p)[4]) __attribute__((always_inline)) {
-            const int kw = g >> 1, s = g & 1;
-            const int i = (r < 9) ? r / 3 : 3, kind = (r < 9) ? r % 3 : (r == 9 ? 0 : 2);
+        f32x4 bv[2], pv[2], av[3];
+        // step G = ((kw*2 + s)*4 + i): staged row i against the weights of (kw, ci group s)
+        auto load_grp = [&](int G, int r) __attribute__((always_inline)) {
+            const int i = G & 3, kw = G >> 3, s = (G >> 2) & 1;
             const int wconst = (kw * CQ + 4 * s) * WROW;
-            if (kind == 0) b[i] = *(const f32x4*)(buf + (boff[i][kw] ^ (16 * s)));
-            else if (kind == 1) a0v[i] = *(const f32x4*)(wl + a0 + i * KH_FLOATS + wconst);
-            else {
+            if (r == 0) bv[G & 1] = *(const f32x4*)(buf + (bcol[kw] ^ (16 * s)) + i * ROWP);
+            else if (r == 1) {
                 int off = ap + i * KH_FLOATS + wconst;
                 if (i == 0) off = hi ? ZOFF : off;       // rows 8-15 would need kh = -1
                 if (i == 3) off = hi ? off : ZOFF;       // rows 0-7 would need kh = 3
-                p[i] = *(const f32x4*)(wl + off);
-            }
+                pv[G & 1] = *(const f32x4*)(wl + off);
+            } else if (i < 3) av[i] = *(const f32x4*)(wl + a0 + i * KH_FLOATS + wconst);
         };
-        constexpr int NG = 6, NR = 11, NM = 40;
+        constexpr int NG = 24;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) load_one(0, r, bv[0], av[0], pv[0]);
+        for (int r = 0; r < 3; ++r) load_grp(0, r);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
+        for (int G = 0; G < NG; ++G) {
+            const int i = G & 3;
+            const int NC = (i == 0 || i == 3) ? 2 : 3;      // MFMA tiles of this step
+            const int NM = 4 * NC;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                if (g + 1 < NG) load_one(g + 1, r, bv[(g + 1) & 1], av[(g + 1) & 1], pv[(g + 1) & 1]);
+            for (int r = 0; r < 3; ++r) {
+                if (G + 1 < NG) load_grp(G + 1, r);
 #pragma unroll
-                for (int m = (r * NM) / NR; m < ((r + 1) * NM) / NR; ++m) {
-                    const int j = m / 10, c = m % 10;
-                    // c: 0 v0.b0a0  1 P.b0p0  2 v1.b1a0  3 v0.b1a1  4 P.b1p1  5 v1.b2a1  6 v0.b2a2  7 P.b2p2  8 v1.b3a2  9 P.b3p3
-                    const int t = (c == 9) ? 2 : (c % 3 == 0 ? 0 : (c % 3 == 1 ? 2 : 1));
-                    const int bi = (c == 9) ? 3 : (c + 1) / 3;
-                    const int ai = (c == 9) ? 3 : c / 3;
-                    const float av_ = (t == 2) ? pv[g & 1][ai][j] : av[g & 1][ai][j];
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, bv[g & 1][bi][j], acc[t], 0, 0, 0);
+                for (int m = (r * NM) / 3; m < ((r + 1) * NM) / 3; ++m) {
+                    const int j = m / NC, c = m % NC;
+                    // i = 0: row r kh 0 | packed;  i = 1,2: row r+1 kh i-1 | row r kh i | packed;  i = 3: row r+1 kh 2 | packed
+                    int t; float aval;
+                    if (c == NC - 1) { t = 2; aval = pv[G & 1][j]; }
+                    else if (i == 0) { t = 0; aval = av[0][j]; }
+                    else if (c == 0) { t = 1; aval = av[i - 1][j]; }
+                    else { t = 0; aval = av[i][j]; }
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aval, bv[G & 1][j], acc[t], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -191,6 +214,81 @@ conv3d_c8_kernel(ConvArgs a) {
         }
     };
 
+    // ---- stride-2 part ---------------------------------------------------------------------------
+    // Column tile ct, lane column n: output (oh, ow) = (h0/2 + 2ct + (n>>3), w0/2 + (n&7)); input tap
+    // (kh, kw) sits at staged (row 4ct + 2(n>>3) + kh + 1, col 2(n&7) + kw + 1).  This wave's k index
+    // kq of step j is input channel 8*wave + 2kq + j (one ds_read_b64 per tap and tile).
+    float wS[3][9][2];                             // dead (eliminated) when !FUSE
+    f32x4 cur[2], prv[2];                          // output planes od_cur / od_cur - 1, per column tile
+    int s2b[3];
+    float st2_s[4] = {0.f, 0.f, 0.f, 0.f}, st2_q[4] = {0.f, 0.f, 0.f, 0.f};
+    int fin_od = -1;                               // output plane whose partial tiles wait in `red`
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    if (FUSE) {
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    wS[kd][tap][j] = fa.w2[((size_t)(kd * 9 + tap) * CIN + 8 * wave + 2 * kq + j) * COUT2 + n];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            s2b[kw] = slab_off(2 * (n >> 3), 2 * (n & 7) + kw + 1, 2 * wave + (kq >> 1)) + 2 * (kq & 1);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) { cur[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; prv[ct] = cur[ct]; }
+    }
+
+    auto s2_sweep = [&](auto Ec, const float* buf) __attribute__((always_inline)) {
+        constexpr bool EVEN = decltype(Ec)::value;   // even plane: kd 0 -> cur, kd 2 -> prv; odd: kd 1 -> cur
+        f32x2 b2[2][2];
+        auto ld = [&](int tap, f32x2 (&b)[2]) __attribute__((always_inline)) {
+            const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) b[ct] = *(const f32x2*)(buf + s2b[kw] + (4 * ct + kh + 1) * ROWP);
+        };
+        ld(0, b2[0]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) ld(tap + 1, b2[(tap + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const float bval = b2[tap & 1][ct][j];
+                    if (EVEN) {
+                        cur[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wS[0][tap][j], bval, cur[ct], 0, 0, 0);
+                        prv[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wS[2][tap][j], bval, prv[ct], 0, 0, 0);
+                    } else {
+                        cur[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wS[1][tap][j], bval, cur[ct], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // wave 0: sum the four K-quarters of output plane fin_od, store, BatchNorm sums
+    auto s2_finish = [&]() __attribute__((always_inline)) {
+        if (fin_od >= 0 && wave == 0) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                f32x4 r = prv[ct];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    f32x4 p = *(const f32x4*)(red + ((w * 2 + ct) * 64 + lane) * 4);
+                    r[0] += p[0]; r[1] += p[1]; r[2] += p[2]; r[3] += p[3];
+                }
+                const int oh = h0 / 2 + 2 * ct + (n >> 3), ow = w0 / 2 + (n & 7);
+                if (oh < Ho && ow < Wo) {
+                    float* dst = fa.y2 + ((((size_t)fin_od * Ho + oh) * Wo) + ow) * COUT2 + 4 * kq;
+                    *(float4*)dst = make_float4(r[0], r[1], r[2], r[3]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { st2_s[k] += r[k]; st2_q[k] += r[k] * r[k]; }
+                }
+            }
+        }
+        fin_od = -1;
+    };
+
     // ---- plane march -----------------------------------------------------------------------------
     issue_loads(d0 - 1);
     write_slab(d0 - 1, slab);
@@ -198,11 +296,32 @@ conv3d_c8_kernel(ConvArgs a) {
 
     auto plane = [&](auto Pc, int t) __attribute__((always_inline)) {
         const int q = d0 - 1 + t;
-        float* cur = slab + (t & 1) * SLAB_FLOATS;
+        float* cur_buf = slab + (t & 1) * SLAB_FLOATS;
         float* nxt = slab + ((t + 1) & 1) * SLAB_FLOATS;
         const bool more = (t + 1 < T);
+        const bool in_vol = (q >= 0) && (q < a.D);
         if (more) issue_loads(q + 1);
-        if (q >= 0 && q < a.D) sweep(Pc, cur);
+        if (FUSE) s2_finish();
+        if (in_vol) sweep(Pc, cur_buf);
+        if (FUSE && q >= d0) {
+            if (q & 1) {
+                if (in_vol) s2_sweep(std::false_type{}, cur_buf);
+            } else {
+                // plane q = 2*od_cur: od_cur starts (kd 0), od_cur - 1 completes (kd 2)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) { prv[ct] = cur[ct]; cur[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                if (in_vol) s2_sweep(std::true_type{}, cur_buf);
+                const int od_prev = q / 2 - 1;
+                if (2 * od_prev >= d0) {
+                    if (wave > 0) {
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+                            *(f32x4*)(red + (((wave - 1) * 2 + ct) * 64 + lane) * 4) = prv[ct];
+                    }
+                    fin_od = od_prev;
+                }
+            }
+        }
         retire(Pc, q - 1);
         if (more) write_slab(q + 1, nxt);
         __syncthreads();
@@ -212,27 +331,65 @@ conv3d_c8_kernel(ConvArgs a) {
         if (t + 1 < T) plane(std::integral_constant<int, 1>{}, t + 1);
         if (t + 2 < T) plane(std::integral_constant<int, 2>{}, t + 2);
     }
+    if (FUSE) {
+        s2_finish();
+        if (fa.stats2 && wave == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float sv = st2_s[k], qv = st2_q[k];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+                if (n == 0) {
+                    atomicAdd(&fa.stats2[4 * kq + k], (double)sv);
+                    atomicAdd(&fa.stats2[COUT2 + 4 * kq + k], (double)qv);
+                }
+            }
+        }
+    }
 
     // every lane's st_* are the sums of channels 4*(kq&1) .. +3: fold lanes l and l^32
     if (a.stats) stats_commit<COUT>(st_s, st_q, true, slab, a.stats, a.cout_total, 0);
 }
 
-}  // namespace
-
-int mvs_conv3d_c8_launch(const ConvArgs& a0, hipStream_t st) {
+template <bool FUSE>
+int launch_c8(const ConvArgs& a0, const FuseArgs& fa, hipStream_t st) {
     ConvArgs a = a0;
-    if (a.x2 || a.cout_total != COUT) return MVS_E_SHAPE;
     const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
-    a.planes_per_wg = conv_pick_planes(a.D, tiles, 2);
+    if (FUSE) {
+        // chunks start on even planes so that stride-2 output planes never straddle workgroups
+        int best = 2; long long best_cost = 1LL << 60;
+        for (int dr = 2; dr <= a.D; dr += 2) {
+            long long wgs = (long long)tiles * ((a.D + dr - 1) / dr);
+            long long cost = ((wgs + 255) / 256) * (dr + 3);
+            if (cost < best_cost) { best_cost = cost; best = dr; }
+        }
+        a.planes_per_wg = best;
+    } else {
+        a.planes_per_wg = conv_pick_planes(a.D, tiles, 2);
+    }
     dim3 grid(tiles, 1, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
-    const size_t smem = (size_t)LDS_FLOATS * sizeof(float);
-    static bool attr_done = false;
+    const size_t smem = (size_t)(LDS_FLOATS + (FUSE ? RED_FLOATS : 0)) * sizeof(float);
+    static bool attr_done = false;       // per template instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3d_c8_kernel,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3d_c8_kernel<FUSE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv3d_c8_kernel<<<grid, 256, smem, st>>>(a);
+    conv3d_c8_kernel<FUSE><<<grid, 256, smem, st>>>(a, fa);
     return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int mvs_conv3d_c8_launch(const ConvArgs& a, hipStream_t st) {
+    if (a.x2 || a.cout_total != COUT) return MVS_E_SHAPE;
+    return launch_c8<false>(a, FuseArgs{nullptr, nullptr, nullptr}, st);
+}
+
+// Both consumers of a 32-channel volume in one pass: y = conv3d(x, w 32->8, stride 1) as above and
+// y2 = conv3d(x, w2 32->16, stride 2).  Even D, H, W only (SAME pads nothing in front).
+int mvs_conv3d_c8_s2_launch(const ConvArgs& a, const float* w2, float* y2, double* stats2, hipStream_t st) {
+    if (a.x2 || a.cout_total != COUT || (a.D & 1) || (a.H & 1) || (a.W & 1)) return MVS_E_SHAPE;
+    return launch_c8<true>(a, FuseArgs{w2, y2, stats2}, st);
 }

@@ -2,6 +2,7 @@
 // (mvsnet/cnn_wrapper/mvsnetworks.py:122-158) and library bookkeeping entry points.
 // No kernels here; every launch goes to the caller's stream and nothing allocates or syncs.
 #include "conv_common.h"
+#include <cstdlib>
 
 // scalar path (conv3d_scalar.hip)
 int mvs_conv3d_scalar(const float*, const float*, const float*, const float*, const float*,
@@ -72,6 +73,15 @@ extern "C" int mvs_deconv3d_f32(const float* x, const float* xs, const float* xb
         if (rc != MVS_E_SHAPE || g_conv_impl == MVS_CONV_IMPL_MFMA) return rc;
     }
     return mvs_deconv3d_scalar(x, xs, xb, x2, x2s, x2b, w, D, H, W, Cin, Cout, y, stats, st);
+}
+
+extern "C" int mvs_conv3d_pair_f32(const float* x, const float* w1, const float* w2, int D, int H, int W,
+                                   int Cin, int Cout1, int Cout2, float* y1, double* stats1,
+                                   float* y2, double* stats2, void* stream) {
+    MVS_CHECK_ARG(x && w1 && w2 && y1 && y2 && D > 0 && H > 0 && W > 0);
+    if (Cin != 32 || Cout1 != 8 || Cout2 != 16 || g_conv_impl == MVS_CONV_IMPL_SCALAR) return MVS_E_SHAPE;
+    ConvArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, w1, y1, stats1, D, H, W, Cout1, 0, 0, 0, 0, {}, {}, nullptr, nullptr};
+    return mvs_conv3d_c8_s2_launch(a, w2, y2, stats2, mvs_stream(stream));
 }
 
 // ---- RegNetUS0 -----------------------------------------------------------------------------------
@@ -217,9 +227,21 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
                       : mvs_conv3d_scalar(x, s1, t1, x2, s2, t2, weights[out], d, h, w, ci, co, stride, y, so, hs);
     };
 #define RUN(call) do { if ((rc = (call))) return rc; } while (0)
-    // encoder on the raw cost volume (mvsnetworks.py:130-136)
-    RUN(layer(false, -1, -1, L10, D, H, W, cin, 2 * b, 2));
-    RUN(layer(false, -1, -1, L01, D, H, W, cin, b, 1));
+    // encoder on the raw cost volume (mvsnetworks.py:130-136).  3dconv1_0 and 3dconv0_1 read the same
+    // volume: one fused pass when the shape is the one conv3d_c8.hip is built for.
+    bool pair_done = false;
+    if ((g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA) && cin == 32 && b == 8 &&
+        !getenv("MVS_NO_PAIR_FUSION")) {
+        ConvArgs a{cost, nullptr, nullptr, nullptr, nullptr, nullptr, weights[L01], ws.y[L01], st(L01), D, H, W, b,
+                   0, 0, 0, 0, {}, {}, prepared ? prepared + lay.off[L01] : nullptr, nullptr};
+        rc = mvs_conv3d_c8_s2_launch(a, weights[L10], ws.y[L10], st(L10), hs);
+        if (rc == 0) pair_done = true;
+        else if (rc != MVS_E_SHAPE) return rc;
+    }
+    if (!pair_done) {
+        RUN(layer(false, -1, -1, L10, D, H, W, cin, 2 * b, 2));
+        RUN(layer(false, -1, -1, L01, D, H, W, cin, b, 1));
+    }
     RUN(layer(false, L10, -1, L20, D1, H1, W1, 2 * b, 4 * b, 2));
     RUN(layer(false, L20, -1, L30, D2, H2, W2, 4 * b, 8 * b, 2));
     // same-resolution branches (mvsnetworks.py:138-145)

@@ -136,6 +136,20 @@ def conv3d(x, w, stride=1, x_affine=None, skip=None, skip_affine=None, stats=Non
     return y
 
 
+def conv3d_pair(x, w1, w2, stats1=None, stats2=None):
+    """3dconv0_1 (32->8, stride 1) and 3dconv1_0 (32->16, stride 2) of RegNetUS0 in one pass over the
+    cost volume (mvsnetworks.py:130-134).  Returns the two raw outputs."""
+    lib = _lib.load()
+    D, H, W, Cin = x.shape
+    C1, C2 = w1.shape[4], w2.shape[4]
+    y1 = torch.empty((D, H, W, C1), device=x.device, dtype=torch.float32)
+    y2 = torch.empty((D // 2, H // 2, W // 2, C2), device=x.device, dtype=torch.float32)
+    _lib.check(lib.mvs_conv3d_pair_f32(_lib.ptr(x), _lib.ptr(w1), _lib.ptr(w2), D, H, W, Cin, C1, C2,
+                                       _lib.ptr(y1), _lib.ptr(stats1), _lib.ptr(y2), _lib.ptr(stats2),
+                                       _lib.stream_ptr()), "mvs_conv3d_pair_f32")
+    return y1, y2
+
+
 def bn_finalize(stats, count, gamma, beta, eps=BN_EPSILON):
     """(2,C) float64 sums -> per-channel (scale, shift) of training-mode BN (network.py:496-506)."""
     lib = _lib.load()

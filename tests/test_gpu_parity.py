@@ -148,6 +148,28 @@ CONV_CASES = [  # D,H,W,Cin,Cout,stride
 ]
 
 
+@pytest.mark.parametrize("shape", [(8, 8, 16), (6, 16, 32), (10, 12, 24), (20, 8, 16)])
+def test_conv3d_pair_matches_oracle(shape):
+    """The fused pass over the cost volume (3dconv0_1 + 3dconv1_0) against two oracle convolutions;
+    shapes cover partial h/w tiles and depth chunks that split the stride-2 output planes."""
+    from mvsnet_amd.model import conv3d_pair
+    D, H, W = shape
+    rs = np.random.RandomState(D * 1000 + H * 10 + W)
+    x = rs.standard_normal((D, H, W, 32)).astype(np.float32)
+    w1 = (rs.standard_normal((3, 3, 3, 32, 8)) / np.sqrt(27 * 32)).astype(np.float32)
+    w2 = (rs.standard_normal((3, 3, 3, 32, 16)) / np.sqrt(27 * 32)).astype(np.float32)
+    s1 = torch.zeros((2, 8), dtype=torch.float64, device=DEV)
+    s2 = torch.zeros((2, 16), dtype=torch.float64, device=DEV)
+    y1, y2 = conv3d_pair(t(x), t(w1), t(w2), s1, s2)
+    e1 = O.conv3d_same(x, w1, 1, np.float64)
+    e2 = O.conv3d_same(x, w2, 2, np.float64)
+    np.testing.assert_allclose(n(y1), e1, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(n(y2), e2, rtol=1e-4, atol=2e-5)
+    for st, e, c in ((n(s1), e1, 8), (n(s2), e2, 16)):
+        np.testing.assert_allclose(st[0], e.reshape(-1, c).sum(0), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(st[1], (e.reshape(-1, c) ** 2).sum(0), rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("impl", ["scalar", "auto"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3d_matches_oracle(case, impl):
