@@ -44,9 +44,11 @@ constexpr int ROWP = PW * SP;                  // floats per staged row
 constexpr int SLAB_FLOATS = NPOS * SP;         // 5760
 constexpr int KH_FLOATS = 3 * CQ * WROW;       // weight floats per kh
 constexpr int RED_FLOATS = 3 * 2 * 64 * 4;     // partial stride-2 tiles of waves 1..3
-constexpr int LDS_FLOATS = 2 * SLAB_FLOATS + W_FLOATS + 4;
+constexpr int LDS_FLOATS = 2 * SLAB_FLOATS + W_FLOATS + 4;   // + zero block
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int OOB = (int)0x80000000u;
 
 // float offset of 16-B channel slot `slot` at staged (row, col)
 __device__ __forceinline__ int slab_off(int row, int col, int slot) {
@@ -59,7 +61,7 @@ struct FuseArgs {
     double* stats2;       // (2,16) float64 sums or null
 };
 
-template <bool FUSE>
+template <bool FUSE, bool AFF>
 __global__ void __launch_bounds__(256, 2)
 conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -94,42 +96,44 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     // ---- staging ---------------------------------------------------------------------------------
     const int c4 = tid % CQ;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool has_aff = a.xs != nullptr || a.bn.stats != nullptr;
-    if (a.xs) { sc = *(const float4*)(a.xs + 4 * c4); sh = *(const float4*)(a.xb + 4 * c4); }
-    else if (a.bn.stats) bn_affine4(a.bn, 4 * c4, sc, sh);
+    if (AFF && a.xs) { sc = *(const float4*)(a.xs + 4 * c4); sh = *(const float4*)(a.xb + 4 * c4); }
+    else if (AFF && a.bn.stats) bn_affine4(a.bn, 4 * c4, sc, sh);
 
     float4 pre[NIT];
     int goff[NIT], loff[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         int f = tid + 256 * i;
+        if (f >= NF4) f -= 256;                    // spare threads of the last piece redo their previous one
         int pos = f / CQ;
         int r = pos / PW, c = pos - r * PW;
         int gh = h0 - 1 + r, gw = w0 - 1 + c;
-        bool inb = (f < NF4) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        goff[i] = inb ? (gh * a.W + gw) * CIN + 4 * c4 : -1;
-        loff[i] = (f < NF4) ? slab_off(r, c, c4) : -1;
+        bool inb = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        goff[i] = inb ? ((gh * a.W + gw) * CIN + 4 * c4) * 4 : OOB;      // byte offset inside a plane
+        loff[i] = slab_off(r, c, c4);
     }
-    const size_t plane_elems = (size_t)a.H * a.W * CIN;
+    // Buffer addressing (the launcher guarantees < 2 GB tensors): 32-bit byte offsets, and an offset
+    // with bit 31 set is out of range -> loads return 0 (= SAME padding), stores are dropped.
+    const int plane_bytes = a.H * a.W * CIN * 4;
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.D * plane_bytes, 0x00020000);
+    const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.D * a.H * a.W * COUT * 4, 0x00020000);
 
-    auto issue_loads = [&](int q) __attribute__((always_inline)) {
+    // piece i of a plane's staging: global -> registers (load_piece), registers -> LDS (stage_piece)
+    // (branch-free: these run between the MFMAs of the sweep)
+    auto load_piece = [&](int i, int q) __attribute__((always_inline)) {
         const bool plane_ok = (q >= 0) && (q < a.D);
-        const float* px = a.x + (size_t)(plane_ok ? q : 0) * plane_elems;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const bool ok = plane_ok && goff[i] >= 0;
-            pre[i] = ok ? *(const float4*)(px + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, goff[i] | (plane_ok ? 0 : OOB),
+                                                           plane_ok ? q * plane_bytes : 0, 0);
+        pre[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     };
-    auto write_slab = [&](int q, float* buf) __attribute__((always_inline)) {
-        const bool plane_ok = (q >= 0) && (q < a.D);
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            if (loff[i] < 0) continue;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (plane_ok && goff[i] >= 0) v = bn_relu4(pre[i], sc, sh, has_aff);   // SAME pads the normalised input
-            *(float4*)(buf + loff[i]) = v;
+    auto stage_piece = [&](int i, int q, float* buf) __attribute__((always_inline)) {
+        float4 v = pre[i];
+        if (AFF) {                                       // SAME pads the NORMALISED input with 0
+            const bool ok = (q >= 0) && (q < a.D) && goff[i] >= 0;
+            v = bn_relu4(v, sc, sh, true);
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
         }
+        *(float4*)(buf + loff[i]) = v;
     };
 
     // ---- stride-1 accumulators: [0],[1] = blocks 0|1 (rows 0-7 | 8-15) of output rows r, r+1;
@@ -146,7 +150,9 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     const int hi = n >> 3;                         // 0: tile rows 0-7, 1: rows 8-15
     const int a_lane = (kq * NROWS + (n & 7)) * 4;
 
-    auto sweep = [&](auto Pc, const float* buf) __attribute__((always_inline)) {
+    // `extra(G)` is called once per step: the plane march hangs the next plane's staging on it so
+    // that those VALU / LDS-write / global-load instructions issue in the shadow of the MFMAs
+    auto sweep = [&](auto Pc, const float* buf, auto&& extra) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
         constexpr int KD_B0 = P % 3, KD_B1 = (P + 2) % 3, KD_B2 = (P + 1) % 3;
         const int a0 = a_lane + (hi ? KD_B1 : KD_B0) * COUT * 4;          // blocks 0|1
@@ -175,6 +181,7 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 if (G + 1 < NG) load_grp(G + 1, r);
+                if (r == 1) extra(G);
 #pragma unroll
                 for (int m = (r * NM) / 3; m < ((r + 1) * NM) / 3; ++m) {
                     const int j = m / NC, c = m % NC;
@@ -192,25 +199,35 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     };
 
     // store + zero the block that has just received kd = 2 (block (P+1)%3), output plane o
+    // per-lane byte offsets inside an output plane: rows r, r+1 (blocks 0|1) and r + (kq>>1) (block 2)
+    int yoff[3];
+    {
+        const int w = w0 + n, co = 4 * (kq & 1);
+        const int hs[3] = {h0 + 2 * wave, h0 + 2 * wave + 1, h0 + 2 * wave + (kq >> 1)};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            yoff[i] = (hs[i] < a.H && w < a.W) ? ((hs[i] * a.W + w) * COUT + co) * 4 : OOB;
+    }
+    const int yplane_bytes = a.H * a.W * COUT * 4;
     auto retire = [&](auto Pc, int o) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
         constexpr int B = (P + 1) % 3;
         const bool plane_ok = (o >= d0) && (o < d1);
-        const int co = 4 * (kq & 1);
-        const int w = w0 + n;
-        auto emit = [&](f32x4& r, int h) __attribute__((always_inline)) {
-            if (plane_ok && h < a.H && w < a.W) {
-                float* dst = a.y + ((((size_t)o * a.H + h) * a.W) + w) * a.cout_total + co;
-                *(float4*)dst = make_float4(r[0], r[1], r[2], r[3]);
+        auto emit = [&](f32x4& r, int yo) __attribute__((always_inline)) {
+            if (plane_ok) {
+                u32x4_t v = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, yrsrc, yo + o * yplane_bytes, 0, 0);
+                if (yo >= 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { st_s[k] += r[k]; st_q[k] += r[k] * r[k]; }
+                    for (int k = 0; k < 4; ++k) { st_s[k] += r[k]; st_q[k] += r[k] * r[k]; }
+                }
             }
             r = (f32x4){0.f, 0.f, 0.f, 0.f};
         };
         if (B < 2) {
-            if ((kq >> 1) == B) { emit(acc[0], h0 + 2 * wave); emit(acc[1], h0 + 2 * wave + 1); }
+            if ((kq >> 1) == B) { emit(acc[0], yoff[0]); emit(acc[1], yoff[1]); }
         } else {
-            emit(acc[2], h0 + 2 * wave + (kq >> 1));
+            emit(acc[2], yoff[2]);
         }
     };
 
@@ -290,19 +307,30 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     };
 
     // ---- plane march -----------------------------------------------------------------------------
-    issue_loads(d0 - 1);
-    write_slab(d0 - 1, slab);
+    // Plane q is swept while plane q+1 moves registers -> LDS (steps 6..11) and plane q+2 is requested
+    // from global memory (steps 14..19).  The two workgroups of a CU fall into lock-step (the one that
+    // is behind gets the whole matrix pipe while the other waits at its barrier), so whatever is NOT
+    // hidden under the MFMAs is idle time for both: only the retire stores and the barrier are left.
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_piece(i, d0 - 1);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) stage_piece(i, d0 - 1, slab);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_piece(i, d0);
     __syncthreads();
 
     auto plane = [&](auto Pc, int t) __attribute__((always_inline)) {
         const int q = d0 - 1 + t;
         float* cur_buf = slab + (t & 1) * SLAB_FLOATS;
         float* nxt = slab + ((t + 1) & 1) * SLAB_FLOATS;
-        const bool more = (t + 1 < T);
         const bool in_vol = (q >= 0) && (q < a.D);
-        if (more) issue_loads(q + 1);
+        // (past the last plane these stage / request planes nobody reads: harmless, and branch-free)
+        auto extra = [&](int G) __attribute__((always_inline)) {
+            if (G >= 6 && G < 6 + NIT) stage_piece(G - 6, q + 1, nxt);
+            if (G >= 14 && G < 14 + NIT) load_piece(G - 14, q + 2);
+        };
         if (FUSE) s2_finish();
-        if (in_vol) sweep(Pc, cur_buf);
+        sweep(Pc, cur_buf, extra);                 // planes outside the volume are staged as zeros
         if (FUSE && q >= d0) {
             if (q & 1) {
                 if (in_vol) s2_sweep(std::false_type{}, cur_buf);
@@ -323,7 +351,6 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
             }
         }
         retire(Pc, q - 1);
-        if (more) write_slab(q + 1, nxt);
         __syncthreads();
     };
     for (int t = 0; t < T; t += 3) {
@@ -354,6 +381,7 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
 template <bool FUSE>
 int launch_c8(const ConvArgs& a0, const FuseArgs& fa, hipStream_t st) {
     ConvArgs a = a0;
+    if ((long long)a.D * a.H * a.W * CIN * 4 >= (1LL << 31)) return MVS_E_SHAPE;   // 32-bit buffer offsets
     const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
     if (FUSE) {
         // chunks start on even planes so that stride-2 output planes never straddle workgroups
@@ -369,14 +397,18 @@ int launch_c8(const ConvArgs& a0, const FuseArgs& fa, hipStream_t st) {
     }
     dim3 grid(tiles, 1, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
     const size_t smem = (size_t)(LDS_FLOATS + (FUSE ? RED_FLOATS : 0)) * sizeof(float);
+    const bool aff = a.xs != nullptr || a.bn.stats != nullptr;
     static bool attr_done = false;       // per template instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3d_c8_kernel<FUSE>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3d_c8_kernel<FUSE, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3d_c8_kernel<FUSE, true>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv3d_c8_kernel<FUSE><<<grid, 256, smem, st>>>(a, fa);
+    if (aff) conv3d_c8_kernel<FUSE, true><<<grid, 256, smem, st>>>(a, fa);
+    else conv3d_c8_kernel<FUSE, false><<<grid, 256, smem, st>>>(a, fa);
     return (int)hipGetLastError();
 }
 

@@ -295,7 +295,10 @@ static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t
     if (stride == 1) {
         if (Cout == 1) return mvs_conv3d_out_launch(a, Cin, st);
         if (a.wprep_bf && mvs_conv3d_bf16x3_supported(Cin, Cout)) return mvs_conv3d_s1_bf16x3(a, Cin, Cout, st);
-        if (Cin == 32 && Cout == 8 && !a.x2 && !g_generic_c8) return mvs_conv3d_c8_launch(a, st);
+        if (Cin == 32 && Cout == 8 && !a.x2 && !g_generic_c8) {
+            int rc = mvs_conv3d_c8_launch(a, st);
+            if (rc != MVS_E_SHAPE) return rc;            // >= 2 GB volumes stay on the generic kernel
+        }
         if (Cin == 32 && Cout == 8) return launch_s1<32, 8, 8>(a, Cout, st);
         if (Cin == 16 && Cout % 16 == 0) return launch_s1<16, 16, 8>(a, Cout, st);
         if (Cin == 32 && Cout % 16 == 0) return launch_s1<32, 16, 8>(a, Cout, st);
