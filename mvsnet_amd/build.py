@@ -18,6 +18,7 @@ SOURCES = ["homography.hip", "cost_volume.hip", "conv3d_scalar.hip", "conv3d_mfm
            "regnet.hip", "softargmin.hip", "gru.hip", "gru_mfma.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("MVS_EXTRA_HIPCC_FLAGS", "").split()      # developer builds, e.g. -DC8_PROF
 
 
 def _stale(out, deps):

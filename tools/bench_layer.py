@@ -18,11 +18,12 @@ def main():
     ap.add_argument("what")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dhw", default="192,128,160")
+    ap.add_argument("--data", default="randn", help="randn | const (low toggle rate: clocks stay high)")
     a = ap.parse_args()
     D, H, W = (int(v) for v in a.dhw.split(","))
     dev = torch.device("cuda", 0)
     g = torch.Generator(device="cpu").manual_seed(0)
-    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    r = (lambda *s: torch.randn(*s, generator=g).to(dev)) if a.data == "randn" else (lambda *s: torch.full(s, 0.001).to(dev))
     if a.what == "pair":
         x, w1, w2 = r(D, H, W, 32), r(3, 3, 3, 32, 8) * 0.03, r(3, 3, 3, 32, 16) * 0.03
         s1 = torch.zeros(2, 8, dtype=torch.float64, device=dev); s2 = torch.zeros(2, 16, dtype=torch.float64, device=dev)
