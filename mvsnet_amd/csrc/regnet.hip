@@ -131,6 +131,24 @@ extern "C" size_t mvs_regnet_workspace_bytes(int D, int H, int W, int cin, int b
 }
 
 namespace {
+// Side stream for the branch layers (created on first use, one per process = one per GPU; calls into
+// the library are expected from one host thread per device, as everywhere else in this file).
+struct SideStream { hipStream_t stream; hipEvent_t fork[2]; hipEvent_t join; };
+SideStream* side_stream() {
+    static SideStream s;
+    static int state = 0;                          // 0 = not tried, 1 = ready, -1 = unavailable
+    if (state == 0) {
+        state = -1;
+        if (!getenv("MVS_NO_SIDE_STREAM") &&
+            hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&s.fork[0], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&s.fork[1], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess)
+            state = 1;
+    }
+    return state == 1 ? &s : nullptr;
+}
+
 // layer table (order of the weights array) and offsets of the pre-laid-out weights
 struct PrepLayout { int kind[11]; int ci[11]; int co[11]; size_t off[11]; bool ok[11]; bool bf[11]; size_t total; };
 PrepLayout prep_layout(int cin, int b) {
@@ -205,7 +223,7 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
     };
     // one layer: in = BN+ReLU(producer p1) [+ BN+ReLU(producer p2)], out = layer `out` (or reg)
     auto layer = [&](bool deconv, int p1, int p2, int out, int d, int h, int w, int ci, int co,
-                     int stride) -> int {
+                     int stride, hipStream_t hs) -> int {
         const float* x = p1 >= 0 ? ws.y[p1] : cost;
         const float* x2 = p2 >= 0 ? ws.y[p2] : nullptr;
         float* y = out == L62 ? reg : ws.y[out];
@@ -227,6 +245,7 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
                       : mvs_conv3d_scalar(x, s1, t1, x2, s2, t2, weights[out], d, h, w, ci, co, stride, y, so, hs);
     };
 #define RUN(call) do { if ((rc = (call))) return rc; } while (0)
+#define HIP_RUN(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return (int)e__; } while (0)
     // encoder on the raw cost volume (mvsnetworks.py:130-136).  3dconv1_0 and 3dconv0_1 read the same
     // volume: one fused pass when the shape is the one conv3d_c8.hip is built for.
     bool pair_done = false;
@@ -239,22 +258,33 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
         else if (rc != MVS_E_SHAPE) return rc;
     }
     if (!pair_done) {
-        RUN(layer(false, -1, -1, L10, D, H, W, cin, 2 * b, 2));
-        RUN(layer(false, -1, -1, L01, D, H, W, cin, b, 1));
+        RUN(layer(false, -1, -1, L10, D, H, W, cin, 2 * b, 2, hs));
+        RUN(layer(false, -1, -1, L01, D, H, W, cin, b, 1, hs));
     }
-    RUN(layer(false, L10, -1, L20, D1, H1, W1, 2 * b, 4 * b, 2));
-    RUN(layer(false, L20, -1, L30, D2, H2, W2, 4 * b, 8 * b, 2));
-    // same-resolution branches (mvsnetworks.py:138-145)
-    RUN(layer(false, L10, -1, L11, D1, H1, W1, 2 * b, 2 * b, 1));
-    RUN(layer(false, L20, -1, L21, D2, H2, W2, 4 * b, 4 * b, 1));
-    RUN(layer(false, L30, -1, L31, D3, H3, W3, 8 * b, 8 * b, 1));
+    // The same-resolution branches 3dconv1_1 / 3dconv2_1 (mvsnetworks.py:138-141) are only needed by
+    // the decoder; the layers below them are too small to fill 256 CUs, so the branches run on a side
+    // stream next to the encoder's tail (fork / join with events: graph-capture safe, no host sync).
+    // (only for the shape every layer of which has an MFMA kernel: the scalar fallback's BatchNorm
+    // finalise bookkeeping is single-stream)
+    SideStream* side = (g_conv_impl != MVS_CONV_IMPL_SCALAR && cin == 32 && b == 8) ? side_stream() : nullptr;
+    hipStream_t ss = side ? side->stream : hs;
+    if (side) { HIP_RUN(hipEventRecord(side->fork[0], hs)); HIP_RUN(hipStreamWaitEvent(ss, side->fork[0], 0)); }
+    RUN(layer(false, L10, -1, L11, D1, H1, W1, 2 * b, 2 * b, 1, ss));
+    RUN(layer(false, L10, -1, L20, D1, H1, W1, 2 * b, 4 * b, 2, hs));
+    if (side) { HIP_RUN(hipEventRecord(side->fork[1], hs)); HIP_RUN(hipStreamWaitEvent(ss, side->fork[1], 0)); }
+    RUN(layer(false, L20, -1, L21, D2, H2, W2, 4 * b, 4 * b, 1, ss));
+    if (side) HIP_RUN(hipEventRecord(side->join, ss));
+    RUN(layer(false, L20, -1, L30, D2, H2, W2, 4 * b, 8 * b, 2, hs));
+    RUN(layer(false, L30, -1, L31, D3, H3, W3, 8 * b, 8 * b, 1, hs));
     // decoder with additive skips (mvsnetworks.py:146-157)
-    RUN(layer(true, L31, -1, L40, D3, H3, W3, 8 * b, 4 * b, 2));
-    RUN(layer(true, L40, L21, L50, D2, H2, W2, 4 * b, 2 * b, 2));
-    RUN(layer(true, L50, L11, L60, D1, H1, W1, 2 * b, b, 2));
+    RUN(layer(true, L31, -1, L40, D3, H3, W3, 8 * b, 4 * b, 2, hs));
+    if (side) HIP_RUN(hipStreamWaitEvent(hs, side->join, 0));
+    RUN(layer(true, L40, L21, L50, D2, H2, W2, 4 * b, 2 * b, 2, hs));
+    RUN(layer(true, L50, L11, L60, D1, H1, W1, 2 * b, b, 2, hs));
     // output conv, no BN / ReLU / bias (mvsnetworks.py:158)
-    RUN(layer(false, L60, L01, L62, D, H, W, b, 1, 1));
+    RUN(layer(false, L60, L01, L62, D, H, W, b, 1, 1, hs));
 #undef RUN
+#undef HIP_RUN
     return 0;
 }
 
