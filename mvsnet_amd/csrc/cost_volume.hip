@@ -9,6 +9,7 @@
 // stores are fully coalesced 16-B-per-lane rows of the volume.  Feature maps (N*H*W*C*4 bytes,
 // 13 MB at the metric config) stay resident in L2 / Infinity Cache across the D planes.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -168,16 +169,19 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
 
     // Plane-vectorised bookkeeping.  The kernel is VALU-bound and everything except the blend itself
     // is identical for the lg lanes of a pixel, so lane `sub` does ALL the per-view bookkeeping of
-    // plane (batch + sub): projective map, floor, clamped tap offsets, zero-fill-masked weights.
-    // While sweeping plane p every lane fetches those 8 numbers per view from lane (base + p) with
-    // ds_bpermute (the LDS crossbar is otherwise idle here) and only pays for the loads and the blend.
-    const int base_lane = (threadIdx.x & 63) - sub;
+    // plane (batch + sub): projective map, floor, clamped tap offsets, zero-fill-masked bilinear
+    // weights (already multiplied out to one weight per tap).  The 8 numbers per (plane, pixel, view)
+    // go through a wave-private LDS table: while sweeping plane p every lane of the pixel reads them
+    // back with two broadcast ds_read_b128 per view and only pays for the loads and the blend.
+    extern __shared__ __attribute__((aligned(16))) float4 book_all[];
+    const int ppw = 64 / lg;                                 // pixels per wave
+    float4* book = book_all + (size_t)(threadIdx.x >> 6) * (64 * NSRC * 2);      // [lg planes][ppw pixels][NSRC][2]
+    const int pixl = (threadIdx.x & 63) / lg;
 
     for (int dlb = dl0; dlb < dl1; dlb += lg) {
-        int mo[NSRC][4];                                  // my plane: tap byte offsets 00, 01, 10, 11
-        float mw[NSRC][4];                                //           weights wx1, wx0, wy1, wy0 (masked)
         {
             const int dmy = d_begin + min(dlb + sub, dl1 - 1);
+            float4* mine = book + ((size_t)sub * ppw + pixl) * (NSRC * 2);
 #pragma unroll
             for (int v = 0; v < NSRC; ++v) {
                 const float* t = transforms + ((size_t)v * depth_total + dmy) * 8;
@@ -191,30 +195,29 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
                 int jx0 = min(max(ix0, 0), W - 1), jx1 = min(max(ix0 + 1, 0), W - 1);
                 int jy0 = min(max(iy0, 0), H - 1), jy1 = min(max(iy0 + 1, 0), H - 1);
                 const int r0 = v * img_bytes + jy0 * row_bytes, r1 = v * img_bytes + jy1 * row_bytes;
-                mo[v][0] = r0 + jx0 * pix_bytes; mo[v][1] = r0 + jx1 * pix_bytes;
-                mo[v][2] = r1 + jx0 * pix_bytes; mo[v][3] = r1 + jx1 * pix_bytes;
+                const int o00 = r0 + jx0 * pix_bytes, o01 = r0 + jx1 * pix_bytes;
+                const int o10 = r1 + jx0 * pix_bytes, o11 = r1 + jx1 * pix_bytes;
                 // per-tap zero fill folded into the separable weights: a tap is dropped iff its row or
                 // its column is outside the image, exactly as reading 0 for it (w * finite = 0)
-                mw[v][0] = (ix0 >= 0 && ix0 < W) ? (x0 + 1.0f) - sx : 0.0f;
-                mw[v][1] = (ix0 + 1 >= 0 && ix0 + 1 < W) ? sx - x0 : 0.0f;
-                mw[v][2] = (iy0 >= 0 && iy0 < H) ? (y0 + 1.0f) - sy : 0.0f;
-                mw[v][3] = (iy0 + 1 >= 0 && iy0 + 1 < H) ? sy - y0 : 0.0f;
+                const float wx1 = (ix0 >= 0 && ix0 < W) ? (x0 + 1.0f) - sx : 0.0f;
+                const float wx0 = (ix0 + 1 >= 0 && ix0 + 1 < W) ? sx - x0 : 0.0f;
+                const float wy1 = (iy0 >= 0 && iy0 < H) ? (y0 + 1.0f) - sy : 0.0f;
+                const float wy0 = (iy0 + 1 >= 0 && iy0 + 1 < H) ? sy - y0 : 0.0f;
+                mine[2 * v] = make_float4(__int_as_float(o00), __int_as_float(o01), __int_as_float(o10), __int_as_float(o11));
+                mine[2 * v + 1] = make_float4(wy1 * wx1, wy1 * wx0, wy0 * wx1, wy0 * wx0);
             }
         }
         const int np = min(lg, dl1 - dlb);
-        for (int p = 0; p < np; ++p) {
+        // one plane: refill the register tap cache where the taps moved, blend, reduce, store
+        auto plane = [&](int p, const float4 (&ofs)[NSRC], const float4 (&wts)[NSRC]) __attribute__((always_inline)) {
             const int dl = dlb + p;
-            const int srcl = base_lane + p;
-            // phase A: this plane's tap offsets; refill the register tap cache where they moved.
-            // All views' loads are issued before the first one is consumed.
-            float wts[NSRC][4];
+            // phase A: all views' loads are issued before the first one is consumed.
 #pragma unroll
             for (int v = 0; v < NSRC; ++v) {
-                const int o00 = __shfl(mo[v][0], srcl, 64), o11 = __shfl(mo[v][3], srcl, 64);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) wts[v][k] = __shfl(mw[v][k], srcl, 64);
+                const float4 of = ofs[v];
+                const int o00 = __float_as_int(of.x), o11 = __float_as_int(of.w);
                 if (o00 != c00[v] || o11 != c11[v]) {
-                    const int o01 = __shfl(mo[v][1], srcl, 64), o10 = __shfl(mo[v][2], srcl, 64);
+                    const int o01 = __float_as_int(of.y), o10 = __float_as_int(of.z);
 #pragma unroll
                     for (int k = 0; k < Q; ++k) {
                         t00[v][k] = ldb(srsrc, o00 + lane_bytes + 16 * k); t01[v][k] = ldb(srsrc, o01 + lane_bytes + 16 * k);
@@ -229,15 +232,15 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
             for (int k = 0; k < 2 * Q; ++k) { S[k] = rr[k]; Qs[k] = rq[k]; }
 #pragma unroll
             for (int v = 0; v < NSRC; ++v) {
-                const float wx1 = wts[v][0], wx0 = wts[v][1], wy1 = wts[v][2], wy0 = wts[v][3];
+                const float w00 = wts[v].x, w01 = wts[v].y, w10 = wts[v].z, w11 = wts[v].w;
 #pragma unroll
                 for (int k = 0; k < Q; ++k) {
                     f32x2 a0 = (f32x2){t00[v][k].x, t00[v][k].y}, a1 = (f32x2){t00[v][k].z, t00[v][k].w};
                     f32x2 b0 = (f32x2){t01[v][k].x, t01[v][k].y}, b1 = (f32x2){t01[v][k].z, t01[v][k].w};
                     f32x2 c0 = (f32x2){t10[v][k].x, t10[v][k].y}, c1 = (f32x2){t10[v][k].z, t10[v][k].w};
                     f32x2 e0 = (f32x2){t11[v][k].x, t11[v][k].y}, e1 = (f32x2){t11[v][k].z, t11[v][k].w};
-                    f32x2 w0 = wy1 * (wx1 * a0 + wx0 * b0) + wy0 * (wx1 * c0 + wx0 * e0);
-                    f32x2 w1 = wy1 * (wx1 * a1 + wx0 * b1) + wy0 * (wx1 * c1 + wx0 * e1);
+                    f32x2 w0 = w00 * a0 + w01 * b0 + w10 * c0 + w11 * e0;
+                    f32x2 w1 = w00 * a1 + w01 * b1 + w10 * c1 + w11 * e1;
                     S[2 * k] += w0; S[2 * k + 1] += w1;
                     Qs[2 * k] += w0 * w0; Qs[2 * k + 1] += w1 * w1;
                 }
@@ -256,6 +259,19 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
                 if (negate) { o0 = -o0; o1 = -o1; }
                 *reinterpret_cast<float4*>(dst + 4 * k) = make_float4(o0[0], o0[1], o1[0], o1[1]);
             }
+        };
+        auto fetch = [&](int p, float4 (&ofs)[NSRC], float4 (&wts)[NSRC]) __attribute__((always_inline)) {
+            const float4* bk = book + ((size_t)min(p, lg - 1) * ppw + pixl) * (NSRC * 2);
+#pragma unroll
+            for (int v = 0; v < NSRC; ++v) { ofs[v] = bk[2 * v]; wts[v] = bk[2 * v + 1]; }
+        };
+        // (reading plane p+1's entries during plane p costs a second register set and an occupancy
+        // step: measured slower)
+        for (int p = 0; p < np; ++p) {
+            float4 ofs[NSRC], wts[NSRC];
+            fetch(p, ofs, wts);
+            __builtin_amdgcn_sched_barrier(0);
+            plane(p, ofs, wts);
         }
     }
 }
@@ -264,18 +280,21 @@ template <int NSRC>
 void launch_sweep(const float* ref, const float* src, const float* transforms, int depth_total,
                   int d_begin, int d_count, int H, int W, int C, int variant, int negate,
                   float* cost, hipStream_t st) {
-    const int ppb = d_count < 16 ? d_count : 16;
+    static const int ppb_env = getenv("MVS_CV_PPB") ? atoi(getenv("MVS_CV_PPB")) : 0;
+    const int ppb0 = ppb_env > 0 ? ppb_env : 16;
+    const int ppb = d_count < ppb0 ? d_count : ppb0;
     // Q = 2 (8 channels per lane) halves the per-lane bookkeeping per channel but needs 236 VGPRs
     // (2 waves/SIMD instead of 3): measured 0.258 ms vs 0.243 ms at the metric config, so it stays off.
     const bool wide = false;
     const int lg = wide ? C / 8 : C / 4;
     long long total = (long long)H * W * lg;
     dim3 grid(mvs_cdiv(total, 256), mvs_cdiv(d_count, ppb));
+    const size_t smem = (size_t)4 * 64 * NSRC * 2 * sizeof(float4);     // bookkeeping table, 2 KB per wave and view
     if (wide)
-        cost_volume_sweep_kernel<NSRC, 2><<<grid, 256, 0, st>>>(ref, src, transforms, depth_total, d_begin,
+        cost_volume_sweep_kernel<NSRC, 2><<<grid, 256, smem, st>>>(ref, src, transforms, depth_total, d_begin,
                                                                 d_count, ppb, H, W, C, variant, negate, cost);
     else
-        cost_volume_sweep_kernel<NSRC, 1><<<grid, 256, 0, st>>>(ref, src, transforms, depth_total, d_begin,
+        cost_volume_sweep_kernel<NSRC, 1><<<grid, 256, smem, st>>>(ref, src, transforms, depth_total, d_begin,
                                                                 d_count, ppb, H, W, C, variant, negate, cost);
 }
 
