@@ -20,6 +20,80 @@ __device__ __forceinline__ float depth_at(int d, int D, float start, float inter
     return start + (float)d * ((end - start) / denom);                    // :487-488
 }
 
+// Tile variant: the block's 32 pixel columns (32 x D floats) are pulled into LDS with every load
+// in flight at once (the plain kernel below walks depth with a few dependent loads per thread and
+// is latency-bound at ~1 workgroup per CU); max / exp-sum / weighted sum / bucket reads then run
+// out of LDS, so the volume is read from memory exactly once.
+constexpr int SA_PX = 32, SA_G = 16;
+__global__ void __launch_bounds__(SA_PX * SA_G)
+softargmin_prob_tile_kernel(const float* __restrict__ reg, int D, int HW, float start, float interval,
+                            int inverse, float* __restrict__ depth_out, float* __restrict__ prob_out) {
+    extern __shared__ float tile[];                  // [D][SA_PX] z = -reg, later exp(z - max)
+    __shared__ float sh_a[SA_G][SA_PX];
+    __shared__ float sh_b[SA_G][SA_PX];
+    const int px = threadIdx.x % SA_PX, g = threadIdx.x / SA_PX;
+    const int pix = blockIdx.x * SA_PX + px;
+    const bool valid = pix < HW;
+    const float* col = reg + (valid ? pix : 0);
+
+    int d = g;
+    for (; d + 3 * SA_G < D; d += 4 * SA_G) {        // four independent loads per trip
+        float v0 = col[(size_t)d * HW], v1 = col[(size_t)(d + SA_G) * HW];
+        float v2 = col[(size_t)(d + 2 * SA_G) * HW], v3 = col[(size_t)(d + 3 * SA_G) * HW];
+        tile[d * SA_PX + px] = -v0; tile[(d + SA_G) * SA_PX + px] = -v1;
+        tile[(d + 2 * SA_G) * SA_PX + px] = -v2; tile[(d + 3 * SA_G) * SA_PX + px] = -v3;
+    }
+    for (; d < D; d += SA_G) tile[d * SA_PX + px] = -col[(size_t)d * HW];
+
+    // pass 1: max of z (own planes: no barrier needed before reading them back)
+    float m = -INFINITY;
+    for (d = g; d < D; d += SA_G) m = fmaxf(m, tile[d * SA_PX + px]);
+    sh_a[g][px] = m;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SA_G; ++i) m = fmaxf(m, sh_a[i][px]);
+    __syncthreads();
+
+    // pass 2: exp, sum of exp and depth-weighted sum (same per-thread order as the plain kernel's
+    // strided walk, then a fixed-order combine)
+    float se = 0.f, sz = 0.f;
+    for (d = g; d < D; d += SA_G) {
+        float e = expf(tile[d * SA_PX + px] - m);
+        tile[d * SA_PX + px] = e;
+        se += e;
+        sz += e * depth_at(d, D, start, interval, inverse);
+    }
+    sh_a[g][px] = se; sh_b[g][px] = sz;
+    __syncthreads();
+    if (g != 0 || !valid) return;
+    se = 0.f; sz = 0.f;
+#pragma unroll
+    for (int i = 0; i < SA_G; ++i) { se += sh_a[i][px]; sz += sh_b[i][px]; }
+    const float dep = sz / se;                                            // model.py:493-494
+    depth_out[pix] = dep;
+
+    int l0, r0;                                                           // model.py:83-140
+    if (inverse) {
+        float end = start + ((float)D - 1.0f) * interval;
+        float inv_s = 1.0f / start, inv_e = 1.0f / end;
+        float inv_int = (inv_s - inv_e) / ((float)D - 1.0f);
+        float idx = (1.0f / dep - inv_e) / inv_int;
+        l0 = D - (int)ceilf(idx) - 1;
+        r0 = D - (int)floorf(idx) - 1;
+    } else {
+        float idx = (dep - start) / interval;
+        l0 = (int)floorf(idx);
+        r0 = (int)ceilf(idx);
+    }
+    l0 = min(max(l0, 0), D - 1);
+    r0 = min(max(r0, 0), D - 1);
+    int l1 = min(max(l0 - 1, 0), D - 1);
+    int r1 = min(max(r0 + 1, 0), D - 1);
+    float pl0 = tile[l0 * SA_PX + px] / se, pr0 = tile[r0 * SA_PX + px] / se;
+    float pl1 = tile[l1 * SA_PX + px] / se, pr1 = tile[r1 * SA_PX + px] / se;
+    prob_out[pix] = (pl0 + pr0) + (pl1 + pr1);
+}
+
 __global__ void __launch_bounds__(256)
 softargmin_prob_kernel(const float* __restrict__ reg, int D, int HW, float start, float interval,
                        int inverse, float* __restrict__ depth_out, float* __restrict__ prob_out) {
@@ -85,6 +159,12 @@ extern "C" int mvs_softargmin_prob_f32(const float* reg, int D, int H, int W, fl
                                        float* prob, void* stream) {
     MVS_CHECK_ARG(reg && depth && prob && D > 0 && H > 0 && W > 0);
     int HW = H * W;
+    const size_t tile_bytes = (size_t)D * SA_PX * sizeof(float);
+    if (tile_bytes <= 60 * 1024) {                   // D <= 480: the whole column tile fits in LDS
+        softargmin_prob_tile_kernel<<<mvs_cdiv(HW, SA_PX), SA_PX * SA_G, tile_bytes, mvs_stream(stream)>>>(
+            reg, D, HW, depth_start, depth_interval, inverse_depth, depth, prob);
+        MVS_LAUNCH_RET();
+    }
     softargmin_prob_kernel<<<mvs_cdiv(HW, 64), 256, 0, mvs_stream(stream)>>>(
         reg, D, HW, depth_start, depth_interval, inverse_depth, depth, prob);
     MVS_LAUNCH_RET();
