@@ -44,6 +44,9 @@ template <int CIN, int COUT, int TH> struct S1Geom {
     static constexpr int WGS_PER_CU = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;
 };
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int OOB = (int)0x80000000u;      // buffer byte offset with bit 31 set: loads give 0, stores are dropped
+
 template <int CIN, int COUT, int TH, bool HAS_X2>
 __global__ void __launch_bounds__(256, (S1Geom<CIN, COUT, TH>::WGS_PER_CU))
 conv3d_s1_kernel(ConvArgs a) {
@@ -59,13 +62,14 @@ conv3d_s1_kernel(ConvArgs a) {
     constexpr int W_FLOATS = 9 * CQ * WROW;
     constexpr int SLAB_FLOATS = NPOS * S;
     static_assert(256 % CQ == 0, "channel quad per thread must be loop invariant");
+    static_assert(NF4 >= 256, "spare threads of the last piece redo their previous one");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;                              // [9 taps][CQ][3 kd][COUT][4]
     float* slab = smem + W_FLOATS;                 // [2][NPOS][S]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
 
     const int tiles_w = (a.W + TW - 1) / TW;
@@ -88,7 +92,7 @@ conv3d_s1_kernel(ConvArgs a) {
         wl[i] = a.w[(((size_t)(kd * 9 + tap)) * CIN + ciq * 4 + j) * a.cout_total + co_base + co];
     }
 
-    // ---- staging helpers ---------------------------------------------------------------------------
+    // ---- staging -----------------------------------------------------------------------------------
     const int c4 = tid % CQ;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 sc2 = sc, sh2 = sh;
@@ -98,51 +102,56 @@ conv3d_s1_kernel(ConvArgs a) {
     const bool has_aff2 = HAS_X2 && (a.x2s != nullptr || a.bn2.stats != nullptr);
     if (HAS_X2 && a.x2s) { sc2 = *(const float4*)(a.x2s + 4 * c4); sh2 = *(const float4*)(a.x2b + 4 * c4); }
     else if (HAS_X2 && a.bn2.stats) bn_affine4(a.bn2, 4 * c4, sc2, sh2);
+    // ReLU floor: -inf turns max(v, lo) into the identity when there is no producer BatchNorm
+    const float lo = has_aff ? 0.f : -INFINITY, lo2 = has_aff2 ? 0.f : -INFINITY;
 
     float4 pre[NIT];
     float4 pre2[HAS_X2 ? NIT : 1];
 
-    // Per-thread staging map, identical for every plane: element offset inside one input plane
-    // (-1 = outside the volume -> SAME padding zero) and float offset inside the LDS slab (-1 = none).
+    // Per-thread staging map, identical for every plane: byte offset inside one input plane (bit 31
+    // set = outside the image: the buffer load returns 0) and float offset inside the LDS slab.
     int goff[NIT], loff[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         int f = tid + 256 * i;
+        if (f >= NF4) f -= 256;                    // spare threads of the last piece redo their previous one
         int pos = f / CQ;
         int r = pos / PW, c = pos - r * PW;
         int gh = h0 - 1 + r, gw = w0 - 1 + c;
-        bool inb = (f < NF4) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        goff[i] = inb ? (gh * a.W + gw) * CIN + 4 * c4 : -1;
-        loff[i] = (f < NF4) ? (pos) * S + 4 * c4 : -1;
+        bool inb = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        goff[i] = inb ? ((gh * a.W + gw) * CIN + 4 * c4) * 4 : OOB;
+        loff[i] = pos * S + 4 * c4;
     }
-    const size_t plane_elems = (size_t)a.H * a.W * CIN;
+    const int plane_bytes = a.H * a.W * CIN * 4;
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.D * plane_bytes, 0x00020000);
+    const auto x2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_X2 ? a.x2 : a.x), 0, a.D * plane_bytes, 0x00020000);
+    const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.D * a.H * a.W * a.cout_total * 4, 0x00020000);
 
-    auto issue_loads = [&](int q) __attribute__((always_inline)) {
-        const bool plane_ok = (q >= 0) && (q < a.D);
-        const float* px = a.x + (size_t)(plane_ok ? q : 0) * plane_elems;
-        const float* px2 = HAS_X2 ? a.x2 + (size_t)(plane_ok ? q : 0) * plane_elems : nullptr;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const bool ok = plane_ok && goff[i] >= 0;
-            pre[i] = ok ? *(const float4*)(px + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (HAS_X2) pre2[i] = ok ? *(const float4*)(px2 + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    // piece i of a plane's staging: global -> registers (load_piece), registers -> LDS (stage_piece);
+    // branch-free, because they are issued between the MFMAs of the sweep
+    auto ld4b = [](auto rsrc, int voff, int soff) __attribute__((always_inline)) {
+        u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     };
-    auto write_slab = [&](int q, float* buf) __attribute__((always_inline)) {
+    auto load_piece = [&](int i, int q) __attribute__((always_inline)) {
         const bool plane_ok = (q >= 0) && (q < a.D);
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            if (loff[i] < 0) continue;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (plane_ok && goff[i] >= 0) {             // SAME padding pads the NORMALISED input with 0
-                v = bn_relu4(pre[i], sc, sh, has_aff);
-                if (HAS_X2) {
-                    float4 v2 = bn_relu4(pre2[i], sc2, sh2, has_aff2);
-                    v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
-                }
-            }
-            *(float4*)(buf + loff[i]) = v;
+        const int voff = goff[i] | (plane_ok ? 0 : OOB), soff = plane_ok ? q * plane_bytes : 0;
+        pre[i] = ld4b(xrsrc, voff, soff);
+        if (HAS_X2) pre2[i] = ld4b(x2rsrc, voff, soff);
+    };
+    auto stage_piece = [&](int i, int q, float* buf) __attribute__((always_inline)) {
+        // SAME padding pads the NORMALISED input with 0: positions outside the volume are forced to 0
+        const bool ok = (q >= 0) && (q < a.D) && goff[i] >= 0;
+        float4 v = pre[i];
+        v.x = fmaxf(v.x * sc.x + sh.x, lo); v.y = fmaxf(v.y * sc.y + sh.y, lo);
+        v.z = fmaxf(v.z * sc.z + sh.z, lo); v.w = fmaxf(v.w * sc.w + sh.w, lo);
+        if (HAS_X2) {
+            float4 u = pre2[i];
+            v.x += fmaxf(u.x * sc2.x + sh2.x, lo2); v.y += fmaxf(u.y * sc2.y + sh2.y, lo2);
+            v.z += fmaxf(u.z * sc2.z + sh2.z, lo2); v.w += fmaxf(u.w * sc2.w + sh2.w, lo2);
         }
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        *(float4*)(buf + loff[i]) = v;
     };
 
     // ---- accumulators ------------------------------------------------------------------------------
@@ -162,8 +171,11 @@ conv3d_s1_kernel(ConvArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) { int r = m * 16 + n; row_blk[m] = r / COUT; row_co[m] = r % COUT; }
 
-    // one plane sweep; P = plane counter mod 3 (static), block b carries kd = (P - b) mod 3
-    auto sweep = [&](auto Pc, const float* buf) __attribute__((always_inline)) {
+    // One plane sweep; P = plane counter mod 3 (static), block b carries kd = (P - b) mod 3.
+    // `extra(g)` is called once per operand group: the plane march hangs the next planes' staging on
+    // it, so that those VALU / LDS-write / global-load instructions issue between the MFMAs.
+    constexpr int NG = 9 * (CIN / 16);
+    auto sweep = [&](auto Pc, const float* buf, auto&& extra) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
         int a_off[MT];
 #pragma unroll
@@ -175,76 +187,91 @@ conv3d_s1_kernel(ConvArgs a) {
         // Operand groups g = (kh, kw, s): one ds_read_b128 per operand tile feeds 4 k-steps.  The
         // reads of group g+1 are issued before the MFMAs of group g (register double buffer), so a
         // lone wave per SIMD never waits on LDS latency with an idle matrix pipe.
-        constexpr int NG = 9 * (CIN / 16);
-        constexpr int NR = V + MT;                 // LDS reads per group
-        constexpr int NM = 4 * MT * V;             // MFMAs per group
         f32x4 bv[2][V], av[2][MT];
-        // read r of group g: r < V -> B tile r, else A tile r - V
-        auto load_one = [&](int g, int r, f32x4 (&b)[V], f32x4 (&aop)[MT]) __attribute__((always_inline)) {
+        auto load_grp = [&](int g, f32x4 (&b)[V], f32x4 (&aop)[MT]) __attribute__((always_inline)) {
             const int tap = g / (CIN / 16), s = g % (CIN / 16);
             const int kh = tap / 3, kw = tap % 3;
-            if (r < V) b[r] = *(const f32x4*)(buf + b_off[r] + (kh * PW + kw) * S + 16 * s);
-            else aop[r - V] = *(const f32x4*)(wl + a_off[r - V] + (tap * CQ + 4 * s) * WROW);
-        };
 #pragma unroll
-        for (int r = 0; r < NR; ++r) load_one(0, r, bv[0], av[0]);
+            for (int v = 0; v < V; ++v) b[v] = *(const f32x4*)(buf + b_off[v] + (kh * PW + kw) * S + 16 * s);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) aop[m] = *(const f32x4*)(wl + a_off[m] + (tap * CQ + 4 * s) * WROW);
+        };
+        load_grp(0, bv[0], av[0]);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            // NR slices: one read of the next group, then NM/NR MFMAs of this group; the
-            // sched_barrier keeps hipcc from sinking the read down to its first use
+            if (g + 1 < NG) load_grp(g + 1, bv[(g + 1) & 1], av[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            extra(g);
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                if (g + 1 < NG) load_one(g + 1, r, bv[(g + 1) & 1], av[(g + 1) & 1]);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = (r * NM) / NR; i < ((r + 1) * NM) / NR; ++i) {
-                    const int j = i / (MT * V), m = (i / V) % MT, v = i % V;
-                    acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][j], bv[g & 1][v][j], acc[m][v], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][j], bv[g & 1][v][j], acc[m][v], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     // store + zero the block that has just received kd = 2 (block (P+1)%3), output plane o
+    int yoff[V];                                        // per-lane byte offset inside an output plane
+    const int yplane_bytes = a.H * a.W * a.cout_total * 4;
     auto retire = [&](auto Pc, int o) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
         constexpr int B = (P + 1) % 3;
         constexpr int mt = (B * COUT) / 16;                 // tile holding the block
         constexpr int row0 = (B * COUT) % 16;               // first row of the block inside the tile
         const bool plane_ok = (o >= d0) && (o < d1);
-        const int q4 = kq;                                  // lane group holds rows 4*q4 .. 4*q4+3
-        const bool mine = (4 * q4 >= row0) && (4 * q4 < row0 + COUT);
-        const int co = 4 * q4 - row0;                       // first of this lane's 4 channels
+        const bool mine = (4 * kq >= row0) && (4 * kq < row0 + COUT);   // lane group holds rows 4kq .. 4kq+3
+        const int co = 4 * kq - row0;                       // first of this lane's 4 channels
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             if (mine) {
-                int h = h0 + V * wave + v, w = w0 + n;
-                if (plane_ok && h < a.H && w < a.W) {
+                if (plane_ok) {
                     f32x4 r = acc[mt][v];
-                    float* dst = a.y + ((((size_t)o * a.H + h) * a.W) + w) * a.cout_total + co_base + co;
-                    *(float4*)dst = make_float4(r[0], r[1], r[2], r[3]);
+                    u32x4_t u = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(u, yrsrc, yoff[v] + co * 4, o * yplane_bytes, 0);
+                    if (yoff[v] >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { st_s[k] += r[k]; st_q[k] += r[k] * r[k]; }
+                        for (int k = 0; k < 4; ++k) { st_s[k] += r[k]; st_q[k] += r[k] * r[k]; }
+                    }
                 }
                 acc[mt][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
     };
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int h = h0 + V * wave + v, w = w0 + n;
+        yoff[v] = (h < a.H && w < a.W) ? ((h * a.W + w) * a.cout_total + co_base) * 4 : OOB;
+    }
 
     // ---- plane march -------------------------------------------------------------------------------
-    issue_loads(d0 - 1);
-    write_slab(d0 - 1, slab);
+    // Plane q is swept while plane q+1 moves registers -> LDS (first half of the operand groups) and
+    // plane q+2 is requested from global memory (second half): with one or two waves per SIMD,
+    // whatever is not issued under the MFMAs is idle matrix-pipe time.
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_piece(i, d0 - 1);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) stage_piece(i, d0 - 1, slab);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_piece(i, d0);
     __syncthreads();
 
     auto plane = [&](auto Pc, int t) __attribute__((always_inline)) {
         const int q = d0 - 1 + t;
         float* cur = slab + (t & 1) * SLAB_FLOATS;
         float* nxt = slab + ((t + 1) & 1) * SLAB_FLOATS;
-        const bool more = (t + 1 < T);
-        if (more) issue_loads(q + 1);
-        if (q >= 0 && q < a.D) sweep(Pc, cur);
+        // (past the last plane these stage / request planes nobody reads: harmless, and branch-free)
+        auto extra = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                if ((i * (NG / 2)) / NIT == g) stage_piece(i, q + 1, nxt);
+                if (NG / 2 + (i * (NG - NG / 2)) / NIT == g) load_piece(i, q + 2);
+            }
+        };
+        sweep(Pc, cur, extra);                      // planes outside the volume are staged as zeros
         retire(Pc, q - 1);
-        if (more) write_slab(q + 1, nxt);
         __syncthreads();
     };
     for (int t = 0; t < T; t += 3) {
@@ -267,6 +294,7 @@ size_t s1_smem_bytes() {
 template <int CIN, int COUT, int TH>
 int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
     ConvArgs a = a0;
+    if ((long long)a.D * a.H * a.W * (CIN > Cout ? CIN : Cout) * 4 >= (1LL << 31)) return MVS_E_SHAPE;   // 32-bit buffer offsets
     const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
     const int groups = Cout / COUT;
     a.planes_per_wg = conv_pick_planes(a.D, (long long)tiles * groups, 2);

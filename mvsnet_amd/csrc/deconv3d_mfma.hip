@@ -11,6 +11,7 @@
 // in-plane parity classes (kh&1, kw&1) select the accumulator, taps with k = 2 read the (-1) shifted
 // position.
 #include "conv_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -246,6 +247,11 @@ int launch_deconv(const ConvArgs& a0, int Cout, hipStream_t st) {
 }  // namespace
 
 int mvs_deconv3d_mfma_launch(const ConvArgs& a, int Cin, int Cout, hipStream_t st) {
+    static const bool generic_only = getenv("MVS_GENERIC_DECONV") != nullptr;     // test hook (A/B timing, parity)
+    if (!generic_only && Cout % 8 == 0 && ((Cin == 16 && Cout == 8) || Cin == 64)) {
+        int rc = mvs_deconv3d_c8_launch(a, Cin, Cout, st);       // packed 8-channel kernel (deconv3d_c8.hip)
+        if (rc != MVS_E_SHAPE) return rc;
+    }
     if (Cin == 16 && Cout == 8) return launch_deconv<16, 8, 8>(a, Cout, st);
     if (Cin == 32 && Cout % 16 == 0) return launch_deconv<32, 16, 8>(a, Cout, st);
     if (Cin == 64 && Cout % 8 == 0) return launch_deconv<64, 8, 8>(a, Cout, st);
