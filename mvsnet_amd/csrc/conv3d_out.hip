@@ -25,7 +25,10 @@ conv3d_out_kernel(ConvArgs a) {
     constexpr int NIT = (NF4 + 255) / 256;
     static_assert(256 % CQ == 0, "channel quad per thread must be loop invariant");
     __shared__ __attribute__((aligned(16))) float slab[2][NPOS * S];
-    __shared__ float wsh[27 * CIN];
+    // the 27*CIN weights are read through the scalar cache (constant address space, wave-uniform
+    // addresses -> s_load into SGPRs): as LDS broadcast reads they took 3/4 of the LDS pipe
+    typedef const __attribute__((address_space(4))) float cfloat;
+    cfloat* wsh = (cfloat*)(a.w);
 
     const int tid = threadIdx.x;
     const int row = tid >> 5, col = tid & 31;
@@ -36,8 +39,6 @@ conv3d_out_kernel(ConvArgs a) {
     const int d0 = blockIdx.z * a.planes_per_wg;
     const int d1 = min(d0 + a.planes_per_wg, a.D);
     const int T = d1 - d0 + 2;
-
-    for (int i = tid; i < 27 * CIN; i += 256) wsh[i] = a.w[i];      // (3,3,3,Cin,1)
 
     const int c4 = tid % CQ;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -114,9 +115,9 @@ conv3d_out_kernel(ConvArgs a) {
 #pragma unroll
                     for (int cq = 0; cq < CQ; ++cq) {
                         float4 x = *(const float4*)(cur + base + (kh * OPW + kw) * S + 4 * cq);
-                        const float* w0p = wsh + ((0 * 9 + kh * 3 + kw) * CIN + 4 * cq);
-                        const float* w1p = wsh + ((1 * 9 + kh * 3 + kw) * CIN + 4 * cq);
-                        const float* w2p = wsh + ((2 * 9 + kh * 3 + kw) * CIN + 4 * cq);
+                        cfloat* w0p = wsh + ((0 * 9 + kh * 3 + kw) * CIN + 4 * cq);       // (3,3,3,Cin,1)
+                        cfloat* w1p = wsh + ((1 * 9 + kh * 3 + kw) * CIN + 4 * cq);
+                        cfloat* w2p = wsh + ((2 * 9 + kh * 3 + kw) * CIN + 4 * cq);
                         acc0 += x.x * w0p[0] + x.y * w0p[1] + x.z * w0p[2] + x.w * w0p[3];
                         acc1 += x.x * w1p[0] + x.y * w1p[1] + x.z * w1p[2] + x.w * w1p[3];
                         acc2 += x.x * w2p[0] + x.y * w2p[1] + x.z * w2p[2] + x.w * w2p[3];
