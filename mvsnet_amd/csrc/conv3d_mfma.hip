@@ -28,7 +28,6 @@
 namespace {
 
 constexpr int TW = CONV_TW;
-constexpr int PW = TW + 2;      // staged row width with halo
 
 // ------------------------------------------------------------------------------------------------
 // stride-1 convolution, input-stationary.  COUT = output channels handled by this workgroup (8|16).
@@ -36,26 +35,34 @@ constexpr int PW = TW + 2;      // staged row width with halo
 // Per-instance geometry.  The big full-resolution layer (32 -> 8) trades the conflict-free slab
 // pitch (Cin+8) for Cin+4 (2-way conflicts on the B reads, LDS is ~12 % busy) so that two
 // workgroups fit in a CU's 160 KB LDS: two waves per SIMD hide each other's LDS / barrier stalls.
-template <int CIN, int COUT, int TH> struct S1Geom {
-    static constexpr bool TIGHT = (CIN == 32 && COUT == 8 && TH == 8);
+// The workgroup tile is TH x TWG voxels, cut into 16-voxel MFMA column tiles of CR rows x 16/CR
+// columns (CR = 1: 16 voxels along w; CR = 2, 4: 2x8 / 4x4 patches for the low-resolution layers,
+// whose widths 40 and 20 are not multiples of 16 -- a 16-wide tiling would run 17 % / 38 % of the
+// MFMA columns on padding).
+template <int CIN, int COUT, int TH, int TWG = CONV_TW> struct S1Geom {
+    static constexpr bool TIGHT = (CIN == 32 && COUT == 8 && TH == 8 && TWG == CONV_TW);
     static constexpr int S = TIGHT ? CIN + 4 : SlabGeom<CIN>::S;
     // LDS bytes = weights + two slabs; two workgroups per CU whenever that fits in 160 KB
-    static constexpr int LDS_BYTES = (9 * (CIN / 4) * 3 * COUT * 4 + 2 * (TH + 2) * (CONV_TW + 2) * S) * 4;
+    static constexpr int LDS_BYTES = (9 * (CIN / 4) * 3 * COUT * 4 + 2 * (TH + 2) * (TWG + 2) * S) * 4;
     static constexpr int WGS_PER_CU = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int OOB = (int)0x80000000u;      // buffer byte offset with bit 31 set: loads give 0, stores are dropped
 
-template <int CIN, int COUT, int TH, bool HAS_X2>
-__global__ void __launch_bounds__(256, (S1Geom<CIN, COUT, TH>::WGS_PER_CU))
+template <int CIN, int COUT, int TH, bool HAS_X2, int TWG = CONV_TW, int CR = 1>
+__global__ void __launch_bounds__(256, (S1Geom<CIN, COUT, TH, TWG>::WGS_PER_CU))
 conv3d_s1_kernel(ConvArgs a) {
-    constexpr int S = S1Geom<CIN, COUT, TH>::S;
+    constexpr int S = S1Geom<CIN, COUT, TH, TWG>::S;
+    constexpr int PW = TWG + 2;                    // staged row width with halo
+    constexpr int CC = 16 / CR;                    // columns of a 16-voxel MFMA column tile
+    constexpr int TPR = TWG / CC;                  // column tiles per tile row
+    static_assert(TH % CR == 0 && TWG % CC == 0 && (TH * TWG) % 64 == 0, "tile must split into 4 x V column tiles");
     constexpr int NPOS = (TH + 2) * PW;
     constexpr int CQ = CIN / 4;                    // float4 per position
     constexpr int NF4 = NPOS * CQ;
     constexpr int NIT = (NF4 + 255) / 256;
-    constexpr int V = TH / 4;                      // voxel tiles (rows of the h x w tile) per wave
+    constexpr int V = TH * TWG / 64;               // 16-voxel column tiles per wave
     constexpr int NROWS = 3 * COUT;                // (kd, co) weight rows
     constexpr int MT = (NROWS + 15) / 16;          // 16-row MFMA tiles
     constexpr int WROW = NROWS * 4;                // floats per (tap, ci-quad) weight group
@@ -72,14 +79,22 @@ conv3d_s1_kernel(ConvArgs a) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
 
-    const int tiles_w = (a.W + TW - 1) / TW;
+    const int tiles_w = (a.W + TWG - 1) / TWG;
     const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tile_h = bid / tiles_w, tile_w = bid - tile_h * tiles_w;
-    const int h0 = tile_h * TH, w0 = tile_w * TW;
+    const int h0 = tile_h * TH, w0 = tile_w * TWG;
     const int co_base = blockIdx.y * COUT;
     const int d0 = blockIdx.z * a.planes_per_wg;
     const int d1 = min(d0 + a.planes_per_wg, a.D);
     const int T = d1 - d0 + 2;                     // input planes d0-1 .. d1
+    // this lane's voxel (row, column inside the workgroup tile) in each of the wave's column tiles
+    int vrow[V], vcol[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int ct = V * wave + v;
+        vrow[v] = (ct / TPR) * CR + n / CC;
+        vcol[v] = (ct % TPR) * CC + n % CC;
+    }
 
     // ---- weights -> LDS, re-laid out as [tap][ci/4][kd][co][ci%4] ------------------------------
     if (a.wprep) load_prepared_weights(wl, a.wprep, W_FLOATS);
@@ -165,7 +180,7 @@ conv3d_s1_kernel(ConvArgs a) {
     // lane constants: B-operand base (floats) per voxel tile, A-operand row decomposition
     int b_off[V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) b_off[v] = ((V * wave + v) * PW + n) * S + 4 * kq;
+    for (int v = 0; v < V; ++v) b_off[v] = (vrow[v] * PW + vcol[v]) * S + 4 * kq;
     // row m of tile mt -> block (mt*16+m)/COUT, channel (mt*16+m)%COUT
     int row_blk[MT], row_co[MT];
 #pragma unroll
@@ -242,7 +257,7 @@ conv3d_s1_kernel(ConvArgs a) {
     };
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        const int h = h0 + V * wave + v, w = w0 + n;
+        const int h = h0 + vrow[v], w = w0 + vcol[v];
         yoff[v] = (h < a.H && w < a.W) ? ((h * a.W + w) * a.cout_total + co_base) * 4 : OOB;
     }
 
@@ -286,31 +301,26 @@ conv3d_s1_kernel(ConvArgs a) {
     if (a.stats) stats_commit<COUT>(st_s, st_q, COUT == 8, slab, a.stats, a.cout_total, co_base);
 }
 
-template <int CIN, int COUT, int TH>
-size_t s1_smem_bytes() {
-    return (size_t)(9 * (CIN / 4) * 3 * COUT * 4 + 2 * (TH + 2) * PW * S1Geom<CIN, COUT, TH>::S) * sizeof(float);
-}
-
-template <int CIN, int COUT, int TH>
+template <int CIN, int COUT, int TH, int TWG = CONV_TW, int CR = 1>
 int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
     ConvArgs a = a0;
     if ((long long)a.D * a.H * a.W * (CIN > Cout ? CIN : Cout) * 4 >= (1LL << 31)) return MVS_E_SHAPE;   // 32-bit buffer offsets
-    const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
+    const int tiles = ((a.H + TH - 1) / TH) * ((a.W + TWG - 1) / TWG);
     const int groups = Cout / COUT;
     a.planes_per_wg = conv_pick_planes(a.D, (long long)tiles * groups, 2);
     dim3 grid(tiles, groups, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
-    size_t smem = s1_smem_bytes<CIN, COUT, TH>();
+    size_t smem = (size_t)S1Geom<CIN, COUT, TH, TWG>::LDS_BYTES;
     static bool attr_done = false;       // per template instantiation
     if (!attr_done) {
         hipError_t e;
-        if ((e = hipFuncSetAttribute((const void*)conv3d_s1_kernel<CIN, COUT, TH, true>,
+        if ((e = hipFuncSetAttribute((const void*)conv3d_s1_kernel<CIN, COUT, TH, true, TWG, CR>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess) return (int)e;
-        if ((e = hipFuncSetAttribute((const void*)conv3d_s1_kernel<CIN, COUT, TH, false>,
+        if ((e = hipFuncSetAttribute((const void*)conv3d_s1_kernel<CIN, COUT, TH, false, TWG, CR>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess) return (int)e;
         attr_done = true;
     }
-    if (a.x2) conv3d_s1_kernel<CIN, COUT, TH, true><<<grid, 256, smem, st>>>(a);
-    else conv3d_s1_kernel<CIN, COUT, TH, false><<<grid, 256, smem, st>>>(a);
+    if (a.x2) conv3d_s1_kernel<CIN, COUT, TH, true, TWG, CR><<<grid, 256, smem, st>>>(a);
+    else conv3d_s1_kernel<CIN, COUT, TH, false, TWG, CR><<<grid, 256, smem, st>>>(a);
     return (int)hipGetLastError();
 }
 
@@ -318,6 +328,7 @@ int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
 
 // test hook: MVS_GENERIC_C8=1 keeps the 32 -> 8 layer on the generic kernel (A/B timing, parity)
 static const bool g_generic_c8 = getenv("MVS_GENERIC_C8") != nullptr;
+static const bool g_wide_tiles = getenv("MVS_WIDE_TILES") != nullptr;        // test hook: 16-wide column tiles only
 
 static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t st) {
     if (stride == 1) {
@@ -329,7 +340,10 @@ static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t
         }
         if (Cin == 32 && Cout == 8) return launch_s1<32, 8, 8>(a, Cout, st);
         if (Cin == 16 && Cout % 16 == 0) return launch_s1<16, 16, 8>(a, Cout, st);
+        // widths that are not multiples of 16 (the /4 and /8 levels of a 160-wide volume): 2x8 / 4x4 column tiles
+        if (Cin == 32 && Cout % 16 == 0 && a.W % 16 != 0 && a.W % 8 == 0 && !g_wide_tiles) return launch_s1<32, 16, 8, 8, 2>(a, Cout, st);
         if (Cin == 32 && Cout % 16 == 0) return launch_s1<32, 16, 8>(a, Cout, st);
+        if (Cin == 64 && Cout % 8 == 0 && a.W % 16 != 0 && a.W % 4 == 0 && a.H % 16 == 0 && !g_wide_tiles) return launch_s1<64, 8, 16, 4, 4>(a, Cout, st);
         if (Cin == 64 && Cout % 8 == 0) return launch_s1<64, 8, 4>(a, Cout, st);
         if (Cin == 16 && Cout == 8) return launch_s1<16, 8, 8>(a, Cout, st);
         return MVS_E_SHAPE;

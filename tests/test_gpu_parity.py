@@ -145,6 +145,9 @@ def test_cost_volume_identical_views_is_zero_and_padding_views():
 CONV_CASES = [  # D,H,W,Cin,Cout,stride
     (8, 8, 16, 32, 8, 1), (8, 8, 16, 32, 16, 2), (4, 8, 8, 16, 16, 1), (4, 4, 8, 16, 32, 2),
     (4, 4, 4, 64, 64, 1), (8, 16, 16, 8, 1, 1), (6, 10, 12, 8, 8, 1), (6, 10, 12, 12, 6, 2),
+    # widths 40 / 20 of the quarter / eighth resolution levels: 2x8 and 4x4 MFMA column tiles
+    (6, 16, 24, 32, 32, 1), (5, 12, 40, 32, 16, 1), (4, 16, 20, 64, 64, 1), (5, 32, 12, 64, 16, 1),
+    (7, 8, 16, 32, 8, 1), (6, 16, 32, 16, 16, 1),
 ]
 
 
