@@ -4,9 +4,10 @@
         --width 640 --height 512 --regularization 3DCNN [--weights weights.npz]
 
 One process per GPU; under torch.distributed.run the clusters (reference views) of the session are
-sharded round-robin across ranks with no collective on the data path.  Without
---weights the networks are randomly initialised (no checkpoint exists offline; TF-checkpoint import
-is SURVEY 8f row f5), which exercises the full pipeline and output formats.
+sharded round-robin across ranks with no collective on the data path.  --model_dir /
+--ckpt_step restore a TensorFlow checkpoint of the reference (mvsnet_amd/tf_checkpoint.py, no TF
+needed); without them (and without --weights) the networks are randomly initialised -- no checkpoint
+exists offline -- which still exercises the full pipeline and output formats.
 """
 from __future__ import annotations
 
@@ -20,9 +21,19 @@ import numpy as np
 logger = logging.getLogger("mvsnet_amd.inference")
 
 
-def build_weights(config, device, weights_path=None):
+def build_weights(config, device, weights_path=None, model_dir=None, ckpt_step=None):
+    """Weights from (in order of preference) a TensorFlow checkpoint of the reference
+    (<model_dir>/<regularization>/<network_mode>/model.ckpt-<ckpt_step>, inference.py:23-27 +
+    utils.py:75-96), an .npz of parameter dictionaries, or a seeded random initialisation."""
     from . import synthetic as S
     from .model import MVSNetWeights
+    if model_dir:
+        from . import tf_checkpoint as ck
+        prefix = ck.model_path(ck.ckpt_path(model_dir, config.regularization, config.network_mode), ckpt_step)
+        params = ck.load_mvsnet_params(prefix, config.network_mode, config.regularization)
+        logger.info("restored %s", prefix)
+        return MVSNetWeights.from_numpy(config.network_mode, unet=params["unet"], regnet=params["regnet"],
+                                        gru=params["gru"], device=device)
     if weights_path:
         z = np.load(weights_path, allow_pickle=True)
         unet, regnet, gru = z["unet"].item(), z["regnet"].item(), z["gru"].item()
@@ -109,6 +120,8 @@ def main(argv=None):
         else:
             ap.add_argument("--" + name, type=type(default) if default is not None else str, default=default)
     ap.add_argument("--weights", default=None, help=".npz with 'unet', 'regnet', 'gru' parameter dicts")
+    ap.add_argument("--model_dir", default=None, help="reference checkpoint root (TensorFlow V2 checkpoint, read without TF)")
+    ap.add_argument("--ckpt_step", type=int, default=400000)
     args = ap.parse_args(argv)
     logging.basicConfig(level=os.environ.get("LOG_LEVEL", "INFO"))
     weights_path = args.weights
@@ -127,7 +140,7 @@ def main(argv=None):
     import torch
     rank, local_rank, world = sh.rank_world()
     device = torch.device("cuda", local_rank)
-    weights = build_weights(cfg, device, weights_path)
+    weights = build_weights(cfg, device, weights_path, args.model_dir, args.ckpt_step)
     total = 0
     for d in dirs:
         total += compute_depth_maps(d, cfg, weights, device)
