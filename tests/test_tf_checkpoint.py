@@ -21,6 +21,10 @@ def test_crc32c_known_answers():
     # the masking of leveldb / tensorflow: rotate right by 15 and add a constant
     assert ck.mask_crc(0) == 0xA282EAD8
     assert ck.mask_crc(0xE3069283) == (((0xE3069283 >> 15) | (0xE3069283 << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+    # the chunked / vectorised path (long buffers) against the bytewise definition, with and without a seed
+    d = np.random.RandomState(5).bytes(300_007)
+    assert ck.crc32c(d) == ck._crc_bytes(d)
+    assert ck.crc32c(d[1234:], ck._crc_bytes(d[:1234])) == ck._crc_bytes(d)
 
 
 def test_entry_proto_bytes():
