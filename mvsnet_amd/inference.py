@@ -30,10 +30,12 @@ def build_weights(config, device, weights_path=None, model_dir=None, ckpt_step=N
     if model_dir:
         from . import tf_checkpoint as ck
         prefix = ck.model_path(ck.ckpt_path(model_dir, config.regularization, config.network_mode), ckpt_step)
-        params = ck.load_mvsnet_params(prefix, config.network_mode, config.regularization)
+        params = ck.load_mvsnet_params(prefix, config.network_mode, config.regularization,
+                                       refinement=config.refinement_network if config.refinement else None)
         logger.info("restored %s", prefix)
         return MVSNetWeights.from_numpy(config.network_mode, unet=params["unet"], regnet=params["regnet"],
-                                        gru=params["gru"], device=device)
+                                        gru=params["gru"], device=device, refine=params.get("refine"),
+                                        refine_type=config.refinement_network)
     if weights_path:
         z = np.load(weights_path, allow_pickle=True)
         unet, regnet, gru = z["unet"].item(), z["regnet"].item(), z["gru"].item()
@@ -42,7 +44,13 @@ def build_weights(config, device, weights_path=None, model_dir=None, ckpt_step=N
         regnet = S.make_regnet_params(config.network_mode, seed=1)
         gru = S.make_gru_params(config.network_mode, seed=2,
                                 in_channels=4 * S.base_filter(config.network_mode))
-    return MVSNetWeights.from_numpy(config.network_mode, unet=unet, regnet=regnet, gru=gru, device=device)
+    refine = None
+    if config.refinement:
+        from .refine import make_refine_params
+        refine = make_refine_params(config.refinement_network, config.network_mode,
+                                    4 + int(config.refine_with_confidence), seed=4)
+    return MVSNetWeights.from_numpy(config.network_mode, unet=unet, regnet=regnet, gru=gru, device=device,
+                                    refine=refine, refine_type=config.refinement_network)
 
 
 def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwargs):
@@ -100,10 +108,16 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
         depth_interval = float(out_cams[0, 1, 3, 1])
         depth_num = int(out_cams[0, 1, 3, 2])
         depth_end = float(out_cams[0, 1, 3, 3])
+        ref_image = torch.as_tensor(in_images[0:1], dtype=torch.float32, device=device) if config.refinement else None
         d, p, _ = pl.get_depth_and_prob_map(None, cams, depth_start, depth_interval, config, weights,
-                                            depth_num=depth_num, depth_end=depth_end, features=features)
-        pl.write_output_slice(output_dir, d.cpu().numpy(), p.cpu().numpy(), out_images[0], out_cams[0],
-                              index, config.visualize)
+                                            depth_num=depth_num, depth_end=depth_end, features=features,
+                                            ref_image=ref_image)
+        if config.refinement and config.upsample_before_refinement:      # full-size outputs (predictlib.py:107-115)
+            pl.write_output_slice(output_dir, d.cpu().numpy(), p.cpu().numpy(), in_images[0], full_cams[0],
+                                  index, config.visualize, prob_upsample=1.0 / config.sample_scale)
+        else:
+            pl.write_output_slice(output_dir, d.cpu().numpy(), p.cpu().numpy(), out_images[0], out_cams[0],
+                                  index, config.visualize)
         done += 1
         logger.info("Depth inference %d/%d finished. (%.3f sec/step)", done, len(mine), time.time() - start)
     return done

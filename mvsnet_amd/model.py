@@ -78,13 +78,17 @@ class MVSNetWeights:
     unet: Optional[UNetDS2GN] = None
     regnet: Optional[RegNetWeights] = None
     gru: Optional[GRUWeights] = None
+    refine: Optional[object] = None          # refine.RefineNet, only for --refinement (model.py:753-811)
 
     @classmethod
-    def from_numpy(cls, network_mode="normal", unet=None, regnet=None, gru=None, device="cuda"):
+    def from_numpy(cls, network_mode="normal", unet=None, regnet=None, gru=None, device="cuda",
+                   refine=None, refine_type="original"):
+        from .refine import RefineNet
         return cls(network_mode,
                    UNetDS2GN(unet, device) if unet is not None else None,
                    RegNetWeights(regnet, device) if regnet is not None else None,
-                   GRUWeights(gru, device) if gru is not None else None)
+                   GRUWeights(gru, device) if gru is not None else None,
+                   RefineNet(refine, refine_type, device) if refine is not None else None)
 
 
 # ------------------------------------------------------------------------------------------------

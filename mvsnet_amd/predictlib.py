@@ -32,6 +32,9 @@ class InferenceConfig:
     inverse_depth: bool = False
     network_mode: str = "normal"
     refinement: bool = False
+    refinement_network: str = "original"              # 'original' | 'unet' (inference.py:57-59)
+    upsample_before_refinement: bool = False
+    refine_with_confidence: bool = False
     visualize: bool = False
     max_clusters_per_session: Optional[int] = None
 
@@ -45,19 +48,29 @@ def setup_output_dir(input_dir, output_dir):
 
 
 def get_depth_and_prob_map(full_images, scaled_cams, depth_start, depth_interval, config, weights,
-                           depth_num=None, depth_end=None, features=None):
+                           depth_num=None, depth_end=None, features=None, ref_image=None):
     """predictlib.py:79-99.  Returns (depth_map, prob_map, None).  The reference's GRU branch
     raises NameError as shipped (undefined depth_num / depth_end, predictlib.py:95-96); here they
     are explicit arguments (default: config.max_d and start + (D-1)*interval).  `features`
-    (N,H/4,W/4,C) skips the 2D towers (used by the per-image feature cache of inference.py)."""
+    (N,H/4,W/4,C) skips the 2D towers (used by the per-image feature cache of inference.py); then
+    `ref_image` (1,Himg,Wimg,3) supplies the reference image the refinement tower looks at.
+    With config.refinement the third result is the residual depth map (predictlib.py:86-92)."""
     from .model import inference_mem, inference_winner_take_all
     D = int(depth_num if depth_num is not None else config.max_d)
     if config.regularization == "3DCNN":
-        if config.refinement:
-            raise NotImplementedError("depth refinement is outside the hot path (SURVEY 8f row f3)")
         d, p = inference_mem(full_images, scaled_cams, D, depth_start, depth_interval,
                              config.network_mode, inverse_depth=config.inverse_depth,
                              weights=weights, view_num=config.view_num, features=features)
+        if config.refinement:
+            from .refine import depth_refine
+            if weights.refine is None:
+                raise ValueError("config.refinement needs weights.refine (MVSNetWeights.from_numpy(refine=...))")
+            if ref_image is None:
+                ref_image = full_images[:, 0] if full_images.dim() == 5 else full_images[0:1]
+            d, residual = depth_refine(d, ref_image.to(d.device), p, D, depth_start, depth_interval, weights.refine,
+                                       upsample_depth=config.upsample_before_refinement,
+                                       refine_with_confidence=config.refine_with_confidence)
+            return d, p, residual
     elif config.regularization == "GRU":
         if depth_end is None:
             depth_end = float(depth_start) + (D - 1) * float(depth_interval)
@@ -71,13 +84,16 @@ def get_depth_and_prob_map(full_images, scaled_cams, depth_start, depth_interval
 
 
 def write_output_slice(output_dir, out_depth_map, out_prob_map, out_ref_image, out_ref_cam, out_index,
-                       visualize=False):
+                       visualize=False, prob_upsample=None):
     """predictlib.py:105-159: <idx>_init.pfm, <idx>_prob.pfm, <idx>_depth.png (uint16 mm),
     <idx>_prob.png (x65535), <idx>.jpg, <idx>.txt with <idx> the un-padded reference index.
     out_ref_image: (H,W,3) in the pipeline's BGR order (write_reference_image swaps back to RGB)."""
     from PIL import Image
     depth = np.squeeze(np.asarray(out_depth_map)).astype(np.float32)
     prob = np.squeeze(np.asarray(out_prob_map)).astype(np.float32)
+    if prob_upsample:                 # depth was refined at input resolution: nearest-neighbour prob (predictlib.py:110-115)
+        from .mvs_data_generation import scale_image
+        prob = scale_image(prob, prob_upsample, "nearest")
     idx = int(np.squeeze(out_index))
     pp.write_pfm(os.path.join(output_dir, "{}_init.pfm".format(idx)), depth)
     pp.write_pfm(os.path.join(output_dir, "{}_prob.pfm".format(idx)), prob)

@@ -360,7 +360,7 @@ def model_path(ckpt, ckpt_step):
 
 
 # ---- variable-name map ----------------------------------------------------------------------------------
-def variable_names(network_mode="normal", regularization="3DCNN"):
+def variable_names(network_mode="normal", regularization="3DCNN", refinement=None):
     """{(group, layer, field): TensorFlow variable name} for the networks on the inference path.
     Names follow the layer names of mvsnet/cnn_wrapper/mvsnetworks.py:53-158 through
     tf.layers (``<layer>/kernel``), Network.batch_normalization (``<layer>/bn/{gamma,beta}``,
@@ -397,16 +397,21 @@ def variable_names(network_mode="normal", regularization="3DCNN"):
         m[("gru", None, "prob_b")] = "prob_conv/bias"
     else:
         raise NotImplementedError(regularization)
+    if refinement:                                     # 'original' | 'unet' (mvsnetworks.py:178-193,261-324)
+        from .refine import refine_layers
+        for layer in refine_layers(refinement)[0]:
+            m[("refine", layer[0], "w")] = layer[0] + "/kernel"
+            m[("refine", layer[0], "b")] = layer[0] + "/bias"
     return m
 
 
-def load_mvsnet_params(prefix, network_mode="normal", regularization="3DCNN"):
+def load_mvsnet_params(prefix, network_mode="normal", regularization="3DCNN", refinement=None):
     """Reads the inference-path variables of a reference checkpoint into this package's parameter
     dictionaries: returns {"unet": ..., "regnet": ... | None, "gru": ... | None} ready for
     ``MVSNetWeights.from_numpy``.  Missing variables raise KeyError naming the variable."""
-    names = variable_names(network_mode, regularization)
+    names = variable_names(network_mode, regularization, refinement)
     values = read_checkpoint(prefix, sorted(set(names.values())))
-    out = {"unet": {}, "regnet": None, "gru": None}
+    out = {"unet": {}, "regnet": None, "gru": None, "refine": None}
     for (group, layer, field), var in names.items():
         if out[group] is None:
             out[group] = {}
@@ -415,11 +420,12 @@ def load_mvsnet_params(prefix, network_mode="normal", regularization="3DCNN"):
     return out
 
 
-def export_mvsnet_params(prefix, unet=None, regnet=None, gru=None, network_mode="normal"):
+def export_mvsnet_params(prefix, unet=None, regnet=None, gru=None, network_mode="normal", refine=None,
+                         refinement="original"):
     """Inverse of `load_mvsnet_params`: writes parameter dictionaries under the reference's names."""
     tensors = {}
-    for reg, params in (("3DCNN", {"unet": unet, "regnet": regnet}), ("GRU", {"unet": unet, "gru": gru})):
-        for (group, layer, field), var in variable_names(network_mode, reg).items():
+    for reg, params in (("3DCNN", {"unet": unet, "regnet": regnet, "refine": refine}), ("GRU", {"unet": unet, "gru": gru})):
+        for (group, layer, field), var in variable_names(network_mode, reg, refinement if refine is not None else None).items():
             src = params.get(group)
             if src is None:
                 continue

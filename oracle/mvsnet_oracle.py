@@ -635,6 +635,91 @@ def unet_ds2gn(image, params, dtype=np.float32):
 
 
 # --------------------------------------------------------------------------------------
+# 8f row f3  depth refinement (model.py:753-811, mvsnetworks.py:178-193,261-324)
+# --------------------------------------------------------------------------------------
+
+# (name, kind 'c'|'d', sources, out-channel multiple of the base filter (0 = one channel), stride, relu)
+REFINE_ORIGINAL = tuple(("refine_conv%d" % i, "c", ("concat_image",) if i == 0 else ("refine_conv%d" % (i - 1),),
+                         1 if i < 3 else 0, 1, i < 3) for i in range(4))
+
+
+def _refine_unet_table():
+    n = lambda s: "2dconv%s_refine" % s
+    t = []
+    prev = "concat_image"
+    for lvl, mult in ((1, 2), (2, 4), (3, 8), (4, 16)):            # strided encoder chain (:272-276)
+        t.append((n("%d_0" % lvl), "c", (prev,), mult, 2, True)); prev = n("%d_0" % lvl)
+    for lvl, mult, src in ((0, 1, "concat_image"), (1, 2, n("1_0")), (2, 4, n("2_0")), (3, 8, n("3_0")), (4, 16, n("4_0"))):
+        t.append((n("%d_1" % lvl), "c", (src,), mult, 1, True))    # same-resolution pairs (:278-296)
+        t.append((n("%d_2" % lvl), "c", (n("%d_1" % lvl),), mult, 1, True))
+    for up, skip, mult in ((5, 3, 8), (6, 2, 4), (7, 1, 2), (8, 0, 1)):   # decoder (:297-320)
+        below = n("4_2") if up == 5 else n("%d_2" % (up - 1))
+        t.append((n("%d_0" % up), "d", (below,), mult, 2, True))
+        t.append((n("%d_1" % up), "c", (n("%d_0" % up), n("%d_2" % skip)), mult, 1, True))
+        t.append((n("%d_2" % up), "c", (n("%d_1" % up),), mult, 1, True))
+    t.append((n("8_3"), "c", (n("8_2"),), 4, 1, True))              # (:322-324)
+    t.append((n("8_4"), "c", (n("8_3"),), 0, 1, False))
+    return tuple(t)
+
+
+REFINE_UNET = _refine_unet_table()
+
+
+def resize_bilinear_tf1(x, out_h, out_w, dtype=np.float32):
+    """tf.image.resize_bilinear(x, [out_h, out_w]) with TF 1.x defaults (align_corners=False):
+    src = dst * (in / out), lower index floor(src), upper index min(lower + 1, in - 1)
+    (model.py:768-781).  x (H,W,C)."""
+    x = np.asarray(x, dtype=dtype)
+    h, w = x.shape[:2]
+
+    def axis(n_in, n_out):
+        src = (np.arange(n_out, dtype=dtype) * dtype(n_in / float(n_out))).astype(dtype)
+        i0 = np.minimum(np.floor(src).astype(np.int64), n_in - 1)
+        return i0, np.minimum(i0 + 1, n_in - 1), (src - i0.astype(dtype)).astype(dtype)
+
+    y0, y1, fy = axis(h, out_h)
+    x0, x1, fx = axis(w, out_w)
+    fx = fx[None, :, None]; fy = fy[:, None, None]
+    top = x[y0][:, x0] * (1 - fx) + x[y0][:, x1] * fx
+    bot = x[y1][:, x0] * (1 - fx) + x[y1][:, x1] * fx
+    return (top * (1 - fy) + bot * fy).astype(dtype)
+
+
+def refine_net(color_image, depth_image, params, network_type="original", dtype=np.float32):
+    """RefineNetConv / RefineUNetConv: Network.conv / deconv with their defaults -- bias, ReLU except
+    on the last layer, SAME (network.py:171-215,300-329).  Inputs (H,W,3), (H,W,1|2) -> (H,W,1)."""
+    table = REFINE_ORIGINAL if network_type == "original" else REFINE_UNET
+    layers = {"concat_image": np.concatenate([np.asarray(color_image, dtype), np.asarray(depth_image, dtype)], -1)}
+    for name, kind, srcs, _mult, stride, relu in table:
+        x = layers[srcs[0]] if len(srcs) == 1 else np.concatenate([layers[s] for s in srcs], -1)
+        p = params[name]
+        y = convnd_transpose_same(x, p["w"], stride, dtype) if kind == "d" else convnd_same(x, p["w"], stride, dtype)
+        y = y + np.asarray(p["b"], dtype)
+        layers[name] = np.maximum(y, dtype(0)) if relu else y
+    return layers[table[-1][0]]
+
+
+def depth_refine(init_depth_map, image, prob_map, depth_num, depth_start, depth_interval, params,
+                 network_type="original", upsample_depth=False, refine_with_confidence=False,
+                 residual_refinement=True, dtype=np.float32):
+    """model.py:753-811 for one sample: init_depth_map, prob_map (h,w,1); image (H,W,3)."""
+    d = np.asarray(init_depth_map, dtype)
+    scale = dtype((depth_start + (float(depth_num) - 1.0) * depth_interval) - depth_start)
+    norm = (d - dtype(depth_start)) / scale
+    image = np.asarray(image, dtype); prob_map = np.asarray(prob_map, dtype)
+    if upsample_depth:
+        H, W = image.shape[:2]
+        norm, d = resize_bilinear_tf1(norm, H, W, dtype), resize_bilinear_tf1(d, H, W, dtype)
+        if refine_with_confidence:
+            prob_map = resize_bilinear_tf1(prob_map, H, W, dtype)
+    else:
+        image = resize_bilinear_tf1(image, d.shape[0], d.shape[1], dtype)
+    data = np.concatenate([norm, prob_map], -1) if refine_with_confidence else norm
+    residual = refine_net(image, data, params, network_type, dtype) * scale
+    return (residual + d if residual_refinement else residual), residual
+
+
+# --------------------------------------------------------------------------------------
 # R10  composition
 # --------------------------------------------------------------------------------------
 

@@ -39,6 +39,26 @@ def test_compute_depth_maps_on_session_dir(tmp_path, lib_built, regularization):
         assert cam[1, 3, 2] == 8
 
 
+@pytest.mark.parametrize("network,upsample", [("original", False), ("unet", True)])
+def test_compute_depth_maps_with_refinement(tmp_path, lib_built, network, upsample):
+    """--refinement: the refined depth lands in <idx>_init.pfm; with
+    --upsample_before_refinement the outputs are written at input resolution (predictlib.py:107-115)."""
+    from tests.test_data_and_sharding import make_session
+    from mvsnet_amd.inference import compute_depth_maps
+    from mvsnet_amd import predictlib as pl, preprocess as pp
+    sess = make_session(str(tmp_path / "sess"), n_images=4, h=96, w=128)
+    cfg = pl.InferenceConfig(view_num=3, max_d=8, width=64, height=64, base_image_size=8, refinement=True,
+                             refinement_network=network, upsample_before_refinement=upsample,
+                             refine_with_confidence=upsample, max_clusters_per_session=1)
+    assert compute_depth_maps(sess, cfg) == 1
+    out = os.path.join(sess, "depths_mvsnet")
+    size = (64, 64) if upsample else (16, 16)
+    d = pp.load_pfm(os.path.join(out, "0_init.pfm")); p = pp.load_pfm(os.path.join(out, "0_prob.pfm"))
+    assert d.shape == size and p.shape == size and np.isfinite(d).all() and np.isfinite(p).all()
+    cam = pp.load_cam(os.path.join(out, "0.txt"))
+    assert cam[1, 0, 0] == pytest.approx(60.0 * 2 / 3 * (1.0 if upsample else 0.25))      # full vs /4 intrinsics
+
+
 def test_metric_workload_properties_and_mfma_vs_scalar(lib_built):
     """Full-size (N=5, D=192, 160x128) checks that do not need the oracle: the depth map stays
     inside the swept range, probabilities are finite, the MFMA and scalar regularisers agree, and
