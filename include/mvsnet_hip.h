@@ -151,6 +151,14 @@ int mvs_regnet_us0_prepared_f32(const float* cost, int D, int H, int W, int cin,
                                 const float* const* weights, const float* prepared,
                                 const float* const* gammas, const float* const* betas, float eps,
                                 void* workspace, size_t workspace_bytes, float* reg, void* stream);
+
+/* Live timing of the dominant kernel for bench.py's `roofline` object: while enabled, every
+ * mvs_regnet_us0_*_f32 call brackets its first launch (the fused 3dconv0_1 + 3dconv1_0 pass over the
+ * cost volume, conv3d_c8_kernel) with HIP events on the caller's stream (up to 64 calls).
+ * mvs_profile_dominant_ms waits for those events, returns their average duration in milliseconds and
+ * the number of samples, and clears them.  Do not enable during hipGraph capture. */
+int mvs_profile_dominant(int enable);
+int mvs_profile_dominant_ms(double* avg_ms, int* count);
 int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int cin, int base,
                        const float* const* weights, const float* const* gammas,
                        const float* const* betas, float eps, void* workspace,

@@ -84,6 +84,33 @@ extern "C" int mvs_conv3d_pair_f32(const float* x, const float* w1, const float*
     return mvs_conv3d_c8_s2_launch(a, w2, y2, stats2, mvs_stream(stream));
 }
 
+// ---- live timing of the dominant kernel (bench.py's roofline object) --------------------------------
+// When enabled, every RegNetUS0 run brackets its first launch -- the fused 3dconv0_1 + 3dconv1_0 pass,
+// ~45 % of a depth map -- with a pair of HIP events on the caller's stream.  Not for graph capture.
+namespace {
+struct DominantProfile { bool on = false; hipEvent_t ev[64][2]; int used = 0; int created = 0; } g_prof;
+}
+extern "C" int mvs_profile_dominant(int enable) {
+    g_prof.on = enable != 0;
+    g_prof.used = 0;
+    return 0;
+}
+extern "C" int mvs_profile_dominant_ms(double* avg_ms, int* count) {
+    MVS_CHECK_ARG(avg_ms && count);
+    double sum = 0.0;
+    for (int i = 0; i < g_prof.used; ++i) {
+        hipError_t e = hipEventSynchronize(g_prof.ev[i][1]);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        if ((e = hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1])) != hipSuccess) return (int)e;
+        sum += ms;
+    }
+    *count = g_prof.used;
+    *avg_ms = g_prof.used ? sum / g_prof.used : 0.0;
+    g_prof.used = 0;
+    return 0;
+}
+
 // ---- RegNetUS0 -----------------------------------------------------------------------------------
 
 namespace {
@@ -253,7 +280,17 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
         !getenv("MVS_NO_PAIR_FUSION")) {
         ConvArgs a{cost, nullptr, nullptr, nullptr, nullptr, nullptr, weights[L01], ws.y[L01], st(L01), D, H, W, b,
                    0, 0, 0, 0, {}, {}, prepared ? prepared + lay.off[L01] : nullptr, nullptr};
+        int slot = -1;
+        if (g_prof.on && g_prof.used < 64) {
+            slot = g_prof.used;
+            if (slot >= g_prof.created) {
+                if (hipEventCreate(&g_prof.ev[slot][0]) != hipSuccess || hipEventCreate(&g_prof.ev[slot][1]) != hipSuccess) slot = -1;
+                else g_prof.created = slot + 1;
+            }
+        }
+        if (slot >= 0) HIP_RUN(hipEventRecord(g_prof.ev[slot][0], hs));
         rc = mvs_conv3d_c8_s2_launch(a, weights[L10], ws.y[L10], st(L10), hs);
+        if (slot >= 0 && rc == 0) { HIP_RUN(hipEventRecord(g_prof.ev[slot][1], hs)); g_prof.used = slot + 1; }
         if (rc == 0) pair_done = true;
         else if (rc != MVS_E_SHAPE) return rc;
     }
