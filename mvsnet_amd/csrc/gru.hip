@@ -381,20 +381,24 @@ extern "C" int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, i
 namespace {
 struct GruWs {
     float *x, *g, *c, *rh, *u, *h1, *h2, *h3, *reg, *max_prob, *exp_sum, *wprep_g, *wprep_o;
-    double* stats;     // 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
+    double* stats;     // per plane of a batch: 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
     size_t bytes;
 };
+// Planes per cost-volume batch of the recurrent sweep: the -variance slices of XB consecutive planes
+// come from ONE depth-sweep launch (register tap reuse along depth, cost_volume.hip) into a ring of
+// XB slices, instead of one single-plane launch per step (26 -> ~6 us per plane at 400 x 300).
+constexpr int XB = 16;
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     size_t hw = (size_t)H * W, off = 0;
     auto take = [&](size_t nfloat) { char* p = base ? base + off : nullptr; off += align256(nfloat * 4); return (float*)p; };
     GruWs w;
     int fmax = f1 > f2 ? (f1 > f3 ? f1 : f3) : (f2 > f3 ? f2 : f3);
-    w.x = take(hw * C); w.g = take(hw * 2 * fmax); w.c = take(hw * fmax); w.rh = take(hw * fmax);
+    w.x = take(hw * C * XB); w.g = take(hw * 2 * fmax); w.c = take(hw * fmax); w.rh = take(hw * fmax);
     w.u = take(hw * fmax); w.h1 = take(hw * f1); w.h2 = take(hw * f2); w.h3 = take(hw * f3);
     w.reg = take(hw); w.max_prob = take(hw); w.exp_sum = take(hw);
     w.wprep_g = take((size_t)9 * (C + f1) * 2 * f1); w.wprep_o = take((size_t)9 * (C + f1) * f1);
-    w.stats = (double*)(base ? base + off : nullptr); off += align256(18 * 8);
+    w.stats = (double*)(base ? base + off : nullptr); off += align256((size_t)XB * 18 * 8);
     w.bytes = off;
     return w;
 }
@@ -435,16 +439,20 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     }
     const long long hw_ll = (long long)H * W;
     for (int d = 0; d < depth_num; ++d) {
-        if ((e = hipMemsetAsync(ws.stats, 0, 18 * 8, st)) != hipSuccess) return (int)e;
-        // x = -variance cost of plane d (model.py:680-693,698)
-        rc = mvs_cost_volume_f32(ref, src, transforms, view_num, depth_num, d, 1, H, W, C,
-                                 /*variant*/ 1, /*negate*/ 1, /*border*/ 0, ws.x, stream);
-        if (rc) return rc;
-        const float* xin = ws.x;
+        const int slot = d % XB;
+        if (slot == 0) {
+            // x = -variance cost of planes d .. d+XB-1 (model.py:680-693,698), LayerNorm sums of the batch
+            const int nb = depth_num - d < XB ? depth_num - d : XB;
+            if ((e = hipMemsetAsync(ws.stats, 0, (size_t)XB * 18 * 8, st)) != hipSuccess) return (int)e;
+            rc = mvs_cost_volume_f32(ref, src, transforms, view_num, depth_num, d, nb, H, W, C,
+                                     /*variant*/ 1, /*negate*/ 1, /*border*/ 0, ws.x, stream);
+            if (rc) return rc;
+        }
+        const float* xin = ws.x + (size_t)slot * hw * C;
         int cin = C;
         for (int k = 0; k < 3; ++k) {
             const float* const* p = params + 10 * k;
-            double* sg = ws.stats + 6 * k;
+            double* sg = ws.stats + 18 * slot + 6 * k;
             double* so = sg + 4;
             if (k == 0 && mfma1) {
                 if ((rc = mvs_gru1_gates_mfma(xin, hs[0], ws.wprep_g, p[1], H, W, C, f1, ws.g, sg, st))) return rc;
