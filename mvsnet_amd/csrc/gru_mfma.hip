@@ -35,9 +35,6 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     constexpr int S = CT + 8;
     constexpr int NPOS = (TH2 + 2) * PW2;
     constexpr int CQ = CT / 4, CQA = CA / 4;
-    constexpr int NF4 = NPOS * CQ;
-    constexpr int STG = (256 / CQ) * CQ;            // staging threads: a thread keeps one channel quad
-    constexpr int NIT = (NF4 + STG - 1) / STG;
     constexpr int MT = COUT / 16;
     constexpr int V = 2;
     constexpr int WROW = COUT * 4;
@@ -49,7 +46,7 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     float* wl = smem;
     float* slab = smem + W_FLOATS;                  // [2][NPOS][S]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
     const int ntiles = a.tiles_h * a.tiles_w;
 
@@ -58,12 +55,19 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         for (int i = tid; i < W_FLOATS / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = s4[i];
     }
 
-    // this thread's channel quad of the concatenation; quads >= CQA come from xb
-    const int c4 = tid % CQ;
-    const bool from_b = c4 >= CQA;
+    // ---- staging, in pieces that are issued between the MFMAs of the sweep (branch-free) -------------
+    // Piece i of a tile: global -> registers (load_piece), registers -> LDS (stage_piece).  The xa
+    // channels (pieces 0..NA-1) and the xb channels (pieces NA..NA+NB-1) are staged by separate pieces,
+    // so that the reset-gate sigmoid of MODE 1 is only evaluated where it applies.  Addresses are
+    // 32-bit buffer offsets: rows above / below the image fall outside the buffer and read 0, only
+    // the horizontal wrap needs a test.
+    constexpr int CQB = CB / 4;
+    constexpr int NFA = NPOS * CQA, NFB = NPOS * CQB;
+    constexpr int NA = (NFA + 255) / 256, NB = (NFB + 255) / 256, NIT = NA + NB;
+    static_assert(256 % CQA == 0 && 256 % CQB == 0 && NFA >= 256 && NFB >= 256, "staging map");
+    const int qb = tid % CQB;                        // this thread's channel quad in the xb pieces
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;      // MODE 1: LayerNorm affine of the reset gate
-    if (MODE == 1 && from_b) {
-        const int f0 = 4 * (c4 - CQA);
+    if (MODE == 1) {
         const double cnt = (double)a.H * a.W * CB;
         double mean = a.g_stats[0] / cnt;
         double var = a.g_stats[1] / cnt - mean * mean;
@@ -71,56 +75,56 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         float s[4], t[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            double inv = (double)a.r_gamma[f0 + k] / sqrt(var + 1e-12);
-            s[k] = (float)inv; t[k] = (float)((double)a.r_beta[f0 + k] - mean * inv);
+            double inv = (double)a.r_gamma[4 * qb + k] / sqrt(var + 1e-12);
+            s[k] = (float)inv; t[k] = (float)((double)a.r_beta[4 * qb + k] - mean * inv);
         }
         ra = make_float4(s[0], s[1], s[2], s[3]); rb = make_float4(t[0], t[1], t[2], t[3]);
     }
-
-    float4 pre[NIT], preg[MODE == 1 ? NIT : 1];
-    auto issue_loads = [&](int tile) __attribute__((always_inline)) {
-        const int th = tile / a.tiles_w, tw = tile - th * a.tiles_w;
-        const int h0 = th * TH2, w0 = tw * TW2;
+    const int bytes_a = a.H * a.W * CA * 4, bytes_b = a.H * a.W * CB * 4;
+    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.xa, 0, bytes_a, 0x00020000);
+    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.xb, 0, bytes_b, 0x00020000);
+    const auto rsrc_g = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 1 ? a.g : a.xb), 0, MODE == 1 ? 2 * bytes_b : bytes_b, 0x00020000);
+    // per piece: byte offset relative to the tile's (h0-1, w0-1) pixel, staged column, LDS float offset
+    int poff[NIT], pcol[NIT], loff[NIT];
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            int f = tid + STG * i;
-            int pos = f / CQ;
-            int r = pos / PW2, c = pos - r * PW2;
-            int gh = h0 - 1 + r, gw = w0 - 1 + c;
-            bool ok = (tid < STG) && (f < NF4) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-            size_t pix = (size_t)gh * a.W + gw;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), vg = v;
-            if (ok) {
-                if (!from_b) v = *(const float4*)(a.xa + pix * CA + 4 * c4);
-                else {
-                    v = *(const float4*)(a.xb + pix * CB + 4 * (c4 - CQA));
-                    if (MODE == 1) vg = *(const float4*)(a.g + pix * (2 * CB) + 4 * (c4 - CQA));
-                }
-            }
-            pre[i] = v;
-            if (MODE == 1) preg[i] = vg;
+    for (int i = 0; i < NIT; ++i) {
+        const bool isb = i >= NA;
+        const int cq = isb ? CQB : CQA, nf = isb ? NFB : NFA;
+        int f = tid + 256 * (isb ? i - NA : i);
+        if (f >= nf) f -= 256;                       // spare threads of a family's last piece redo their previous one
+        const int pos = f / cq, q = f % cq;
+        const int r = pos / PW2, c = pos - r * PW2;
+        pcol[i] = c;
+        poff[i] = ((r * a.W + c) * (isb ? CB : CA) + 4 * q) * 4;
+        loff[i] = pos * S + (isb ? CA : 0) + 4 * q;
+    }
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    auto ldb = [](auto rsrc, int voff) __attribute__((always_inline)) {
+        u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+        return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    };
+    float4 pre[NIT], preg[MODE == 1 ? NB : 1];
+    auto load_piece = [&](int i, int tile) __attribute__((always_inline)) {
+        const int tl = tile < ntiles ? tile : 0;     // past the end: a harmless reload of tile 0
+        const int th = tl / a.tiles_w, h0 = th * TH2, w0 = (tl - th * a.tiles_w) * TW2;
+        const int base = (h0 - 1) * a.W + (w0 - 1);  // may be negative: such offsets are out of range as unsigned
+        const bool ok = (unsigned)(w0 - 1 + pcol[i]) < (unsigned)a.W;
+        if (i < NA) pre[i] = ldb(rsrc_a, ok ? base * (CA * 4) + poff[i] : (int)0x80000000);
+        else {
+            pre[i] = ldb(rsrc_b, ok ? base * (CB * 4) + poff[i] : (int)0x80000000);
+            // the reset gate is channels [0, CB) of the (H, W, 2*CB) gate tensor: pixel stride doubles
+            if (MODE == 1) preg[i - NA] = ldb(rsrc_g, ok ? base * (2 * CB * 4) + 2 * poff[i] - 16 * qb : (int)0x80000000);
         }
     };
-    auto sig = [](float x) { return 1.0f / (1.0f + expf(-x)); };
-    auto write_slab = [&](int tile, float* buf) __attribute__((always_inline)) {
-        const int th = tile / a.tiles_w, tw = tile - th * a.tiles_w;
-        const int h0 = th * TH2, w0 = tw * TW2;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            int f = tid + STG * i;
-            if (tid >= STG || f >= NF4) continue;
-            int pos = f / CQ;
-            int r = pos / PW2, c = pos - r * PW2;
-            int gh = h0 - 1 + r, gw = w0 - 1 + c;
-            bool ok = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-            float4 v = pre[i];
-            if (MODE == 1 && from_b && ok) {       // xb = sigmoid(LN(g_r)) * h ; zero outside the image
-                float4 gq = preg[i];
-                v.x *= sig(gq.x * ra.x + rb.x); v.y *= sig(gq.y * ra.y + rb.y);
-                v.z *= sig(gq.z * ra.z + rb.z); v.w *= sig(gq.w * ra.w + rb.w);
-            }
-            *(float4*)(buf + pos * S + 4 * c4) = v;
+    auto sig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); };
+    auto stage_piece = [&](int i, float* buf) __attribute__((always_inline)) {
+        float4 v = pre[i];                           // zeros outside the image (SAME padding)
+        if (MODE == 1 && i >= NA) {                  // xb = sigmoid(LN(g_r)) * h (convgru.py:97,101,107)
+            const float4 gq = preg[i - NA];
+            v.x *= sig(gq.x * ra.x + rb.x); v.y *= sig(gq.y * ra.y + rb.y);
+            v.z *= sig(gq.z * ra.z + rb.z); v.w *= sig(gq.w * ra.w + rb.w);
         }
+        *(float4*)(buf + loff[i]) = v;
     };
 
     int b_off[V];
@@ -136,55 +140,65 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) { st_s[m] = 0.f; st_q[m] = 0.f; }
 
+    // Tile t is swept while tile t+1 moves registers -> LDS (first half of the operand groups) and
+    // tile t+2 is requested from memory (second half): with one wave per SIMD everything that is not
+    // issued under the MFMAs -- above all the global-load latency of a 3 us tile -- would be exposed.
+    const int stride = gridDim.x;
     int tile = blockIdx.x;
-    if (tile < ntiles) issue_loads(tile);
-    if (tile < ntiles) write_slab(tile, slab);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_piece(i, tile);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) stage_piece(i, slab);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_piece(i, tile + stride);
     __syncthreads();
     int it = 0;
-    for (; tile < ntiles; tile += gridDim.x, ++it) {
+    for (; tile < ntiles; tile += stride, ++it) {
         const float* cur = slab + (it & 1) * SLAB_FLOATS;
         float* nxt = slab + ((it + 1) & 1) * SLAB_FLOATS;
-        const int next_tile = tile + gridDim.x;
-        const bool more = next_tile < ntiles;
-        if (more) issue_loads(next_tile);
 
         f32x4 acc[MT][V];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[m][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        {   // software-pipelined sweep (see conv3d_mfma.hip): group g+1's LDS reads are interleaved
-            // with group g's MFMAs; a lone wave per SIMD never idles the matrix pipe on LDS latency
-            constexpr int NG = 9 * (CT / 16), NR = V + MT, NM = 4 * MT * V;
+        {   // operand reads of group g+1 are issued before the MFMAs of group g (register double buffer)
+            constexpr int NG = 9 * (CT / 16);
             f32x4 bv[2][V], av[2][MT];
-            auto load_one = [&](int g, int r, f32x4 (&b)[V], f32x4 (&aop)[MT]) __attribute__((always_inline)) {
+            auto load_grp = [&](int g, f32x4 (&b)[V], f32x4 (&aop)[MT]) __attribute__((always_inline)) {
                 const int tap = g / (CT / 16), s = g % (CT / 16);
                 const int kh = tap / 3, kw = tap % 3;
-                if (r < V) b[r] = *(const f32x4*)(cur + b_off[r] + (kh * PW2 + kw) * S + 16 * s);
-                else aop[r - V] = *(const f32x4*)(wl + a_off + (r - V) * 64 + (tap * CQ + 4 * s) * WROW);
-            };
 #pragma unroll
-            for (int r = 0; r < NR; ++r) load_one(0, r, bv[0], av[0]);
+                for (int v = 0; v < V; ++v) b[v] = *(const f32x4*)(cur + b_off[v] + (kh * PW2 + kw) * S + 16 * s);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) aop[m] = *(const f32x4*)(wl + a_off + m * 64 + (tap * CQ + 4 * s) * WROW);
+            };
+            load_grp(0, bv[0], av[0]);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_grp(g + 1, bv[(g + 1) & 1], av[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    if (g + 1 < NG) load_one(g + 1, r, bv[(g + 1) & 1], av[(g + 1) & 1]);
-#pragma unroll
-                    for (int i = (r * NM) / NR; i < ((r + 1) * NM) / NR; ++i) {
-                        const int j = i / (MT * V), m = (i / V) % MT, v = i % V;
-                        acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][j], bv[g & 1][v][j], acc[m][v], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < NIT; ++i) {
+                    if ((i * (NG / 2)) / NIT == g) stage_piece(i, nxt);
+                    if (NG / 2 + (i * (NG - NG / 2)) / NIT == g) load_piece(i, tile + 2 * stride);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int v = 0; v < V; ++v)
+                            acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][j], bv[g & 1][v][j], acc[m][v], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // store (+bias) and LayerNorm moments
         {
-            const int th = tile / a.tiles_w, tw = tile - th * a.tiles_w;
+            const int th = tile / a.tiles_w, h0 = th * TH2, w0 = (tile - th * a.tiles_w) * TW2;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                int h = th * TH2 + V * wave + v, w = tw * TW2 + n;
+                int h = h0 + V * wave + v, w = w0 + n;
                 if (h < a.H && w < a.W) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
@@ -197,7 +211,6 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
                 }
             }
         }
-        if (more) write_slab(next_tile, nxt);
         __syncthreads();
     }
 
