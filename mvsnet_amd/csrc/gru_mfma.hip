@@ -50,10 +50,7 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     const int n = lane & 15, kq = lane >> 4;
     const int ntiles = a.tiles_h * a.tiles_w;
 
-    {   // weights: coalesced copy of the prepared layout
-        const float4* s4 = reinterpret_cast<const float4*>(a.wprep);
-        for (int i = tid; i < W_FLOATS / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = s4[i];
-    }
+    copy_weights_to_lds(wl, a.wprep, W_FLOATS);      // prepared layout, eight loads in flight per thread
 
     // ---- staging, in pieces that are issued between the MFMAs of the sweep (branch-free) -------------
     // Piece i of a tile: global -> registers (load_piece), registers -> LDS (stage_piece).  The xa
