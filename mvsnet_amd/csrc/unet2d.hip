@@ -1,0 +1,375 @@
+// 2D convolutions of the UNetDS2GN feature extractor (mvsnet/cnn_wrapper/
+// mvsnetworks.py:53-115, Network.conv_gn / deconv_gn network.py:217-276,350-409) as fp32-MFMA
+// implicit GEMMs with the producer's GroupNorm (+ReLU) folded into the consumer's load -- the same
+// fusion the 3D stack uses for BatchNorm:
+//
+//   y_raw = conv(k x k, stride s, SAME, no bias)( concat_c[ act1(gn1(x1)), act2(gn2(x2)) ] )
+//   stats[v][g] += (sum, sum of squares) of y_raw over the 8-channel group g of view v
+//
+// A consumer turns a producer's raw group sums into per-channel (scale, shift) itself, so a layer is
+// ONE launch and activations are stored once, raw.  Views are independent samples (GroupNorm is per
+// sample), so the N towers of mvsnet/model.py:392-406 run as one batched launch.
+//
+// GEMM roles as in conv3d_mfma.hip: rows = 16*MT output channels, columns = 16 output pixels along w,
+// K = (kh, kw, ci) walked in chunks of CK input channels (the staged patch and the chunk's weights
+// live in LDS; v_mfma_f32_16x16x4_f32, exact fp32).  CG = channels per operand read: 16 (ds_read_b128,
+// 4 MFMAs), 8 (b64, 2 MFMAs) or 4 (b32, 1 MFMA) for the 3/4-, 8- and >=16-channel layers.
+// Transposed convolutions (4 small layers) are a VALU gather kernel.
+#include "common.h"
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+// producer GroupNorm of one source, given as raw float64 group sums (or stats == null: identity)
+struct GnSrc {
+    const float* x;           // (V,H,W,C) raw producer output (or the image)
+    const double* stats;      // (V, C/8, 2) [sum, sumsq] per view and group, or null
+    const float* gamma; const float* beta;
+    double count;             // elements per (view, group) = H*W*8
+    int C;                    // channels of this source
+    int relu;                 // ReLU after the affine (conv_gn) or not (deconv_gn, network.py:357)
+};
+
+struct Conv2dArgs {
+    GnSrc a, b;               // b.x == null: single source
+    const float* wprep;       // [cout group][chunk][tap][CK/4][16*MT][4]
+    float* y;                 // (V,Ho,Wo,Cout) raw
+    double* stats;            // (V, Cout/8, 2) or null
+    int V, H, W, Ho, Wo, Cout, pad_h, pad_w;
+};
+
+constexpr int TH = 8, TW = 16;
+
+__device__ __forceinline__ void gn_affine4(const GnSrc& s, int view, int c0, float4& sc, float4& sh) {
+    sc = make_float4(1.f, 1.f, 1.f, 1.f); sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!s.stats) return;
+    const double* st = s.stats + ((size_t)view * (s.C / 8) + c0 / 8) * 2;       // 4 channels share a group
+    const double mean = st[0] / s.count;
+    double var = st[1] / s.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double inv = 1.0 / sqrt(var + 1e-5);                                   // network.py:55,254
+    float a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = (float)((double)s.gamma[c0 + k] * inv);
+        b[k] = (float)((double)s.beta[c0 + k] - mean * (double)s.gamma[c0 + k] * inv);
+    }
+    sc = make_float4(a[0], a[1], a[2], a[3]); sh = make_float4(b[0], b[1], b[2], b[3]);
+}
+
+template <int KS, int STRIDE, int CG, int MT>
+__global__ void __launch_bounds__(256)
+conv2d_gn_kernel(Conv2dArgs p) {
+    constexpr int CK = CG;                          // channels per chunk
+    constexpr int CQ = CK / 4;
+    constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
+    constexpr int NPOS = IH * IW;
+    constexpr int S = (CG == 16) ? 24 : (CG == 8 ? 10 : 5);       // slab pitch (floats): conflict-free operand reads
+    constexpr int COUT_T = 16 * MT;
+    constexpr int WCH = KS * KS * CQ * COUT_T * 4;  // weight floats per chunk
+    constexpr int V2 = 2;                           // column tiles (output rows) per wave
+    extern __shared__ __attribute__((aligned(16))) float smem2d[];
+    float* slab = smem2d;                           // [NPOS][S]
+    float* wl = smem2d + ((NPOS * S + 3) & ~3);     // [KS*KS][CQ][COUT_T][4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int view = bid / (tiles_h * tiles_w); bid -= view * tiles_h * tiles_w;
+    const int tile_h = bid / tiles_w, tile_w = bid - tile_h * tiles_w;
+    const int oh0 = tile_h * TH, ow0 = tile_w * TW;
+    const int ih0 = oh0 * STRIDE - p.pad_h, iw0 = ow0 * STRIDE - p.pad_w;
+    const int cog = blockIdx.y;
+    const int Ctot = p.a.C + (p.b.x ? p.b.C : 0);
+    const int nchunks = Ctot / CK;
+
+    f32x4 acc[MT][V2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int v = 0; v < V2; ++v) acc[m][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int b_off[V2];
+#pragma unroll
+    for (int v = 0; v < V2; ++v) b_off[v] = ((V2 * wave + v) * STRIDE * IW + n * STRIDE) * S + (CG / 4) * kq;
+    const int a_off = (kq * COUT_T + n) * 4;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CK;                     // first channel of the chunk in the concatenation
+        const bool from_b = c0 >= p.a.C;
+        const GnSrc& src = from_b ? p.b : p.a;
+        const int cs = from_b ? c0 - p.a.C : c0;    // first channel inside its source
+        __syncthreads();                            // previous chunk's operands are dead
+        // ---- stage the input patch of this chunk: GroupNorm affine (+ReLU), zeros outside the image
+        const int q = tid % CQ;                     // 256 % CQ == 0: a thread keeps one channel quad
+        float4 sc, sh;
+        gn_affine4(src, view, cs + 4 * q, sc, sh);
+        for (int f = tid; f < NPOS * CQ; f += 256) {
+            const int pos = f / CQ;
+            const int r = pos / IW, c = pos - r * IW;
+            const int gh = ih0 + r, gw = iw0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) {
+                v = *(const float4*)(src.x + (((size_t)view * p.H + gh) * p.W + gw) * src.C + cs + 4 * q);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (src.relu) { v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w); }
+            }
+            if (CG == 4) { float* d = slab + pos * S; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+            else if (CG == 8) { *(f32x2*)(slab + pos * S + 4 * q) = (f32x2){v.x, v.y}; *(f32x2*)(slab + pos * S + 4 * q + 2) = (f32x2){v.z, v.w}; }
+            else *(float4*)(slab + pos * S + 4 * q) = v;
+        }
+        // ---- this chunk's weights (prepared layout: one contiguous block)
+        {
+            const float4* w4 = reinterpret_cast<const float4*>(p.wprep + ((size_t)cog * nchunks + ch) * WCH);
+            for (int i = tid; i < WCH / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = w4[i];
+        }
+        __syncthreads();
+        // ---- MFMAs: all taps of the chunk
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const int tap = kh * KS + kw;
+                float bq[V2][4], aq[MT][4];
+#pragma unroll
+                for (int v = 0; v < V2; ++v) {
+                    const float* bp = slab + b_off[v] + (kh * IW + kw) * S;
+                    if (CG == 16) { f32x4 t = *(const f32x4*)bp; bq[v][0] = t[0]; bq[v][1] = t[1]; bq[v][2] = t[2]; bq[v][3] = t[3]; }
+                    else if (CG == 8) { f32x2 t = *(const f32x2*)bp; bq[v][0] = t[0]; bq[v][1] = t[1]; }
+                    else bq[v][0] = *bp;
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    // A rows: [tap][ciq][co][4]; this lane supplies ci = (CG/4)*kq + j of the chunk
+                    if (CG == 16) { f32x4 t = *(const f32x4*)(wl + a_off + m * 64 + tap * CQ * COUT_T * 4); aq[m][0] = t[0]; aq[m][1] = t[1]; aq[m][2] = t[2]; aq[m][3] = t[3]; }
+                    else if (CG == 8) {
+                        // ci = 2kq + j -> ci-quad kq>>1, element 2(kq&1) + j
+                        f32x2 t = *(const f32x2*)(wl + (((tap * CQ + (kq >> 1)) * COUT_T + m * 16 + n) * 4 + 2 * (kq & 1)));
+                        aq[m][0] = t[0]; aq[m][1] = t[1];
+                    } else aq[m][0] = wl[((tap * COUT_T) + m * 16 + n) * 4 + kq];
+                }
+#pragma unroll
+                for (int j = 0; j < CG / 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int v = 0; v < V2; ++v)
+                            acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[m][j], bq[v][j], acc[m][v], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- store raw outputs, GroupNorm sums per 8-channel group ----------------------------------------
+    float gs[MT] , gq[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { gs[m] = 0.f; gq[m] = 0.f; }
+    const int co_base = cog * COUT_T;
+#pragma unroll
+    for (int v = 0; v < V2; ++v) {
+        const int oh = oh0 + V2 * wave + v, ow = ow0 + n;
+        if (oh < p.Ho && ow < p.Wo) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co = co_base + m * 16 + 4 * kq;
+                if (co < p.Cout) {
+                    f32x4 r = acc[m][v];
+                    *(float4*)(p.y + (((size_t)view * p.Ho + oh) * p.Wo + ow) * p.Cout + co) = make_float4(r[0], r[1], r[2], r[3]);
+                    gs[m] += (r[0] + r[1]) + (r[2] + r[3]);
+                    gq[m] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        // lane (kq, n) holds channels 4kq..4kq+3 of tile m: group 2m + (kq >> 1); fold n and the kq pair
+        __shared__ float red[4][MT][2][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float s = gs[m], q = gq[m];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+            s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+            if (n == 0 && (kq & 1) == 0) { red[wave][m][kq >> 1][0] = s; red[wave][m][kq >> 1][1] = q; }
+        }
+        __syncthreads();
+        if (tid < MT * 4) {
+            const int m = tid >> 2, h = (tid >> 1) & 1, k = tid & 1;
+            const int g = (co_base + m * 16) / 8 + h;
+            if (g * 8 < p.Cout) {
+                double t = (double)red[0][m][h][k] + (double)red[1][m][h][k] + (double)red[2][m][h][k] + (double)red[3][m][h][k];
+                atomicAdd(&p.stats[((size_t)view * (p.Cout / 8) + g) * 2 + k], t);
+            }
+        }
+    }
+}
+
+// TensorFlow conv2d kernel (k,k,Cin,Cout) -> [cout group][chunk][tap][CK/4][COUT_T][4], zero padded
+__global__ void conv2d_weight_layout_kernel(const float* __restrict__ w, int KS, int Cin, int Cout, int CK,
+                                            int COUT_T, int CinPad, float* __restrict__ out) {
+    const int nch = CinPad / CK, CQ = CK / 4, groups = (Cout + COUT_T - 1) / COUT_T;
+    const long long total = (long long)groups * nch * KS * KS * CQ * COUT_T * 4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int j = r & 3; r >>= 2;
+    const int co = r % COUT_T; r /= COUT_T;
+    const int ciq = r % CQ; r /= CQ;
+    const int tap = r % (KS * KS); r /= (KS * KS);
+    const int ch = r % nch; const int g = r / nch;
+    const int ci = ch * CK + ciq * 4 + j, cout = g * COUT_T + co;
+    out[i] = (ci < Cin && cout < Cout) ? w[((size_t)tap * Cin + ci) * Cout + cout] : 0.f;
+}
+
+// ---- transposed convolution k3 s2 SAME (out = 2n, cropped at the end), bias-free, VALU gather --------------
+// out[2i + k] += in[i] * W[k][co][ci] per axis (weight layout (3,3,Cout,Cin), TF conv2d_transpose).
+struct Deconv2dArgs {
+    GnSrc a;
+    const float* w;           // (3,3,Cout,Cin)
+    float* y;                 // (V,2H,2W,Cout) raw
+    double* stats;            // (V, Cout/8, 2) or null
+    int V, H, W, Cout;
+};
+
+__global__ void __launch_bounds__(256)
+deconv2d_gn_kernel(Deconv2dArgs p) {
+    const int Ho = 2 * p.H, Wo = 2 * p.W, CQo = p.Cout / 4, Cin = p.a.C;
+    const long long total = (long long)Ho * Wo * CQo;            // items of one view (grid.y = view)
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool live = idx < total;
+    int coq = 0; const int view = blockIdx.y; long long pix = 0;
+    // GroupNorm affine of all input channels of this view, once per block
+    __shared__ float aff_s[256], aff_b[256];
+    {
+        if ((int)threadIdx.x < Cin / 4) {
+            float4 sc, sh;
+            gn_affine4(p.a, view, 4 * threadIdx.x, sc, sh);
+            *(float4*)(aff_s + 4 * threadIdx.x) = sc; *(float4*)(aff_b + 4 * threadIdx.x) = sh;
+        }
+        __syncthreads();
+    }
+    if (live) {
+        coq = (int)(idx % CQo); pix = idx / CQo;
+        const int ow = (int)(pix % Wo); const int oh = (int)(pix / Wo);
+        pix += (long long)view * Ho * Wo;
+        // taps: even o = 2m: (i = m, k = 0), (i = m-1, k = 2); odd o = 2m+1: (i = m, k = 1)
+        int ih[2], kh[2], nh = 0, iw[2], kw[2], nw = 0;
+        if (oh & 1) { ih[0] = oh >> 1; kh[0] = 1; nh = 1; } else { ih[0] = oh >> 1; kh[0] = 0; nh = 1; if (oh >= 2) { ih[1] = (oh >> 1) - 1; kh[1] = 2; nh = 2; } }
+        if (ow & 1) { iw[0] = ow >> 1; kw[0] = 1; nw = 1; } else { iw[0] = ow >> 1; kw[0] = 0; nw = 1; if (ow >= 2) { iw[1] = (ow >> 1) - 1; kw[1] = 2; nw = 2; } }
+        for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b) {
+                const float* xin = p.a.x + (((size_t)view * p.H + ih[a]) * p.W + iw[b]) * Cin;
+                const float* wt = p.w + ((size_t)(kh[a] * 3 + kw[b]) * p.Cout + 4 * coq) * Cin;
+                for (int c = 0; c < Cin; c += 4) {
+                    const float4 sc = *(const float4*)(aff_s + c), sh = *(const float4*)(aff_b + c);
+                    float4 v = *(const float4*)(xin + c);
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    if (p.a.relu) { v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w); }
+                    const float4 w0 = *(const float4*)(wt + c), w1 = *(const float4*)(wt + Cin + c);
+                    const float4 w2 = *(const float4*)(wt + 2 * Cin + c), w3 = *(const float4*)(wt + 3 * Cin + c);
+                    acc.x += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
+                    acc.y += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
+                    acc.z += v.x * w2.x + v.y * w2.y + v.z * w2.z + v.w * w2.w;
+                    acc.w += v.x * w3.x + v.y * w3.y + v.z * w3.z + v.w * w3.w;
+                }
+            }
+        *(float4*)(p.y + pix * p.Cout + 4 * coq) = acc;
+    }
+    if (p.stats) {
+        // a wave covers consecutive (pixel, quad) items of one view, lane % CQo = quad;
+        // quads q and q^1 form a group of 8 channels: lanes l and l^1
+        float s = live ? (acc.x + acc.y) + (acc.z + acc.w) : 0.f;
+        float q = live ? (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w) : 0.f;
+        s += __shfl_xor(s, 1, 64); q += __shfl_xor(q, 1, 64);
+        // fold the lanes that share a group: same (lane mod CQo) >> 1; CQo is a power of two <= 32
+        for (int o = CQo; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        const int lane = threadIdx.x & 63;
+        if (live && lane < CQo && (lane & 1) == 0) {
+            const int g = (coq >> 1);
+            atomicAdd(&p.stats[((size_t)view * (p.Cout / 8) + g) * 2], (double)s);
+            atomicAdd(&p.stats[((size_t)view * (p.Cout / 8) + g) * 2 + 1], (double)q);
+        }
+    }
+}
+
+template <int KS, int STRIDE, int CG, int MT>
+int launch_conv2d(const Conv2dArgs& p, hipStream_t st) {
+    const int tiles = ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW);
+    dim3 grid(p.V * tiles, (p.Cout + 16 * MT - 1) / (16 * MT));
+    constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
+    constexpr int S = (CG == 16) ? 24 : (CG == 8 ? 10 : 5);
+    constexpr size_t smem = (size_t)(((IH * IW * S + 3) & ~3) + KS * KS * CG * 16 * MT) * sizeof(float);
+    static bool attr_done = false;       // per template instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv2d_gn_kernel<KS, STRIDE, CG, MT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    conv2d_gn_kernel<KS, STRIDE, CG, MT><<<grid, 256, smem, st>>>(p);
+    return (int)hipGetLastError();
+}
+
+// operand-read width and row tiles per workgroup chosen from the layer shape (the weight pre-layout uses the same rule)
+void conv2d_tiling(int Cin_total, int Cout, int c1, int& CG, int& MT) {
+    CG = (Cin_total % 16 == 0 && c1 % 16 == 0) ? 16 : (Cin_total % 8 == 0 && c1 % 8 == 0 ? 8 : 4);
+    MT = (Cout >= 32) ? 2 : 1;
+}
+
+}  // namespace
+
+extern "C" size_t mvs_conv2d_prepared_floats(int ks, int cin1, int cin2, int cout) {
+    int CG, MT; conv2d_tiling(cin1 + cin2, cout, cin1, CG, MT);
+    const int cin = cin1 + cin2, cpad = (cin + CG - 1) / CG * CG, ct = 16 * MT;
+    return (size_t)((cout + ct - 1) / ct) * (cpad / CG) * ks * ks * (CG / 4) * ct * 4;
+}
+
+extern "C" int mvs_conv2d_prepare_f32(const float* w, int ks, int cin1, int cin2, int cout, float* prepared, void* stream) {
+    MVS_CHECK_ARG(w && prepared && (ks == 3 || ks == 5) && cin1 > 0 && cin2 >= 0 && cout > 0);
+    int CG, MT; conv2d_tiling(cin1 + cin2, cout, cin1, CG, MT);
+    const int cin = cin1 + cin2, cpad = (cin + CG - 1) / CG * CG;
+    const size_t total = mvs_conv2d_prepared_floats(ks, cin1, cin2, cout);
+    conv2d_weight_layout_kernel<<<mvs_cdiv((long long)total, 256), 256, 0, mvs_stream(stream)>>>(w, ks, cin, cout, CG, 16 * MT, cpad, prepared);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_conv2d_gn_f32(const float* x1, const double* stats1, const float* gamma1, const float* beta1, int c1, int relu1,
+                                 const float* x2, const double* stats2, const float* gamma2, const float* beta2, int c2, int relu2,
+                                 const float* prepared, int V, int H, int W, int cout, int ks, int stride,
+                                 float* y, double* stats_out, void* stream) {
+    MVS_CHECK_ARG(x1 && prepared && y && V > 0 && H > 0 && W > 0 && c1 > 0 && cout > 0 && c2 >= 0);
+    MVS_CHECK_ARG((stats1 == nullptr) == (gamma1 == nullptr) && (c2 == 0) == (x2 == nullptr));
+    if ((c1 % 4) || (c2 % 4) || (cout % 8) || (stats1 && c1 % 8) || (stats2 && c2 % 8)) return MVS_E_SHAPE;
+    int CG, MT; conv2d_tiling(c1 + c2, cout, c1, CG, MT);
+    if ((c1 % CG) || (c2 % CG)) return MVS_E_SHAPE;
+    Conv2dArgs p;
+    const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+    auto pad_before = [&](int n, int o) { int t = (o - 1) * stride + ks - n; return t < 0 ? 0 : t / 2; };
+    p.a = GnSrc{x1, stats1, gamma1, beta1, (double)H * W * 8, c1, relu1};
+    p.b = GnSrc{x2, stats2, gamma2, beta2, (double)H * W * 8, c2, relu2};
+    p.wprep = prepared; p.y = y; p.stats = stats_out;
+    p.V = V; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cout = cout;
+    p.pad_h = pad_before(H, Ho); p.pad_w = pad_before(W, Wo);
+    hipStream_t st = mvs_stream(stream);
+#define CASE(K, S_, G, M) if (ks == K && stride == S_ && CG == G && MT == M) return launch_conv2d<K, S_, G, M>(p, st);
+    CASE(3, 1, 4, 1) CASE(3, 1, 8, 1) CASE(3, 1, 16, 1) CASE(3, 1, 16, 2) CASE(3, 1, 8, 2) CASE(3, 1, 4, 2)
+    CASE(3, 2, 4, 1) CASE(3, 2, 8, 1) CASE(3, 2, 16, 1) CASE(3, 2, 16, 2) CASE(3, 2, 8, 2) CASE(3, 2, 4, 2)
+    CASE(5, 2, 8, 1) CASE(5, 2, 16, 1) CASE(5, 2, 16, 2) CASE(5, 2, 8, 2)
+#undef CASE
+    return MVS_E_SHAPE;
+}
+
+extern "C" int mvs_deconv2d_gn_f32(const float* x, const double* stats, const float* gamma, const float* beta, int cin, int relu,
+                                   const float* w, int V, int H, int W, int cout, float* y, double* stats_out, void* stream) {
+    MVS_CHECK_ARG(x && w && y && V > 0 && H > 0 && W > 0 && cin > 0 && cout > 0);
+    MVS_CHECK_ARG((stats == nullptr) == (gamma == nullptr));
+    const int cqo = cout / 4;
+    if ((cin % 4) || cin > 256 || (cout % 8) || (stats && cin % 8) || cqo > 32 || (cqo & (cqo - 1))) return MVS_E_SHAPE;
+    Deconv2dArgs p{GnSrc{x, stats, gamma, beta, (double)H * W * 8, cin, relu}, w, y, stats_out, V, H, W, cout};
+    const long long per_view = (long long)4 * H * W * cqo;
+    deconv2d_gn_kernel<<<dim3(mvs_cdiv(per_view, 256), V), 256, 0, mvs_stream(stream)>>>(p);
+    MVS_LAUNCH_RET();
+}

@@ -1,0 +1,103 @@
+"""UNetDS2GN feature extractor on the HIP library: the same network as
+`feature_net.UNetDS2GN` (mvsnet/cnn_wrapper/mvsnetworks.py:53-115), every layer one launch of
+`mvs_conv2d_gn_f32` / `mvs_deconv2d_gn_f32` with the producer's GroupNorm (+ReLU) folded into the
+consumer's load (csrc/unet2d.hip).  Same constructor and call signature as the PyTorch module, so
+`MVSNetWeights` can hold either; the PyTorch/MIOpen module stays as the reference implementation of
+the glue (north_star) and as the cross-check in tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .feature_net import UNET_LAYERS
+
+
+class HipUNetDS2GN:
+    """``params`` in TensorFlow variable layouts as for `UNetDS2GN` (conv (k,k,Cin,Cout), transposed
+    conv (k,k,Cout,Cin), GroupNorm gamma/beta)."""
+
+    def __init__(self, params, device="cuda"):
+        self.device = torch.device(device)
+        lib = _lib.load()
+        chans = {"data": 4}                               # the image is padded 3 -> 4 channels
+        self.layers = []
+        for name, kind, srcs, k, _mult, stride in UNET_LAYERS:
+            p = params[name]
+            w = np.asarray(p["w"], np.float32)
+            cins = [chans[s] for s in srcs]
+            if kind == "dg":
+                cout = w.shape[2]
+                wd = torch.as_tensor(w).contiguous().to(self.device)
+            else:
+                cout = w.shape[3]
+                if srcs == ("data",):                     # zero weights for the padding channel
+                    w = np.concatenate([w, np.zeros(w.shape[:2] + (1, cout), np.float32)], axis=2)
+                c1, c2 = cins[0], (cins[1] if len(cins) > 1 else 0)
+                n = lib.mvs_conv2d_prepared_floats(k, c1, c2, cout)
+                wd = torch.empty(n, dtype=torch.float32, device=self.device)
+                wt = torch.as_tensor(w).contiguous().to(self.device)
+                _lib.check(lib.mvs_conv2d_prepare_f32(_lib.ptr(wt), k, c1, c2, cout, _lib.ptr(wd), _lib.stream_ptr()),
+                           "mvs_conv2d_prepare_f32")
+            g = b = None
+            if kind != "c":
+                g = torch.as_tensor(np.asarray(p["gamma"], np.float32)).to(self.device)
+                b = torch.as_tensor(np.asarray(p["beta"], np.float32)).to(self.device)
+            chans[name] = cout
+            self.layers.append((name, kind, srcs, k, stride, wd, g, b, cins, cout))
+        torch.cuda.synchronize(self.device)
+        self.out_channels = self.layers[-1][9]
+        self._bufs = {}
+
+    def _plan(self, V, H, W):
+        """Activation buffers and one float64 slab of GroupNorm sums for a (V, H, W) input."""
+        key = (V, H, W)
+        if key in self._bufs:
+            return self._bufs[key]
+        shapes = {"data": (H, W)}
+        acts, offs, total = {}, {}, 0
+        for name, kind, srcs, k, stride, _w, _g, _b, _cins, cout in self.layers:
+            h, w = shapes[srcs[0]]
+            ho, wo = (2 * h, 2 * w) if kind == "dg" else (-(-h // stride), -(-w // stride))
+            shapes[name] = (ho, wo)
+            acts[name] = torch.empty((V, ho, wo, cout), dtype=torch.float32, device=self.device)
+            offs[name] = total
+            total += V * (cout // 8) * 2
+        stats = torch.zeros(total, dtype=torch.float64, device=self.device)
+        self._bufs[key] = (acts, offs, stats, shapes)
+        return self._bufs[key]
+
+    @torch.no_grad()
+    def __call__(self, images):
+        """images (V,H,W,3) channel-last float32 -> features (V,H/4,W/4,C) contiguous."""
+        lib = _lib.load()
+        x = images.to(self.device, torch.float32)
+        V, H, W, _ = x.shape
+        if H % 16 or W % 16:
+            raise ValueError("UNetDS2GN needs image sizes divisible by 16")
+        acts, offs, stats, shapes = self._plan(V, H, W)
+        stats.zero_()
+        data = torch.zeros((V, H, W, 4), dtype=torch.float32, device=self.device)
+        data[..., :3] = x
+        st = _lib.stream_ptr()
+        src_of = {"data": (data, None, None, None, 0)}    # tensor, stats view, gamma, beta, relu
+        for name, kind, srcs, k, stride, wd, g, b, cins, cout in self.layers:
+            h, w = shapes[srcs[0]]
+            y = acts[name]
+            so = stats[offs[name]:offs[name] + V * (cout // 8) * 2] if kind != "c" else None
+            a = src_of[srcs[0]]
+            if kind == "dg":
+                _lib.check(lib.mvs_deconv2d_gn_f32(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]), cins[0], a[4],
+                                                   _lib.ptr(wd), V, h, w, cout, _lib.ptr(y), _lib.ptr(so), st),
+                           "mvs_deconv2d_gn_f32")
+            else:
+                bsrc = src_of[srcs[1]] if len(srcs) > 1 else (None, None, None, None, 0)
+                _lib.check(lib.mvs_conv2d_gn_f32(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]), cins[0], a[4],
+                                                 _lib.ptr(bsrc[0]), _lib.ptr(bsrc[1]), _lib.ptr(bsrc[2]), _lib.ptr(bsrc[3]),
+                                                 cins[1] if len(cins) > 1 else 0, bsrc[4],
+                                                 _lib.ptr(wd), V, h, w, cout, k, stride, _lib.ptr(y), _lib.ptr(so), st),
+                           "mvs_conv2d_gn_f32")
+            # consumers apply this layer's GroupNorm: ReLU after conv_gn, none after deconv_gn (network.py:357)
+            src_of[name] = (y, so, g, b, 1 if kind == "cg" else 0)
+        return acts["conv10_2"].clone()

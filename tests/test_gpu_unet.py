@@ -1,0 +1,108 @@
+"""GPU parity of the HIP feature extractor: every 2D layer against the numpy oracle,
+the whole UNetDS2GN against the oracle and against the PyTorch/MIOpen module."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mvsnet_oracle as O
+from mvsnet_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+n = lambda x: x.detach().cpu().numpy()
+
+
+def _gn_relu(x, gamma, beta, relu):
+    y = O.group_norm_nhwc(x, gamma, beta, dtype=np.float64)
+    return np.maximum(y, 0) if relu else y
+
+
+@pytest.mark.parametrize("case", [  # V,H,W,C1,C2,Cout,k,stride
+    (2, 16, 32, 4, 0, 8, 3, 1), (1, 16, 32, 8, 0, 8, 3, 1), (2, 16, 16, 16, 0, 16, 3, 1), (1, 8, 16, 32, 0, 32, 3, 1),
+    (1, 16, 32, 4, 0, 16, 3, 2), (2, 16, 32, 16, 0, 32, 3, 2), (1, 16, 32, 8, 0, 16, 5, 2), (1, 16, 32, 16, 0, 32, 5, 2),
+    (1, 16, 16, 8, 8, 8, 3, 1), (2, 8, 16, 16, 16, 16, 3, 1), (1, 8, 16, 64, 64, 64, 3, 1), (1, 10, 20, 16, 0, 24, 3, 1),
+])
+def test_conv2d_gn_matches_oracle(case, lib_built):
+    from mvsnet_amd import _lib as L
+    lib = L.load()
+    V, H, W, C1, C2, Cout, k, stride = case
+    rs = np.random.RandomState(sum(case))
+    x1 = rs.standard_normal((V, H, W, C1)).astype(np.float32)
+    x2 = rs.standard_normal((V, H, W, C2)).astype(np.float32) if C2 else None
+    w = (rs.standard_normal((k, k, C1 + C2, Cout)) / np.sqrt(k * k * (C1 + C2))).astype(np.float32)
+    gn1 = C1 % 8 == 0
+    g1 = (1 + 0.3 * rs.standard_normal(C1)).astype(np.float32); b1 = (0.2 * rs.standard_normal(C1)).astype(np.float32)
+    g2 = (1 + 0.3 * rs.standard_normal(max(C2, 1))).astype(np.float32); b2 = (0.2 * rs.standard_normal(max(C2, 1))).astype(np.float32)
+
+    def sums(x, C):                                          # raw group sums of a "producer" output
+        xs = x.reshape(V, -1, C // 8, 8).astype(np.float64)
+        return np.stack([xs.sum((1, 3)), (xs ** 2).sum((1, 3))], -1)          # (V, C/8, 2)
+
+    s1 = t(sums(x1, C1)) if gn1 else None
+    s2 = t(sums(x2, C2)) if C2 else None
+    wp = torch.empty(lib.mvs_conv2d_prepared_floats(k, C1, C2, Cout), dtype=torch.float32, device=DEV)
+    tw = t(w)
+    L.check(lib.mvs_conv2d_prepare_f32(L.ptr(tw), k, C1, C2, Cout, L.ptr(wp), L.stream_ptr()), "prepare")
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    y = torch.empty((V, Ho, Wo, Cout), dtype=torch.float32, device=DEV)
+    so = torch.zeros((V, Cout // 8, 2), dtype=torch.float64, device=DEV)
+    tx1, tx2 = t(x1), (t(x2) if C2 else None)
+    tg1, tb1, tg2, tb2 = t(g1), t(b1), t(g2), t(b2)          # keep the device tensors alive across the async launch
+    L.check(lib.mvs_conv2d_gn_f32(L.ptr(tx1), L.ptr(s1), L.ptr(tg1) if gn1 else None, L.ptr(tb1) if gn1 else None, C1, 1 if gn1 else 0,
+                                  L.ptr(tx2), L.ptr(s2), L.ptr(tg2) if C2 else None, L.ptr(tb2) if C2 else None, C2, 0,
+                                  L.ptr(wp), V, H, W, Cout, k, stride, L.ptr(y), L.ptr(so), L.stream_ptr()), "conv2d")
+    got, got_s = n(y), n(so)
+    for v in range(V):
+        xin = _gn_relu(x1[v], g1, b1, True) if gn1 else x1[v].astype(np.float64)
+        if C2:
+            xin = np.concatenate([xin, _gn_relu(x2[v], g2, b2, False)], -1)          # second source: no ReLU (deconv_gn)
+        exp = O.convnd_same(xin, w, stride, np.float64)
+        np.testing.assert_allclose(got[v], exp, rtol=2e-4, atol=2e-4)
+        es = exp.reshape(-1, Cout // 8, 8)
+        np.testing.assert_allclose(got_s[v, :, 0], es.sum((0, 2)), rtol=1e-4, atol=5e-3)
+        np.testing.assert_allclose(got_s[v, :, 1], (es ** 2).sum((0, 2)), rtol=1e-4, atol=5e-3)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 8), (1, 8, 8, 128, 64), (1, 16, 16, 32, 16)])  # V,H,W,Cin,Cout
+def test_deconv2d_gn_matches_oracle(case, lib_built):
+    from mvsnet_amd import _lib as L
+    lib = L.load()
+    V, H, W, Cin, Cout = case
+    rs = np.random.RandomState(sum(case))
+    x = rs.standard_normal((V, H, W, Cin)).astype(np.float32)
+    w = (rs.standard_normal((3, 3, Cout, Cin)) / np.sqrt(9 * Cin)).astype(np.float32)
+    g = (1 + 0.3 * rs.standard_normal(Cin)).astype(np.float32); b = (0.2 * rs.standard_normal(Cin)).astype(np.float32)
+    xs = x.reshape(V, -1, Cin // 8, 8).astype(np.float64)
+    st = t(np.stack([xs.sum((1, 3)), (xs ** 2).sum((1, 3))], -1))
+    y = torch.empty((V, 2 * H, 2 * W, Cout), dtype=torch.float32, device=DEV)
+    so = torch.zeros((V, Cout // 8, 2), dtype=torch.float64, device=DEV)
+    tx, tg, tb, tw = t(x), t(g), t(b), t(w)
+    L.check(lib.mvs_deconv2d_gn_f32(L.ptr(tx), L.ptr(st), L.ptr(tg), L.ptr(tb), Cin, 1, L.ptr(tw), V, H, W, Cout,
+                                    L.ptr(y), L.ptr(so), L.stream_ptr()), "deconv2d")
+    got, got_s = n(y), n(so)
+    for v in range(V):
+        exp = O.convnd_transpose_same(_gn_relu(x[v], g, b, True), w, 2, np.float64)
+        np.testing.assert_allclose(got[v], exp, rtol=2e-4, atol=2e-4)
+        es = exp.reshape(-1, Cout // 8, 8)
+        np.testing.assert_allclose(got_s[v, :, 0], es.sum((0, 2)), rtol=1e-4, atol=5e-3)
+        np.testing.assert_allclose(got_s[v, :, 1], (es ** 2).sum((0, 2)), rtol=1e-4, atol=5e-3)
+
+
+def test_hip_unet_matches_oracle_and_torch(lib_built):
+    from mvsnet_amd.feature_net import UNetDS2GN
+    from mvsnet_amd.feature_net_hip import HipUNetDS2GN
+    params = S.make_unet_params("normal", seed=3)
+    rs = np.random.RandomState(0)
+    small = rs.standard_normal((2, 32, 48, 3)).astype(np.float32)
+    hip = HipUNetDS2GN(params, DEV)
+    got = n(hip(t(small)))
+    assert got.shape == (2, 8, 12, 32)
+    for v in range(2):
+        exp = O.unet_ds2gn(small[v], params, np.float64)
+        err = np.abs(got[v] - exp).max() / np.abs(exp).max()
+        assert err < 2e-4, err
+    big = rs.standard_normal((3, 128, 160, 3)).astype(np.float32)
+    ref = n(UNetDS2GN(params, DEV)(t(big)))
+    got = n(hip(t(big)))
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-4
