@@ -158,24 +158,31 @@ int mvs_regnet_us0_prepared_f32(const float* cost, int D, int H, int W, int cin,
  * over the V views of a cluster (GroupNorm is per view).  As in the 3D stack a layer stores its RAW
  * output plus float64 group sums, and the consumer applies the producer's GroupNorm (eps 1e-5,
  * 8 channels per group, biased variance) while loading:
- *      in(v,p,c) = act(x(v,p,c) * s(v,c) + t(v,c)),  s, t from stats (V, C/8, 2) [sum, sumsq], gamma, beta
+ *      in(v,p,c) = act(x(v,p,c) * s(v,c) + t(v,c)),  s, t from stats (V, C/8, S, 2) [sum, sumsq], gamma, beta
+ * where S = mvs_gn_stat_slots() partial accumulators per (view, group) that consumers add up (they keep
+ * the float64 atomics of ~10^4 workgroups from serialising on one address).
  * (stats == NULL: identity, e.g. the image; relu != 0 for conv_gn producers, 0 for deconv_gn).
  *   mvs_conv2d_gn_f32     k x k (3 or 5) SAME convolution, stride 1 or 2, no bias, of the channel
  *                         concatenation of one or two sources; weights pre-laid-out by
  *                         mvs_conv2d_prepare_f32 (from the TensorFlow (k,k,Cin,Cout) layout, same
  *                         cin1/cin2/cout); channel counts multiples of 4 (image: pad 3 -> 4), Cout of 8
- *   mvs_deconv2d_gn_f32   3x3 stride-2 SAME transposed convolution (out = 2H x 2W), weights in the
- *                         TensorFlow (3,3,Cout,Cin) layout
- *   stats_out             NULL or zeroed (V, Cout/8, 2) float64 accumulators of the raw output
+ *   mvs_deconv2d_gn_f32   3x3 stride-2 SAME transposed convolution (out = 2H x 2W): MFMA path when
+ *                         `prepared` (mvs_deconv2d_prepare_f32, Cin a multiple of 16) is given, else a
+ *                         VALU gather on `w` in the TensorFlow (3,3,Cout,Cin) layout
+ *   stats_out             NULL or zeroed (V, Cout/8, S, 2) float64 accumulators of the raw output
  */
+int mvs_gn_stat_slots(void);
 size_t mvs_conv2d_prepared_floats(int ks, int cin1, int cin2, int cout);
 int mvs_conv2d_prepare_f32(const float* w, int ks, int cin1, int cin2, int cout, float* prepared, void* stream);
 int mvs_conv2d_gn_f32(const float* x1, const double* stats1, const float* gamma1, const float* beta1, int c1, int relu1,
                       const float* x2, const double* stats2, const float* gamma2, const float* beta2, int c2, int relu2,
                       const float* prepared, int V, int H, int W, int cout, int ks, int stride,
                       float* y, double* stats_out, void* stream);
+size_t mvs_deconv2d_prepared_floats(int cin, int cout);
+int mvs_deconv2d_prepare_f32(const float* w, int cin, int cout, float* prepared, void* stream);
 int mvs_deconv2d_gn_f32(const float* x, const double* stats, const float* gamma, const float* beta, int cin, int relu,
-                        const float* w, int V, int H, int W, int cout, float* y, double* stats_out, void* stream);
+                        const float* w, const float* prepared, int V, int H, int W, int cout, float* y,
+                        double* stats_out, void* stream);
 
 /* Live timing of the dominant kernel for bench.py's `roofline` object: while enabled, every
  * mvs_regnet_us0_*_f32 call brackets its first launch (the fused 3dconv0_1 + 3dconv1_0 pass over the

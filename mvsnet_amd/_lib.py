@@ -31,10 +31,13 @@ SIGNATURES = {
     "mvs_conv3d_f32": (_i, [_p] * 7 + [_i] * 6 + [_p, _p, _p]),
     "mvs_deconv3d_f32": (_i, [_p] * 7 + [_i] * 5 + [_p, _p, _p]),
     "mvs_conv3d_pair_f32": (_i, [_p] * 3 + [_i] * 6 + [_p] * 5),
+    "mvs_gn_stat_slots": (_i, []),
     "mvs_conv2d_prepared_floats": (_sz, [_i, _i, _i, _i]),
     "mvs_conv2d_prepare_f32": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "mvs_conv2d_gn_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
-    "mvs_deconv2d_gn_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "mvs_deconv2d_prepared_floats": (_sz, [_i, _i]),
+    "mvs_deconv2d_prepare_f32": (_i, [_p, _i, _i, _p, _p]),
+    "mvs_deconv2d_gn_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "mvs_profile_dominant": (_i, [_i]),
     "mvs_profile_dominant_ms": (_i, [_p, _p]),
     "mvs_bn_finalize_f32": (_i, [_p, _i, C.c_double, _p, _p, _f, _p, _p, _p]),

@@ -42,13 +42,20 @@ struct Conv2dArgs {
 };
 
 constexpr int TH = 8, TW = 16;
+// GroupNorm sums are spread over NSLOT partial accumulators per (view, group): a full-resolution layer
+// has ~13 000 workgroups adding into ~10 (view, group) pairs, and that many float64 atomics on one
+// address serialise in L2 (measured: 287 us for a 20 us layer).  Consumers add the slots up.
+constexpr int NSLOT = 32;
 
 __device__ __forceinline__ void gn_affine4(const GnSrc& s, int view, int c0, float4& sc, float4& sh) {
     sc = make_float4(1.f, 1.f, 1.f, 1.f); sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!s.stats) return;
-    const double* st = s.stats + ((size_t)view * (s.C / 8) + c0 / 8) * 2;       // 4 channels share a group
-    const double mean = st[0] / s.count;
-    double var = st[1] / s.count - mean * mean;
+    const double* st = s.stats + ((size_t)view * (s.C / 8) + c0 / 8) * (NSLOT * 2);   // 4 channels share a group
+    double sum = 0.0, sq = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < NSLOT; ++i) { sum += st[2 * i]; sq += st[2 * i + 1]; }
+    const double mean = sum / s.count;
+    double var = sq / s.count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double inv = 1.0 / sqrt(var + 1e-5);                                   // network.py:55,254
     float a[4], b[4];
@@ -60,7 +67,11 @@ __device__ __forceinline__ void gn_affine4(const GnSrc& s, int view, int c0, flo
     sc = make_float4(a[0], a[1], a[2], a[3]); sh = make_float4(b[0], b[1], b[2], b[3]);
 }
 
-template <int KS, int STRIDE, int CG, int MT>
+// DECONV: the 3x3 stride-2 transposed convolution as a 2x2-tap convolution over the coarse input with
+// the four output parity classes stacked as 4*Cout "channels" (class (ph,pw) of coarse pixel (m,n) is
+// output pixel (2m+ph, 2n+pw); tap offsets 0 / -1 carry kernel index 0|1 / 2 per axis, absent
+// combinations have zero weights), stored depth-to-space.  KS = 2, STRIDE = 1, pad 1 in front.
+template <int KS, int STRIDE, int CG, int MT, bool DECONV = false>
 __global__ void __launch_bounds__(256)
 conv2d_gn_kernel(Conv2dArgs p) {
     constexpr int CK = CG;                          // channels per chunk
@@ -97,16 +108,26 @@ conv2d_gn_kernel(Conv2dArgs p) {
     for (int v = 0; v < V2; ++v) b_off[v] = ((V2 * wave + v) * STRIDE * IW + n * STRIDE) * S + (CG / 4) * kq;
     const int a_off = (kq * COUT_T + n) * 4;
 
+    // GroupNorm (scale, shift) of every input channel of this view: float64 group statistics -> LDS,
+    // once per workgroup by Ctot/4 threads (every thread doing it per chunk cost more than the MFMAs
+    // of the 8-channel full-resolution layers)
+    __shared__ __attribute__((aligned(16))) float aff_s[256], aff_b[256];
+    if (tid < Ctot / 4) {
+        const int c = 4 * tid;
+        float4 sc, sh;
+        if (c < p.a.C) gn_affine4(p.a, view, c, sc, sh); else gn_affine4(p.b, view, c - p.a.C, sc, sh);
+        *(float4*)(aff_s + c) = sc; *(float4*)(aff_b + c) = sh;
+    }
+
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * CK;                     // first channel of the chunk in the concatenation
         const bool from_b = c0 >= p.a.C;
         const GnSrc& src = from_b ? p.b : p.a;
         const int cs = from_b ? c0 - p.a.C : c0;    // first channel inside its source
-        __syncthreads();                            // previous chunk's operands are dead
+        __syncthreads();                            // previous chunk's operands are dead (first trip: affine table written)
         // ---- stage the input patch of this chunk: GroupNorm affine (+ReLU), zeros outside the image
         const int q = tid % CQ;                     // 256 % CQ == 0: a thread keeps one channel quad
-        float4 sc, sh;
-        gn_affine4(src, view, cs + 4 * q, sc, sh);
+        const float4 sc = *(const float4*)(aff_s + c0 + 4 * q), sh = *(const float4*)(aff_b + c0 + 4 * q);
         for (int f = tid; f < NPOS * CQ; f += 256) {
             const int pos = f / CQ;
             const int r = pos / IW, c = pos - r * IW;
@@ -167,6 +188,7 @@ conv2d_gn_kernel(Conv2dArgs p) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) { gs[m] = 0.f; gq[m] = 0.f; }
     const int co_base = cog * COUT_T;
+    const int cout_rows = DECONV ? 4 * p.Cout : p.Cout;     // GEMM rows in total
 #pragma unroll
     for (int v = 0; v < V2; ++v) {
         const int oh = oh0 + V2 * wave + v, ow = ow0 + n;
@@ -174,9 +196,14 @@ conv2d_gn_kernel(Conv2dArgs p) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int co = co_base + m * 16 + 4 * kq;
-                if (co < p.Cout) {
+                if (co < cout_rows) {
                     f32x4 r = acc[m][v];
-                    *(float4*)(p.y + (((size_t)view * p.Ho + oh) * p.Wo + ow) * p.Cout + co) = make_float4(r[0], r[1], r[2], r[3]);
+                    float* dst;
+                    if (DECONV) {
+                        const int cls = co / p.Cout, c = co - cls * p.Cout;
+                        dst = p.y + (((size_t)view * 2 * p.Ho + 2 * oh + (cls >> 1)) * (2 * p.Wo) + 2 * ow + (cls & 1)) * p.Cout + c;
+                    } else dst = p.y + (((size_t)view * p.Ho + oh) * p.Wo + ow) * p.Cout + co;
+                    *(float4*)dst = make_float4(r[0], r[1], r[2], r[3]);
                     gs[m] += (r[0] + r[1]) + (r[2] + r[3]);
                     gq[m] += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
                 }
@@ -197,10 +224,11 @@ conv2d_gn_kernel(Conv2dArgs p) {
         __syncthreads();
         if (tid < MT * 4) {
             const int m = tid >> 2, h = (tid >> 1) & 1, k = tid & 1;
-            const int g = (co_base + m * 16) / 8 + h;
-            if (g * 8 < p.Cout) {
+            const int row8 = co_base + m * 16 + 8 * h;                   // first GEMM row of this 8-channel half
+            const int g = (DECONV ? row8 % p.Cout : row8) / 8;
+            if (row8 < cout_rows) {
                 double t = (double)red[0][m][h][k] + (double)red[1][m][h][k] + (double)red[2][m][h][k] + (double)red[3][m][h][k];
-                atomicAdd(&p.stats[((size_t)view * (p.Cout / 8) + g) * 2 + k], t);
+                atomicAdd(&p.stats[(((size_t)view * (p.Cout / 8) + g) * NSLOT + (blockIdx.x & (NSLOT - 1))) * 2 + k], t);
             }
         }
     }
@@ -223,7 +251,34 @@ __global__ void conv2d_weight_layout_kernel(const float* __restrict__ w, int KS,
     out[i] = (ci < Cin && cout < Cout) ? w[((size_t)tap * Cin + ci) * Cout + cout] : 0.f;
 }
 
+// TensorFlow conv2d_transpose kernel (3,3,Cout,Cin) -> the stacked 2x2-tap form described at
+// conv2d_gn_kernel: [group][chunk][tap 2x2][CK/4][COUT_T][4], rows = (class, cout)
+__global__ void deconv2d_weight_layout_kernel(const float* __restrict__ w, int Cin, int Cout, int CK, int COUT_T,
+                                              float* __restrict__ out) {
+    const int nch = Cin / CK, CQ = CK / 4, rows = 4 * Cout, groups = (rows + COUT_T - 1) / COUT_T;
+    const long long total = (long long)groups * nch * 4 * CQ * COUT_T * 4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int j = r & 3; r >>= 2;
+    const int co = r % COUT_T; r /= COUT_T;
+    const int ciq = r % CQ; r /= CQ;
+    const int tap = r % 4; r /= 4;
+    const int ch = r % nch; const int g = r / nch;
+    const int ci = ch * CK + ciq * 4 + j, row = g * COUT_T + co;
+    float v = 0.f;
+    if (row < rows) {
+        const int cls = row / Cout, c = row - cls * Cout, ph = cls >> 1, pw = cls & 1;
+        const int dh = 1 - (tap >> 1), dw = 1 - (tap & 1);        // staged tap 0 is the (-1) neighbour
+        // class parity 0: offset 0 -> k = 0, offset -1 -> k = 2;  parity 1: offset 0 -> k = 1, offset -1 -> none
+        const int kh = ph ? (dh ? -1 : 1) : (dh ? 2 : 0), kw = pw ? (dw ? -1 : 1) : (dw ? 2 : 0);
+        if (kh >= 0 && kw >= 0) v = w[((size_t)(kh * 3 + kw) * Cout + c) * Cin + ci];
+    }
+    out[i] = v;
+}
+
 // ---- transposed convolution k3 s2 SAME (out = 2n, cropped at the end), bias-free, VALU gather --------------
+// (reference implementation of the kernel above; used for shapes outside the MFMA tiling)
 // out[2i + k] += in[i] * W[k][co][ci] per axis (weight layout (3,3,Cout,Cin), TF conv2d_transpose).
 struct Deconv2dArgs {
     GnSrc a;
@@ -289,27 +344,28 @@ deconv2d_gn_kernel(Deconv2dArgs p) {
         const int lane = threadIdx.x & 63;
         if (live && lane < CQo && (lane & 1) == 0) {
             const int g = (coq >> 1);
-            atomicAdd(&p.stats[((size_t)view * (p.Cout / 8) + g) * 2], (double)s);
-            atomicAdd(&p.stats[((size_t)view * (p.Cout / 8) + g) * 2 + 1], (double)q);
+            double* dst = p.stats + (((size_t)view * (p.Cout / 8) + g) * NSLOT + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (NSLOT - 1))) * 2;
+            atomicAdd(dst, (double)s);
+            atomicAdd(dst + 1, (double)q);
         }
     }
 }
 
-template <int KS, int STRIDE, int CG, int MT>
+template <int KS, int STRIDE, int CG, int MT, bool DECONV = false>
 int launch_conv2d(const Conv2dArgs& p, hipStream_t st) {
     const int tiles = ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW);
-    dim3 grid(p.V * tiles, (p.Cout + 16 * MT - 1) / (16 * MT));
+    dim3 grid(p.V * tiles, ((DECONV ? 4 : 1) * p.Cout + 16 * MT - 1) / (16 * MT));
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr int S = (CG == 16) ? 24 : (CG == 8 ? 10 : 5);
     constexpr size_t smem = (size_t)(((IH * IW * S + 3) & ~3) + KS * KS * CG * 16 * MT) * sizeof(float);
     static bool attr_done = false;       // per template instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv2d_gn_kernel<KS, STRIDE, CG, MT>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv2d_gn_kernel<KS, STRIDE, CG, MT, DECONV>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv2d_gn_kernel<KS, STRIDE, CG, MT><<<grid, 256, smem, st>>>(p);
+    conv2d_gn_kernel<KS, STRIDE, CG, MT, DECONV><<<grid, 256, smem, st>>>(p);
     return (int)hipGetLastError();
 }
 
@@ -320,6 +376,8 @@ void conv2d_tiling(int Cin_total, int Cout, int c1, int& CG, int& MT) {
 }
 
 }  // namespace
+
+extern "C" int mvs_gn_stat_slots(void) { return NSLOT; }
 
 extern "C" size_t mvs_conv2d_prepared_floats(int ks, int cin1, int cin2, int cout) {
     int CG, MT; conv2d_tiling(cin1 + cin2, cout, cin1, CG, MT);
@@ -342,7 +400,7 @@ extern "C" int mvs_conv2d_gn_f32(const float* x1, const double* stats1, const fl
                                  float* y, double* stats_out, void* stream) {
     MVS_CHECK_ARG(x1 && prepared && y && V > 0 && H > 0 && W > 0 && c1 > 0 && cout > 0 && c2 >= 0);
     MVS_CHECK_ARG((stats1 == nullptr) == (gamma1 == nullptr) && (c2 == 0) == (x2 == nullptr));
-    if ((c1 % 4) || (c2 % 4) || (cout % 8) || (stats1 && c1 % 8) || (stats2 && c2 % 8)) return MVS_E_SHAPE;
+    if ((c1 % 4) || (c2 % 4) || (cout % 8) || (stats1 && c1 % 8) || (stats2 && c2 % 8) || c1 + c2 > 256) return MVS_E_SHAPE;
     int CG, MT; conv2d_tiling(c1 + c2, cout, c1, CG, MT);
     if ((c1 % CG) || (c2 % CG)) return MVS_E_SHAPE;
     Conv2dArgs p;
@@ -362,10 +420,36 @@ extern "C" int mvs_conv2d_gn_f32(const float* x1, const double* stats1, const fl
     return MVS_E_SHAPE;
 }
 
+extern "C" size_t mvs_deconv2d_prepared_floats(int cin, int cout) {
+    if (cin % 16 || cout % 8) return 0;
+    const int ct = 32;                              // 4*cout rows in tiles of 32
+    return (size_t)((4 * cout + ct - 1) / ct) * (cin / 16) * 4 * 4 * ct * 4;
+}
+
+extern "C" int mvs_deconv2d_prepare_f32(const float* w, int cin, int cout, float* prepared, void* stream) {
+    MVS_CHECK_ARG(w && prepared && cin > 0 && cout > 0);
+    const size_t total = mvs_deconv2d_prepared_floats(cin, cout);
+    if (!total) return MVS_E_SHAPE;
+    deconv2d_weight_layout_kernel<<<mvs_cdiv((long long)total, 256), 256, 0, mvs_stream(stream)>>>(w, cin, cout, 16, 32, prepared);
+    MVS_LAUNCH_RET();
+}
+
+// `prepared` != NULL (from mvs_deconv2d_prepare_f32; cin a multiple of 16): MFMA path; else the VALU gather on `w`
 extern "C" int mvs_deconv2d_gn_f32(const float* x, const double* stats, const float* gamma, const float* beta, int cin, int relu,
-                                   const float* w, int V, int H, int W, int cout, float* y, double* stats_out, void* stream) {
-    MVS_CHECK_ARG(x && w && y && V > 0 && H > 0 && W > 0 && cin > 0 && cout > 0);
+                                   const float* w, const float* prepared, int V, int H, int W, int cout, float* y,
+                                   double* stats_out, void* stream) {
+    MVS_CHECK_ARG(x && (w || prepared) && y && V > 0 && H > 0 && W > 0 && cin > 0 && cout > 0);
     MVS_CHECK_ARG((stats == nullptr) == (gamma == nullptr));
+    if (prepared) {
+        if ((cin % 16) || (cout % 8)) return MVS_E_SHAPE;
+        Conv2dArgs q;
+        q.a = GnSrc{x, stats, gamma, beta, (double)H * W * 8, cin, relu};
+        q.b = GnSrc{nullptr, nullptr, nullptr, nullptr, 1.0, 0, 0};
+        q.wprep = prepared; q.y = y; q.stats = stats_out;
+        q.V = V; q.H = H; q.W = W; q.Ho = H; q.Wo = W; q.Cout = cout; q.pad_h = 1; q.pad_w = 1;
+        return launch_conv2d<2, 1, 16, 2, true>(q, mvs_stream(stream));
+    }
+    MVS_CHECK_ARG(w);
     const int cqo = cout / 4;
     if ((cin % 4) || cin > 256 || (cout % 8) || (stats && cin % 8) || cqo > 32 || (cqo & (cqo - 1))) return MVS_E_SHAPE;
     Deconv2dArgs p{GnSrc{x, stats, gamma, beta, (double)H * W * 8, cin, relu}, w, y, stats_out, V, H, W, cout};

@@ -21,15 +21,23 @@ class HipUNetDS2GN:
     def __init__(self, params, device="cuda"):
         self.device = torch.device(device)
         lib = _lib.load()
+        self.slots = lib.mvs_gn_stat_slots()               # partial GroupNorm accumulators per (view, group)
         chans = {"data": 4}                               # the image is padded 3 -> 4 channels
         self.layers = []
         for name, kind, srcs, k, _mult, stride in UNET_LAYERS:
             p = params[name]
             w = np.asarray(p["w"], np.float32)
             cins = [chans[s] for s in srcs]
+            wraw = None
             if kind == "dg":
                 cout = w.shape[2]
-                wd = torch.as_tensor(w).contiguous().to(self.device)
+                wraw = torch.as_tensor(w).contiguous().to(self.device)
+                n = lib.mvs_deconv2d_prepared_floats(cins[0], cout)
+                wd = None
+                if n:                                      # MFMA path; otherwise the VALU gather on the raw weights
+                    wd = torch.empty(n, dtype=torch.float32, device=self.device)
+                    _lib.check(lib.mvs_deconv2d_prepare_f32(_lib.ptr(wraw), cins[0], cout, _lib.ptr(wd), _lib.stream_ptr()),
+                               "mvs_deconv2d_prepare_f32")
             else:
                 cout = w.shape[3]
                 if srcs == ("data",):                     # zero weights for the padding channel
@@ -45,7 +53,7 @@ class HipUNetDS2GN:
                 g = torch.as_tensor(np.asarray(p["gamma"], np.float32)).to(self.device)
                 b = torch.as_tensor(np.asarray(p["beta"], np.float32)).to(self.device)
             chans[name] = cout
-            self.layers.append((name, kind, srcs, k, stride, wd, g, b, cins, cout))
+            self.layers.append((name, kind, srcs, k, stride, wd, g, b, cins, cout, wraw))
         torch.cuda.synchronize(self.device)
         self.out_channels = self.layers[-1][9]
         self._bufs = {}
@@ -57,13 +65,13 @@ class HipUNetDS2GN:
             return self._bufs[key]
         shapes = {"data": (H, W)}
         acts, offs, total = {}, {}, 0
-        for name, kind, srcs, k, stride, _w, _g, _b, _cins, cout in self.layers:
+        for name, kind, srcs, k, stride, _w, _g, _b, _cins, cout, _wr in self.layers:
             h, w = shapes[srcs[0]]
             ho, wo = (2 * h, 2 * w) if kind == "dg" else (-(-h // stride), -(-w // stride))
             shapes[name] = (ho, wo)
             acts[name] = torch.empty((V, ho, wo, cout), dtype=torch.float32, device=self.device)
             offs[name] = total
-            total += V * (cout // 8) * 2
+            total += V * (cout // 8) * 2 * self.slots
         stats = torch.zeros(total, dtype=torch.float64, device=self.device)
         self._bufs[key] = (acts, offs, stats, shapes)
         return self._bufs[key]
@@ -82,14 +90,14 @@ class HipUNetDS2GN:
         data[..., :3] = x
         st = _lib.stream_ptr()
         src_of = {"data": (data, None, None, None, 0)}    # tensor, stats view, gamma, beta, relu
-        for name, kind, srcs, k, stride, wd, g, b, cins, cout in self.layers:
+        for name, kind, srcs, k, stride, wd, g, b, cins, cout, wraw in self.layers:
             h, w = shapes[srcs[0]]
             y = acts[name]
-            so = stats[offs[name]:offs[name] + V * (cout // 8) * 2] if kind != "c" else None
+            so = stats[offs[name]:offs[name] + V * (cout // 8) * 2 * self.slots] if kind != "c" else None
             a = src_of[srcs[0]]
             if kind == "dg":
                 _lib.check(lib.mvs_deconv2d_gn_f32(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]), cins[0], a[4],
-                                                   _lib.ptr(wd), V, h, w, cout, _lib.ptr(y), _lib.ptr(so), st),
+                                                   _lib.ptr(wraw), _lib.ptr(wd), V, h, w, cout, _lib.ptr(y), _lib.ptr(so), st),
                            "mvs_deconv2d_gn_f32")
             else:
                 bsrc = src_of[srcs[1]] if len(srcs) > 1 else (None, None, None, None, 0)

@@ -35,9 +35,14 @@ def test_conv2d_gn_matches_oracle(case, lib_built):
     g1 = (1 + 0.3 * rs.standard_normal(C1)).astype(np.float32); b1 = (0.2 * rs.standard_normal(C1)).astype(np.float32)
     g2 = (1 + 0.3 * rs.standard_normal(max(C2, 1))).astype(np.float32); b2 = (0.2 * rs.standard_normal(max(C2, 1))).astype(np.float32)
 
-    def sums(x, C):                                          # raw group sums of a "producer" output
+    SL = lib.mvs_gn_stat_slots()
+
+    def sums(x, C):                                          # raw group sums of a "producer" output, split over 3 slots
         xs = x.reshape(V, -1, C // 8, 8).astype(np.float64)
-        return np.stack([xs.sum((1, 3)), (xs ** 2).sum((1, 3))], -1)          # (V, C/8, 2)
+        full = np.stack([xs.sum((1, 3)), (xs ** 2).sum((1, 3))], -1)          # (V, C/8, 2)
+        out = np.zeros((V, C // 8, SL, 2))
+        out[:, :, 0] = 0.5 * full; out[:, :, 5] = 0.25 * full; out[:, :, SL - 1] = 0.25 * full
+        return out
 
     s1 = t(sums(x1, C1)) if gn1 else None
     s2 = t(sums(x2, C2)) if C2 else None
@@ -46,13 +51,13 @@ def test_conv2d_gn_matches_oracle(case, lib_built):
     L.check(lib.mvs_conv2d_prepare_f32(L.ptr(tw), k, C1, C2, Cout, L.ptr(wp), L.stream_ptr()), "prepare")
     Ho, Wo = -(-H // stride), -(-W // stride)
     y = torch.empty((V, Ho, Wo, Cout), dtype=torch.float32, device=DEV)
-    so = torch.zeros((V, Cout // 8, 2), dtype=torch.float64, device=DEV)
+    so = torch.zeros((V, Cout // 8, SL, 2), dtype=torch.float64, device=DEV)
     tx1, tx2 = t(x1), (t(x2) if C2 else None)
     tg1, tb1, tg2, tb2 = t(g1), t(b1), t(g2), t(b2)          # keep the device tensors alive across the async launch
     L.check(lib.mvs_conv2d_gn_f32(L.ptr(tx1), L.ptr(s1), L.ptr(tg1) if gn1 else None, L.ptr(tb1) if gn1 else None, C1, 1 if gn1 else 0,
                                   L.ptr(tx2), L.ptr(s2), L.ptr(tg2) if C2 else None, L.ptr(tb2) if C2 else None, C2, 0,
                                   L.ptr(wp), V, H, W, Cout, k, stride, L.ptr(y), L.ptr(so), L.stream_ptr()), "conv2d")
-    got, got_s = n(y), n(so)
+    got, got_s = n(y), n(so).sum(2)
     for v in range(V):
         xin = _gn_relu(x1[v], g1, b1, True) if gn1 else x1[v].astype(np.float64)
         if C2:
@@ -64,8 +69,9 @@ def test_conv2d_gn_matches_oracle(case, lib_built):
         np.testing.assert_allclose(got_s[v, :, 1], (es ** 2).sum((0, 2)), rtol=1e-4, atol=5e-3)
 
 
-@pytest.mark.parametrize("case", [(2, 8, 16, 16, 8), (1, 8, 8, 128, 64), (1, 16, 16, 32, 16)])  # V,H,W,Cin,Cout
-def test_deconv2d_gn_matches_oracle(case, lib_built):
+@pytest.mark.parametrize("mfma", [False, True])
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 8), (1, 8, 8, 128, 64), (1, 16, 16, 32, 16), (1, 10, 12, 16, 8)])  # V,H,W,Cin,Cout
+def test_deconv2d_gn_matches_oracle(case, mfma, lib_built):
     from mvsnet_amd import _lib as L
     lib = L.load()
     V, H, W, Cin, Cout = case
@@ -73,14 +79,20 @@ def test_deconv2d_gn_matches_oracle(case, lib_built):
     x = rs.standard_normal((V, H, W, Cin)).astype(np.float32)
     w = (rs.standard_normal((3, 3, Cout, Cin)) / np.sqrt(9 * Cin)).astype(np.float32)
     g = (1 + 0.3 * rs.standard_normal(Cin)).astype(np.float32); b = (0.2 * rs.standard_normal(Cin)).astype(np.float32)
+    SL = lib.mvs_gn_stat_slots()
     xs = x.reshape(V, -1, Cin // 8, 8).astype(np.float64)
-    st = t(np.stack([xs.sum((1, 3)), (xs ** 2).sum((1, 3))], -1))
+    full = np.zeros((V, Cin // 8, SL, 2)); full[:, :, 3] = np.stack([xs.sum((1, 3)), (xs ** 2).sum((1, 3))], -1)
+    st = t(full)
     y = torch.empty((V, 2 * H, 2 * W, Cout), dtype=torch.float32, device=DEV)
-    so = torch.zeros((V, Cout // 8, 2), dtype=torch.float64, device=DEV)
+    so = torch.zeros((V, Cout // 8, SL, 2), dtype=torch.float64, device=DEV)
     tx, tg, tb, tw = t(x), t(g), t(b), t(w)
-    L.check(lib.mvs_deconv2d_gn_f32(L.ptr(tx), L.ptr(st), L.ptr(tg), L.ptr(tb), Cin, 1, L.ptr(tw), V, H, W, Cout,
+    wp = None
+    if mfma:
+        wp = torch.empty(lib.mvs_deconv2d_prepared_floats(Cin, Cout), dtype=torch.float32, device=DEV)
+        L.check(lib.mvs_deconv2d_prepare_f32(L.ptr(tw), Cin, Cout, L.ptr(wp), L.stream_ptr()), "prepare")
+    L.check(lib.mvs_deconv2d_gn_f32(L.ptr(tx), L.ptr(st), L.ptr(tg), L.ptr(tb), Cin, 1, L.ptr(tw), L.ptr(wp), V, H, W, Cout,
                                     L.ptr(y), L.ptr(so), L.stream_ptr()), "deconv2d")
-    got, got_s = n(y), n(so)
+    got, got_s = n(y), n(so).sum(2)
     for v in range(V):
         exp = O.convnd_transpose_same(_gn_relu(x[v], g, b, True), w, 2, np.float64)
         np.testing.assert_allclose(got[v], exp, rtol=2e-4, atol=2e-4)
