@@ -125,6 +125,7 @@ def main():
                     help="independent depth maps in flight per GPU (one plan + HIP stream each)")
     ap.add_argument("--regularization", default="3DCNN", choices=["3DCNN", "GRU"],
                     help="GRU = R-MVSNet recurrent sweep (config 3); reported as an extra, not the metric")
+    ap.add_argument("--extractor", choices=("hip", "torch"), default="hip", help="2D towers for --with-images")
     ap.add_argument("--with-images", action="store_true",
                     help="also time images->depth (adds the PyTorch UNetDS2GN towers)")
     args = ap.parse_args()
@@ -303,7 +304,10 @@ def main():
         out["roofline"]["traffic_source"] = tr.get("source")
         if args.with_images:
             up = S.make_unet_params(args.network_mode, seed=3)
-            from mvsnet_amd.feature_net import UNetDS2GN
+            if args.extractor == "hip":
+                from mvsnet_amd.feature_net_hip import HipUNetDS2GN as UNetDS2GN
+            else:
+                from mvsnet_amd.feature_net import UNetDS2GN
             net = UNetDS2GN(up, dev)
             imgs = torch.as_tensor(S.make_images(w.view_num, 4 * w.height, 4 * w.width, seed=0)).to(dev)
             for _ in range(3):
@@ -316,6 +320,7 @@ def main():
                 plan.run_3dcnn(f, w.depth_start, w.depth_interval)
             torch.cuda.synchronize()
             out["images_to_depth_maps_per_s"] = args.steps / (time.perf_counter() - t1)
+            out["extractor"] = args.extractor
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, rp, args.cpu_budget)
         print(json.dumps(out), flush=True)

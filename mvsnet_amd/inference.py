@@ -21,7 +21,7 @@ import numpy as np
 logger = logging.getLogger("mvsnet_amd.inference")
 
 
-def build_weights(config, device, weights_path=None, model_dir=None, ckpt_step=None):
+def build_weights(config, device, weights_path=None, model_dir=None, ckpt_step=None, extractor="hip"):
     """Weights from (in order of preference) a TensorFlow checkpoint of the reference
     (<model_dir>/<regularization>/<network_mode>/model.ckpt-<ckpt_step>, inference.py:23-27 +
     utils.py:75-96), an .npz of parameter dictionaries, or a seeded random initialisation."""
@@ -35,7 +35,7 @@ def build_weights(config, device, weights_path=None, model_dir=None, ckpt_step=N
         logger.info("restored %s", prefix)
         return MVSNetWeights.from_numpy(config.network_mode, unet=params["unet"], regnet=params["regnet"],
                                         gru=params["gru"], device=device, refine=params.get("refine"),
-                                        refine_type=config.refinement_network)
+                                        refine_type=config.refinement_network, extractor=extractor)
     if weights_path:
         z = np.load(weights_path, allow_pickle=True)
         unet, regnet, gru = z["unet"].item(), z["regnet"].item(), z["gru"].item()
@@ -50,7 +50,7 @@ def build_weights(config, device, weights_path=None, model_dir=None, ckpt_step=N
         refine = make_refine_params(config.refinement_network, config.network_mode,
                                     4 + int(config.refine_with_confidence), seed=4)
     return MVSNetWeights.from_numpy(config.network_mode, unet=unet, regnet=regnet, gru=gru, device=device,
-                                    refine=refine, refine_type=config.refinement_network)
+                                    refine=refine, refine_type=config.refinement_network, extractor=extractor)
 
 
 def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwargs):
@@ -136,6 +136,8 @@ def main(argv=None):
     ap.add_argument("--weights", default=None, help=".npz with 'unet', 'regnet', 'gru' parameter dicts")
     ap.add_argument("--model_dir", default=None, help="reference checkpoint root (TensorFlow V2 checkpoint, read without TF)")
     ap.add_argument("--ckpt_step", type=int, default=400000)
+    ap.add_argument("--extractor", choices=("hip", "torch"), default="hip",
+                    help="2D feature towers: HIP library kernels (default) or the PyTorch/MIOpen module")
     args = ap.parse_args(argv)
     logging.basicConfig(level=os.environ.get("LOG_LEVEL", "INFO"))
     weights_path = args.weights
@@ -154,7 +156,7 @@ def main(argv=None):
     import torch
     rank, local_rank, world = sh.rank_world()
     device = torch.device("cuda", local_rank)
-    weights = build_weights(cfg, device, weights_path, args.model_dir, args.ckpt_step)
+    weights = build_weights(cfg, device, weights_path, args.model_dir, args.ckpt_step, args.extractor)
     total = 0
     for d in dirs:
         total += compute_depth_maps(d, cfg, weights, device)

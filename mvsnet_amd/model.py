@@ -82,10 +82,18 @@ class MVSNetWeights:
 
     @classmethod
     def from_numpy(cls, network_mode="normal", unet=None, regnet=None, gru=None, device="cuda",
-                   refine=None, refine_type="original"):
+                   refine=None, refine_type="original", extractor="hip"):
+        """`extractor`: "hip" = the 2D towers on the HIP library (feature_net_hip.HipUNetDS2GN, SURVEY 8f
+        f2, ~12x the PyTorch/MIOpen module at 5 x 512 x 640), "torch" = feature_net.UNetDS2GN."""
         from .refine import RefineNet
+        if extractor == "hip":
+            from .feature_net_hip import HipUNetDS2GN as Extractor
+        elif extractor == "torch":
+            Extractor = UNetDS2GN
+        else:
+            raise ValueError("extractor must be 'hip' or 'torch'")
         return cls(network_mode,
-                   UNetDS2GN(unet, device) if unet is not None else None,
+                   Extractor(unet, device) if unet is not None else None,
                    RegNetWeights(regnet, device) if regnet is not None else None,
                    GRUWeights(gru, device) if gru is not None else None,
                    RefineNet(refine, refine_type, device) if refine is not None else None)
