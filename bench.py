@@ -81,7 +81,7 @@ def pmc_traffic():
     return out
 
 
-def cpu_baseline(workload, rp, budget_s=20.0):
+def cpu_baseline(workload, rp, budget_s=20.0, gpu_depth=None):
     """CPU restatement (oracle/torch_restatement.py, fp32, all host cores) timed on a bounded
     sample of the same workload: whole depth maps until ~budget_s have elapsed (at least one)."""
     from oracle import torch_restatement as TR       # measurement only; never on the product path
@@ -101,12 +101,15 @@ def cpu_baseline(workload, rp, budget_s=20.0):
     w = workload
     n_done, t0 = 0, time.perf_counter()
     while True:
-        TR.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start, w.depth_interval, rp)
+        cpu_depth, _ = TR.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start, w.depth_interval, rp)
         n_done += 1
         el = time.perf_counter() - t0
         if el > budget_s or n_done >= 8:
             break
-    return {"value": n_done / el, "unit": "depth maps/s", "cores": cores, "kind": "port",
+    extra = {}
+    if gpu_depth is not None:      # the metric's "abs-rel vs ref" at full size, against the CPU restatement
+        extra["abs_rel_gpu_vs_cpu"] = float(np.mean(np.abs(np.squeeze(gpu_depth) - cpu_depth) / cpu_depth))
+    return {**extra, "value": n_done / el, "unit": "depth maps/s", "cores": cores, "kind": "port",
             "sample": "%d whole depth map(s) of workload %s (features->depth, torch-CPU fp32 restatement "
                       "of the reference; TensorFlow reference not runnable offline) in %.1f s" % (n_done, w.name, el)}
 
@@ -322,7 +325,7 @@ def main():
             out["images_to_depth_maps_per_s"] = args.steps / (time.perf_counter() - t1)
             out["extractor"] = args.extractor
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w, rp, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(w, rp, args.cpu_budget, depth_np)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
