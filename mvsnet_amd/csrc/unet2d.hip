@@ -119,35 +119,67 @@ conv2d_gn_kernel(Conv2dArgs p) {
         *(float4*)(aff_s + c) = sc; *(float4*)(aff_b + c) = sh;
     }
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int c0 = ch * CK;                     // first channel of the chunk in the concatenation
+    // Chunk ch+1's patch and weights are requested from global memory (into registers) before the
+    // MFMAs of chunk ch and written to LDS after them: the load latency hides under the matrix work.
+    constexpr int NIN = (NPOS * CQ + 255) / 256, NWT = (WCH / 4 + 255) / 256;
+    float4 pin[NIN], pwt[NWT];
+    const int q = tid % CQ;                         // 256 % CQ == 0: a thread keeps one channel quad
+    auto fetch = [&](int ch) __attribute__((always_inline)) {
+        const int c0 = ch * CK;
         const bool from_b = c0 >= p.a.C;
         const GnSrc& src = from_b ? p.b : p.a;
         const int cs = from_b ? c0 - p.a.C : c0;    // first channel inside its source
-        __syncthreads();                            // previous chunk's operands are dead (first trip: affine table written)
-        // ---- stage the input patch of this chunk: GroupNorm affine (+ReLU), zeros outside the image
-        const int q = tid % CQ;                     // 256 % CQ == 0: a thread keeps one channel quad
-        const float4 sc = *(const float4*)(aff_s + c0 + 4 * q), sh = *(const float4*)(aff_b + c0 + 4 * q);
-        for (int f = tid; f < NPOS * CQ; f += 256) {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int f = tid + 256 * i;
             const int pos = f / CQ;
             const int r = pos / IW, c = pos - r * IW;
             const int gh = ih0 + r, gw = iw0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = f < NPOS * CQ && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+            pin[i] = ok ? *(const float4*)(src.x + (((size_t)view * p.H + gh) * p.W + gw) * src.C + cs + 4 * q)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4* w4 = reinterpret_cast<const float4*>(p.wprep + ((size_t)cog * nchunks + ch) * WCH);
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int k = tid + 256 * i;
+            pwt[i] = k < WCH / 4 ? w4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // registers -> LDS: GroupNorm affine (+ReLU) on the way, zeros outside the image (SAME padding)
+    auto stage = [&](int ch) __attribute__((always_inline)) {
+        const int c0 = ch * CK;
+        const bool relu_on = (c0 >= p.a.C ? p.b.relu : p.a.relu) != 0;
+        const float4 sc = *(const float4*)(aff_s + c0 + 4 * q), sh = *(const float4*)(aff_b + c0 + 4 * q);
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int f = tid + 256 * i;
+            if (f >= NPOS * CQ) break;
+            const int pos = f / CQ;
+            const int r = pos / IW, c = pos - r * IW;
+            const int gh = ih0 + r, gw = iw0 + c;
+            float4 v = pin[i];
             if (gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) {
-                v = *(const float4*)(src.x + (((size_t)view * p.H + gh) * p.W + gw) * src.C + cs + 4 * q);
                 v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                if (src.relu) { v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w); }
+                if (relu_on) { v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w); }
             }
             if (CG == 4) { float* d = slab + pos * S; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
             else if (CG == 8) { *(f32x2*)(slab + pos * S + 4 * q) = (f32x2){v.x, v.y}; *(f32x2*)(slab + pos * S + 4 * q + 2) = (f32x2){v.z, v.w}; }
             else *(float4*)(slab + pos * S + 4 * q) = v;
         }
-        // ---- this chunk's weights (prepared layout: one contiguous block)
-        {
-            const float4* w4 = reinterpret_cast<const float4*>(p.wprep + ((size_t)cog * nchunks + ch) * WCH);
-            for (int i = tid; i < WCH / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = w4[i];
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int k = tid + 256 * i;
+            if (k < WCH / 4) reinterpret_cast<float4*>(wl)[k] = pwt[i];
         }
+    };
+
+    fetch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();                            // previous chunk's operands are dead (first trip: affine table written)
+        stage(ch);
         __syncthreads();
+        if (ch + 1 < nchunks) fetch(ch + 1);
         // ---- MFMAs: all taps of the chunk
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh) {
@@ -372,7 +404,7 @@ int launch_conv2d(const Conv2dArgs& p, hipStream_t st) {
 // operand-read width and row tiles per workgroup chosen from the layer shape (the weight pre-layout uses the same rule)
 void conv2d_tiling(int Cin_total, int Cout, int c1, int& CG, int& MT) {
     CG = (Cin_total % 16 == 0 && c1 % 16 == 0) ? 16 : (Cin_total % 8 == 0 && c1 % 8 == 0 ? 8 : 4);
-    MT = (Cout >= 32) ? 2 : 1;
+    MT = (Cout >= 32) ? 2 : 1;          // (64 couts per workgroup measured slower: too few workgroups on the low-resolution layers)
 }
 
 }  // namespace
