@@ -174,9 +174,11 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
                     const float* __restrict__ w, const float* __restrict__ bias, int H, int W,
                     float* __restrict__ y, double* __restrict__ stats, int groups) {
     constexpr int CT = CA + CB;
-    __shared__ __attribute__((aligned(16))) float wsh[9 * CT * CO];
+    // weights through the scalar cache (constant address space, wave-uniform addresses -> s_load into
+    // SGPRs): as LDS broadcast reads they were one ds_read per FMA operand and bound the kernel
+    typedef const __attribute__((address_space(4))) float cfloat;
+    cfloat* wsh = (cfloat*)w;
     __shared__ float red[4][2][2];
-    for (int i = threadIdx.x; i < 9 * CT * CO; i += 256) wsh[i] = w[i];
     float ra[CB], rb[CB];
     if (MODE == 1) {
         const double cnt = (double)H * W * CB;
@@ -215,7 +217,7 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
 #pragma unroll
                     for (int f = 0; f < CB; ++f) vb[f] *= 1.0f / (1.0f + expf(-(gr[f] * ra[f] + rb[f])));
                 }
-                const float* wt = wsh + (kh * 3 + kw) * CT * CO;
+                cfloat* wt = wsh + (kh * 3 + kw) * CT * CO;
 #pragma unroll
                 for (int ci = 0; ci < CA; ++ci)
 #pragma unroll
