@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--regularization", default="3DCNN", choices=["3DCNN", "GRU"],
                     help="GRU = R-MVSNet recurrent sweep (config 3); reported as an extra, not the metric")
     ap.add_argument("--extractor", choices=("hip", "torch"), default="hip", help="2D towers for --with-images")
+    ap.add_argument("--no-extra", action="store_true", help="skip the informative two-stream pass")
     ap.add_argument("--with-images", action="store_true",
                     help="also time images->depth (adds the PyTorch UNetDS2GN towers)")
     args = ap.parse_args()
@@ -324,6 +325,27 @@ def main():
             torch.cuda.synchronize()
             out["images_to_depth_maps_per_s"] = args.steps / (time.perf_counter() - t1)
             out["extractor"] = args.extractor
+        if world == 1 and n_streams == 1 and not args.no_extra:
+            # informative only (never `value`): the same work with two depth maps in flight per GPU --
+            # the small, latency-bound layers of one map overlap the large kernels of the other
+            p2 = [plan, DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", dev)]
+            s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+            def step2(i):
+                pl = p2[i % 2]
+                with torch.cuda.stream(s2[i % 2]):
+                    pl.set_cameras(cams, w.depth_start, w.depth_interval, end, False)
+                    cost_volume(feats[0], feats[1:], pl.transforms, 0, pl.D, "mem", out=pl.cost)
+                    regnet_us0(pl.cost, weights.regnet, pl.workspace, pl.reg)
+                    softargmin_prob(pl.reg, w.depth_start, w.depth_interval, False, pl.depth, pl.prob)
+            for i in range(4):
+                step2(i)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(args.steps):
+                step2(i)
+            torch.cuda.synchronize()
+            out["depth_maps_per_s_two_streams"] = args.steps / (time.perf_counter() - t2)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, rp, args.cpu_budget, depth_np)
         print(json.dumps(out), flush=True)
