@@ -266,24 +266,35 @@ bool launch_small_cell(const float* xin, float* h, const float* const* p, int H,
 }
 
 // blend with the update gate evaluated in place: h = u*h + (1-u)*tanh(LN(c)), u = sigmoid(LN(g_u))
-// (convgru.py:98,102,114-120); g holds the raw gate convolution (reset | update).
+// (convgru.py:98,102,114-120); g holds the raw gate convolution (reset | update).  One thread handles
+// VEC consecutive channels of a pixel (VEC | F), so the float64 LayerNorm statistics are folded into
+// (scale, shift) once per thread instead of once per element.
+template <int VEC>
 __global__ void __launch_bounds__(256)
 gru_blend_fused_kernel(const float* __restrict__ c, const double* __restrict__ stats_c,
                        const float* __restrict__ og, const float* __restrict__ ob,
                        const float* __restrict__ g, const double* __restrict__ stats_u,
                        const float* __restrict__ ug, const float* __restrict__ ub, int HW, int F,
                        float* __restrict__ h) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i >= (long long)HW * F) return;
-    int f = (int)(i % F);
-    long long pix = i / F;
+    const int f = (int)(i % F);
+    const long long pix = i / F;
     const double n = (double)HW * F;
-    float a, b;
-    ln_affine(stats_u, n, ug[f], ub[f], a, b);
-    float uu = sigmoidf(g[pix * 2 * F + F + f] * a + b);
-    ln_affine(stats_c, n, og[f], ob[f], a, b);
-    float yv = tanhf(c[i] * a + b);
-    h[i] = uu * h[i] + (1.0f - uu) * yv;
+    float cv[VEC], gv[VEC], hv[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { cv[k] = c[i + k]; gv[k] = g[pix * 2 * F + F + f + k]; hv[k] = h[i + k]; }
+    // the moments are shared by all channels: one mean / inverse deviation per LayerNorm
+    double mu = stats_u[0] / n, vu = stats_u[1] / n - mu * mu; if (vu < 0.0) vu = 0.0;
+    double mc = stats_c[0] / n, vc = stats_c[1] / n - mc * mc; if (vc < 0.0) vc = 0.0;
+    const double iu = 1.0 / sqrt(vu + 1e-12), ic = 1.0 / sqrt(vc + 1e-12);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const double au = (double)ug[f + k] * iu, ac = (double)og[f + k] * ic;
+        const float uu = sigmoidf(gv[k] * (float)au + (float)((double)ub[f + k] - mu * au));
+        const float yv = tanhf(cv[k] * (float)ac + (float)((double)ob[f + k] - mc * ac));
+        h[i + k] = uu * hv[k] + (1.0f - uu) * yv;
+    }
 }
 
 // prob_conv (3x3, F3 -> 1, bias) + exp + winner-take-all update in one pass
@@ -471,8 +482,15 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
                 rc = launch_conv2d(xin, cin, ws.rh, F[k], p[6], p[7], H, W, F[k], ws.c, so, 1, st);
                 if (rc) return rc;
             }
-            gru_blend_fused_kernel<<<mvs_cdiv(hw_ll * F[k], 256), 256, 0, st>>>(
-                ws.c, so, p[8], p[9], ws.g, sg + 2, p[4], p[5], H * W, F[k], hs[k]);
+            if (F[k] % 4 == 0)
+                gru_blend_fused_kernel<4><<<mvs_cdiv(hw_ll * F[k] / 4, 256), 256, 0, st>>>(
+                    ws.c, so, p[8], p[9], ws.g, sg + 2, p[4], p[5], H * W, F[k], hs[k]);
+            else if (F[k] % 2 == 0)
+                gru_blend_fused_kernel<2><<<mvs_cdiv(hw_ll * F[k] / 2, 256), 256, 0, st>>>(
+                    ws.c, so, p[8], p[9], ws.g, sg + 2, p[4], p[5], H * W, F[k], hs[k]);
+            else
+                gru_blend_fused_kernel<1><<<mvs_cdiv(hw_ll * F[k], 256), 256, 0, st>>>(
+                    ws.c, so, p[8], p[9], ws.g, sg + 2, p[4], p[5], H * W, F[k], hs[k]);
             if ((rc = (int)hipGetLastError())) return rc;
             xin = hs[k];
             cin = F[k];
