@@ -1,0 +1,103 @@
+"""Forward evaluation of the reference's depth losses and accuracies (mvsnet/loss.py:15-220), used by
+the benchmark driver `mvsnet_amd/test.py` (the caller `test.benchmark_depth_maps`, test.py:92-100).
+Tensors are torch (B,H,W,1); a ground-truth value of 0 marks an invalid pixel.  Training (SURVEY 8f
+f4) is not built; these are the same expressions, so autograd differentiates them if it ever is."""
+from __future__ import annotations
+
+import torch
+
+
+def _mask(y_true):
+    return (y_true != 0).to(y_true.dtype)
+
+
+def original_loss(y_true, y_pred, interval):
+    """loss.py:15-28: non-zero mean absolute error in units of the depth interval, summed over the batch."""
+    m = _mask(y_true)
+    denom = m.sum(dim=(1, 2, 3)).abs() + 1e-6
+    mae = (m * (y_true - y_pred)).abs().sum(dim=(1, 2, 3))
+    return ((mae / interval.reshape(-1)) / denom).sum()
+
+
+def power_loss(y_true, y_pred, interval, alpha, beta, no_interval_norm=False):
+    """loss.py:31-92: N * (|y_true - y_pred| + 0.005 y_true)^alpha / y_true^beta averaged over valid pixels."""
+    m = _mask(y_true)
+    num_valid = m.sum(dim=(1, 2, 3)).abs() + 1e-6
+    if beta == 0.0:
+        denominator = num_valid.reshape(-1, 1, 1, 1)
+    else:
+        denominator = torch.pow(y_true + 1e-9, beta) * num_valid.reshape(-1, 1, 1, 1)
+    numerator = (y_true - y_pred).abs() + 0.005 * y_true
+    if alpha != 1.0:
+        numerator = torch.pow(numerator, alpha)
+    loss = (numerator * m / denominator).sum(dim=(1, 2, 3))
+    mean_true = (y_true * m).sum() / num_valid
+    if no_interval_norm:
+        norm = torch.pow(mean_true, beta)
+    else:
+        norm = 10.0 * torch.pow(mean_true, beta) / torch.pow(interval.reshape(-1), alpha)
+    return loss * norm
+
+
+def gaussian_loss(y_true, y_pred, interval, eta):
+    """loss.py:95-131: -exp(-x^2 / 2 sigma^2) with sigma = eta * y_true, over valid pixels.  As in the
+    reference the exponential is summed over ALL pixels (masked errors contribute -1 each)."""
+    m = _mask(y_true)
+    num_valid = m.sum(dim=(1, 2, 3)).abs() + 1e-6
+    sigma = eta * y_true + 1e-6
+    x = -torch.pow((y_true - y_pred) * m / sigma, 2.0) / 2.0
+    return (-torch.exp(x)).sum() / num_valid
+
+
+def gradient_loss(y_true, y_pred, log=True):
+    """loss.py:134-158.  The reference slices the FIRST TWO axes of the (B,H,W,1) tensors, i.e. the
+    "vertical" difference runs along the batch axis (empty for B < 3) and the "horizontal" one along
+    image rows; reproduced as written."""
+    m = _mask(y_true)
+    num_valid = m.sum()
+    diff = y_true - y_pred
+    v = ((diff[0:-2, :] - diff[2:, :]) * (m[0:-2, :] * m[2:, :])).abs()
+    h = ((diff[:, 0:-2] - diff[:, 2:]) * (m[:, 0:-2] * m[:, 2:])).abs()
+    if log:
+        v, h = torch.log(1.0 + v), torch.log(1.0 + h)
+    return (v.sum() + h.sum()) / num_valid
+
+
+def _less_than(y_true, y_pred, interval, k):
+    m = _mask(y_true)
+    denom = m.sum().abs() + 1e-6
+    diff = (y_true - y_pred).abs() / interval.reshape(-1, 1, 1, 1)
+    return (m * (diff <= k).to(y_true.dtype)).sum() / denom
+
+
+def less_one_percentage(y_true, y_pred, interval):
+    """loss.py:161-172"""
+    return _less_than(y_true, y_pred, interval, 1.0)
+
+
+def less_three_percentage(y_true, y_pred, interval):
+    """loss.py:175-186"""
+    return _less_than(y_true, y_pred, interval, 3.0)
+
+
+def mvsnet_regression_loss(estimated_depth_image, depth_image, depth_start, depth_end, loss_type="original",
+                           alpha=1.0, beta=0.0, eta=0.02, grad_loss=True):
+    """loss.py:189-220.  Returns (loss, less_one_accuracy, less_three_accuracy, debug); the interval
+    is (depth_end - depth_start) / 191 regardless of the number of planes ("for historical reasons")."""
+    dt, dev = depth_image.dtype, depth_image.device
+    interval = (torch.as_tensor(depth_end, dtype=dt, device=dev) - torch.as_tensor(depth_start, dtype=dt, device=dev)) / 191.0
+    interval = interval.reshape(-1)
+    debug = None
+    if loss_type == "original":
+        loss = original_loss(depth_image, estimated_depth_image, interval)
+    elif loss_type == "power":
+        loss = power_loss(depth_image, estimated_depth_image, interval, alpha, beta).sum()
+    elif loss_type == "gaussian":
+        loss = gaussian_loss(depth_image, estimated_depth_image, interval, eta).sum()
+    else:
+        raise NotImplementedError(loss_type)
+    if grad_loss:
+        debug = gradient_loss(depth_image, estimated_depth_image)
+        loss = loss + 0.5 * debug
+    return (loss, less_one_percentage(depth_image, estimated_depth_image, interval),
+            less_three_percentage(depth_image, estimated_depth_image, interval), debug)

@@ -72,15 +72,28 @@ def scale_image(image, scale=1, interpolation="linear"):
     return out.astype(img.dtype)
 
 
-def scale_mvs_input(images, cams, scale=1):
-    """mvs_data_generation/utils.py:103-116 (without the GT-depth branch)."""
-    return [scale_image(i, scale) for i in images], [scale_camera(c, scale) for c in cams]
+def mask_depth_image(depth_image, min_depth, max_depth):
+    """mvs_data_generation/utils.py:156-163: two cv2.threshold calls -- THRESH_TOZERO keeps values
+    strictly above min_depth, THRESH_TOZERO_INV zeroes values strictly above max_depth -- then a
+    trailing channel axis."""
+    d = np.asarray(depth_image)
+    d = np.where(d > min_depth, d, 0)
+    d = np.where(d > max_depth, 0, d).astype(np.asarray(depth_image).dtype)
+    return d[:, :, None]
 
 
-def crop_mvs_input(images, cams, width, height, base_image_size):
-    """mvs_data_generation/utils.py:119-153: centre-crop to at most (height, width), otherwise
+def scale_mvs_input(images, cams, scale=1, depth_image=None):
+    """mvs_data_generation/utils.py:107-118; the GT depth is resized with nearest neighbour."""
+    images, cams = [scale_image(i, scale) for i in images], [scale_camera(c, scale) for c in cams]
+    if depth_image is None:
+        return images, cams
+    return images, cams, scale_image(depth_image, scale, "nearest")
+
+
+def crop_mvs_input(images, cams, width, height, base_image_size, depth_image=None):
+    """mvs_data_generation/utils.py:121-153: centre-crop to at most (height, width), otherwise
     round the size UP to a multiple of base_image_size (as the reference does), shifting the
-    principal point."""
+    principal point.  A GT depth image is cropped with the window of the last view (as the reference)."""
     images, cams = list(images), [np.copy(c) for c in cams]
     for view in range(len(images)):
         h, w = images[view].shape[0:2]
@@ -91,6 +104,8 @@ def crop_mvs_input(images, cams, width, height, base_image_size):
         images[view] = images[view][start_h:start_h + new_h, start_w:start_w + new_w]
         cams[view][1][0][2] = cams[view][1][0][2] - start_w
         cams[view][1][1][2] = cams[view][1][1][2] - start_h
+    if depth_image is not None:
+        return images, cams, depth_image[start_h:start_h + new_h, start_w:start_w + new_w]
     return images, cams
 
 
@@ -116,6 +131,27 @@ class Cluster:
 
     def camera_path(self, index):
         return os.path.join(self.session_dir, "cameras", "{}.json".format(index))
+
+    def depth_path(self, index):
+        return os.path.join(self.session_dir, "depths", "{}.png".format(index))
+
+    def load_depth(self, index):
+        """uint16 millimetre depth PNG, or None when missing (mvs_cluster.py:78-89)."""
+        from PIL import Image
+        try:
+            return np.asarray(Image.open(self.depth_path(index))).astype(np.uint16)
+        except Exception:
+            return None
+
+    def masked_reference_depth(self):
+        """mvs_cluster.py:163-177: GT depth brought to the input image's scale (nearest), values
+        outside (min_depth, max_depth] zeroed; call after images()."""
+        depth = self.load_depth(self.ref_index)
+        if depth is None:
+            return None
+        scale = float(self.original_image_shape[0]) / float(depth.shape[0])
+        depth = scale_image(depth, scale, "nearest")
+        return mask_depth_image(depth, self.min_depth, self.max_depth)
 
     def load_image(self, index):
         """RGB decode then RGB->BGR, as mvs_cluster.py:72-76."""
@@ -143,6 +179,7 @@ class Cluster:
 
     def images(self):
         imgs = [self.load_image(i) for i in self.indices]
+        self.original_image_shape = imgs[0].shape                            # mvs_cluster.py:154
         h_scale = max(float(self.image_height) / im.shape[0] for im in imgs)
         w_scale = max(float(self.image_width) / im.shape[1] for im in imgs)
         self.rescale = max(h_scale, w_scale)                                 # mvs_cluster.py:178-192
@@ -159,8 +196,9 @@ class ClusterGenerator:
     def __init__(self, data_dir, view_num=3, image_width=1024, image_height=768, depth_num=256,
                  interval_scale=1, base_image_size=1, include_empty=False, mode="inference",
                  output_scale=0.25, max_clusters_per_session=None):
-        if mode != "inference":
-            raise NotImplementedError("only the inference branch is built (SURVEY 8f)")
+        if mode not in ("inference", "test"):
+            raise NotImplementedError("the training branches of the generator are not built (SURVEY 8f f4)")
+        self.mode = mode              # 'test' also yields the masked GT depth (cluster_generator.py:244-251)
         self.data_dir = data_dir
         self.view_num = view_num
         self.image_width, self.image_height = image_width, image_height
@@ -189,14 +227,24 @@ class ClusterGenerator:
     def prepare(self, c: Cluster):
         images = c.images()
         cams = c.cameras()
-        images, cams = scale_mvs_input(images, cams, scale=c.rescale)
-        cropped_images, cropped_cams = crop_mvs_input(images, cams, self.image_width, self.image_height,
-                                                      self.base_image_size)
+        depth = None
+        if self.mode == "test":
+            depth = c.masked_reference_depth()
+            if depth is None:
+                raise IOError("no ground-truth depth for reference view %d" % c.ref_index)
+            images, cams, depth = scale_mvs_input(images, cams, scale=c.rescale, depth_image=depth[:, :, 0])
+            cropped_images, cropped_cams, depth = crop_mvs_input(images, cams, self.image_width, self.image_height,
+                                                                 self.base_image_size, depth)
+            depth = depth.astype(np.float32)[:, :, None]
+        else:
+            images, cams = scale_mvs_input(images, cams, scale=c.rescale)
+            cropped_images, cropped_cams = crop_mvs_input(images, cams, self.image_width, self.image_height,
+                                                          self.base_image_size)
         full_cams = np.stack(cropped_cams, axis=0)
         input_images = np.stack([center_image(i) for i in cropped_images], axis=0)
         output_images, output_cams = scale_mvs_input(cropped_images, cropped_cams, scale=self.output_scale)
-        return (np.stack(output_images, axis=0), input_images, np.stack(output_cams, axis=0),
-                full_cams, c.ref_index)
+        out = (np.stack(output_images, axis=0), input_images, np.stack(output_cams, axis=0), full_cams, c.ref_index)
+        return out + (depth,) if self.mode == "test" else out
 
     def __len__(self):
         return len(self.clusters)

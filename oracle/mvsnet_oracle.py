@@ -720,6 +720,32 @@ def depth_refine(init_depth_map, image, prob_map, depth_num, depth_start, depth_
 
 
 # --------------------------------------------------------------------------------------
+# benchmark metrics of mvsnet/test.py (loss.py:15-28,134-220), forward only
+# --------------------------------------------------------------------------------------
+
+def regression_metrics(estimated, gt, depth_start, depth_end, grad_loss=True):
+    """mvsnet_regression_loss with loss_type='original' (loss.py:189-220) for (B,H,W,1) arrays in
+    float64: (loss, less_one, less_three, debug).  interval = (end - start) / 191; invalid GT = 0.
+    gradient_loss (loss.py:134-158) is written on 2-D maps but is handed the 4-D batch, so its
+    "vertical" term differences the BATCH axis and its "horizontal" term the image rows."""
+    y, p = np.asarray(gt, np.float64), np.asarray(estimated, np.float64)
+    interval = (np.asarray(depth_end, np.float64).reshape(-1) - np.asarray(depth_start, np.float64).reshape(-1)) / 191.0
+    m = (y != 0).astype(np.float64)
+    denom = np.abs(m.sum(axis=(1, 2, 3))) + 1e-6
+    loss = (((m * (y - p)).__abs__().sum(axis=(1, 2, 3)) / interval) / denom).sum()
+    debug = None
+    if grad_loss:
+        diff = y - p
+        v = np.abs((diff[0:-2] - diff[2:]) * (m[0:-2] * m[2:]))
+        h = np.abs((diff[:, 0:-2] - diff[:, 2:]) * (m[:, 0:-2] * m[:, 2:]))
+        debug = (np.log(1.0 + v).sum() + np.log(1.0 + h).sum()) / m.sum()
+        loss = loss + 0.5 * debug
+    rel = np.abs(y - p) / interval.reshape(-1, 1, 1, 1)
+    total = np.abs(m.sum()) + 1e-6
+    return loss, (m * (rel <= 1.0)).sum() / total, (m * (rel <= 3.0)).sum() / total, debug
+
+
+# --------------------------------------------------------------------------------------
 # R10  composition
 # --------------------------------------------------------------------------------------
 

@@ -59,6 +59,20 @@ def test_compute_depth_maps_with_refinement(tmp_path, lib_built, network, upsamp
     assert cam[1, 0, 0] == pytest.approx(60.0 * 2 / 3 * (1.0 if upsample else 0.25))      # full vs /4 intrinsics
 
 
+def test_benchmark_driver_on_session_with_gt_depth(tmp_path, lib_built):
+    """mvsnet_amd.test (the reference's test.py): depth inference scored against ground-truth depth PNGs."""
+    from tests.test_loss_and_benchmark import _session_with_depth
+    from mvsnet_amd import test as T
+    sess = _session_with_depth(str(tmp_path / "sess"))
+    res = str(tmp_path / "results.csv")
+    avg = T.main(["--input_dir", sess, "--view_num", "3", "--max_d", "8", "--width", "64", "--height", "64",
+                  "--base_image_size", "8", "--max_clusters_per_session", "2", "--results_path", res])
+    loss, less_one, less_three, debug = avg
+    assert np.isfinite(loss) and loss > 0 and 0.0 <= less_one <= less_three <= 1.0 and np.isfinite(debug)
+    lines = open(res).readlines()
+    assert lines[0] == T.RESULTS_HEADER and len(lines) == 2
+
+
 def test_metric_workload_properties_and_mfma_vs_scalar(lib_built):
     """Full-size (N=5, D=192, 160x128) checks that do not need the oracle: the depth map stays
     inside the swept range, probabilities are finite, the MFMA and scalar regularisers agree, and
