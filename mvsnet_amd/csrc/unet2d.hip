@@ -108,15 +108,54 @@ conv2d_gn_kernel(Conv2dArgs p) {
     for (int v = 0; v < V2; ++v) b_off[v] = ((V2 * wave + v) * STRIDE * IW + n * STRIDE) * S + (CG / 4) * kq;
     const int a_off = (kq * COUT_T + n) * 4;
 
-    // GroupNorm (scale, shift) of every input channel of this view: float64 group statistics -> LDS,
-    // once per workgroup by Ctot/4 threads (every thread doing it per chunk cost more than the MFMAs
-    // of the 8-channel full-resolution layers)
+    // GroupNorm (scale, shift) of every input channel of this view -> LDS, once per workgroup.  The
+    // NSLOT partial sums of a group are added up by 8 threads (4 slots each, all loads in flight at
+    // once, then a 3-step shuffle): a few threads walking 64 doubles serially cost ~7 us per workgroup.
     __shared__ __attribute__((aligned(16))) float aff_s[256], aff_b[256];
-    if (tid < Ctot / 4) {
-        const int c = 4 * tid;
-        float4 sc, sh;
-        if (c < p.a.C) gn_affine4(p.a, view, c, sc, sh); else gn_affine4(p.b, view, c - p.a.C, sc, sh);
-        *(float4*)(aff_s + c) = sc; *(float4*)(aff_b + c) = sh;
+    __shared__ double g_mean[32], g_inv[32];
+    {
+        const int g = tid >> 3, part = tid & 7;             // up to 32 groups of 8 channels in [a | b]
+        const int ga = p.a.C / 8;
+        const bool in_a = g < ga;
+        const GnSrc& src = in_a ? p.a : p.b;
+        const int gl = in_a ? g : g - ga;
+        double sum = 0.0, sq = 0.0;
+        const bool live = g < Ctot / 8 && src.stats != nullptr;
+        if (live) {
+            const double* st = src.stats + (((size_t)view * (src.C / 8) + gl) * NSLOT + part * (NSLOT / 8)) * 2;
+#pragma unroll
+            for (int i = 0; i < NSLOT / 8; ++i) { sum += st[2 * i]; sq += st[2 * i + 1]; }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { sum += __shfl_xor(sum, o, 64); sq += __shfl_xor(sq, o, 64); }
+        if (part == 0 && g < 32) {
+            double mean = 0.0, inv = 1.0;                    // identity when the source has no GroupNorm
+            if (live) {
+                mean = sum / src.count;
+                double var = sq / src.count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                inv = 1.0 / sqrt(var + 1e-5);               // network.py:55,254
+            }
+            g_mean[g] = mean; g_inv[g] = inv;
+        }
+        __syncthreads();
+        if (tid < Ctot / 4) {
+            const int c = 4 * tid;
+            const bool ca = c < p.a.C;
+            const GnSrc& s2 = ca ? p.a : p.b;
+            const int cl = ca ? c : c - p.a.C;
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+            if (s2.stats) {
+                const double mean = g_mean[c / 8], inv = g_inv[c / 8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double a = (double)s2.gamma[cl + k] * inv;
+                    sc[k] = (float)a; sh[k] = (float)((double)s2.beta[cl + k] - mean * a);
+                }
+            }
+            *(float4*)(aff_s + c) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+            *(float4*)(aff_b + c) = make_float4(sh[0], sh[1], sh[2], sh[3]);
+        }
     }
 
     // Chunk ch+1's patch and weights are requested from global memory (into registers) before the
