@@ -18,6 +18,7 @@ def main():
     ap.add_argument("what")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dhw", default="192,128,160")
+    ap.add_argument("--no-stats", action="store_true", help="do not accumulate BatchNorm sums (measures the atomics' tail)")
     ap.add_argument("--data", default="randn", help="randn | const (low toggle rate: clocks stay high)")
     a = ap.parse_args()
     D, H, W = (int(v) for v in a.dhw.split(","))
@@ -27,7 +28,7 @@ def main():
     if a.what == "pair":
         x, w1, w2 = r(D, H, W, 32), r(3, 3, 3, 32, 8) * 0.03, r(3, 3, 3, 32, 16) * 0.03
         s1 = torch.zeros(2, 8, dtype=torch.float64, device=dev); s2 = torch.zeros(2, 16, dtype=torch.float64, device=dev)
-        fn = lambda: M.conv3d_pair(x, w1, w2, s1, s2)
+        fn = (lambda: M.conv3d_pair(x, w1, w2, None, None)) if a.no_stats else (lambda: M.conv3d_pair(x, w1, w2, s1, s2))
         flops = 2.0 * 27 * 32 * (D * H * W * 8 + D * H * W / 8 * 16)
     elif a.what == "c8":
         x, w1 = r(D, H, W, 32), r(3, 3, 3, 32, 8) * 0.03
@@ -42,7 +43,7 @@ def main():
         x, sk, w = r(D // 2, H // 2, W // 2, 16), r(D // 2, H // 2, W // 2, 16), r(3, 3, 3, 8, 16) * 0.05
         one, zero = torch.ones(16, device=dev), torch.zeros(16, device=dev)
         s = torch.zeros(2, 8, dtype=torch.float64, device=dev)
-        fn = lambda: M.conv3d(x, w, 1, (one, zero), sk, (one, zero), s, transpose=True)
+        fn = lambda: M.conv3d(x, w, 1, (one, zero), sk, (one, zero), None if a.no_stats else s, transpose=True)
         flops = 2.0 * 27 * 16 * 8 * D * H * W / 8
     elif a.what == "out":
         x, sk, w = r(D, H, W, 8), r(D, H, W, 8), r(3, 3, 3, 8, 1) * 0.07
