@@ -164,8 +164,10 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&o)
 }
 
 // Small-channel 3x3 convolution over [xa | xb] for ConvGRU cells 2 and 3 (20 -> 8/4, 6 -> 4/2
-// channels): vector loads of whole pixels, weights broadcast from LDS.  MODE 1 folds the reset gate
-// into the read of xb: xb = sigmoid(LayerNorm(g_r)) * h (convgru.py:97,101,107).
+// channels).  A workgroup owns a 16 x 16 pixel tile: the 18 x 18 neighbourhood of the concatenation is
+// staged once in LDS (MODE 1 folds the reset gate into xb there: xb = sigmoid(LayerNorm(g_r)) * h,
+// convgru.py:97,101,107 -- evaluated once per staged element, not once per tap), every thread then
+// reads its 9 taps from LDS; weights come through the scalar cache.
 template <int CA, int CB, int CO, int MODE>
 __global__ void __launch_bounds__(256)
 conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
@@ -174,10 +176,10 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
                     const float* __restrict__ w, const float* __restrict__ bias, int H, int W,
                     float* __restrict__ y, double* __restrict__ stats, int groups) {
     constexpr int CT = CA + CB;
-    // weights through the scalar cache (constant address space, wave-uniform addresses -> s_load into
-    // SGPRs): as LDS broadcast reads they were one ds_read per FMA operand and bound the kernel
-    typedef const __attribute__((address_space(4))) float cfloat;
+    constexpr int TS = 16, PS = TS + 2;
+    typedef const __attribute__((address_space(4))) float cfloat;      // wave-uniform -> s_load into SGPRs
     cfloat* wsh = (cfloat*)w;
+    __shared__ __attribute__((aligned(16))) float tile[PS * PS * CT];
     __shared__ float red[4][2][2];
     float ra[CB], rb[CB];
     if (MODE == 1) {
@@ -191,44 +193,56 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
             ra[f] = (float)inv; rb[f] = (float)((double)r_beta[f] - mean * inv);
         }
     }
+    const int tiles_x = (W + TS - 1) / TS;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * TS, x0 = tx * TS;
+    for (int f = threadIdx.x; f < PS * PS; f += 256) {
+        const int r = f / PS, c = f - r * PS;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        float va[CA], vb[CB];
+#pragma unroll
+        for (int i = 0; i < CA; ++i) va[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) vb[i] = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t p = (size_t)gy * W + gx;
+            load_vec<CA>(xa + p * CA, va);
+            load_vec<CB>(xb + p * CB, vb);
+            if (MODE == 1) {
+                float gr[CB];
+                load_vec<CB>(g + p * 2 * CB, gr);
+#pragma unroll
+                for (int i = 0; i < CB; ++i) vb[i] *= 1.0f / (1.0f + expf(-(gr[i] * ra[i] + rb[i])));
+            }
+        }
+        float* d = tile + f * CT;
+#pragma unroll
+        for (int i = 0; i < CA; ++i) d[i] = va[i];
+#pragma unroll
+        for (int i = 0; i < CB; ++i) d[CA + i] = vb[i];
+    }
     __syncthreads();
-    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = pix < H * W;
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+    const int py = y0 + ly, px = x0 + lx;
+    const bool valid = py < H && px < W;
     float acc[CO];
 #pragma unroll
     for (int j = 0; j < CO; ++j) acc[j] = bias ? bias[j] : 0.f;
-    if (valid) {
-        const int py = pix / W, px = pix - py * W;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int iy = py + kh - 1;
-            if (iy < 0 || iy >= H) continue;
+    for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ix = px + kw - 1;
-                if (ix < 0 || ix >= W) continue;
-                const size_t p = (size_t)iy * W + ix;
-                float va[CA], vb[CB];
-                load_vec<CA>(xa + p * CA, va);
-                load_vec<CB>(xb + p * CB, vb);
-                if (MODE == 1) {
-                    float gr[CB];
-                    load_vec<CB>(g + p * 2 * CB, gr);
+        for (int kw = 0; kw < 3; ++kw) {
+            float v[CT];
+            load_vec<CT>(tile + ((ly + kh) * PS + lx + kw) * CT, v);
+            cfloat* wt = wsh + (kh * 3 + kw) * CT * CO;
 #pragma unroll
-                    for (int f = 0; f < CB; ++f) vb[f] *= 1.0f / (1.0f + expf(-(gr[f] * ra[f] + rb[f])));
-                }
-                cfloat* wt = wsh + (kh * 3 + kw) * CT * CO;
+            for (int ci = 0; ci < CT; ++ci)
 #pragma unroll
-                for (int ci = 0; ci < CA; ++ci)
-#pragma unroll
-                    for (int j = 0; j < CO; ++j) acc[j] += va[ci] * wt[ci * CO + j];
-#pragma unroll
-                for (int ci = 0; ci < CB; ++ci)
-#pragma unroll
-                    for (int j = 0; j < CO; ++j) acc[j] += vb[ci] * wt[(CA + ci) * CO + j];
-            }
+                for (int j = 0; j < CO; ++j) acc[j] += v[ci] * wt[ci * CO + j];
         }
-        float* dst = y + (size_t)pix * CO;
+    }
+    if (valid) {
+        float* dst = y + ((size_t)py * W + px) * CO;
 #pragma unroll
         for (int j = 0; j < CO; ++j) dst[j] = acc[j];
     }
@@ -258,7 +272,7 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
 template <int CA, int F>
 bool launch_small_cell(const float* xin, float* h, const float* const* p, int H, int W, float* g, float* c,
                        double* sg, double* so, hipStream_t st) {
-    const int grid = mvs_cdiv((long long)H * W, 256);
+    const int grid = ((H + 15) / 16) * ((W + 15) / 16);           // 16 x 16 pixel tiles
     conv2d_small_kernel<CA, F, 2 * F, 0><<<grid, 256, 0, st>>>(xin, h, nullptr, nullptr, nullptr, nullptr,
                                                                p[0], p[1], H, W, g, sg, 2);
     conv2d_small_kernel<CA, F, F, 1><<<grid, 256, 0, st>>>(xin, h, g, sg, p[2], p[3], p[6], p[7], H, W, c, so, 1);
