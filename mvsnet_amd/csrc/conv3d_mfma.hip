@@ -20,8 +20,11 @@
 //     stored (coalesced 16-B lanes), with per-channel sum / sum-of-squares for the consumer's
 //     BatchNorm accumulated on the fly.  Blocks rotate through kd by re-basing the weight address
 //     per plane (loop unrolled by 3), never by moving registers.
-//   * Next plane's global loads are issued before the sweep and written to the other LDS buffer
-//     after it (one barrier per plane).
+//   * Plane q is swept while plane q+1 moves registers -> LDS and plane q+2 is requested from global
+//     memory, as branch-free "pieces" issued between the MFMA groups (32-bit buffer offsets: outside
+//     the image = out of range = 0); one barrier per plane.
+//   * The 32 -> 8 full-resolution layer has its own kernel (conv3d_c8.hip: row packing, fused
+//     stride-2 consumer); the low-resolution layers use 2x8 / 4x4 voxel column tiles (S1Geom).
 #include "conv_common.h"
 #include <cstdlib>
 
