@@ -118,3 +118,22 @@ def test_hip_unet_matches_oracle_and_torch(lib_built):
     ref = n(UNetDS2GN(params, DEV)(t(big)))
     got = n(hip(t(big)))
     assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-4
+
+
+def test_images_to_depth_end_to_end_matches_oracle(lib_built):
+    """The default product path from IMAGES (HIP towers -> warp/variance -> RegNetUS0 -> soft-argmin)
+    against the oracle composition, on the interior-stable quantity (depth) at a toy size."""
+    from mvsnet_amd.model import MVSNetWeights, inference_mem
+    rs = np.random.RandomState(7)
+    N, Hi, Wi, D = 3, 64, 64, 8
+    up = S.make_unet_params("normal", seed=3)
+    rp = S.make_regnet_params("normal", seed=1, random_affine=True)
+    images = rs.standard_normal((N, Hi, Wi, 3)).astype(np.float32)
+    cams = S.make_cams(N, Hi // 4, Wi // 4, D, 425.0, 20.0)
+    weights = MVSNetWeights.from_numpy("normal", unet=up, regnet=rp, device=DEV)           # extractor="hip" by default
+    depth, prob = inference_mem(t(images)[None], t(cams)[None], D, 425.0, 20.0, weights=weights)
+    feats = np.stack([O.unet_ds2gn(images[v], up, np.float64) for v in range(N)]).astype(np.float32)
+    ed, ep = O.inference_mem_from_features(feats, cams, D, 425.0, 20.0, rp, False, np.float64)
+    d = n(depth)[0, :, :, 0]
+    assert float(np.mean(np.abs(d - ed) / ed)) < 1e-3          # north-star bar: 1e-3 relative L1
+    assert float(np.mean(np.abs(d - ed) / ed)) < 2e-5          # what the kernels actually deliver here
