@@ -9,8 +9,13 @@
 // (consecutive ow, i.e. input columns 2ow+kw) are unit-stride in LDS for every kw.
 #include "conv_common.h"
 
+#define S2_STAGE_G(i) (((i) * (NG / 2)) / NIT)
+#define S2_LOAD_G(i) (NG / 2 + ((i) * (NG - NG / 2)) / NIT)
+
 namespace {
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int OOB = (int)0x80000000u;   // buffer byte offset with bit 31 set: loads give 0, stores are dropped
 constexpr int TW = CONV_TW;
 constexpr int IW = 2 * TW + 1;          // staged input columns: 2*ow0-pw .. +32
 constexpr int NEVEN = TW + 1;           // even-indexed staged columns (c = 0,2,..,32)
@@ -32,13 +37,14 @@ conv3d_s2_kernel(ConvArgs a) {
     constexpr int W_FLOATS = 9 * CQ * WROW;
     constexpr int SLAB_FLOATS = NPOS * S;
     static_assert(256 % CQ == 0, "channel quad per thread must be loop invariant");
+    static_assert(NF4 >= 256, "spare threads of the last piece redo their previous one");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;                              // [9 taps][CQ][3 kd][16 co][4]
     float* slab = smem + W_FLOATS;                 // [2][NPOS][S]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
 
     const int Do = (a.D + 1) / 2, Ho = (a.H + 1) / 2, Wo = (a.W + 1) / 2;
@@ -72,51 +78,53 @@ conv3d_s2_kernel(ConvArgs a) {
     const bool has_aff2 = HAS_X2 && (a.x2s != nullptr || a.bn2.stats != nullptr);
     if (HAS_X2 && a.x2s) { sc2 = *(const float4*)(a.x2s + 4 * c4); sh2 = *(const float4*)(a.x2b + 4 * c4); }
     else if (HAS_X2 && a.bn2.stats) bn_affine4(a.bn2, 4 * c4, sc2, sh2);
+    const float lo = has_aff ? 0.f : -INFINITY, lo2 = has_aff2 ? 0.f : -INFINITY;   // ReLU floor (or identity)
 
     float4 pre[NIT];
     float4 pre2[HAS_X2 ? NIT : 1];
 
-    // Per-thread staging map, identical for every plane: element offset inside one input plane
-    // (-1 = outside the volume -> SAME padding zero) and float offset inside the LDS slab (-1 = none).
+    // Per-thread staging map, identical for every plane: byte offset inside one input plane (bit 31
+    // set = outside the image: the buffer load returns 0) and float offset inside the LDS slab.
     int goff[NIT], loff[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         int f = tid + 256 * i;
+        if (f >= NF4) f -= 256;                    // spare threads of the last piece redo their previous one
         int pos = f / CQ;
         int r = pos / IW, c = pos - r * IW;
         int gh = ih0 + r, gw = iw0 + c;
-        bool inb = (f < NF4) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        goff[i] = inb ? (gh * a.W + gw) * CIN + 4 * c4 : -1;
-        loff[i] = (f < NF4) ? (r * IW + ((c & 1) ? NEVEN + (c >> 1) : (c >> 1))) * S + 4 * c4 : -1;
+        bool inb = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        goff[i] = inb ? ((gh * a.W + gw) * CIN + 4 * c4) * 4 : OOB;
+        loff[i] = (r * IW + ((c & 1) ? NEVEN + (c >> 1) : (c >> 1))) * S + 4 * c4;
     }
-    const size_t plane_elems = (size_t)a.H * a.W * CIN;
+    const int plane_bytes = a.H * a.W * CIN * 4;
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.D * plane_bytes, 0x00020000);
+    const auto x2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_X2 ? a.x2 : a.x), 0, a.D * plane_bytes, 0x00020000);
 
-    auto issue_loads = [&](int q) __attribute__((always_inline)) {
-        const bool plane_ok = (q >= 0) && (q < a.D);
-        const float* px = a.x + (size_t)(plane_ok ? q : 0) * plane_elems;
-        const float* px2 = HAS_X2 ? a.x2 + (size_t)(plane_ok ? q : 0) * plane_elems : nullptr;
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const bool ok = plane_ok && goff[i] >= 0;
-            pre[i] = ok ? *(const float4*)(px + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (HAS_X2) pre2[i] = ok ? *(const float4*)(px2 + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    // piece i of a plane's staging: global -> registers (load_piece), registers -> LDS (stage_piece);
+    // branch-free, issued between the MFMAs of the sweep (see conv3d_mfma.hip)
+    auto ld4b = [](auto rsrc, int voff, int soff) __attribute__((always_inline)) {
+        u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     };
-    auto write_slab = [&](int q, float* buf) __attribute__((always_inline)) {
+    auto load_piece = [&](int i, int q) __attribute__((always_inline)) {
         const bool plane_ok = (q >= 0) && (q < a.D);
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            if (loff[i] < 0) continue;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (plane_ok && goff[i] >= 0) {             // SAME padding pads the NORMALISED input with 0
-                v = bn_relu4(pre[i], sc, sh, has_aff);
-                if (HAS_X2) {
-                    float4 v2 = bn_relu4(pre2[i], sc2, sh2, has_aff2);
-                    v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
-                }
-            }
-            *(float4*)(buf + loff[i]) = v;
+        const int voff = goff[i] | (plane_ok ? 0 : OOB), soff = plane_ok ? q * plane_bytes : 0;
+        pre[i] = ld4b(xrsrc, voff, soff);
+        if (HAS_X2) pre2[i] = ld4b(x2rsrc, voff, soff);
+    };
+    auto stage_piece = [&](int i, int q, float* buf) __attribute__((always_inline)) {
+        const bool ok = (q >= 0) && (q < a.D) && goff[i] >= 0;       // SAME pads the NORMALISED input with 0
+        float4 v = pre[i];
+        v.x = fmaxf(v.x * sc.x + sh.x, lo); v.y = fmaxf(v.y * sc.y + sh.y, lo);
+        v.z = fmaxf(v.z * sc.z + sh.z, lo); v.w = fmaxf(v.w * sc.w + sh.w, lo);
+        if (HAS_X2) {
+            float4 u = pre2[i];
+            v.x += fmaxf(u.x * sc2.x + sh2.x, lo2); v.y += fmaxf(u.y * sc2.y + sh2.y, lo2);
+            v.z += fmaxf(u.z * sc2.z + sh2.z, lo2); v.w += fmaxf(u.w * sc2.w + sh2.w, lo2);
         }
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        *(float4*)(buf + loff[i]) = v;
     };
 
     f32x4 acc[2][V];                               // block = output plane parity (relative to od0)
@@ -130,79 +138,75 @@ conv3d_s2_kernel(ConvArgs a) {
 #pragma unroll
     for (int v = 0; v < V; ++v) b_off[v] = (2 * (V * wave + v) * IW + n) * S + 4 * kq;
     const int a_lane = (kq * NROWS + n) * 4;
+    constexpr int NG = 9 * (CIN / 16);             // operand groups (kh, kw, s) of one plane
 
-    // acc[BLK] += W[KD] * slab for all 9 in-plane taps
-    auto sweep = [&](auto Bc, auto Kc, const float* buf) __attribute__((always_inline)) {
+    // One plane: BOTH = even input plane (kd 0 -> block NEWB, kd 2 -> the other block), else a single
+    // (block, kd) pair.  `extra(g)` is called once per operand group: the march hangs the staging of
+    // the next planes on it.  Operands of group g+1 are read before the MFMAs of group g.
+    auto sweep = [&](auto Bc, auto Kc, auto Both, const float* buf, auto&& extra) __attribute__((always_inline)) {
         constexpr int BLK = decltype(Bc)::value, KD = decltype(Kc)::value;
-#pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh) {
+        constexpr bool BOTH = decltype(Both)::value;             // BLK = NEWB, KD ignored
+        f32x4 bv[2][V], av[2][2];
+        auto load_grp = [&](int g, f32x4 (&b)[V], f32x4 (&aop)[2]) __attribute__((always_inline)) {
+            const int tap = g / (CIN / 16), s = g % (CIN / 16);
+            const int kh = tap / 3, kw = tap % 3;
+            const int kwoff = (kw == 0) ? 0 : (kw == 1 ? NEVEN : 1);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int kwoff = (kw == 0) ? 0 : (kw == 1 ? NEVEN : 1);
+            for (int v = 0; v < V; ++v) b[v] = *(const f32x4*)(buf + b_off[v] + (kh * IW + kwoff) * S + 16 * s);
+            const float* wp = wl + a_lane + (tap * CQ + 4 * s) * WROW;
+            if (BOTH) { aop[0] = *(const f32x4*)(wp); aop[1] = *(const f32x4*)(wp + 2 * COUT * 4); }
+            else aop[0] = *(const f32x4*)(wp + KD * COUT * 4);
+        };
+        load_grp(0, bv[0], av[0]);
 #pragma unroll
-                for (int s = 0; s < CIN / 16; ++s) {
-                    f32x4 bv[V];
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_grp(g + 1, bv[(g + 1) & 1], av[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            extra(g);
 #pragma unroll
-                    for (int v = 0; v < V; ++v)
-                        bv[v] = *(const f32x4*)(buf + b_off[v] + (kh * IW + kwoff) * S + 16 * s);
-                    f32x4 av = *(const f32x4*)(wl + a_lane + KD * COUT * 4 + ((kh * 3 + kw) * CQ + 4 * s) * WROW);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int v = 0; v < V; ++v)
-                            acc[BLK][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[v][j], acc[BLK][v], 0, 0, 0);
+                for (int v = 0; v < V; ++v) {
+                    acc[BLK][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][0][j], bv[g & 1][v][j], acc[BLK][v], 0, 0, 0);
+                    if (BOTH) acc[1 - BLK][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][1][j], bv[g & 1][v][j], acc[1 - BLK][v], 0, 0, 0);
                 }
-            }
-        }
-    };
-    // both blocks in one pass over the slab (even input planes): block NEW gets kd=0, OLD gets kd=2
-    auto sweep2 = [&](auto Nc, const float* buf) __attribute__((always_inline)) {
-        constexpr int NEWB = decltype(Nc)::value, OLDB = 1 - NEWB;
-#pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int kwoff = (kw == 0) ? 0 : (kw == 1 ? NEVEN : 1);
-#pragma unroll
-                for (int s = 0; s < CIN / 16; ++s) {
-                    f32x4 bv[V];
-#pragma unroll
-                    for (int v = 0; v < V; ++v)
-                        bv[v] = *(const f32x4*)(buf + b_off[v] + (kh * IW + kwoff) * S + 16 * s);
-                    const float* wp = wl + a_lane + ((kh * 3 + kw) * CQ + 4 * s) * WROW;
-                    f32x4 a0 = *(const f32x4*)(wp);                     // kd = 0
-                    f32x4 a2 = *(const f32x4*)(wp + 2 * COUT * 4);      // kd = 2
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int v = 0; v < V; ++v) {
-                            acc[NEWB][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bv[v][j], acc[NEWB][v], 0, 0, 0);
-                            acc[OLDB][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], bv[v][j], acc[OLDB][v], 0, 0, 0);
-                        }
-                }
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
+    const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, Do * Ho * Wo * a.cout_total * 4, 0x00020000);
+    int yoff[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int oh = oh0 + V * wave + v, ow = ow0 + n;
+        yoff[v] = (oh < Ho && ow < Wo) ? ((oh * Wo + ow) * a.cout_total + co_base + 4 * kq) * 4 : OOB;
+    }
+    const int yplane_bytes = Ho * Wo * a.cout_total * 4;
     auto retire = [&](auto Bc, int od) __attribute__((always_inline)) {
         constexpr int BLK = decltype(Bc)::value;
         const bool plane_ok = (od >= od0) && (od < od1);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            int oh = oh0 + V * wave + v, ow = ow0 + n;
-            if (plane_ok && oh < Ho && ow < Wo) {
+            if (plane_ok) {
                 f32x4 r = acc[BLK][v];
-                float* dst = a.y + ((((size_t)od * Ho + oh) * Wo) + ow) * a.cout_total + co_base + 4 * kq;
-                *(float4*)dst = make_float4(r[0], r[1], r[2], r[3]);
+                u32x4_t u = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(u, yrsrc, yoff[v], od * yplane_bytes, 0);
+                if (yoff[v] >= 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { st_s[k] += r[k]; st_q[k] += r[k] * r[k]; }
+                    for (int k = 0; k < 4; ++k) { st_s[k] += r[k]; st_q[k] += r[k] * r[k]; }
+                }
             }
             acc[BLK][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
 
-    issue_loads(q0);
-    write_slab(q0, slab);
+    // ---- plane march: plane q swept, q+1 staged, q+2 requested (all under the MFMAs) ------------------
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_piece(i, q0);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) stage_piece(i, q0, slab);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) load_piece(i, q0 + 1);
     __syncthreads();
 
     // t even: od = od0 + t/2 starts (kd=0), od-1 finishes (kd=2); t odd: od = od0 + (t-1)/2 gets kd=1
@@ -211,22 +215,27 @@ conv3d_s2_kernel(ConvArgs a) {
         const int q = q0 + t;
         float* cur = slab + (t & 1) * SLAB_FLOATS;
         float* nxt = slab + ((t + 1) & 1) * SLAB_FLOATS;
-        const bool more = (t + 1 < T);
-        if (more) issue_loads(q + 1);
-        const bool in_vol = (q >= 0) && (q < a.D);
+        auto extra = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                if (S2_STAGE_G(i) == g) stage_piece(i, q + 1, nxt);
+                if (S2_LOAD_G(i) == g) load_piece(i, q + 2);
+            }
+        };
+        using F = std::false_type; using Tt = std::true_type;
         if (P == 0 || P == 2) {
+            // even plane: kd 0 opens output plane od_new in block NEWB, kd 2 closes od_new-1 in the other.
+            // The last plane of the range (od_new == od1) opens a plane nobody retires: swept anyway --
+            // a second code path here costs more (and lets the compiler hoist the staging arithmetic
+            // above both paths, which gfx950 codegen then got wrong) than the 1/(3n+1) extra MFMAs.
             constexpr int NEWB = (P == 0) ? 0 : 1;
             const int od_new = od0 + t / 2;
-            if (in_vol) {
-                if (od_new < od1) sweep2(std::integral_constant<int, NEWB>{}, cur);
-                else sweep(std::integral_constant<int, 1 - NEWB>{}, std::integral_constant<int, 2>{}, cur);
-            }
+            sweep(std::integral_constant<int, NEWB>{}, std::integral_constant<int, 0>{}, Tt{}, cur, extra);
             retire(std::integral_constant<int, 1 - NEWB>{}, od_new - 1);
         } else {
             constexpr int BLK = (P == 1) ? 0 : 1;
-            if (in_vol) sweep(std::integral_constant<int, BLK>{}, std::integral_constant<int, 1>{}, cur);
+            sweep(std::integral_constant<int, BLK>{}, std::integral_constant<int, 1>{}, F{}, cur, extra);
         }
-        if (more) write_slab(q + 1, nxt);
         __syncthreads();
     };
     for (int t = 0; t < T; t += 4) {
@@ -242,6 +251,7 @@ conv3d_s2_kernel(ConvArgs a) {
 template <int CIN, int TOH>
 int launch_s2(const ConvArgs& a0, int Cout, hipStream_t st) {
     ConvArgs a = a0;
+    if ((long long)a.D * a.H * a.W * (CIN > Cout ? CIN : Cout) * 4 >= (1LL << 31)) return MVS_E_SHAPE;   // 32-bit buffer offsets
     const int Do = (a.D + 1) / 2, Ho = (a.H + 1) / 2, Wo = (a.W + 1) / 2;
     const int tiles = ((Ho + TOH - 1) / TOH) * ((Wo + TW - 1) / TW);
     const int groups = Cout / 16;
