@@ -253,6 +253,58 @@ int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms,
                     const float* const* params, const float* depth_values, void* workspace,
                     size_t workspace_bytes, float* depth_out, float* prob_out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * backward passes of the plane-sweep path for training.  The reference has no such
+ * functions: TensorFlow differentiates the graph of `inference` (mvsnet/model.py:257-372) inside
+ * opt.compute_gradients (mvsnet/train.py:428-429).  Input gradients of the 3D convolutions need no
+ * entry point of their own: a stride-2 convolution's input gradient is mvs_deconv3d_f32 with the SAME
+ * kernel array, a transposed convolution's is mvs_conv3d_f32 (stride 2) with the same array, and a
+ * stride-1 convolution's is mvs_conv3d_f32 with the kernel flipped along kd,kh,kw and Cin/Cout swapped.
+ *
+ * mvs_softargmin_bwd_f32   g_reg(d) = -g_depth * P_d * (z_d - depth), P = softmax(-reg) (model.py:343-366)
+ * mvs_bn_relu_f32          out = act(y*scale+shift) [+ act(y2*scale2+shift2)], act = ReLU when the scale
+ *                          is given: the normalised layer input the forward kernels form on load
+ * mvs_bn_bwd_reduce_f32    BatchNorm(batch statistics)+ReLU backward, pass 1: sums (2,C) float64 (zeroed
+ *                          by the caller) += [sum gz, sum gz*xhat], gz = (g1 [+ g2]) * [y*scale+shift > 0],
+ *                          xhat from `stats` (the forward's (2,C) sums) / count / eps (network.py:492-509)
+ * mvs_bn_bwd_apply_f32     pass 2: g_y = gamma/std * (gz - mean(gz) - xhat*mean(gz*xhat));
+ *                          g_gamma = sum gz*xhat, g_beta = sum gz (either may be NULL)
+ * mvs_conv3d_wgrad_f32     dW(tap,cb,cs) = sum_o big(stride*o + tap - pad, cb) * small(o, cs); big (D,H,W,Cbig),
+ *                          small (D/s,H/s,W/s,Csmall); convolution: big = layer input, small = output
+ *                          gradient -> dW in the conv3d layout; transposed convolution (stride 2): big =
+ *                          output gradient, small = layer input -> dW in the conv3d_transpose layout.
+ *                          Deterministic (per-workgroup partials in `workspace`, fixed-order float64 sum).
+ *                          Built for the channel pairs of RegNetUS0 'normal' (else MVS_E_SHAPE).
+ * mvs_cost_volume_bwd_f32  gradient of mvs_cost_volume_f32 (either variant) w.r.t. the feature maps:
+ *                          g_ref (H,W,C) and g_src (view_num-1,H,W,C), zeroed by the caller, are
+ *                          accumulated with float atomics; g2 may be NULL (second consumer of the volume)
+ * mvs_rmsprop_step_f32     tf.train.RMSPropOptimizer update over a flat parameter buffer (train.py:259):
+ *                          ms += (g^2-ms)(1-decay); mom = momentum*mom + lr*g/sqrt(ms+eps); w -= mom,
+ *                          g = grad * grad_scale (1/world_size after a sum all-reduce)
+ */
+int mvs_softargmin_bwd_f32(const float* reg, const float* g_depth, int D, int H, int W,
+                           float depth_start, float depth_interval, int inverse_depth,
+                           float* g_reg, void* stream);
+int mvs_bn_relu_f32(const float* y, const float* scale, const float* shift, const float* y2,
+                    const float* scale2, const float* shift2, size_t voxels, int C, float* out,
+                    void* stream);
+int mvs_bn_bwd_reduce_f32(const float* y, const double* stats, double count, float eps,
+                          const float* scale, const float* shift, const float* g1,
+                          const float* g2, size_t voxels, int C, double* sums, void* stream);
+int mvs_bn_bwd_apply_f32(const float* y, const double* stats, double count, float eps,
+                         const float* scale, const float* shift, const float* gamma,
+                         const float* g1, const float* g2, const double* sums, size_t voxels,
+                         int C, float* g_y, float* g_gamma, float* g_beta, void* stream);
+size_t mvs_conv3d_wgrad_workspace_bytes(int D, int H, int W, int Cbig, int Csmall, int stride);
+int mvs_conv3d_wgrad_f32(const float* big, const float* small, int D, int H, int W, int Cbig,
+                         int Csmall, int stride, void* workspace, size_t workspace_bytes,
+                         float* dw, void* stream);
+int mvs_cost_volume_bwd_f32(const float* ref, const float* src, const float* transforms,
+                            int view_num, int depth_num, int H, int W, int C, const float* g1,
+                            const float* g2, float* g_ref, float* g_src, void* stream);
+int mvs_rmsprop_step_f32(float* w, const float* g, float* ms, float* mom, size_t n, float lr,
+                         float decay, float momentum, float eps, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

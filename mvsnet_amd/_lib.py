@@ -54,6 +54,14 @@ SIGNATURES = {
     "mvs_wta_update_f32": (_i, [_p, _f, _i, _i, _p, _p, _p, _p]),
     "mvs_wta_finish_f32": (_i, [_p, _p, _i, _i, _p, _p]),
     "mvs_gru_workspace_bytes": (_sz, [_i] * 6),
+    "mvs_softargmin_bwd_f32": (_i, [_p, _p, _i, _i, _i, _f, _f, _i, _p, _p]),
+    "mvs_bn_relu_f32": (_i, [_p] * 6 + [_sz, _i, _p, _p]),
+    "mvs_bn_bwd_reduce_f32": (_i, [_p, _p, C.c_double, _f, _p, _p, _p, _p, _sz, _i, _p, _p]),
+    "mvs_bn_bwd_apply_f32": (_i, [_p, _p, C.c_double, _f, _p, _p, _p, _p, _p, _p, _sz, _i, _p, _p, _p, _p]),
+    "mvs_conv3d_wgrad_workspace_bytes": (_sz, [_i] * 6),
+    "mvs_conv3d_wgrad_f32": (_i, [_p, _p] + [_i] * 6 + [_p, _sz, _p, _p]),
+    "mvs_cost_volume_bwd_f32": (_i, [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _p]),
+    "mvs_rmsprop_step_f32": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),
     "mvs_gru_wta_f32": (_i, [_p, _p, _p] + [_i] * 8 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
 }
 

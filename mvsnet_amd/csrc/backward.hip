@@ -1,0 +1,350 @@
+// Backward kernels of the plane-sweep path for training (the reference gets them from
+// TensorFlow's autodiff of mvsnet/model.py:257-372 via opt.compute_gradients, mvsnet/train.py:428-429):
+//   soft-argmin (model.py:343-366), BatchNorm+ReLU in batch-statistics mode (network.py:492-509),
+//   warp + variance (homography_warping.py:211-253, model.py:315-334), and the RMSProp update
+//   (train.py:259, tf.train.RMSPropOptimizer defaults).
+// Input gradients of the 3D convolutions reuse the forward MFMA kernels (a stride-2 convolution's
+// input gradient IS conv3d_transpose with the same kernel array and vice versa; stride 1 takes the
+// flipped, transposed kernel); weight gradients are in conv3d_wgrad.hip.
+//
+// All of these are HBM-bound elementwise / reduction / scatter passes: float4 per lane, channel-last.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float depth_at(int d, int D, float start, float interval, int inverse) {
+    float end = start + ((float)D - 1.0f) * interval;
+    float denom = (float)(D > 1 ? D - 1 : 1);
+    if (inverse) {
+        float a = 1.0f / start, b = 1.0f / end;
+        return 1.0f / (a + (float)d * ((b - a) / denom));
+    }
+    return start + (float)d * ((end - start) / denom);
+}
+
+// depth = sum_d P_d z_d, P = softmax(-reg)  =>  d depth / d reg_d = -P_d (z_d - depth).
+// One lane per pixel, three coalesced sweeps over depth (max, sums, write).
+__global__ void __launch_bounds__(256)
+softargmin_bwd_kernel(const float* __restrict__ reg, const float* __restrict__ g_depth, int D, int HW,
+                      float start, float interval, int inverse, float* __restrict__ g_reg) {
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= HW) return;
+    const float* col = reg + pix;
+    float m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, -col[(size_t)d * HW]);
+    float se = 0.f, sz = 0.f;
+    for (int d = 0; d < D; ++d) {
+        float e = __expf(-col[(size_t)d * HW] - m);
+        se += e; sz += e * depth_at(d, D, start, interval, inverse);
+    }
+    const float depth = sz / se, g = g_depth[pix] / se;
+    for (int d = 0; d < D; ++d) {
+        float e = __expf(-col[(size_t)d * HW] - m);
+        g_reg[(size_t)d * HW + pix] = -g * e * (depth_at(d, D, start, interval, inverse) - depth);
+    }
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// out = act(y*s+t) [+ act(y2*s2+t2)]; act = ReLU when the scale pointer is given, identity otherwise:
+// the normalised layer input the forward kernels build on load, materialised for the weight gradient.
+__global__ void __launch_bounds__(256)
+bn_relu_kernel(const float* __restrict__ y, const float* __restrict__ s, const float* __restrict__ t,
+               const float* __restrict__ y2, const float* __restrict__ s2, const float* __restrict__ t2,
+               size_t n4, int cq, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % cq) * 4;
+        float4 v = ld4(y + 4 * i);
+        if (s) {
+            float4 a = ld4(s + c), b = ld4(t + c);
+            v.x = relu(v.x * a.x + b.x); v.y = relu(v.y * a.y + b.y);
+            v.z = relu(v.z * a.z + b.z); v.w = relu(v.w * a.w + b.w);
+        }
+        if (y2) {
+            float4 u = ld4(y2 + 4 * i);
+            if (s2) {
+                float4 a = ld4(s2 + c), b = ld4(t2 + c);
+                u.x = relu(u.x * a.x + b.x); u.y = relu(u.y * a.y + b.y);
+                u.z = relu(u.z * a.z + b.z); u.w = relu(u.w * a.w + b.w);
+            }
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        st4(out + 4 * i, v);
+    }
+}
+
+// BatchNorm(batch statistics) + ReLU backward, pass 1: per channel  sum gz  and  sum gz * xhat  with
+// z = y*scale + shift, gz = (g1 [+ g2]) * [z > 0], xhat = (y - mean) * inv_std.
+// A thread keeps one channel quad (the grid stride is a multiple of C/4); float partials per thread,
+// LDS tree per quad, one float64 atomic per channel per workgroup.
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_kernel(const float* __restrict__ y, const double* __restrict__ stats, double count, float eps,
+                     const float* __restrict__ scale, const float* __restrict__ shift,
+                     const float* __restrict__ g1, const float* __restrict__ g2, size_t n4, int cq,
+                     double* __restrict__ sums) {
+    __shared__ float red[256][8];
+    const int tid = threadIdx.x;
+    const int c = (tid % cq) * 4, C = cq * 4;
+    float mean[4], inv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double mu = stats[c + k] / count, var = stats[C + c + k] / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean[k] = (float)mu; inv[k] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    const float4 sc = ld4(scale + c), sh = ld4(shift + c);
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = ld4(y + 4 * i), g = ld4(g1 + 4 * i);
+        if (g2) { float4 h = ld4(g2 + 4 * i); g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
+        const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+        const float ss[4] = {sc.x, sc.y, sc.z, sc.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gz = (vv[k] * ss[k] + tt[k] > 0.f) ? gg[k] : 0.f;
+            a[k] += gz; b[k] += gz * ((vv[k] - mean[k]) * inv[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[tid][k] = a[k]; red[tid][4 + k] = b[k]; }
+    __syncthreads();
+    if (tid < cq) {                                    // threads tid, tid+cq, ... share this quad
+        double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+        for (int j = tid; j < 256; j += cq)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sa[k] += red[j][k]; sb[k] += red[j][4 + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(sums + c + k, sa[k]);
+            atomicAdd(sums + C + c + k, sb[k]);
+        }
+    }
+}
+
+// pass 2: g_y = gamma * inv_std * (gz - mean(gz) - xhat * mean(gz * xhat)); block 0 also emits
+// g_gamma = sum gz*xhat and g_beta = sum gz.
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(const float* __restrict__ y, const double* __restrict__ stats, double count, float eps,
+                    const float* __restrict__ scale, const float* __restrict__ shift,
+                    const float* __restrict__ gamma, const float* __restrict__ g1,
+                    const float* __restrict__ g2, const double* __restrict__ sums, size_t n4, int cq,
+                    float* __restrict__ g_y, float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+    const int tid = threadIdx.x;
+    const int c = (tid % cq) * 4, C = cq * 4;
+    float mean[4], inv[4], k0[4], k1[4], k2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double mu = stats[c + k] / count, var = stats[C + c + k] / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        double is = 1.0 / sqrt(var + (double)eps);
+        mean[k] = (float)mu; inv[k] = (float)is;
+        k0[k] = (float)((double)gamma[c + k] * is);
+        k1[k] = (float)(sums[c + k] / count);
+        k2[k] = (float)(sums[C + c + k] / count);
+    }
+    if (blockIdx.x == 0 && tid < cq) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (g_beta) g_beta[c + k] = (float)sums[c + k];
+            if (g_gamma) g_gamma[c + k] = (float)sums[C + c + k];
+        }
+    }
+    const float4 sc = ld4(scale + c), sh = ld4(shift + c);
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = ld4(y + 4 * i), g = ld4(g1 + 4 * i);
+        if (g2) { float4 h = ld4(g2 + 4 * i); g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
+        const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+        const float ss[4] = {sc.x, sc.y, sc.z, sc.w}, tt[4] = {sh.x, sh.y, sh.z, sh.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gz = (vv[k] * ss[k] + tt[k] > 0.f) ? gg[k] : 0.f;
+            o[k] = k0[k] * (gz - k1[k] - (vv[k] - mean[k]) * inv[k] * k2[k]);
+        }
+        st4(g_y + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+// Warp + variance backward.  cost = Q/N - (S/N)^2 with S = F_ref + sum_v W_v, Q = F_ref^2 + sum_v W_v^2
+// (both forward variants have this derivative):  d cost / d X = (2/N) (X - S/N) for X in {F_ref, W_v}.
+// One lane = (pixel, 4 channels) marching over `planes_per_block` planes: recomputes the taps exactly as
+// the forward does (zero fill per tap), accumulates the reference-view gradient in registers and
+// scatters each source view's gradient through its four bilinear weights with float atomics
+// (red.add, no return: the taps of neighbouring pixels coalesce in L2).
+struct Tap { int o00, o01, o10, o11; float w00, w01, w10, w11; };
+__device__ __forceinline__ Tap make_tap(const float* __restrict__ t, float xf, float yf, int H, int W, int C, int c) {
+    float proj = t[6] * xf + t[7] * yf + 1.0f;
+    float sx = (t[0] * xf + t[1] * yf + t[2]) / proj;
+    float sy = (t[3] * xf + t[4] * yf + t[5]) / proj;
+    float x0 = floorf(sx), y0 = floorf(sy);
+    float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    bool okx0 = (x0 >= 0.0f) && (x0 < (float)W), okx1 = (x1 >= 0.0f) && (x1 < (float)W);
+    bool oky0 = (y0 >= 0.0f) && (y0 < (float)H), oky1 = (y1 >= 0.0f) && (y1 < (float)H);
+    int ix0 = okx0 ? (int)x0 : 0, ix1 = okx1 ? (int)x1 : 0;
+    int iy0 = oky0 ? (int)y0 : 0, iy1 = oky1 ? (int)y1 : 0;
+    float wx1 = x1 - sx, wx0 = sx - x0, wy1 = y1 - sy, wy0 = sy - y0;
+    Tap p;
+    p.o00 = (okx0 && oky0) ? (iy0 * W + ix0) * C + c : -1;
+    p.o01 = (okx1 && oky0) ? (iy0 * W + ix1) * C + c : -1;
+    p.o10 = (okx0 && oky1) ? (iy1 * W + ix0) * C + c : -1;
+    p.o11 = (okx1 && oky1) ? (iy1 * W + ix1) * C + c : -1;
+    p.w00 = wy1 * wx1; p.w01 = wy1 * wx0; p.w10 = wy0 * wx1; p.w11 = wy0 * wx0;
+    return p;
+}
+__device__ __forceinline__ float4 tap_gather(const float* __restrict__ img, const Tap& p) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a = p.o00 >= 0 ? ld4(img + p.o00) : z, b = p.o01 >= 0 ? ld4(img + p.o01) : z;
+    float4 c = p.o10 >= 0 ? ld4(img + p.o10) : z, d = p.o11 >= 0 ? ld4(img + p.o11) : z;
+    float4 o;
+    o.x = p.w00 * a.x + p.w01 * b.x + p.w10 * c.x + p.w11 * d.x;
+    o.y = p.w00 * a.y + p.w01 * b.y + p.w10 * c.y + p.w11 * d.y;
+    o.z = p.w00 * a.z + p.w01 * b.z + p.w10 * c.z + p.w11 * d.z;
+    o.w = p.w00 * a.w + p.w01 * b.w + p.w10 * c.w + p.w11 * d.w;
+    return o;
+}
+__device__ __forceinline__ void red_add4(float* p, float w, float4 g) {
+    unsafeAtomicAdd(p + 0, w * g.x); unsafeAtomicAdd(p + 1, w * g.y);
+    unsafeAtomicAdd(p + 2, w * g.z); unsafeAtomicAdd(p + 3, w * g.w);
+}
+
+constexpr int CVB_MAX_SRC = 8;
+__global__ void __launch_bounds__(256)
+cost_volume_bwd_kernel(const float* __restrict__ ref, const float* __restrict__ src,
+                       const float* __restrict__ transforms, int n_src, int D, int planes_per_block,
+                       int H, int W, int C, const float* __restrict__ g1, const float* __restrict__ g2,
+                       float* __restrict__ g_ref, float* __restrict__ g_src) {
+    const int cq = C >> 2;
+    const long long total = (long long)H * W * cq;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cq) * 4;
+    const long long pix = idx / cq;
+    const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+    const float xf = (float)x, yf = (float)y;
+    const size_t img = (size_t)H * W * C;
+    const float n = (float)(n_src + 1), two_n = 2.0f / n;
+    const float4 r = ld4(ref + (size_t)pix * C + c);
+    float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int d0 = blockIdx.y * planes_per_block, d1 = min(d0 + planes_per_block, D);
+    for (int d = d0; d < d1; ++d) {
+        const size_t vo = ((size_t)d * H * W + pix) * C + c;
+        float4 g = ld4(g1 + vo);
+        if (g2) { float4 h = ld4(g2 + vo); g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
+        g.x *= two_n; g.y *= two_n; g.z *= two_n; g.w *= two_n;
+        Tap tp[CVB_MAX_SRC]; float4 wv[CVB_MAX_SRC];
+        float4 S = r;
+#pragma unroll
+        for (int v = 0; v < CVB_MAX_SRC; ++v) {
+            if (v < n_src) {
+                tp[v] = make_tap(transforms + ((size_t)v * D + d) * 8, xf, yf, H, W, C, c);
+                wv[v] = tap_gather(src + v * img, tp[v]);
+                S.x += wv[v].x; S.y += wv[v].y; S.z += wv[v].z; S.w += wv[v].w;
+            }
+        }
+        S.x /= n; S.y /= n; S.z /= n; S.w /= n;
+        gr.x += g.x * (r.x - S.x); gr.y += g.y * (r.y - S.y);
+        gr.z += g.z * (r.z - S.z); gr.w += g.w * (r.w - S.w);
+#pragma unroll
+        for (int v = 0; v < CVB_MAX_SRC; ++v) {
+            if (v < n_src) {
+                float4 gw = make_float4(g.x * (wv[v].x - S.x), g.y * (wv[v].y - S.y),
+                                        g.z * (wv[v].z - S.z), g.w * (wv[v].w - S.w));
+                float* gs = g_src + v * img;
+                if (tp[v].o00 >= 0) red_add4(gs + tp[v].o00, tp[v].w00, gw);
+                if (tp[v].o01 >= 0) red_add4(gs + tp[v].o01, tp[v].w01, gw);
+                if (tp[v].o10 >= 0) red_add4(gs + tp[v].o10, tp[v].w10, gw);
+                if (tp[v].o11 >= 0) red_add4(gs + tp[v].o11, tp[v].w11, gw);
+            }
+        }
+    }
+    float* pr = g_ref + (size_t)pix * C + c;
+    unsafeAtomicAdd(pr + 0, gr.x); unsafeAtomicAdd(pr + 1, gr.y);
+    unsafeAtomicAdd(pr + 2, gr.z); unsafeAtomicAdd(pr + 3, gr.w);
+}
+
+// tf.train.RMSPropOptimizer (decay 0.9, momentum 0, epsilon 1e-10, not centered; its `rms` slot starts
+// at ONE):  ms += (g*g - ms) * (1 - decay);  mom = momentum*mom + lr * g / sqrt(ms + eps);  w -= mom.
+// One launch over the flat parameter buffer (all variables of the model are views into it).
+__global__ void __launch_bounds__(256)
+rmsprop_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ ms,
+               float* __restrict__ mom, size_t n, float lr, float decay, float momentum, float eps,
+               float grad_scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float gi = g[i] * grad_scale;
+        float m = ms[i] + (gi * gi - ms[i]) * (1.0f - decay);
+        float mo = momentum * mom[i] + lr * gi / sqrtf(m + eps);
+        ms[i] = m; mom[i] = mo; w[i] -= mo;
+    }
+}
+
+inline int grid_for(size_t n4) { size_t b = (n4 + 255) / 256; return (int)(b < 4096 ? (b ? b : 1) : 4096); }
+
+}  // namespace
+
+extern "C" int mvs_softargmin_bwd_f32(const float* reg, const float* g_depth, int D, int H, int W,
+                                      float depth_start, float depth_interval, int inverse_depth,
+                                      float* g_reg, void* stream) {
+    MVS_CHECK_ARG(reg && g_depth && g_reg && D > 0 && H > 0 && W > 0);
+    const int HW = H * W;
+    softargmin_bwd_kernel<<<mvs_cdiv(HW, 256), 256, 0, mvs_stream(stream)>>>(
+        reg, g_depth, D, HW, depth_start, depth_interval, inverse_depth, g_reg);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_bn_relu_f32(const float* y, const float* scale, const float* shift, const float* y2,
+                               const float* scale2, const float* shift2, size_t voxels, int C, float* out,
+                               void* stream) {
+    MVS_CHECK_ARG(y && out && voxels > 0 && C > 0);
+    if (C % 4 || 256 % (C / 4)) return MVS_E_SHAPE;
+    MVS_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (scale2 == nullptr) == (shift2 == nullptr));
+    const size_t n4 = voxels * (size_t)(C / 4);
+    bn_relu_kernel<<<grid_for(n4), 256, 0, mvs_stream(stream)>>>(y, scale, shift, y2, scale2, shift2, n4, C / 4, out);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_bn_bwd_reduce_f32(const float* y, const double* stats, double count, float eps,
+                                     const float* scale, const float* shift, const float* g1,
+                                     const float* g2, size_t voxels, int C, double* sums, void* stream) {
+    MVS_CHECK_ARG(y && stats && scale && shift && g1 && sums && voxels > 0 && C > 0 && count > 0);
+    if (C % 4 || 256 % (C / 4)) return MVS_E_SHAPE;
+    const size_t n4 = voxels * (size_t)(C / 4);
+    int grid = grid_for(n4); if (grid > 1024) grid = 1024;
+    bn_bwd_reduce_kernel<<<grid, 256, 0, mvs_stream(stream)>>>(y, stats, count, eps, scale, shift, g1, g2, n4, C / 4, sums);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_bn_bwd_apply_f32(const float* y, const double* stats, double count, float eps,
+                                    const float* scale, const float* shift, const float* gamma,
+                                    const float* g1, const float* g2, const double* sums, size_t voxels,
+                                    int C, float* g_y, float* g_gamma, float* g_beta, void* stream) {
+    MVS_CHECK_ARG(y && stats && scale && shift && gamma && g1 && sums && g_y && voxels > 0 && C > 0 && count > 0);
+    if (C % 4 || 256 % (C / 4)) return MVS_E_SHAPE;
+    const size_t n4 = voxels * (size_t)(C / 4);
+    bn_bwd_apply_kernel<<<grid_for(n4), 256, 0, mvs_stream(stream)>>>(y, stats, count, eps, scale, shift, gamma, g1, g2,
+                                                                      sums, n4, C / 4, g_y, g_gamma, g_beta);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_cost_volume_bwd_f32(const float* ref, const float* src, const float* transforms,
+                                       int view_num, int depth_num, int H, int W, int C, const float* g1,
+                                       const float* g2, float* g_ref, float* g_src, void* stream) {
+    MVS_CHECK_ARG(ref && src && transforms && g1 && g_ref && g_src && view_num >= 2 && depth_num > 0 && H > 0 && W > 0);
+    if (C % 4 || view_num - 1 > CVB_MAX_SRC) return MVS_E_SHAPE;
+    if ((long long)H * W * C >= (1LL << 31)) return MVS_E_SHAPE;
+    const long long total = (long long)H * W * (C / 4);
+    const int bx = mvs_cdiv(total, 256);
+    int ppb = 8;
+    while (ppb > 1 && (long long)bx * mvs_cdiv(depth_num, ppb) < 2048) ppb >>= 1;
+    dim3 grid(bx, mvs_cdiv(depth_num, ppb));
+    cost_volume_bwd_kernel<<<grid, 256, 0, mvs_stream(stream)>>>(ref, src, transforms, view_num - 1, depth_num, ppb,
+                                                                 H, W, C, g1, g2, g_ref, g_src);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_rmsprop_step_f32(float* w, const float* g, float* ms, float* mom, size_t n, float lr,
+                                    float decay, float momentum, float eps, float grad_scale, void* stream) {
+    MVS_CHECK_ARG(w && g && ms && mom && n > 0);
+    rmsprop_kernel<<<grid_for(n), 256, 0, mvs_stream(stream)>>>(w, g, ms, mom, n, lr, decay, momentum, eps, grad_scale);
+    MVS_LAUNCH_RET();
+}

@@ -1,0 +1,205 @@
+"""GPU parity of the training backward kernels against torch-CPU float64 autograd of the
+same expressions (oracle/torch_grad.py; in the reference TensorFlow's autodiff supplies these gradients,
+mvsnet/train.py:428-429).  All device calls go through the C ABI.  Tolerances: fp32 kernels against a
+float64 checker, relative L1 <= 1e-4 unless stated.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mvsnet_oracle as O
+from oracle import torch_grad as TG
+from mvsnet_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib(lib_built):
+    from mvsnet_amd import _lib as L
+    L.load()
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    yield
+
+
+def t(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(DEV)
+
+
+def n(x):
+    torch.cuda.synchronize()
+    return x.detach().cpu().numpy().astype(np.float64)
+
+
+def rel_l1(a, b):
+    return float(np.abs(a - b).sum() / max(np.abs(b).sum(), 1e-30))
+
+
+def d64(a, grad=False):
+    x = torch.tensor(np.asarray(a, np.float64))
+    return x.requires_grad_(grad)
+
+
+def test_softargmin_backward_matches_autograd():
+    from mvsnet_amd import backward as B
+    rs = np.random.RandomState(0)
+    D, H, W = 24, 9, 21
+    reg = rs.randn(D, H, W).astype(np.float32)
+    g = rs.randn(H, W).astype(np.float32)
+    x = d64(reg, True)
+    (TG.soft_argmin(x, 425.0, 2.5) * d64(g)).sum().backward()
+    got = n(B.softargmin_bwd(t(reg), t(g), 425.0, 2.5))
+    assert rel_l1(got, x.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("C,two", [(8, True), (16, False), (64, True)])
+def test_bn_relu_and_its_backward_match_autograd(C, two):
+    from mvsnet_amd import backward as B
+    from mvsnet_amd import model as M
+    rs = np.random.RandomState(C)
+    shape = (6, 10, 12, C)
+    y = rs.randn(*shape).astype(np.float32) * 1.5 + 0.3
+    gamma = (1.0 + 0.3 * rs.randn(C)).astype(np.float32)
+    beta = (0.2 * rs.randn(C)).astype(np.float32)
+    g1 = rs.randn(*shape).astype(np.float32)
+    g2 = rs.randn(*shape).astype(np.float32) if two else None
+    # checker
+    yy, gg, bb = d64(y, True), d64(gamma, True), d64(beta, True)
+    a = F.relu(F.batch_norm(yy.permute(3, 0, 1, 2)[None], None, None, gg, bb, training=True, eps=1e-5))[0].permute(1, 2, 3, 0)
+    gsum = d64(g1) + (d64(g2) if two else 0.0)
+    (a * gsum).sum().backward()
+    # device: forward statistics exactly as the conv kernels emit them
+    yt = t(y)
+    stats = torch.stack([yt.double().sum((0, 1, 2)), (yt.double() ** 2).sum((0, 1, 2))]).contiguous()
+    aff = M.bn_finalize(stats, yt.numel() // C, t(gamma), t(beta))
+    assert rel_l1(n(B.bn_relu(yt, aff)), a.detach().numpy()) < 1e-6
+    g_y, g_gamma, g_beta = B.bn_relu_bwd(yt, stats, aff, t(gamma), t(g1), t(g2) if two else None)
+    assert rel_l1(n(g_y), yy.grad.numpy()) < 1e-5
+    assert rel_l1(n(g_gamma), gg.grad.numpy()) < 1e-5
+    assert rel_l1(n(g_beta), bb.grad.numpy()) < 1e-5
+
+
+# (Cbig, Csmall, stride, kind): every layer shape of RegNetUS0 'normal'
+WGRAD_CASES = [(32, 8, 1, "conv"), (16, 16, 1, "conv"), (32, 32, 1, "conv"), (64, 64, 1, "conv"), (8, 1, 1, "conv"),
+               (32, 16, 2, "conv"), (16, 32, 2, "conv"), (32, 64, 2, "conv"),
+               (32, 64, 2, "deconv"), (16, 32, 2, "deconv"), (8, 16, 2, "deconv")]
+
+
+@pytest.mark.parametrize("cb,cs,stride,kind", WGRAD_CASES)
+@pytest.mark.parametrize("dims", [(8, 8, 16), (6, 12, 40)])
+def test_conv3d_weight_gradient_matches_autograd(cb, cs, stride, kind, dims):
+    from mvsnet_amd import backward as B
+    rs = np.random.RandomState(cb * 100 + cs + stride)
+    D, H, W = dims
+    small_dims = tuple(v // stride for v in dims)
+    big = rs.randn(D, H, W, cb).astype(np.float32)
+    small = rs.randn(*small_dims, cs).astype(np.float32)
+    if kind == "conv":            # y = conv(x=big, w (3,3,3,cb,cs)); small = g_y
+        w = d64(np.zeros((3, 3, 3, cb, cs)), True)
+        y = TG._conv(d64(big).permute(3, 0, 1, 2)[None], w, stride)[0].permute(1, 2, 3, 0)
+        (y * d64(small)).sum().backward()
+    else:                         # y = deconv(x=small, w (3,3,3,Cout=cb,Cin=cs)); big = g_y
+        w = d64(np.zeros((3, 3, 3, cb, cs)), True)
+        y = TG._deconv(d64(small).permute(3, 0, 1, 2)[None], w)[0].permute(1, 2, 3, 0)
+        (y * d64(big)).sum().backward()
+    got = n(B.conv3d_wgrad(t(big), t(small), stride))
+    assert got.shape == (3, 3, 3, cb, cs)
+    assert rel_l1(got, w.grad.numpy()) < 2e-5
+    # deterministic: a second launch gives the same bits
+    assert np.array_equal(got, n(B.conv3d_wgrad(t(big), t(small), stride)))
+
+
+@pytest.mark.parametrize("cin,cout,kind", [(32, 8, "s1"), (16, 16, "s1"), (8, 1, "s1"), (64, 64, "s1"),
+                                           (32, 16, "s2"), (16, 32, "s2"), (32, 64, "s2"),
+                                           (64, 32, "deconv"), (32, 16, "deconv"), (16, 8, "deconv")])
+def test_conv3d_input_gradients_match_autograd(cin, cout, kind):
+    from mvsnet_amd import backward as B
+    rs = np.random.RandomState(cin + 3 * cout)
+    D, H, W = 8, 8, 16
+    x = d64(rs.randn(D, H, W, cin), True)
+    if kind == "deconv":
+        w = rs.randn(3, 3, 3, cout, cin).astype(np.float32) * 0.1
+        y = TG._deconv(x.permute(3, 0, 1, 2)[None], d64(w))[0].permute(1, 2, 3, 0)
+    else:
+        w = rs.randn(3, 3, 3, cin, cout).astype(np.float32) * 0.1
+        y = TG._conv(x.permute(3, 0, 1, 2)[None], d64(w), 1 if kind == "s1" else 2)[0].permute(1, 2, 3, 0)
+    g = rs.randn(*y.shape).astype(np.float32)
+    (y * d64(g)).sum().backward()
+    fn = {"s1": B.conv_s1_input_grad, "s2": B.conv_s2_input_grad, "deconv": B.deconv_input_grad}[kind]
+    got = n(fn(t(g), t(w)))
+    assert got.shape == tuple(x.shape)
+    assert rel_l1(got, x.grad.numpy()) < 2e-5
+
+
+def _toy_problem(N=3, D=16, H=16, W=32, C=32):
+    cams = S.make_cams(N, H, W, D)
+    feats = S.make_features(N, H, W, C, seed=5)
+    start, interval = float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1])
+    Hs = np.stack([O.get_homographies(cams[0], cams[v], D, start, interval, np.float32) for v in range(1, N)])
+    t8 = O.homography_to_transform8(Hs, np.float32)
+    return feats, t8, start, interval
+
+
+def test_cost_volume_backward_matches_autograd():
+    from mvsnet_amd import backward as B
+    feats, t8, _, _ = _toy_problem()
+    rs = np.random.RandomState(3)
+    g1 = rs.randn(t8.shape[1], *feats.shape[1:]).astype(np.float32)
+    g2 = rs.randn(*g1.shape).astype(np.float32)
+    f = d64(feats, True)
+    cost = TG.cost_volume(f, d64(t8)).permute(1, 2, 3, 0)               # (D,H,W,C)
+    (cost * (d64(g1) + d64(g2))).sum().backward()
+    ft = t(feats)
+    g_ref, g_src = B.cost_volume_bwd(ft[0], ft[1:], t(t8), t(g1), t(g2))
+    got = np.concatenate([n(g_ref)[None], n(g_src)], 0)
+    # the warp is piecewise bilinear: fp32 sample coordinates that land within rounding of a pixel boundary
+    # may pick the neighbouring cell; the contribution is continuous, so the L1 error stays at rounding level
+    assert rel_l1(got, f.grad.numpy()) < 1e-4
+
+
+def test_plane_sweep_depth_gradients_match_autograd():
+    """features -> depth -> scalar: every RegNetUS0 parameter gradient and the feature gradient."""
+    from mvsnet_amd import backward as B
+    feats, t8, start, interval = _toy_problem()
+    params = S.make_regnet_params("normal", seed=1, random_affine=True)
+    rs = np.random.RandomState(11)
+    g = rs.randn(feats.shape[1], feats.shape[2]).astype(np.float32)
+    # checker
+    f64 = d64(feats, True)
+    p64 = {k: {kk: d64(vv, True) for kk, vv in v.items()} for k, v in params.items()}
+    depth64 = TG.depth_from_features(f64, d64(t8), start, interval, p64)
+    (depth64 * d64(g)).sum().backward()
+    # device
+    ft = t(feats).requires_grad_(True)
+    pt = {k: {kk: t(vv).requires_grad_(True) for kk, vv in v.items()} for k, v in params.items()}
+    depth, prob = B.plane_sweep_depth(ft, t(t8), start, interval, pt)
+    assert rel_l1(n(depth), depth64.detach().numpy()) < 1e-5
+    (depth * t(g)).sum().backward()
+    assert rel_l1(n(ft.grad), f64.grad.numpy()) < 2e-3
+    for name in p64:
+        for key in p64[name]:
+            ref = p64[name][key].grad.numpy()
+            got = n(pt[name][key].grad)
+            assert rel_l1(got, ref) < 2e-3, (name, key, rel_l1(got, ref))
+
+
+def test_rmsprop_step_matches_tensorflow_formula():
+    from mvsnet_amd import _lib as L
+    lib = L.load()
+    rs = np.random.RandomState(2)
+    nel = 10007
+    w, g = rs.randn(nel).astype(np.float32), rs.randn(nel).astype(np.float32)
+    ms, mom = np.ones(nel, np.float32), np.zeros(nel, np.float32)          # TF: rms slot starts at one
+    wt, gt, mst, momt = t(w), t(g), t(ms), t(mom)
+    lr, decay, momentum, eps = 1e-3, 0.9, 0.0, 1e-10
+    for _ in range(3):
+        L.check(lib.mvs_rmsprop_step_f32(L.ptr(wt), L.ptr(gt), L.ptr(mst), L.ptr(momt), nel, lr, decay, momentum, eps,
+                                         0.5, L.stream_ptr()))
+        gs = g.astype(np.float64) * 0.5
+        ms = ms + (gs * gs - ms) * (1 - decay)
+        mom = momentum * mom + lr * gs / np.sqrt(ms + eps)
+        w = w - mom
+    assert np.allclose(n(wt), w, rtol=1e-5, atol=1e-7)
+    assert np.allclose(n(mst), ms, rtol=1e-5)
