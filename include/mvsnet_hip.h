@@ -304,6 +304,13 @@ int mvs_cost_volume_bwd_f32(const float* ref, const float* src, const float* tra
                             const float* g2, float* g_ref, float* g_src, void* stream);
 int mvs_rmsprop_step_f32(float* w, const float* g, float* ms, float* mom, size_t n, float lr,
                          float decay, float momentum, float eps, float grad_scale, void* stream);
+/* The other two optimisers of setup_optimizer (train.py:248-271): tf.train.MomentumOptimizer
+ * (accum = momentum*accum + g; w -= lr*accum) and tf.train.AdamOptimizer (lr_t = lr*sqrt(1-beta2^t)/
+ * (1-beta1^t) formed by the caller; w -= lr_t*m/(sqrt(v)+eps)). */
+int mvs_momentum_step_f32(float* w, const float* g, float* accum, size_t n, float lr, float momentum,
+                          float grad_scale, void* stream);
+int mvs_adam_step_f32(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1,
+                      float beta2, float eps, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
 //
 // All of these are HBM-bound elementwise / reduction / scatter passes: float4 per lane, channel-last.
 #include "common.h"
+#include <climits>
 
 namespace {
 
@@ -209,9 +210,33 @@ __device__ __forceinline__ void red_add4(float* p, float w, float4 g) {
 }
 
 constexpr int CVB_MAX_SRC = 8;
+
+// One view's pending scatter: the 2x2 cell the lane's sample point is in and the gradient gathered for its
+// four taps.  Along depth the sample point slides along the epipolar line by a fraction of a pixel per
+// plane, so consecutive planes mostly hit the SAME cell: their contributions are summed here and go to
+// memory (float atomics) only when the cell changes -- several times fewer atomics than one per plane.
+struct Pending {
+    int ix0, iy0;                    // floor of the sample point (may be -1 .. W-1 / H-1); INT_MIN = empty
+    float4 a00, a01, a10, a11;
+};
+__device__ __forceinline__ void pend_flush(Pending& p, float* __restrict__ gs, int H, int W, int C, int c) {
+    if (p.ix0 == INT_MIN) return;
+    const bool okx0 = p.ix0 >= 0 && p.ix0 < W, okx1 = p.ix0 + 1 >= 0 && p.ix0 + 1 < W;
+    const bool oky0 = p.iy0 >= 0 && p.iy0 < H, oky1 = p.iy0 + 1 >= 0 && p.iy0 + 1 < H;
+    float* b = gs + ((long long)p.iy0 * W + p.ix0) * C + c;
+    if (okx0 && oky0) red_add4(b, 1.f, p.a00);
+    if (okx1 && oky0) red_add4(b + C, 1.f, p.a01);
+    if (okx0 && oky1) red_add4(b + (long long)W * C, 1.f, p.a10);
+    if (okx1 && oky1) red_add4(b + (long long)W * C + C, 1.f, p.a11);
+}
+__device__ __forceinline__ void acc4(float4& a, float w, float4 g) {
+    a.x += w * g.x; a.y += w * g.y; a.z += w * g.z; a.w += w * g.w;
+}
+
+template <int NSRC>
 __global__ void __launch_bounds__(256)
 cost_volume_bwd_kernel(const float* __restrict__ ref, const float* __restrict__ src,
-                       const float* __restrict__ transforms, int n_src, int D, int planes_per_block,
+                       const float* __restrict__ transforms, int D, int planes_per_block,
                        int H, int W, int C, const float* __restrict__ g1, const float* __restrict__ g2,
                        float* __restrict__ g_ref, float* __restrict__ g_src) {
     const int cq = C >> 2;
@@ -223,41 +248,53 @@ cost_volume_bwd_kernel(const float* __restrict__ ref, const float* __restrict__ 
     const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
     const float xf = (float)x, yf = (float)y;
     const size_t img = (size_t)H * W * C;
-    const float n = (float)(n_src + 1), two_n = 2.0f / n;
+    const float n = (float)(NSRC + 1), two_n = 2.0f / n;
     const float4 r = ld4(ref + (size_t)pix * C + c);
-    float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gr = z4;
+    Pending pd[NSRC];
+#pragma unroll
+    for (int v = 0; v < NSRC; ++v) { pd[v].ix0 = INT_MIN; pd[v].iy0 = 0; pd[v].a00 = pd[v].a01 = pd[v].a10 = pd[v].a11 = z4; }
     const int d0 = blockIdx.y * planes_per_block, d1 = min(d0 + planes_per_block, D);
     for (int d = d0; d < d1; ++d) {
         const size_t vo = ((size_t)d * H * W + pix) * C + c;
         float4 g = ld4(g1 + vo);
         if (g2) { float4 h = ld4(g2 + vo); g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
         g.x *= two_n; g.y *= two_n; g.z *= two_n; g.w *= two_n;
-        Tap tp[CVB_MAX_SRC]; float4 wv[CVB_MAX_SRC];
+        Tap tp[NSRC]; float4 wv[NSRC]; int cx[NSRC], cy[NSRC];
         float4 S = r;
 #pragma unroll
-        for (int v = 0; v < CVB_MAX_SRC; ++v) {
-            if (v < n_src) {
-                tp[v] = make_tap(transforms + ((size_t)v * D + d) * 8, xf, yf, H, W, C, c);
-                wv[v] = tap_gather(src + v * img, tp[v]);
-                S.x += wv[v].x; S.y += wv[v].y; S.z += wv[v].z; S.w += wv[v].w;
+        for (int v = 0; v < NSRC; ++v) {
+            const float* t = transforms + ((size_t)v * D + d) * 8;
+            tp[v] = make_tap(t, xf, yf, H, W, C, c);
+            {   // the cell index itself (make_tap only keeps the in-range tap offsets)
+                float proj = t[6] * xf + t[7] * yf + 1.0f;
+                float fx = floorf((t[0] * xf + t[1] * yf + t[2]) / proj), fy = floorf((t[3] * xf + t[4] * yf + t[5]) / proj);
+                // far outside the image nothing is in range: one shared "nowhere" cell keeps the ints finite
+                const bool near_img = fx >= -1.f && fx < (float)W && fy >= -1.f && fy < (float)H;
+                cx[v] = near_img ? (int)fx : -2; cy[v] = near_img ? (int)fy : -2;
             }
+            wv[v] = tap_gather(src + v * img, tp[v]);
+            S.x += wv[v].x; S.y += wv[v].y; S.z += wv[v].z; S.w += wv[v].w;
         }
         S.x /= n; S.y /= n; S.z /= n; S.w /= n;
         gr.x += g.x * (r.x - S.x); gr.y += g.y * (r.y - S.y);
         gr.z += g.z * (r.z - S.z); gr.w += g.w * (r.w - S.w);
 #pragma unroll
-        for (int v = 0; v < CVB_MAX_SRC; ++v) {
-            if (v < n_src) {
-                float4 gw = make_float4(g.x * (wv[v].x - S.x), g.y * (wv[v].y - S.y),
-                                        g.z * (wv[v].z - S.z), g.w * (wv[v].w - S.w));
-                float* gs = g_src + v * img;
-                if (tp[v].o00 >= 0) red_add4(gs + tp[v].o00, tp[v].w00, gw);
-                if (tp[v].o01 >= 0) red_add4(gs + tp[v].o01, tp[v].w01, gw);
-                if (tp[v].o10 >= 0) red_add4(gs + tp[v].o10, tp[v].w10, gw);
-                if (tp[v].o11 >= 0) red_add4(gs + tp[v].o11, tp[v].w11, gw);
+        for (int v = 0; v < NSRC; ++v) {
+            if (cx[v] != pd[v].ix0 || cy[v] != pd[v].iy0) {
+                pend_flush(pd[v], g_src + v * img, H, W, C, c);
+                pd[v].ix0 = cx[v]; pd[v].iy0 = cy[v];
+                pd[v].a00 = pd[v].a01 = pd[v].a10 = pd[v].a11 = z4;
             }
+            const float4 gw = make_float4(g.x * (wv[v].x - S.x), g.y * (wv[v].y - S.y),
+                                          g.z * (wv[v].z - S.z), g.w * (wv[v].w - S.w));
+            acc4(pd[v].a00, tp[v].w00, gw); acc4(pd[v].a01, tp[v].w01, gw);
+            acc4(pd[v].a10, tp[v].w10, gw); acc4(pd[v].a11, tp[v].w11, gw);
         }
     }
+#pragma unroll
+    for (int v = 0; v < NSRC; ++v) pend_flush(pd[v], g_src + v * img, H, W, C, c);
     float* pr = g_ref + (size_t)pix * C + c;
     unsafeAtomicAdd(pr + 0, gr.x); unsafeAtomicAdd(pr + 1, gr.y);
     unsafeAtomicAdd(pr + 2, gr.z); unsafeAtomicAdd(pr + 3, gr.w);
@@ -275,6 +312,29 @@ rmsprop_kernel(float* __restrict__ w, const float* __restrict__ g, float* __rest
         float m = ms[i] + (gi * gi - ms[i]) * (1.0f - decay);
         float mo = momentum * mom[i] + lr * gi / sqrtf(m + eps);
         ms[i] = m; mom[i] = mo; w[i] -= mo;
+    }
+}
+
+// tf.train.MomentumOptimizer (train.py:262-263): accum = momentum*accum + g; w -= lr*accum.
+__global__ void __launch_bounds__(256)
+momentum_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ accum, size_t n, float lr,
+                float momentum, float grad_scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float a = momentum * accum[i] + g[i] * grad_scale;
+        accum[i] = a; w[i] -= lr * a;
+    }
+}
+
+// tf.train.AdamOptimizer (train.py:266): m, v moments; w -= lr_t * m / (sqrt(v) + eps) with
+// lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) formed by the caller.
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+            size_t n, float lr_t, float beta1, float beta2, float eps, float grad_scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float gi = g[i] * grad_scale;
+        float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+        float vi = v[i] + (gi * gi - v[i]) * (1.0f - beta2);
+        m[i] = mi; v[i] = vi; w[i] -= lr_t * mi / (sqrtf(vi) + eps);
     }
 }
 
@@ -334,11 +394,18 @@ extern "C" int mvs_cost_volume_bwd_f32(const float* ref, const float* src, const
     if ((long long)H * W * C >= (1LL << 31)) return MVS_E_SHAPE;
     const long long total = (long long)H * W * (C / 4);
     const int bx = mvs_cdiv(total, 256);
-    int ppb = 8;
-    while (ppb > 1 && (long long)bx * mvs_cdiv(depth_num, ppb) < 2048) ppb >>= 1;
+    int ppb = depth_num;                              // long runs along depth keep the pending cells alive
+    while (ppb > 16 && (long long)bx * mvs_cdiv(depth_num, ppb) < 2048) ppb = (ppb + 1) / 2;
     dim3 grid(bx, mvs_cdiv(depth_num, ppb));
-    cost_volume_bwd_kernel<<<grid, 256, 0, mvs_stream(stream)>>>(ref, src, transforms, view_num - 1, depth_num, ppb,
-                                                                 H, W, C, g1, g2, g_ref, g_src);
+    hipStream_t st = mvs_stream(stream);
+#define CVB_LAUNCH(NS) cost_volume_bwd_kernel<NS><<<grid, 256, 0, st>>>(ref, src, transforms, depth_num, ppb, H, W, C, \
+                                                                        g1, g2, g_ref, g_src)
+    switch (view_num - 1) {
+        case 1: CVB_LAUNCH(1); break; case 2: CVB_LAUNCH(2); break; case 3: CVB_LAUNCH(3); break;
+        case 4: CVB_LAUNCH(4); break; case 5: CVB_LAUNCH(5); break; case 6: CVB_LAUNCH(6); break;
+        case 7: CVB_LAUNCH(7); break; default: CVB_LAUNCH(8); break;
+    }
+#undef CVB_LAUNCH
     MVS_LAUNCH_RET();
 }
 
@@ -346,5 +413,19 @@ extern "C" int mvs_rmsprop_step_f32(float* w, const float* g, float* ms, float* 
                                     float decay, float momentum, float eps, float grad_scale, void* stream) {
     MVS_CHECK_ARG(w && g && ms && mom && n > 0);
     rmsprop_kernel<<<grid_for(n), 256, 0, mvs_stream(stream)>>>(w, g, ms, mom, n, lr, decay, momentum, eps, grad_scale);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_momentum_step_f32(float* w, const float* g, float* accum, size_t n, float lr, float momentum,
+                                     float grad_scale, void* stream) {
+    MVS_CHECK_ARG(w && g && accum && n > 0);
+    momentum_kernel<<<grid_for(n), 256, 0, mvs_stream(stream)>>>(w, g, accum, n, lr, momentum, grad_scale);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_adam_step_f32(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1,
+                                 float beta2, float eps, float grad_scale, void* stream) {
+    MVS_CHECK_ARG(w && g && m && v && n > 0);
+    adam_kernel<<<grid_for(n), 256, 0, mvs_stream(stream)>>>(w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
     MVS_LAUNCH_RET();
 }

@@ -200,13 +200,24 @@ wgrad_kernel(WgradArgs a) {
     }
 }
 
+// dW[i] = sum_p partial[p][i] in float64, fixed order: a workgroup owns 16 consecutive elements, its 16
+// "p lanes" walk the partials 16 apart (64-byte segments per row), then fold through LDS in lane order.
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ partial, int P, size_t wsz, float* __restrict__ dw) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= wsz) return;
+    __shared__ double red[16][17];
+    const int e = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + e;
     double s = 0.0;
-    for (int p = 0; p < P; ++p) s += (double)partial[(size_t)p * wsz + i];
-    dw[i] = (float)s;
+    if (i < wsz)
+        for (int p = pl; p < P; p += 16) s += (double)partial[(size_t)p * wsz + i];
+    red[pl][e] = s;
+    __syncthreads();
+    if (pl == 0 && i < wsz) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][e];
+        dw[i] = (float)t;
+    }
 }
 
 struct Plan { int tiles, chunks, ppw, slices; size_t lds; };
@@ -249,7 +260,7 @@ int run(const float* big, const float* small, int D, int H, int W, int CS, void*
     kern<<<grid, 256, p.lds, st>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    wgrad_reduce_kernel<<<mvs_cdiv((long long)wsz, 256), 256, 0, st>>>((const float*)ws, p.tiles * p.chunks, wsz, dw);
+    wgrad_reduce_kernel<<<mvs_cdiv((long long)wsz, 16), 256, 0, st>>>((const float*)ws, p.tiles * p.chunks, wsz, dw);
     return (int)hipGetLastError();
 }
 

@@ -4,7 +4,8 @@ Restates mvsnet/cnn_wrapper/mvsnetworks.py:53-115 with the layer semantics of
 mvsnet/cnn_wrapper/network.py:217-276 (conv_gn: conv no-bias -> GroupNorm(G = C//8, eps 1e-5,
 gamma, beta) -> ReLU), :350-409 (deconv_gn: no ReLU) and :171-215 (plain conv for conv10_2),
 all with TensorFlow 'SAME' padding (asymmetric for stride 2).  It produces the hot path's input;
-it is plumbing, not a HIP target this round.
+the HIP towers for inference are feature_net_hip.HipUNetDS2GN; this module
+is the fallback-free PyTorch-ROCm tower that training differentiates (north_star keeps it on torch).
 """
 from __future__ import annotations
 
@@ -43,7 +44,7 @@ def _same_pad(n, k, s):
 
 
 class UNetDS2GN:
-    """Inference-only functional module.  ``params`` uses TensorFlow variable layouts
+    """Functional module (inference entry point; see unet_forward / trainable_layers for training).  ``params`` uses TensorFlow variable layouts
     (numpy or torch): conv 'w' (k,k,Cin,Cout), transposed conv 'w' (k,k,Cout,Cin), 'gamma',
     'beta' (Cout,)."""
 
@@ -70,28 +71,45 @@ class UNetDS2GN:
         """images (V,H,W,3) channel-last float32 -> features (V,H/4,W/4,C) contiguous.
         Each view is normalised independently (GroupNorm is per sample), so running the V
         towers of mvsnet/model.py:392-406 as one batch is equivalent."""
-        x = images.to(self.device).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
-        acts = {"data": x}
-        for name, kind, srcs, k, stride, w, g, b in self.layers:
-            x = acts[srcs[0]] if len(srcs) == 1 else torch.cat([acts[s] for s in srcs], dim=1)
-            if kind == "dg":
-                n_h, n_w = x.shape[2], x.shape[3]
-                y = F.conv_transpose2d(x, w, stride=stride)          # full length s*(n-1)+k
-                pb_h = _same_pad(n_h * stride, k, stride)[0]
-                pb_w = _same_pad(n_w * stride, k, stride)[0]
-                y = y[:, :, pb_h:pb_h + n_h * stride, pb_w:pb_w + n_w * stride]
+        return unet_forward(self.layers, images.to(self.device))
+
+
+def unet_forward(layers, images):
+    """The tower itself; differentiable (training, SURVEY 8f f4, runs it under torch autograd with the
+    layer tensors being views of the trainer's flat parameter buffer).  `layers`: tuples
+    (name, kind, srcs, k, stride, w torch-layout, gamma, beta)."""
+    x = images.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    acts = {"data": x}
+    for name, kind, srcs, k, stride, w, g, b in layers:
+        x = acts[srcs[0]] if len(srcs) == 1 else torch.cat([acts[s] for s in srcs], dim=1)
+        if kind == "dg":
+            n_h, n_w = x.shape[2], x.shape[3]
+            y = F.conv_transpose2d(x, w, stride=stride)          # full length s*(n-1)+k
+            pb_h = _same_pad(n_h * stride, k, stride)[0]
+            pb_w = _same_pad(n_w * stride, k, stride)[0]
+            y = y[:, :, pb_h:pb_h + n_h * stride, pb_w:pb_w + n_w * stride]
+        else:
+            ph = _same_pad(x.shape[2], k, stride)
+            pw = _same_pad(x.shape[3], k, stride)
+            if ph[0] == ph[1] and pw[0] == pw[1]:
+                y = F.conv2d(x, w, stride=stride, padding=(ph[0], pw[0]))
             else:
-                ph = _same_pad(x.shape[2], k, stride)
-                pw = _same_pad(x.shape[3], k, stride)
-                if ph[0] == ph[1] and pw[0] == pw[1]:
-                    y = F.conv2d(x, w, stride=stride, padding=(ph[0], pw[0]))
-                else:
-                    y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), w, stride=stride)
-            if kind != "c":
-                C = y.shape[1]
-                y = F.group_norm(y, max(1, C // 8), g, b, eps=1e-5)   # network.py:246-254
-                if kind == "cg":
-                    y = F.relu(y)
-            acts[name] = y
-        out = acts["conv10_2"]
-        return out.permute(0, 2, 3, 1).contiguous()
+                y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), w, stride=stride)
+        if kind != "c":
+            C = y.shape[1]
+            y = F.group_norm(y, max(1, C // 8), g, b, eps=1e-5)   # network.py:246-254
+            if kind == "cg":
+                y = F.relu(y)
+        acts[name] = y
+    return acts["conv10_2"].permute(0, 2, 3, 1).contiguous()
+
+
+def trainable_layers(params):
+    """`params[name]` = {'w', 'gamma', 'beta'} torch tensors in the TensorFlow layouts (leaves or views that
+    require grad) -> the `layers` list of unet_forward (kernels permuted to the torch layouts per call)."""
+    layers = []
+    for name, kind, srcs, k, _mult, stride in UNET_LAYERS:
+        p = params[name]
+        w = p["w"].permute(3, 2, 0, 1)           # conv (k,k,Cin,Cout) -> (Cout,Cin,k,k); deconv (k,k,Cout,Cin) -> (Cin,Cout,k,k)
+        layers.append((name, kind, srcs, k, stride, w, p.get("gamma"), p.get("beta")))
+    return layers

@@ -82,6 +82,15 @@ def mask_depth_image(depth_image, min_depth, max_depth):
     return d[:, :, None]
 
 
+def flip_cams(cams, depth_num):
+    """mvs_data_generation/utils.py:166-171: reverse the reference view's depth range (start at the far
+    plane, negative interval) -- the GRU training augmentation.  Returns a copy."""
+    cams = np.copy(cams)
+    cams[0][1, 3, 0] = cams[0][1, 3, 0] + (depth_num - 1) * cams[0][1, 3, 1]
+    cams[0][1, 3, 1] = -cams[0][1, 3, 1]
+    return cams
+
+
 def scale_mvs_input(images, cams, scale=1, depth_image=None):
     """mvs_data_generation/utils.py:107-118; the GT depth is resized with nearest neighbour."""
     images, cams = [scale_image(i, scale) for i in images], [scale_camera(c, scale) for c in cams]
@@ -190,14 +199,20 @@ class Cluster:
 
 
 class ClusterGenerator:
-    """Inference-mode iterator of cluster_generator.py:27-286: yields
-    (output_images, input_images, output_cams, full_cams, image_index) once per cluster."""
+    """Iterator of cluster_generator.py:27-286.  'inference' / 'test': `data_dir` is one session; yields
+    (output_images, input_images, output_cams, full_cams, image_index[, depth]) once per cluster.
+    'train' / 'val' (cluster_generator.py:61-64,166-223): `data_dir`/train|val holds one sub-directory per
+    session; clusters of all sessions are shuffled (`seed`; the reference uses the global `random` state) and
+    each yields (images (N,H,W,3) centred, cams (N,2,4,4) scaled to the output, depth (H/4,W/4,1) nearest-
+    neighbour down-sampled masked GT, full depth (H,W,1)); clusters that fail to load are skipped as in the
+    reference (:217-220); with `flip_cams` (GRU training) every cluster is also yielded with its depth range
+    reversed."""
 
     def __init__(self, data_dir, view_num=3, image_width=1024, image_height=768, depth_num=256,
                  interval_scale=1, base_image_size=1, include_empty=False, mode="inference",
-                 output_scale=0.25, max_clusters_per_session=None):
-        if mode not in ("inference", "test"):
-            raise NotImplementedError("the training branches of the generator are not built (SURVEY 8f f4)")
+                 output_scale=0.25, max_clusters_per_session=None, flip_cams=False, sessions_frac=1.0, seed=0):
+        if mode not in ("inference", "test", "train", "val"):
+            raise ValueError("mode must be one of inference, test, train, val")
         self.mode = mode              # 'test' also yields the masked GT depth (cluster_generator.py:244-251)
         self.data_dir = data_dir
         self.view_num = view_num
@@ -207,8 +222,36 @@ class ClusterGenerator:
         self.include_empty = include_empty
         self.output_scale = output_scale
         self.max_clusters_per_session = max_clusters_per_session
+        self.flip_cams = flip_cams
         self.clusters = []
-        self.load_clusters(data_dir, self.clusters)
+        if mode in ("train", "val"):
+            sessions_dir = os.path.join(data_dir, mode)
+            sessions = sorted(f for f in os.listdir(sessions_dir)
+                              if not f.startswith(".") and not f.endswith(".txt") and not f.endswith(".pickle"))
+            for session in sessions[:int(len(sessions) * sessions_frac)]:
+                try:
+                    self.load_clusters(os.path.join(sessions_dir, session), self.clusters)
+                except (OSError, ValueError, KeyError):
+                    continue                                   # cluster_generator.py:110-113
+            import random
+            random.Random(seed).shuffle(self.clusters)         # :124-125
+        else:
+            self.load_clusters(data_dir, self.clusters)
+
+    def prepare_training(self, c):
+        """cluster_generator.py:171-196"""
+        images, cams = c.images(), c.cameras()
+        depth = c.masked_reference_depth()
+        if depth is None:
+            raise IOError("no ground-truth depth for reference view %d" % c.ref_index)
+        images, cams, depth = scale_mvs_input(images, cams, scale=c.rescale, depth_image=depth[:, :, 0])
+        images, cams, depth = crop_mvs_input(images, cams, self.image_width, self.image_height,
+                                             self.base_image_size, depth)
+        images = np.stack([center_image(i) for i in images], axis=0)
+        depth = depth.astype(np.float32)
+        rescaled = scale_image(depth, self.output_scale, "nearest")[:, :, None]
+        cams = np.stack([scale_camera(cam, self.output_scale) for cam in cams], axis=0)
+        return images, cams, rescaled, depth[:, :, None]
 
     def load_clusters(self, session_dir, clusters):
         with open(os.path.join(session_dir, "covisibility.json")) as f:
@@ -251,7 +294,16 @@ class ClusterGenerator:
 
     def __iter__(self):
         for c in self.clusters:
-            yield self.prepare(c)
+            if self.mode in ("train", "val"):
+                try:
+                    images, cams, rescaled, depth = self.prepare_training(c)
+                except (OSError, ValueError, KeyError):
+                    continue                                   # bad clusters are skipped (:217-220)
+                yield images, cams, rescaled, depth
+                if self.flip_cams:
+                    yield images, flip_cams(cams, self.depth_num), rescaled, depth
+            else:
+                yield self.prepare(c)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,322 @@
+"""Training of MVSNet (3D-CNN regulariser) on MI355X: host-side mirror of mvsnet/train.py.
+
+    python -m mvsnet_amd.train --train_data_root <root with train/ and val/ session folders> --model_dir <out>
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m mvsnet_amd.train ...
+
+What the reference does (train.py:412-523) and how it maps here:
+  * one TF graph with `num_gpus` towers, each pulling its own batch; tower gradients are averaged on the host
+    graph (`average_gradients`, train.py:155-187) and applied once per step  ->  one process per GPU
+    (`torch.distributed`, backend "nccl" = RCCL), every rank draws its own clusters (rank r takes clusters
+    r, r+P, ...), ONE all-reduce of the flat gradient buffer per step, then the optimiser update as one HIP
+    launch over the flat parameter buffer (all variables are views into it);
+  * loss = mvsnet_regression_loss on the 1/4-resolution depth map (train.py:350-353), flags loss_type / alpha /
+    beta / eta / grad_loss (train.py:121-134);
+  * tf.train.exponential_decay(base_lr, global_step, stepvalue, gamma) (train.py:256-257), RMSProp / momentum /
+    Adam with TensorFlow's defaults and update formulas (train.py:258-266);
+  * checkpoints `<model_dir>/<regularization>/<network_mode>/model.ckpt-<step>` (train.py:360-365) written in
+    TensorFlow's own bundle format with the reference's variable names (tf_checkpoint.py), so that either
+    code base can read them; optimiser slots ride along as `<var>/RMSProp`, `<var>/RMSProp_1`, ... and
+    `global_step`.
+The forward / backward of the hot path run in libmvsnet_hip.so (backward.py); the 2D towers are
+feature_net.unet_forward under torch autograd (north_star keeps them on PyTorch-ROCm).
+Not built: GRU training (the reference's GRU branch has arity bugs, train.py:355-364 vs model.py:505) and
+training through the refinement network (train.py:317-349): both raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import time
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import _lib, tf_checkpoint
+from .feature_net import UNET_LAYERS, trainable_layers, unet_forward
+from .homography_warping import homography_transforms
+from .loss import mvsnet_regression_loss
+from .synthetic import base_filter, make_regnet_params, make_unet_params
+
+
+def glorot_uniform_like(params, seed=0):
+    """tf.layers.conv2d/conv3d default kernel initialiser (glorot_uniform: limit = sqrt(6/(fan_in+fan_out)),
+    fan = receptive field x channels); gamma = 1, beta = 0 (network.py:257-267)."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name, p in params.items():
+        w = np.asarray(p["w"])
+        rf = int(np.prod(w.shape[:-2]))
+        limit = math.sqrt(6.0 / (rf * w.shape[-2] + rf * w.shape[-1]))
+        q = {"w": rs.uniform(-limit, limit, w.shape).astype(np.float32)}
+        if "gamma" in p:
+            q["gamma"] = np.ones_like(np.asarray(p["gamma"], np.float32))
+            q["beta"] = np.zeros_like(np.asarray(p["beta"], np.float32))
+        out[name] = q
+    return out
+
+
+def exponential_decay(base_lr, global_step, decay_steps, decay_rate):
+    """tf.train.exponential_decay, staircase=False (train.py:256-257)."""
+    return base_lr * decay_rate ** (float(global_step) / float(decay_steps))
+
+
+OPTIMIZER_SLOTS = {"rmsprop": ("RMSProp", "RMSProp_1"), "momentum": ("Momentum",), "adam": ("Adam", "Adam_1")}
+
+
+class FlatParameters:
+    """All trainable variables in one device buffer, TensorFlow layouts, addressed by the reference's variable
+    names; `grad` is a second flat buffer the leaves' .grad tensors are views of, so one all-reduce and one
+    optimiser launch cover the whole model."""
+
+    def __init__(self, unet, regnet, network_mode, device):
+        self.names = tf_checkpoint.variable_names(network_mode, "3DCNN")
+        src = {"unet": unet, "regnet": regnet}
+        self.index = []                                   # (key, var_name, offset, shape)
+        off = 0
+        for key in sorted(self.names, key=lambda k: self.names[k]):
+            group, layer, field = key
+            a = np.asarray(src[group][layer][field], np.float32)
+            self.index.append((key, self.names[key], off, a.shape))
+            off += a.size
+        self.numel = off
+        self.data = torch.empty(off, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=device, dtype=torch.float32)
+        host = np.empty(off, np.float32)
+        for key, _v, o, shape in self.index:
+            group, layer, field = key
+            host[o:o + int(np.prod(shape))] = np.asarray(src[group][layer][field], np.float32).ravel()
+        self.data.copy_(torch.from_numpy(host))
+        self.leaves: Dict[tuple, torch.Tensor] = {}
+        for key, _v, o, shape in self.index:
+            n = int(np.prod(shape))
+            leaf = self.data[o:o + n].view(shape).requires_grad_(True)
+            leaf.grad = self.grad[o:o + n].view(shape)
+            self.leaves[key] = leaf
+
+    def group(self, group):
+        out: Dict[str, Dict[str, torch.Tensor]] = {}
+        for (g, layer, field), leaf in self.leaves.items():
+            if g == group:
+                out.setdefault(layer, {})[field] = leaf
+        return out
+
+    def named_arrays(self, flat):
+        host = flat.detach().cpu().numpy()
+        return {v: host[o:o + int(np.prod(shape))].reshape(shape) for _k, v, o, shape in self.index}
+
+
+class Trainer:
+    def __init__(self, network_mode="normal", device="cuda", optimizer="rmsprop", base_lr=1e-3, stepvalue=70000,
+                 gamma=0.5, loss_type="power", alpha=0.25, beta=0.0, eta=0.02, grad_loss=True, init=None, seed=0):
+        if optimizer not in OPTIMIZER_SLOTS:
+            raise NotImplementedError("Optimizer %s is not implemented" % optimizer)       # train.py:268-271
+        self.network_mode, self.device = network_mode, torch.device(device)
+        self.optimizer, self.base_lr, self.stepvalue, self.gamma = optimizer, base_lr, stepvalue, gamma
+        self.loss_args = dict(loss_type=loss_type, alpha=alpha, beta=beta, eta=eta, grad_loss=grad_loss)
+        if init is None:
+            init = {"unet": glorot_uniform_like(make_unet_params(network_mode), seed),
+                    "regnet": glorot_uniform_like(make_regnet_params(network_mode), seed + 1)}
+        self.params = FlatParameters(init["unet"], init["regnet"], network_mode, self.device)
+        n = self.params.numel
+        ones = optimizer == "rmsprop"                    # TF's RMSProp `rms` slot starts at one
+        self.slots = [torch.ones(n, device=self.device) if (ones and i == 0) else torch.zeros(n, device=self.device)
+                      for i in range(len(OPTIMIZER_SLOTS[optimizer]))]
+        self.global_step = 0
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+
+    # -- one optimisation step ------------------------------------------------------------------------
+    def loss(self, images, cams, depth_image):
+        """images (N,H,W,3), cams (N,2,4,4) at the output scale, depth_image (H/4,W/4,1) GT.  Returns
+        (loss, less_one, less_three, depth_map) exactly as get_loss (train.py:307-353), batch 1."""
+        from .backward import plane_sweep_depth
+        images = torch.as_tensor(images, dtype=torch.float32, device=self.device)
+        cams_t = torch.as_tensor(cams, dtype=torch.float32, device=self.device)
+        gt = torch.as_tensor(depth_image, dtype=torch.float32, device=self.device)[None]
+        depth_start, depth_interval = float(cams[0][1][3][0]), float(cams[0][1][3][1])
+        depth_num = self.depth_num
+        depth_end = float(cams[0][1][3][3])
+        feats = unet_forward(trainable_layers(self.params.group("unet")), images)
+        transforms = homography_transforms(cams_t, depth_num, depth_start, depth_interval)
+        depth, _prob = plane_sweep_depth(feats, transforms, depth_start, depth_interval, self.params.group("regnet"))
+        est = depth[None, :, :, None]
+        ds = torch.tensor([depth_start], device=self.device)
+        de = torch.tensor([depth_end], device=self.device)
+        loss, l1, l3, _dbg = mvsnet_regression_loss(est, gt, ds, de, **self.loss_args)
+        return loss, l1, l3, depth
+
+    def learning_rate(self):
+        return exponential_decay(self.base_lr, self.global_step, self.stepvalue, self.gamma)
+
+    def reduce_gradients(self):
+        """average_gradients (train.py:155-187): ONE sum all-reduce of the flat gradient buffer (RCCL on the
+        GPUs, gloo in the CPU tests); returns the 1/world factor the update kernel applies."""
+        if self.world > 1:
+            torch.distributed.all_reduce(self.params.grad)
+        return 1.0 / self.world
+
+    def apply_gradients(self):
+        """average over ranks + optimiser update (train.py:444), one launch each."""
+        lib = _lib.load()
+        p, g = self.params.data, self.params.grad
+        scale = self.reduce_gradients()
+        lr, n = self.learning_rate(), self.params.numel
+        P = _lib.ptr
+        if self.optimizer == "rmsprop":
+            rc = lib.mvs_rmsprop_step_f32(P(p), P(g), P(self.slots[0]), P(self.slots[1]), n, lr, 0.9, 0.0, 1e-10, scale,
+                                          _lib.stream_ptr())
+        elif self.optimizer == "momentum":
+            rc = lib.mvs_momentum_step_f32(P(p), P(g), P(self.slots[0]), n, lr, 0.9, scale, _lib.stream_ptr())
+        else:
+            t = self.global_step + 1
+            lr_t = lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t)
+            rc = lib.mvs_adam_step_f32(P(p), P(g), P(self.slots[0]), P(self.slots[1]), n, lr_t, 0.9, 0.999, 1e-8, scale,
+                                       _lib.stream_ptr())
+        _lib.check(rc, "optimizer step")
+        g.zero_()
+        self.global_step += 1
+
+    def train_step(self, images, cams, depth_image, depth_num):
+        self.depth_num = depth_num
+        loss, l1, l3, _ = self.loss(images, cams, depth_image)
+        loss.backward()
+        self.apply_gradients()
+        return loss.detach(), l1.detach(), l3.detach()
+
+    @torch.no_grad()
+    def validate_step(self, images, cams, depth_image, depth_num):
+        self.depth_num = depth_num
+        loss, l1, l3, _ = self.loss(images, cams, depth_image)
+        return loss, l1, l3
+
+    # -- checkpoints ----------------------------------------------------------------------------------
+    def save(self, model_dir, regularization="3DCNN"):
+        """train.py:360-365: <model_dir>/<regularization>/<network_mode>/model.ckpt-<global step>."""
+        ck = tf_checkpoint.ckpt_path(model_dir, regularization, self.network_mode)
+        os.makedirs(os.path.dirname(ck), exist_ok=True)
+        prefix = tf_checkpoint.model_path(ck, self.global_step)
+        tensors = dict(self.params.named_arrays(self.params.data))
+        for slot, buf in zip(OPTIMIZER_SLOTS[self.optimizer], self.slots):
+            for var, arr in self.params.named_arrays(buf).items():
+                tensors[var + "/" + slot] = arr
+        tensors["global_step"] = np.asarray(self.global_step, np.int64)
+        tf_checkpoint.write_checkpoint(prefix, tensors)
+        return prefix
+
+    def restore(self, prefix):
+        """load_model (train.py:139-153): variables, optimiser slots when present, global_step."""
+        have = {name for name, _shape, _dt in tf_checkpoint.list_variables(prefix)}
+        want = [v for _k, v, _o, _s in self.params.index]
+        slot_names = [(v + "/" + s) for s in OPTIMIZER_SLOTS[self.optimizer] for v in want]
+        names = want + [s for s in slot_names if s in have] + (["global_step"] if "global_step" in have else [])
+        vals = tf_checkpoint.read_checkpoint(prefix, names)
+
+        def fill(buf, suffix):
+            host = buf.detach().cpu().numpy()
+            for _k, v, o, shape in self.params.index:
+                if v + suffix in vals:
+                    host[o:o + int(np.prod(shape))] = np.asarray(vals[v + suffix], np.float32).ravel()
+            buf.copy_(torch.from_numpy(host))
+
+        fill(self.params.data, "")
+        for slot, buf in zip(OPTIMIZER_SLOTS[self.optimizer], self.slots):
+            fill(buf, "/" + slot)
+        if "global_step" in vals:
+            self.global_step = int(np.asarray(vals["global_step"]).reshape(-1)[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# program entrance (train.py:526-535)
+# ------------------------------------------------------------------------------------------------
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Train MVSNet (3D-CNN regulariser) on MI355X")
+    a = p.add_argument
+    a("--train_data_root", required=True); a("--model_dir", required=True)
+    a("--model_load_dir", default=None); a("--ckpt_step", type=int, default=None)
+    a("--view_num", type=int, default=3); a("--max_d", type=int, default=192)
+    a("--width", type=int, default=640); a("--height", type=int, default=480)
+    a("--sample_scale", type=float, default=0.25); a("--interval_scale", type=float, default=1.0)
+    a("--base_image_size", type=int, default=8)
+    a("--regularization", default="3DCNN"); a("--optimizer", default="rmsprop")
+    a("--refinement", action="store_true"); a("--network_mode", default="lite")
+    a("--epoch", type=int, default=1); a("--max_steps_per_epoch", type=int, default=None)
+    a("--base_lr", type=float, default=0.001); a("--display", type=int, default=1)
+    a("--stepvalue", type=int, default=70000); a("--snapshot", type=int, default=5000)
+    a("--gamma", type=float, default=0.5); a("--val_batch_size", type=int, default=100)
+    a("--train_steps_per_val", type=int, default=500); a("--dataset_fraction", type=float, default=1.0)
+    a("--loss_type", default="power"); a("--alpha", type=float, default=0.25); a("--beta", type=float, default=0.0)
+    a("--eta", type=float, default=0.02); a("--no_grad_loss", action="store_true")
+    a("--seed", type=int, default=0)
+    return p
+
+
+def train(args):
+    from .mvs_data_generation import ClusterGenerator
+    from .shard import shard_indices
+    if args.regularization != "3DCNN":
+        raise NotImplementedError("only the 3DCNN regulariser trains here (the reference's GRU branch is broken)")
+    if args.refinement:
+        raise NotImplementedError("training through the refinement network is not built")
+    if args.network_mode != "normal":
+        raise NotImplementedError("weight-gradient kernels are built for network_mode 'normal' only")
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    tr = Trainer(args.network_mode, "cuda", args.optimizer, args.base_lr, args.stepvalue, args.gamma, args.loss_type,
+                 args.alpha, args.beta, args.eta, not args.no_grad_loss, seed=args.seed)
+    if args.ckpt_step:
+        ck = tf_checkpoint.ckpt_path(args.model_load_dir or args.model_dir, args.regularization, args.network_mode)
+        tr.restore(tf_checkpoint.model_path(ck, args.ckpt_step))
+    mk = lambda mode: ClusterGenerator(args.train_data_root, args.view_num, args.width, args.height, args.max_d,
+                                       args.interval_scale, args.base_image_size, mode=mode,
+                                       output_scale=args.sample_scale, sessions_frac=args.dataset_fraction,
+                                       seed=args.seed)
+    train_gen, val_gen = mk("train"), mk("val")
+    mine = shard_indices(len(train_gen.clusters), rank, world)
+    steps = len(mine) if args.max_steps_per_epoch is None else min(len(mine), args.max_steps_per_epoch)
+    if world > 1:                                   # every rank must take the same number of steps
+        t = torch.tensor([steps], device="cuda"); torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+        steps = int(t.item())
+    for epoch in range(args.epoch):
+        for step, ci in enumerate(mine[:steps]):
+            t0 = time.time()
+            try:
+                images, cams, depth, _full = train_gen.prepare_training(train_gen.clusters[ci])
+            except (OSError, ValueError, KeyError):
+                if world > 1:
+                    raise                              # a skipped step would desynchronise the all-reduce
+                continue
+            loss, l1, l3 = tr.train_step(images, cams, depth, args.max_d)
+            if step % args.display == 0 and rank == 0:
+                print("epoch, %d, step %d, total_step %d, loss = %.4f, (< 1px) = %.4f, (< 3px) = %.4f (%.3f sec/step)"
+                      % (epoch, step, tr.global_step, float(loss), float(l1), float(l3), time.time() - t0), flush=True)
+            if not math.isfinite(float(loss)):
+                raise SystemExit(1)                    # train.py:486-488
+            if rank == 0 and (tr.global_step % args.snapshot == 0 or step == steps - 1):
+                print("Saving model to", tr.save(args.model_dir, args.regularization), flush=True)
+            if rank == 0 and (step + 1) % args.train_steps_per_val == 0:
+                vals = []
+                for k, vc in enumerate(val_gen.clusters[:args.val_batch_size]):
+                    try:
+                        vi, vcam, vd, _ = val_gen.prepare_training(vc)
+                    except (OSError, ValueError, KeyError):
+                        continue
+                    vals.append([float(x) for x in tr.validate_step(vi, vcam, vd, args.max_d)])
+                if vals:
+                    m = np.mean(np.asarray(vals), axis=0)
+                    print("VAL STEP COMPLETED. Average loss: %g, Average less one: %g, Average less three: %g"
+                          % (m[0], m[1], m[2]), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def main(argv=None):
+    train(build_parser().parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()
