@@ -264,8 +264,9 @@ int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms,
  * mvs_softargmin_bwd_f32   g_reg(d) = -g_depth * P_d * (z_d - depth), P = softmax(-reg) (model.py:343-366)
  * mvs_bn_relu_f32          out = act(y*scale+shift) [+ act(y2*scale2+shift2)], act = ReLU when the scale
  *                          is given: the normalised layer input the forward kernels form on load
- * mvs_bn_bwd_reduce_f32    BatchNorm(batch statistics)+ReLU backward, pass 1: sums (2,C) float64 (zeroed
- *                          by the caller) += [sum gz, sum gz*xhat], gz = (g1 [+ g2]) * [y*scale+shift > 0],
+ * mvs_bn_bwd_reduce_f32    BatchNorm(batch statistics)+ReLU backward, pass 1: sums (S,2,C) float64 (zeroed
+ *                          by the caller; S = mvs_bn_bwd_sum_slots() partial rows that pass 2 folds, so that
+ *                          the float64 atomics of ~1000 workgroups do not serialise) += [sum gz, sum gz*xhat], gz = (g1 [+ g2]) * [y*scale+shift > 0],
  *                          xhat from `stats` (the forward's (2,C) sums) / count / eps (network.py:492-509)
  * mvs_bn_bwd_apply_f32     pass 2: g_y = gamma/std * (gz - mean(gz) - xhat*mean(gz*xhat));
  *                          g_gamma = sum gz*xhat, g_beta = sum gz (either may be NULL)
@@ -288,6 +289,7 @@ int mvs_softargmin_bwd_f32(const float* reg, const float* g_depth, int D, int H,
 int mvs_bn_relu_f32(const float* y, const float* scale, const float* shift, const float* y2,
                     const float* scale2, const float* shift2, size_t voxels, int C, float* out,
                     void* stream);
+int mvs_bn_bwd_sum_slots(void);
 int mvs_bn_bwd_reduce_f32(const float* y, const double* stats, double count, float eps,
                           const float* scale, const float* shift, const float* g1,
                           const float* g2, size_t voxels, int C, double* sums, void* stream);

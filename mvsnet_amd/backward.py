@@ -21,7 +21,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from .model import BN_EPSILON, REGNET_ORDER, bn_finalize, conv3d, cost_volume
+from .model import BN_EPSILON, REGNET_ORDER, bn_finalize, conv3d, conv3d_pair, cost_volume
 
 BN_LAYERS = REGNET_ORDER[:-1]
 
@@ -58,7 +58,7 @@ def bn_relu_bwd(y, stats, affine, gamma, g1, g2=None, eps=BN_EPSILON):
     lib = _lib.load()
     Cn = y.shape[-1]
     vox = y.numel() // Cn
-    sums = torch.zeros((2, Cn), device=y.device, dtype=torch.float64)
+    sums = torch.zeros((lib.mvs_bn_bwd_sum_slots(), 2, Cn), device=y.device, dtype=torch.float64)
     s, t = affine
     _lib.check(lib.mvs_bn_bwd_reduce_f32(_lib.ptr(y), _lib.ptr(stats), float(vox), float(eps), _lib.ptr(s), _lib.ptr(t),
                                          _lib.ptr(g1), _lib.ptr(g2), vox, Cn, _lib.ptr(sums), _lib.stream_ptr()),
@@ -156,10 +156,22 @@ def regnet_forward_train(cost, p: Dict[str, Dict[str, torch.Tensor]]):
         y[name], st[name] = out, s
         aff[name] = bn_finalize(s, out.numel() // cout, p[name]["gamma"], p[name]["beta"])
 
-    layer("3dconv1_0", cost, 2)
+    if cost.shape[3] == 32 and p["3dconv0_1"]["w"].shape[4] == 8 and not (cost.shape[0] | cost.shape[1] | cost.shape[2]) & 1:
+        # both consumers of the cost volume in one pass over it (mvs_conv3d_pair_f32)
+        s01 = torch.zeros((2, 8), device=dev, dtype=torch.float64)
+        s10 = torch.zeros((2, 16), device=dev, dtype=torch.float64)
+        y["3dconv0_1"], y["3dconv1_0"] = conv3d_pair(cost, p["3dconv0_1"]["w"], p["3dconv1_0"]["w"], s01, s10)
+        for nm, s in (("3dconv0_1", s01), ("3dconv1_0", s10)):
+            st[nm] = s
+            aff[nm] = bn_finalize(s, y[nm].numel() // y[nm].shape[3], p[nm]["gamma"], p[nm]["beta"])
+        fused = True
+    else:
+        fused = False
+        layer("3dconv1_0", cost, 2)
     layer("3dconv2_0", y["3dconv1_0"], 2, aff["3dconv1_0"])
     layer("3dconv3_0", y["3dconv2_0"], 2, aff["3dconv2_0"])
-    layer("3dconv0_1", cost, 1)
+    if not fused:
+        layer("3dconv0_1", cost, 1)
     layer("3dconv1_1", y["3dconv1_0"], 1, aff["3dconv1_0"])
     layer("3dconv2_1", y["3dconv2_0"], 1, aff["3dconv2_0"])
     layer("3dconv3_1", y["3dconv3_0"], 1, aff["3dconv3_0"])

@@ -75,6 +75,10 @@ bn_relu_kernel(const float* __restrict__ y, const float* __restrict__ s, const f
     }
 }
 
+// float64 atomics on one address serialise at ~80 ns each: the ~1000 workgroups of a pass-1 launch add into
+// BN_BWD_SLOTS partial rows that pass 2 folds.
+constexpr int BN_BWD_SLOTS = 32;
+
 // BatchNorm(batch statistics) + ReLU backward, pass 1: per channel  sum gz  and  sum gz * xhat  with
 // z = y*scale + shift, gz = (g1 [+ g2]) * [z > 0], xhat = (y - mean) * inv_std.
 // A thread keeps one channel quad (the grid stride is a multiple of C/4); float partials per thread,
@@ -115,10 +119,11 @@ bn_bwd_reduce_kernel(const float* __restrict__ y, const double* __restrict__ sta
         for (int j = tid; j < 256; j += cq)
 #pragma unroll
             for (int k = 0; k < 4; ++k) { sa[k] += red[j][k]; sb[k] += red[j][4 + k]; }
+        double* slot = sums + (size_t)(blockIdx.x % BN_BWD_SLOTS) * 2 * C;     // spread the float64 atomics
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            atomicAdd(sums + c + k, sa[k]);
-            atomicAdd(sums + C + c + k, sb[k]);
+            atomicAdd(slot + c + k, sa[k]);
+            atomicAdd(slot + C + c + k, sb[k]);
         }
     }
 }
@@ -133,6 +138,13 @@ bn_bwd_apply_kernel(const float* __restrict__ y, const double* __restrict__ stat
                     float* __restrict__ g_y, float* __restrict__ g_gamma, float* __restrict__ g_beta) {
     const int tid = threadIdx.x;
     const int c = (tid % cq) * 4, C = cq * 4;
+    __shared__ double tot[2 * 64];                     // folded slot rows: [sum gz | sum gz*xhat] per channel (C <= 64)
+    if (tid < 2 * C) {
+        double t = 0.0;
+        for (int sl = 0; sl < BN_BWD_SLOTS; ++sl) t += sums[(size_t)sl * 2 * C + tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
     float mean[4], inv[4], k0[4], k1[4], k2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -141,14 +153,12 @@ bn_bwd_apply_kernel(const float* __restrict__ y, const double* __restrict__ stat
         double is = 1.0 / sqrt(var + (double)eps);
         mean[k] = (float)mu; inv[k] = (float)is;
         k0[k] = (float)((double)gamma[c + k] * is);
-        k1[k] = (float)(sums[c + k] / count);
-        k2[k] = (float)(sums[C + c + k] / count);
-    }
-    if (blockIdx.x == 0 && tid < cq) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (g_beta) g_beta[c + k] = (float)sums[c + k];
-            if (g_gamma) g_gamma[c + k] = (float)sums[C + c + k];
+        const double s1 = tot[c + k], s2 = tot[C + c + k];
+        k1[k] = (float)(s1 / count);
+        k2[k] = (float)(s2 / count);
+        if (blockIdx.x == 0 && tid < cq) {
+            if (g_beta) g_beta[c + k] = (float)s1;
+            if (g_gamma) g_gamma[c + k] = (float)s2;
         }
     }
     const float4 sc = ld4(scale + c), sh = ld4(shift + c);
@@ -214,7 +224,10 @@ constexpr int CVB_MAX_SRC = 8;
 // One view's pending scatter: the 2x2 cell the lane's sample point is in and the gradient gathered for its
 // four taps.  Along depth the sample point slides along the epipolar line by a fraction of a pixel per
 // plane, so consecutive planes mostly hit the SAME cell: their contributions are summed here and go to
-// memory (float atomics) only when the cell changes -- several times fewer atomics than one per plane.
+// memory (float atomics) only when the cell changes -- several times fewer atomics than one per plane
+// (11.9 -> 2.9 ms at N=3, D=192, 120x160).  Tried and dropped: scattering into an LDS window of the source
+// patch per 8x8 / 16x8 pixel tile (ds_add_f32, flushed when the patch drifts out): ~20x fewer global
+// atomics but 5.3 ms -- a barrier per plane and the LDS read-modify-writes cost more than they saved.
 struct Pending {
     int ix0, iy0;                    // floor of the sample point (may be -1 .. W-1 / H-1); INT_MIN = empty
     float4 a00, a01, a10, a11;
@@ -352,6 +365,8 @@ extern "C" int mvs_softargmin_bwd_f32(const float* reg, const float* g_depth, in
     MVS_LAUNCH_RET();
 }
 
+extern "C" int mvs_bn_bwd_sum_slots(void) { return BN_BWD_SLOTS; }
+
 extern "C" int mvs_bn_relu_f32(const float* y, const float* scale, const float* shift, const float* y2,
                                const float* scale2, const float* shift2, size_t voxels, int C, float* out,
                                void* stream) {
@@ -379,7 +394,7 @@ extern "C" int mvs_bn_bwd_apply_f32(const float* y, const double* stats, double 
                                     const float* g1, const float* g2, const double* sums, size_t voxels,
                                     int C, float* g_y, float* g_gamma, float* g_beta, void* stream) {
     MVS_CHECK_ARG(y && stats && scale && shift && gamma && g1 && sums && g_y && voxels > 0 && C > 0 && count > 0);
-    if (C % 4 || 256 % (C / 4)) return MVS_E_SHAPE;
+    if (C % 4 || 256 % (C / 4) || C > 64) return MVS_E_SHAPE;
     const size_t n4 = voxels * (size_t)(C / 4);
     bn_bwd_apply_kernel<<<grid_for(n4), 256, 0, mvs_stream(stream)>>>(y, stats, count, eps, scale, shift, gamma, g1, g2,
                                                                       sums, n4, C / 4, g_y, g_gamma, g_beta);
@@ -392,12 +407,12 @@ extern "C" int mvs_cost_volume_bwd_f32(const float* ref, const float* src, const
     MVS_CHECK_ARG(ref && src && transforms && g1 && g_ref && g_src && view_num >= 2 && depth_num > 0 && H > 0 && W > 0);
     if (C % 4 || view_num - 1 > CVB_MAX_SRC) return MVS_E_SHAPE;
     if ((long long)H * W * C >= (1LL << 31)) return MVS_E_SHAPE;
+    hipStream_t st = mvs_stream(stream);
     const long long total = (long long)H * W * (C / 4);
     const int bx = mvs_cdiv(total, 256);
     int ppb = depth_num;                              // long runs along depth keep the pending cells alive
     while (ppb > 16 && (long long)bx * mvs_cdiv(depth_num, ppb) < 2048) ppb = (ppb + 1) / 2;
     dim3 grid(bx, mvs_cdiv(depth_num, ppb));
-    hipStream_t st = mvs_stream(stream);
 #define CVB_LAUNCH(NS) cost_volume_bwd_kernel<NS><<<grid, 256, 0, st>>>(ref, src, transforms, depth_num, ppb, H, W, C, \
                                                                         g1, g2, g_ref, g_src)
     switch (view_num - 1) {

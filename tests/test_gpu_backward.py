@@ -144,9 +144,11 @@ def _toy_problem(N=3, D=16, H=16, W=32, C=32):
     return feats, t8, start, interval
 
 
-def test_cost_volume_backward_matches_autograd():
+@pytest.mark.parametrize("shape", [(3, 16, 16, 32, 32), (5, 24, 40, 72, 32), (2, 8, 24, 24, 16)])
+def test_cost_volume_backward_matches_autograd(shape):
+    """2 / 4 / 1 source views, ragged sizes, 32 and 16 channels."""
     from mvsnet_amd import backward as B
-    feats, t8, _, _ = _toy_problem()
+    feats, t8, _, _ = _toy_problem(*shape)
     rs = np.random.RandomState(3)
     g1 = rs.randn(t8.shape[1], *feats.shape[1:]).astype(np.float32)
     g2 = rs.randn(*g1.shape).astype(np.float32)
