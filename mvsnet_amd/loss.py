@@ -1,7 +1,7 @@
 """Forward evaluation of the reference's depth losses and accuracies (mvsnet/loss.py:15-220), used by
 the benchmark driver `mvsnet_amd/test.py` (the caller `test.benchmark_depth_maps`, test.py:92-100).
-Tensors are torch (B,H,W,1); a ground-truth value of 0 marks an invalid pixel.  Training (SURVEY 8f
-f4) is not built; these are the same expressions, so autograd differentiates them if it ever is."""
+Tensors are torch (B,H,W,1); a ground-truth value of 0 marks an invalid pixel.  The trainer
+(`mvsnet_amd/train.py`) differentiates these same expressions with torch autograd."""
 from __future__ import annotations
 
 import torch
