@@ -270,7 +270,7 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
 
 // cells 2 / 3: gate conv then candidate conv (reset gate folded in); false if the shape has no instance
 template <int CA, int F>
-bool launch_small_cell(const float* xin, float* h, const float* const* p, int H, int W, float* g, float* c,
+bool launch_small_cell(const float* xin, const float* h, const float* const* p, int H, int W, float* g, float* c,
                        double* sg, double* so, hipStream_t st) {
     const int grid = ((H + 15) / 16) * ((W + 15) / 16);           // 16 x 16 pixel tiles
     conv2d_small_kernel<CA, F, 2 * F, 0><<<grid, 256, 0, st>>>(xin, h, nullptr, nullptr, nullptr, nullptr,
@@ -289,7 +289,7 @@ gru_blend_fused_kernel(const float* __restrict__ c, const double* __restrict__ s
                        const float* __restrict__ og, const float* __restrict__ ob,
                        const float* __restrict__ g, const double* __restrict__ stats_u,
                        const float* __restrict__ ug, const float* __restrict__ ub, int HW, int F,
-                       float* __restrict__ h) {
+                       const float* h, float* h_out) {       // may alias (non-pipelined sweep)
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i >= (long long)HW * F) return;
     const int f = (int)(i % F);
@@ -307,7 +307,7 @@ gru_blend_fused_kernel(const float* __restrict__ c, const double* __restrict__ s
         const double au = (double)ug[f + k] * iu, ac = (double)og[f + k] * ic;
         const float uu = sigmoidf(gv[k] * (float)au + (float)((double)ub[f + k] - mu * au));
         const float yv = tanhf(cv[k] * (float)ac + (float)((double)ob[f + k] - mc * ac));
-        h[i + k] = uu * hv[k] + (1.0f - uu) * yv;
+        h_out[i + k] = uu * hv[k] + (1.0f - uu) * yv;
     }
 }
 
@@ -407,7 +407,7 @@ extern "C" int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, i
 
 namespace {
 struct GruWs {
-    float *x, *g, *c, *rh, *u, *h1, *h2, *h3, *reg, *max_prob, *exp_sum, *wprep_g, *wprep_o;
+    float *x, *g[3], *c[3], *rh, *u, *h[3][2], *reg, *max_prob, *exp_sum, *wprep_g, *wprep_o;
     double* stats;     // per plane of a batch: 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
     size_t bytes;
 };
@@ -420,14 +420,38 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     size_t hw = (size_t)H * W, off = 0;
     auto take = [&](size_t nfloat) { char* p = base ? base + off : nullptr; off += align256(nfloat * 4); return (float*)p; };
     GruWs w;
+    const int F[3] = {f1, f2, f3};
     int fmax = f1 > f2 ? (f1 > f3 ? f1 : f3) : (f2 > f3 ? f2 : f3);
-    w.x = take(hw * C * XB); w.g = take(hw * 2 * fmax); w.c = take(hw * fmax); w.rh = take(hw * fmax);
-    w.u = take(hw * fmax); w.h1 = take(hw * f1); w.h2 = take(hw * f2); w.h3 = take(hw * f3);
+    w.x = take(hw * C * XB);
+    // every cell has its own gate / candidate buffers and a ping-pong state: the three cells of
+    // consecutive planes run concurrently (see mvs_gru_wta_f32)
+    for (int k = 0; k < 3; ++k) {
+        w.g[k] = take(hw * 2 * F[k]); w.c[k] = take(hw * F[k]);
+        w.h[k][0] = take(hw * F[k]); w.h[k][1] = take(hw * F[k]);
+    }
+    w.rh = take(hw * fmax); w.u = take(hw * fmax);
     w.reg = take(hw); w.max_prob = take(hw); w.exp_sum = take(hw);
     w.wprep_g = take((size_t)9 * (C + f1) * 2 * f1); w.wprep_o = take((size_t)9 * (C + f1) * f1);
-    w.stats = (double*)(base ? base + off : nullptr); off += align256((size_t)XB * 18 * 8);
+    w.stats = (double*)(base ? base + off : nullptr); off += align256((size_t)2 * XB * 18 * 8);   // two batches deep
     w.bytes = off;
     return w;
+}
+
+// Two side streams for cells 2 and 3 (created on first use; one host thread per device as elsewhere).
+struct GruStreams { hipStream_t s[2]; hipEvent_t fork, join[2], ready[2][2], read[2][2]; };
+GruStreams* gru_streams() {
+    static GruStreams g;
+    static int state = 0;
+    if (state == 0) {
+        state = -1;
+        bool ok = !getenv("MVS_GRU_ONE_STREAM");
+        for (int i = 0; ok && i < 2; ++i) ok = hipStreamCreateWithFlags(&g.s[i], hipStreamNonBlocking) == hipSuccess;
+        auto ev = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
+        ev(&g.fork);
+        for (int i = 0; i < 2; ++i) { ev(&g.join[i]); for (int j = 0; j < 2; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
+        if (ok) state = 1;
+    }
+    return state == 1 ? &g : nullptr;
 }
 }  // namespace
 
@@ -447,16 +471,14 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     hipStream_t st = mvs_stream(stream);
     const size_t hw = (size_t)H * W;
     hipError_t e;
+    const int F[3] = {f1, f2, f3};
     // zero initial states and WTA accumulators (model.py:649-654, 737-739)
-    if ((e = hipMemsetAsync(ws.h1, 0, hw * f1 * 4, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(ws.h2, 0, hw * f2 * 4, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(ws.h3, 0, hw * f3 * 4, st)) != hipSuccess) return (int)e;
+    for (int k = 0; k < 3; ++k)
+        if ((e = hipMemsetAsync(ws.h[k][0], 0, hw * F[k] * 4, st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(ws.max_prob, 0, hw * 4, st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(ws.exp_sum, 0, hw * 4, st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(depth_out, 0, hw * 4, st)) != hipSuccess) return (int)e;
 
-    const int F[3] = {f1, f2, f3};
-    float* hs[3] = {ws.h1, ws.h2, ws.h3};
     int rc;
     // cell 1 (90 % of the MACs) runs on the fp32-MFMA kernels when its shape fits their tiling
     bool mfma1 = (mvs_get_conv_impl() != MVS_CONV_IMPL_SCALAR) && C == 32 && f1 == 16;
@@ -464,64 +486,101 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
         if ((rc = mvs_gru_weight_layout(params[0], C + f1, 2 * f1, ws.wprep_g, st))) return rc;
         if ((rc = mvs_gru_weight_layout(params[6], C + f1, f1, ws.wprep_o, st))) return rc;
     }
+    // which kernels each cell gets; the generic conv + gates route shares rh / u and stays on one stream
+    const int cins[3] = {C, f1, f2};
+    int route[3];                                    // 0 generic, 1 MFMA (cell 1), 2 small-cell kernels
+    for (int k = 0; k < 3; ++k) {
+        const int ci = cins[k], f = F[k];
+        route[k] = (k == 0 && mfma1) ? 1
+                 : ((ci == 16 && f == 4) || (ci == 4 && f == 2) || (ci == 8 && f == 2) || (ci == 2 && f == 1)) ? 2 : 0;
+    }
+    // Wavefront over (plane, cell): cell k of plane d needs cell k-1 of plane d and cell k of plane d-1, so
+    // the three cells run on three streams, cell 1 of plane d+1 alongside cell 2 of plane d and cell 3 of
+    // plane d-1.  The small kernels of cells 2 / 3 (launch-latency bound, a few workgroups per CU) then fill
+    // the machine under cell 1's MFMA kernels instead of serialising behind them.  States ping-pong per plane
+    // (h[k][d&1] -> h[k][(d+1)&1]); events: ready[k][d&1] = state k of plane d written, read[k][d&1] = the
+    // consumer cell is done reading it (the producer may overwrite it two planes later).
+    GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2) ? gru_streams() : nullptr;
+    hipStream_t sk[3] = {st, gs ? gs->s[0] : st, gs ? gs->s[1] : st};
+    if (gs) {
+        if ((e = hipEventRecord(gs->fork, st)) != hipSuccess) return (int)e;
+        for (int i = 0; i < 2; ++i) if ((e = hipStreamWaitEvent(gs->s[i], gs->fork, 0)) != hipSuccess) return (int)e;
+    }
     const long long hw_ll = (long long)H * W;
     for (int d = 0; d < depth_num; ++d) {
-        const int slot = d % XB;
+        const int slot = d % XB, par = d & 1;
+        double* stats_d = ws.stats + (size_t)(((d / XB) & 1) * XB + slot) * 18;
         if (slot == 0) {
             // x = -variance cost of planes d .. d+XB-1 (model.py:680-693,698), LayerNorm sums of the batch
+            // (the other half of the stats ring may still be in use by cells 2 / 3 of the previous planes)
             const int nb = depth_num - d < XB ? depth_num - d : XB;
-            if ((e = hipMemsetAsync(ws.stats, 0, (size_t)XB * 18 * 8, st)) != hipSuccess) return (int)e;
+            if ((e = hipMemsetAsync(stats_d, 0, (size_t)XB * 18 * 8, st)) != hipSuccess) return (int)e;
             rc = mvs_cost_volume_f32(ref, src, transforms, view_num, depth_num, d, nb, H, W, C,
                                      /*variant*/ 1, /*negate*/ 1, /*border*/ 0, ws.x, stream);
             if (rc) return rc;
         }
         const float* xin = ws.x + (size_t)slot * hw * C;
-        int cin = C;
         for (int k = 0; k < 3; ++k) {
             const float* const* p = params + 10 * k;
-            double* sg = ws.stats + 18 * slot + 6 * k;
+            hipStream_t s = sk[k];
+            double* sg = stats_d + 6 * k;
             double* so = sg + 4;
-            if (k == 0 && mfma1) {
-                if ((rc = mvs_gru1_gates_mfma(xin, hs[0], ws.wprep_g, p[1], H, W, C, f1, ws.g, sg, st))) return rc;
-                if ((rc = mvs_gru1_out_mfma(xin, hs[0], ws.g, sg, p[2], p[3], ws.wprep_o, p[7], H, W, C, f1, ws.c, so, st))) return rc;
-            } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hs[k], p, H, W, ws.g, ws.c, sg, so, st)) {
-            } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hs[k], p, H, W, ws.g, ws.c, sg, so, st)) {
-            } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hs[k], p, H, W, ws.g, ws.c, sg, so, st)) {
-            } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hs[k], p, H, W, ws.g, ws.c, sg, so, st)) {
+            const float* hp = ws.h[k][par];
+            float* hn = gs ? ws.h[k][par ^ 1] : ws.h[k][par];        // one stream: in place, h[k][0] throughout
+            if (!gs) hp = hn = ws.h[k][0];
+            const int cin = cins[k];
+            if (gs && k > 0 && (e = hipStreamWaitEvent(s, gs->ready[k - 1][par], 0)) != hipSuccess) return (int)e;
+            if (route[k] == 1) {
+                if ((rc = mvs_gru1_gates_mfma(xin, hp, ws.wprep_g, p[1], H, W, C, f1, ws.g[k], sg, s))) return rc;
+                if ((rc = mvs_gru1_out_mfma(xin, hp, ws.g[k], sg, p[2], p[3], ws.wprep_o, p[7], H, W, C, f1, ws.c[k], so, s))) return rc;
+            } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
+            } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
+            } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
+            } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
             } else {
-                rc = launch_conv2d(xin, cin, hs[k], F[k], p[0], p[1], H, W, 2 * F[k], ws.g, sg, 2, st);
+                rc = launch_conv2d(xin, cin, hp, F[k], p[0], p[1], H, W, 2 * F[k], ws.g[k], sg, 2, s);
                 if (rc) return rc;
-                rc = mvs_gru_gates_f32(ws.g, sg, p[2], p[3], p[4], p[5], hs[k], H, W, F[k], ws.rh, ws.u, stream);
+                rc = mvs_gru_gates_f32(ws.g[k], sg, p[2], p[3], p[4], p[5], hp, H, W, F[k], ws.rh, ws.u, s);
                 if (rc) return rc;
-                rc = launch_conv2d(xin, cin, ws.rh, F[k], p[6], p[7], H, W, F[k], ws.c, so, 1, st);
+                rc = launch_conv2d(xin, cin, ws.rh, F[k], p[6], p[7], H, W, F[k], ws.c[k], so, 1, s);
                 if (rc) return rc;
             }
+            if (gs && k > 0 && (e = hipEventRecord(gs->read[k - 1][par], s)) != hipSuccess) return (int)e;   // x of plane d consumed
+            // the blend overwrites the state buffer cell k+1 read two planes ago
+            if (gs && k < 2 && d >= 2 && (e = hipStreamWaitEvent(s, gs->read[k][par], 0)) != hipSuccess) return (int)e;
             if (F[k] % 4 == 0)
-                gru_blend_fused_kernel<4><<<mvs_cdiv(hw_ll * F[k] / 4, 256), 256, 0, st>>>(
-                    ws.c, so, p[8], p[9], ws.g, sg + 2, p[4], p[5], H * W, F[k], hs[k]);
+                gru_blend_fused_kernel<4><<<mvs_cdiv(hw_ll * F[k] / 4, 256), 256, 0, s>>>(
+                    ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
             else if (F[k] % 2 == 0)
-                gru_blend_fused_kernel<2><<<mvs_cdiv(hw_ll * F[k] / 2, 256), 256, 0, st>>>(
-                    ws.c, so, p[8], p[9], ws.g, sg + 2, p[4], p[5], H * W, F[k], hs[k]);
+                gru_blend_fused_kernel<2><<<mvs_cdiv(hw_ll * F[k] / 2, 256), 256, 0, s>>>(
+                    ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
             else
-                gru_blend_fused_kernel<1><<<mvs_cdiv(hw_ll * F[k], 256), 256, 0, st>>>(
-                    ws.c, so, p[8], p[9], ws.g, sg + 2, p[4], p[5], H * W, F[k], hs[k]);
+                gru_blend_fused_kernel<1><<<mvs_cdiv(hw_ll * F[k], 256), 256, 0, s>>>(
+                    ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
             if ((rc = (int)hipGetLastError())) return rc;
-            xin = hs[k];
-            cin = F[k];
+            if (gs && k < 2 && (e = hipEventRecord(gs->ready[k][par], s)) != hipSuccess) return (int)e;
+            xin = hn;
         }
         // prob_conv + exp + winner-take-all update (model.py:701-731)
         const int grid = mvs_cdiv(hw_ll, 256);
+        hipStream_t s3 = sk[2];
+        const float* h3 = xin;
         switch (f3) {
-            case 1: prob_wta_kernel<1><<<grid, 256, 0, st>>>(ws.h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
-            case 2: prob_wta_kernel<2><<<grid, 256, 0, st>>>(ws.h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
-            case 4: prob_wta_kernel<4><<<grid, 256, 0, st>>>(ws.h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+            case 1: prob_wta_kernel<1><<<grid, 256, 0, s3>>>(h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+            case 2: prob_wta_kernel<2><<<grid, 256, 0, s3>>>(h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+            case 4: prob_wta_kernel<4><<<grid, 256, 0, s3>>>(h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
             default:
-                rc = launch_conv2d(ws.h3, f3, nullptr, 0, params[30], params[31], H, W, 1, ws.reg, nullptr, 1, st);
+                rc = launch_conv2d(h3, f3, nullptr, 0, params[30], params[31], H, W, 1, ws.reg, nullptr, 1, s3);
                 if (rc) return rc;
-                rc = mvs_wta_update_f32(ws.reg, depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum, stream);
+                rc = mvs_wta_update_f32(ws.reg, depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum, s3);
                 if (rc) return rc;
         }
         if ((rc = (int)hipGetLastError())) return rc;
     }
+    if (gs)
+        for (int i = 0; i < 2; ++i) {
+            if ((e = hipEventRecord(gs->join[i], gs->s[i])) != hipSuccess) return (int)e;
+            if ((e = hipStreamWaitEvent(st, gs->join[i], 0)) != hipSuccess) return (int)e;
+        }
     return mvs_wta_finish_f32(ws.max_prob, ws.exp_sum, H, W, prob_out, stream);
 }

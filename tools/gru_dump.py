@@ -1,0 +1,24 @@
+"""Runs the recurrent sweep at a workload size and saves depth / prob maps: used to compare the pipelined
+(three streams) and the single-stream sweep (MVS_GRU_ONE_STREAM=1) at full size."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvsnet_amd import synthetic as S, model as M
+
+wl = S.make_workload(sys.argv[1] if len(sys.argv) > 2 else "c3")
+out = sys.argv[-1]
+weights = M.MVSNetWeights.from_numpy("normal", gru=S.make_gru_params("normal", random_affine=True), device="cuda")
+feats = torch.as_tensor(wl.features).cuda()
+cams = torch.as_tensor(wl.cams).cuda()
+res = []
+for rep in range(3):
+    plan = M.DepthPlan(wl.view_num, wl.depth_num, wl.height, wl.width, 32, weights, "GRU")
+    end = wl.depth_start + (wl.depth_num - 1) * wl.depth_interval
+    plan.set_cameras(cams, wl.depth_start, wl.depth_interval, end, False)
+    dv = [wl.depth_start + i * wl.depth_interval for i in range(wl.depth_num)]
+    d, p = plan.run_gru(feats, dv)
+    torch.cuda.synchronize()
+    res.append((d.cpu().numpy().copy(), p.cpu().numpy().copy()))
+assert all(np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1], r[1]) for r in res[1:]), "run-to-run mismatch"
+np.savez(out, depth=res[0][0], prob=res[0][1])
+print("saved", out, float(res[0][0].mean()), float(res[0][1].mean()))
