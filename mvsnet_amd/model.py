@@ -32,12 +32,43 @@ def _dev(a, device):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(device).contiguous()
 
 
+def pad_regnet_params(params):
+    """Zero-pads RegNetUS0 parameters of a narrower network_mode (semilite / lite / ultralite: base_filter
+    6 / 4 / 2, mvsnetworks.py:126-127) to the channel counts of 'normal' (base 8, 32-channel volume), the
+    shapes the fp32-MFMA kernels tile.  Padded kernels are zero and padded gamma / beta are zero, so the
+    extra channels carry exact zeros through conv, BatchNorm (0 * xhat + 0) and ReLU and the real channels
+    see the same sums: same function, ~8x (lite) to ~25x (semilite) faster than the shape-generic VALU
+    kernels those modes would otherwise fall back to."""
+    from .synthetic import make_regnet_params
+    target = make_regnet_params("normal")
+    out = {}
+    for n in REGNET_ORDER:
+        q = {}
+        for key, a in params[n].items():
+            a = np.asarray(a, np.float32)
+            shape = np.asarray(target[n][key]).shape
+            if any(sa > st for sa, st in zip(a.shape, shape)):
+                return None                                   # wider than 'normal' (fat modes): no padding
+            z = np.zeros(shape, np.float32)
+            z[tuple(slice(0, k) for k in a.shape)] = a
+            q[key] = z
+        out[n] = q
+    return out
+
+
 class RegNetWeights:
     """RegNetUS0 parameters resident on the device, TensorFlow variable layouts
-    (conv (3,3,3,Cin,Cout), conv3d_transpose (3,3,3,Cout,Cin), BN gamma/beta)."""
+    (conv (3,3,3,Cin,Cout), conv3d_transpose (3,3,3,Cout,Cin), BN gamma/beta).  `cin_native` is the
+    channel count of the feature maps the parameters were trained for; `cin` what the kernels run
+    (32 after padding narrower modes, see pad_regnet_params)."""
 
-    def __init__(self, params: Dict[str, dict], device="cuda"):
+    def __init__(self, params: Dict[str, dict], device="cuda", pad_to_mfma=True):
         self.device = torch.device(device)
+        self.cin_native = int(np.asarray(params[REGNET_ORDER[0]]["w"]).shape[3])
+        if pad_to_mfma and self.cin_native < 32:
+            padded = pad_regnet_params(params)
+            if padded is not None:
+                params = padded
         self.w = [_dev(params[n]["w"], device) for n in REGNET_ORDER]
         self.gamma = [_dev(params[n]["gamma"], device) for n in REGNET_ORDER[:-1]]
         self.beta = [_dev(params[n]["beta"], device) for n in REGNET_ORDER[:-1]]
@@ -178,6 +209,9 @@ def regnet_us0(cost_volume_, weights: RegNetWeights, workspace=None, out=None):
     """RegNetUS0 (mvsnetworks.py:122-158): (D,H,W,Cin) -> filtered cost volume (D,H,W)."""
     lib = _lib.load()
     D, H, W, Cin = cost_volume_.shape
+    if Cin == weights.cin_native and Cin != weights.cin:      # narrower mode running zero-padded (RegNetWeights)
+        cost_volume_ = torch.nn.functional.pad(cost_volume_, (0, weights.cin - Cin)).contiguous()
+        Cin = weights.cin
     if Cin != weights.cin:
         raise _lib.MvsnetHipError("cost volume has %d channels, weights expect %d" % (Cin, weights.cin))
     need = lib.mvs_regnet_workspace_bytes(D, H, W, Cin, weights.base)
@@ -257,6 +291,9 @@ class DepthPlan:
         self.depth = f(height, width)
         self.prob = f(height, width)
         if regularization == "3DCNN":
+            # narrower network modes run zero-padded to the MFMA kernels' 32-channel volume (RegNetWeights)
+            self.C = channels = max(channels, weights.regnet.cin)
+            self.fpad = torch.zeros((view_num, height, width, channels), device=dev, dtype=torch.float32)
             self.cost = f(depth_num, height, width, channels)
             self.reg = f(depth_num, height, width)
             nbytes = lib.mvs_regnet_workspace_bytes(depth_num, height, width, channels, weights.regnet.base)
@@ -277,6 +314,9 @@ class DepthPlan:
 
     def run_3dcnn(self, features, depth_start, depth_interval, inverse_depth=False, variant="mem"):
         """features (N,H,W,C): cost volume -> RegNetUS0 -> soft-argmin.  Cameras must be set."""
+        if features.shape[-1] != self.C:
+            self.fpad[..., :features.shape[-1]].copy_(features)       # padded channels stay zero
+            features = self.fpad
         cost_volume(features[0], features[1:], self.transforms, 0, self.D, variant, out=self.cost)
         regnet_us0(self.cost, self.weights.regnet, self.workspace, self.reg)
         softargmin_prob(self.reg, depth_start, depth_interval, inverse_depth, self.depth, self.prob)

@@ -259,15 +259,21 @@ def test_conv_kat_pad_side_and_crop_on_device():
     assert np.array_equal(y, exp)
 
 
-@pytest.mark.parametrize("mode,shape", [("normal", (8, 16, 16)), ("lite", (16, 8, 24)), ("semilite", (8, 8, 8))])
-def test_regnet_matches_oracle(mode, shape):
+@pytest.mark.parametrize("pad", [True, False])
+@pytest.mark.parametrize("mode,shape", [("normal", (8, 16, 16)), ("lite", (16, 8, 24)), ("semilite", (8, 8, 8)),
+                                        ("ultralite", (8, 16, 16))])
+def test_regnet_matches_oracle(mode, shape, pad):
+    """pad=True: narrower modes run zero-padded on the MFMA kernels' shapes (model.pad_regnet_params);
+    pad=False: their native channel counts on the shape-generic kernels."""
     from mvsnet_amd.model import RegNetWeights, regnet_us0
     D, H, W = shape
     params = S.make_regnet_params(mode, seed=11, random_affine=True)
     C = 4 * S.base_filter(mode)
     rs = np.random.RandomState(12)
     cost = np.abs(rs.standard_normal((D, H, W, C))).astype(np.float32)
-    got = n(regnet_us0(t(cost), RegNetWeights(params, DEV)))
+    wts = RegNetWeights(params, DEV, pad_to_mfma=pad)
+    assert wts.cin == (32 if pad else C) and wts.cin_native == C
+    got = n(regnet_us0(t(cost), wts))
     exp = O.regnet_us0(cost, params, np.float64)
     assert got.shape == (D, H, W)
     assert rel_l1(got, exp) < 2e-5
@@ -355,12 +361,13 @@ def test_gru_wta_matches_oracle(inverse):
 
 
 # ---- R10 end to end -------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name,inverse", [("toy", False), ("toy", True), ("small", False)])
-def test_inference_mem_from_features_matches_oracle(name, inverse):
+@pytest.mark.parametrize("name,inverse,mode", [("toy", False, "normal"), ("toy", True, "normal"), ("small", False, "normal"),
+                                               ("toy", False, "lite"), ("small", False, "semilite")])
+def test_inference_mem_from_features_matches_oracle(name, inverse, mode):
     from mvsnet_amd.model import MVSNetWeights, inference_mem
-    w = S.make_workload(name)
-    rp = S.make_regnet_params("normal", seed=1, random_affine=True)
-    weights = MVSNetWeights.from_numpy("normal", regnet=rp, device=DEV)
+    w = S.make_workload(name, network_mode=mode)
+    rp = S.make_regnet_params(mode, seed=1, random_affine=True)
+    weights = MVSNetWeights.from_numpy(mode, regnet=rp, device=DEV)
     depth, prob = inference_mem(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_interval,
                                 inverse_depth=inverse, weights=weights, features=t(w.features))
     ed, ep = O.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start,
