@@ -19,6 +19,8 @@ What the reference does (train.py:412-523) and how it maps here:
     `global_step`.
 The forward / backward of the hot path run in libmvsnet_hip.so (backward.py); the 2D towers are
 feature_net.unet_forward under torch autograd (north_star keeps them on PyTorch-ROCm).
+network_mode: 'normal' natively; 'semilite' / 'lite' (the reference's default) / 'ultralite' zero-padded to the
+'normal' shapes (padded entries provably stay zero); wider modes raise NotImplementedError.
 Not built: GRU training (the reference's GRU branch has arity bugs, train.py:355-364 vs model.py:505) and
 training through the refinement network (train.py:317-349): both raise NotImplementedError.
 """
@@ -118,7 +120,24 @@ class Trainer:
         if init is None:
             init = {"unet": glorot_uniform_like(make_unet_params(network_mode), seed),
                     "regnet": glorot_uniform_like(make_regnet_params(network_mode), seed + 1)}
-        self.params = FlatParameters(init["unet"], init["regnet"], network_mode, self.device)
+        # narrower modes ('lite' is the reference's default, train.py:82) train zero-padded to the shapes the
+        # MFMA kernels tile (model.pad_regnet_params): padded kernels / gamma / beta receive exactly zero
+        # gradients (their inputs or their BN scale are zero), so they stay zero; checkpoints hold the native shapes
+        from .model import pad_regnet_params
+        regnet = init["regnet"]
+        self.native_shapes = {}
+        names = tf_checkpoint.variable_names(network_mode, "3DCNN")
+        for (group, layer, field), var in names.items():
+            if group == "regnet":
+                self.native_shapes[var] = tuple(np.asarray(regnet[layer][field]).shape)
+        if np.asarray(regnet["3dconv1_0"]["w"]).shape[3] < 32:
+            padded = pad_regnet_params(regnet)
+            if padded is None:
+                raise NotImplementedError("network_mode %r: no weight-gradient kernels for these channel counts" % network_mode)
+            regnet = padded
+        elif np.asarray(regnet["3dconv1_0"]["w"]).shape[3] > 32:
+            raise NotImplementedError("network_mode %r: no weight-gradient kernels for these channel counts" % network_mode)
+        self.params = FlatParameters(init["unet"], regnet, network_mode, self.device)
         n = self.params.numel
         ones = optimizer == "rmsprop"                    # TF's RMSProp `rms` slot starts at one
         self.slots = [torch.ones(n, device=self.device) if (ones and i == 0) else torch.zeros(n, device=self.device)
@@ -138,6 +157,8 @@ class Trainer:
         depth_num = self.depth_num
         depth_end = float(cams[0][1][3][3])
         feats = unet_forward(trainable_layers(self.params.group("unet")), images)
+        if feats.shape[-1] < 32:
+            feats = torch.nn.functional.pad(feats, (0, 32 - feats.shape[-1]))      # padded channels: zero cost, zero gradient
         transforms = homography_transforms(cams_t, depth_num, depth_start, depth_interval)
         depth, _prob = plane_sweep_depth(feats, transforms, depth_start, depth_interval, self.params.group("regnet"))
         est = depth[None, :, :, None]
@@ -196,9 +217,12 @@ class Trainer:
         ck = tf_checkpoint.ckpt_path(model_dir, regularization, self.network_mode)
         os.makedirs(os.path.dirname(ck), exist_ok=True)
         prefix = tf_checkpoint.model_path(ck, self.global_step)
-        tensors = dict(self.params.named_arrays(self.params.data))
+        def native(arrays):                           # padded regulariser variables back to their own shapes
+            return {v: np.ascontiguousarray(a[tuple(slice(0, k) for k in self.native_shapes.get(v, a.shape))])
+                    for v, a in arrays.items()}
+        tensors = native(self.params.named_arrays(self.params.data))
         for slot, buf in zip(OPTIMIZER_SLOTS[self.optimizer], self.slots):
-            for var, arr in self.params.named_arrays(buf).items():
+            for var, arr in native(self.params.named_arrays(buf)).items():
                 tensors[var + "/" + slot] = arr
         tensors["global_step"] = np.asarray(self.global_step, np.int64)
         tf_checkpoint.write_checkpoint(prefix, tensors)
@@ -216,7 +240,13 @@ class Trainer:
             host = buf.detach().cpu().numpy()
             for _k, v, o, shape in self.params.index:
                 if v + suffix in vals:
-                    host[o:o + int(np.prod(shape))] = np.asarray(vals[v + suffix], np.float32).ravel()
+                    a = np.asarray(vals[v + suffix], np.float32)
+                    view = host[o:o + int(np.prod(shape))].reshape(shape)
+                    if suffix == "/RMSProp":
+                        view[...] = 1.0                    # padded entries of the rms slot keep TensorFlow's initial one
+                    elif a.shape != tuple(shape):
+                        view[...] = 0.0
+                    view[tuple(slice(0, k) for k in a.shape)] = a
             buf.copy_(torch.from_numpy(host))
 
         fill(self.params.data, "")
@@ -259,8 +289,6 @@ def train(args):
         raise NotImplementedError("only the 3DCNN regulariser trains here (the reference's GRU branch is broken)")
     if args.refinement:
         raise NotImplementedError("training through the refinement network is not built")
-    if args.network_mode != "normal":
-        raise NotImplementedError("weight-gradient kernels are built for network_mode 'normal' only")
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)

@@ -258,3 +258,35 @@ def test_trainer_checkpoint_round_trip(tmp_path):
     # and the inference path loads what training wrote
     loaded = tf_checkpoint.load_mvsnet_params(prefix, "normal", "3DCNN")
     assert np.array_equal(loaded["regnet"]["3dconv6_2"]["w"], saved_w)
+
+
+def test_trainer_lite_mode_trains_padded_and_saves_native_shapes(tmp_path):
+    """'lite' (the reference's training default) runs zero-padded on the 'normal' kernel shapes: the padded
+    entries must stay exactly zero and checkpoints must hold the native shapes."""
+    from mvsnet_amd import train as T
+    from mvsnet_amd import tf_checkpoint
+    images, cams, gt, D = _train_batch()
+    tr = T.Trainer("lite", DEV, seed=0)
+    losses = [float(tr.train_step(images, cams, gt, D)[0]) for _ in range(6)]
+    assert all(np.isfinite(losses)) and min(losses[-2:]) < losses[0], losses
+    w = tr.params.group("regnet")["3dconv0_1"]["w"]
+    assert tuple(w.shape) == (3, 3, 3, 32, 8)
+    w = w.detach()
+    assert float(w[:, :, :, 16:, :].abs().max()) == 0.0 and float(w[:, :, :, :, 4:].abs().max()) == 0.0
+    assert float(w[:, :, :, :16, :4].abs().max()) > 0.0
+    g = tr.params.group("regnet")["3dconv0_1"]["gamma"].detach()
+    assert float(g[4:].abs().max()) == 0.0 and float(g[:4].min()) > 0.5
+    prefix = tr.save(str(tmp_path))
+    shapes = {nm: shp for nm, shp, _d in tf_checkpoint.list_variables(prefix)}
+    assert shapes["3dconv0_1/kernel"] == (3, 3, 3, 16, 4) and shapes["3dconv0_1/kernel/RMSProp"] == (3, 3, 3, 16, 4)
+    assert shapes["2dconv1_0/kernel"][-1] == 8                              # lite towers: base_filter 4
+    tr2 = T.Trainer("lite", DEV, seed=9)
+    tr2.restore(prefix)
+    assert torch.equal(tr2.params.data, tr.params.data)
+    for a, b in zip(tr2.slots, tr.slots):            # slots agree on the native entries (padded ones never matter)
+        na, nb = tr.params.named_arrays(a), tr.params.named_arrays(b)
+        for var, shp in tr.native_shapes.items():
+            sl = tuple(slice(0, k) for k in shp)
+            assert np.array_equal(na[var][sl], nb[var][sl]), var
+    loaded = tf_checkpoint.load_mvsnet_params(prefix, "lite", "3DCNN")       # the inference path reads it back
+    assert loaded["regnet"]["3dconv0_1"]["w"].shape == (3, 3, 3, 16, 4)
