@@ -70,7 +70,7 @@ def pmc_traffic():
         if "hbm_write_bytes" not in d:
             continue
         b = (d["hbm_read_bytes_corrected_x2"] + d["hbm_write_bytes"]) * d.get("launches_per_depth_map", 1.0)
-        if "conv3d_c8_kernel" in name:
+        if "::conv3d_c8_kernel" in name:                  # not deconv3d_c8_kernel
             out["pair"] += d["hbm_read_bytes_corrected_x2"] + d["hbm_write_bytes"]       # per launch
         if "cost_volume" in name:
             out["warp"] += b

@@ -5,14 +5,18 @@ import collections, csv, glob, json, os, sys
 src, dst = sys.argv[1], sys.argv[2]
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 if stats:
-    rows = list(csv.DictReader(open(sorted(stats)[-1])))
+    rows = list(csv.DictReader(open(max(stats, key=os.path.getmtime))))
     with open(dst + "_kernel_stats.csv", "w") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows:
             w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+for pass_dir in glob.glob(os.path.join(src, "pmc_*")):
+    files = glob.glob(os.path.join(pass_dir, "*", "*counter_collection.csv"))
+    if not files:
+        continue
+    f = max(files, key=os.path.getmtime)      # gpurun merges every collection into the same tree: newest only
     for r in csv.DictReader(open(f)):
         pmc[r["Kernel_Name"][:110]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}

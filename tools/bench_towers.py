@@ -1,0 +1,18 @@
+"""Forward + backward of the 2D towers alone (torch autograd), steady state: where a training step's time goes."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvsnet_amd import synthetic as S, train as T
+from mvsnet_amd.feature_net import trainable_layers, unet_forward
+
+N, H, W = 3, 480, 640
+tr = T.Trainer("normal", "cuda")
+images = torch.as_tensor(S.make_images(N, H, W)).cuda()
+def step():
+    f = unet_forward(trainable_layers(tr.params.group("unet")), images)
+    f.sum().backward()
+for _ in range(3): step()
+torch.cuda.synchronize(); t0 = time.time()
+for _ in range(10): step()
+torch.cuda.synchronize()
+print({"towers_fwd_bwd_ms": round((time.time() - t0) / 10 * 1e3, 2)})
