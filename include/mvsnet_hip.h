@@ -306,6 +306,22 @@ int mvs_cost_volume_bwd_f32(const float* ref, const float* src, const float* tra
                             const float* g2, float* g_ref, float* g_src, void* stream);
 int mvs_rmsprop_step_f32(float* w, const float* g, float* ms, float* mom, size_t n, float lr,
                          float decay, float momentum, float eps, float grad_scale, void* stream);
+/* GroupNorm (+ReLU) of the 2D towers for TRAINING (Network.conv_gn / deconv_gn, network.py:217-276, 350-409:
+ * groups of 8 channels, biased variance; inference fuses GroupNorm into mvs_conv2d_gn_f32 instead).
+ *   x, y, g, dx   (V, hw, C) channel-last, C a multiple of 8
+ *   stats         (V, 2, C) float64 per-channel [sum, sum of squares] of x, zeroed by the caller before
+ *                 mvs_gn_stats_f32 (group moments are folded from a group's 8 channel sums where needed)
+ *   sums          (V, 2, C) float64 [sum gz, sum gz*xhat], zeroed by the caller before mvs_gn_bwd_reduce_f32;
+ *                 g_beta(c) = sum_v sums(v,0,c), g_gamma(c) = sum_v sums(v,1,c)
+ *   relu          1: y = ReLU(gamma*xhat+beta) (conv_gn), 0: no activation (deconv_gn) */
+int mvs_gn_stats_f32(const float* x, int V, size_t hw, int C, double* stats, void* stream);
+int mvs_gn_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
+                     int relu, int V, size_t hw, int C, float* y, void* stream);
+int mvs_gn_bwd_reduce_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
+                          int relu, const float* g, int V, size_t hw, int C, double* sums, void* stream);
+int mvs_gn_bwd_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
+                         int relu, const float* g, const double* sums, int V, size_t hw, int C, float* dx,
+                         void* stream);
 /* The other two optimisers of setup_optimizer (train.py:248-271): tf.train.MomentumOptimizer
  * (accum = momentum*accum + g; w -= lr*accum) and tf.train.AdamOptimizer (lr_t = lr*sqrt(1-beta2^t)/
  * (1-beta1^t) formed by the caller; w -= lr_t*m/(sqrt(v)+eps)). */

@@ -313,6 +313,121 @@ cost_volume_bwd_kernel(const float* __restrict__ ref, const float* __restrict__ 
     unsafeAtomicAdd(pr + 2, gr.z); unsafeAtomicAdd(pr + 3, gr.w);
 }
 
+// ---- GroupNorm (+ReLU) of the 2D towers for training (Network.conv_gn / deconv_gn, network.py:217-276,350-409:
+// groups of 8 channels, biased variance, eps 1e-5).  torch's group_norm spends ~0.4 ms per layer in its
+// moments kernel on channel-last tensors (12 of the towers' 14.5 ms forward); these are plain HBM passes.
+// x (V, HW, C) channel-last; stats (V, 2, C) float64 per-channel [sum, sumsq] (group moments are folded from
+// the 8 channel sums of a group wherever they are needed); sums (V, 2, C) float64 [sum gz, sum gz*xhat].
+constexpr int GN_CH = 8;
+
+// mode 0: stats += [x, x^2];  mode 1: sums += [gz, gz*xhat], gz = g * [gamma*xhat+beta > 0] (when relu)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+gn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ g, const double* __restrict__ stats,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
+                 size_t hw, int cq, double* __restrict__ out) {
+    __shared__ float red[256][8];
+    const int tid = threadIdx.x, v = blockIdx.y;
+    const int c = (tid % cq) * 4, C = cq * 4;
+    const size_t n4 = hw * cq;
+    const float* xv = x + (size_t)v * n4 * 4;
+    const float* gv = MODE ? g + (size_t)v * n4 * 4 : nullptr;
+    float mean = 0.f, inv = 1.f, ga[4] = {1, 1, 1, 1}, be[4] = {0, 0, 0, 0};
+    if (MODE) {
+        const int c0 = c & ~(GN_CH - 1);
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < GN_CH; ++k) { s += stats[((size_t)v * 2) * C + c0 + k]; q += stats[((size_t)v * 2 + 1) * C + c0 + k]; }
+        const double nn = (double)hw * GN_CH, mu = s / nn;
+        double var = q / nn - mu * mu; if (var < 0.0) var = 0.0;
+        mean = (float)mu; inv = (float)(1.0 / sqrt(var + (double)eps));
+        for (int k = 0; k < 4; ++k) { ga[k] = gamma[c + k]; be[k] = beta[c + k]; }
+    }
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 xx = ld4(xv + 4 * i);
+        const float vv[4] = {xx.x, xx.y, xx.z, xx.w};
+        if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] += vv[k]; b[k] += vv[k] * vv[k]; }
+        } else {
+            const float4 g4 = ld4(gv + 4 * i);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (vv[k] - mean) * inv;
+                const float gz = (!relu || ga[k] * xh + be[k] > 0.f) ? gg[k] : 0.f;
+                a[k] += gz; b[k] += gz * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[tid][k] = a[k]; red[tid][4 + k] = b[k]; }
+    __syncthreads();
+    if (tid < cq) {
+        double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+        for (int j = tid; j < 256; j += cq)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sa[k] += red[j][k]; sb[k] += red[j][4 + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(out + ((size_t)v * 2) * C + c + k, sa[k]);
+            atomicAdd(out + ((size_t)v * 2 + 1) * C + c + k, sb[k]);
+        }
+    }
+}
+
+// mode 0: y = act(gamma*xhat + beta);  mode 1: dx = inv * (gamma*gz - mean_g(gamma*gz) - xhat * mean_g(gamma*gz*xhat))
+template <int MODE>
+__global__ void __launch_bounds__(256)
+gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ g, const double* __restrict__ stats,
+                const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                float eps, int relu, size_t hw, int cq, float* __restrict__ out) {
+    const int tid = threadIdx.x, v = blockIdx.y;
+    const int c = (tid % cq) * 4, C = cq * 4;
+    const size_t n4 = hw * cq;
+    const int c0 = c & ~(GN_CH - 1);
+    double s = 0.0, q = 0.0, ta = 0.0, tb = 0.0;
+    for (int k = 0; k < GN_CH; ++k) {
+        s += stats[((size_t)v * 2) * C + c0 + k]; q += stats[((size_t)v * 2 + 1) * C + c0 + k];
+        if (MODE) {
+            ta += (double)gamma[c0 + k] * sums[((size_t)v * 2) * C + c0 + k];
+            tb += (double)gamma[c0 + k] * sums[((size_t)v * 2 + 1) * C + c0 + k];
+        }
+    }
+    const double nn = (double)hw * GN_CH, mu = s / nn;
+    double var = q / nn - mu * mu; if (var < 0.0) var = 0.0;
+    const float mean = (float)mu, inv = (float)(1.0 / sqrt(var + (double)eps));
+    const float m1 = (float)(ta / nn), m2 = (float)(tb / nn);
+    float ga[4], be[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ga[k] = gamma[c + k]; be[k] = beta[c + k]; }
+    const float* xv = x + (size_t)v * n4 * 4;
+    const float* gv = MODE ? g + (size_t)v * n4 * 4 : nullptr;
+    float* ov = out + (size_t)v * n4 * 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 xx = ld4(xv + 4 * i);
+        const float vv[4] = {xx.x, xx.y, xx.z, xx.w};
+        float o[4];
+        if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float z = ga[k] * ((vv[k] - mean) * inv) + be[k];
+                o[k] = relu ? fmaxf(z, 0.f) : z;
+            }
+        } else {
+            const float4 g4 = ld4(gv + 4 * i);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (vv[k] - mean) * inv;
+                const float gz = (!relu || ga[k] * xh + be[k] > 0.f) ? gg[k] : 0.f;
+                o[k] = inv * (ga[k] * gz - m1 - xh * m2);
+            }
+        }
+        st4(ov + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
 // tf.train.RMSPropOptimizer (decay 0.9, momentum 0, epsilon 1e-10, not centered; its `rms` slot starts
 // at ONE):  ms += (g*g - ms) * (1 - decay);  mom = momentum*mom + lr * g / sqrt(ms + eps);  w -= mom.
 // One launch over the flat parameter buffer (all variables of the model are views into it).
@@ -442,5 +557,51 @@ extern "C" int mvs_adam_step_f32(float* w, const float* g, float* m, float* v, s
                                  float beta2, float eps, float grad_scale, void* stream) {
     MVS_CHECK_ARG(w && g && m && v && n > 0);
     adam_kernel<<<grid_for(n), 256, 0, mvs_stream(stream)>>>(w, g, m, v, n, lr_t, beta1, beta2, eps, grad_scale);
+    MVS_LAUNCH_RET();
+}
+
+// GroupNorm entry points: mode selects the pass (see the kernels above).
+static int gn_check(const void* x, int V, size_t hw, int C) {
+    if (!x || V <= 0 || hw == 0 || C <= 0) return MVS_E_BADARG;
+    if (C % GN_CH || 256 % (C / 4)) return MVS_E_SHAPE;
+    return 0;
+}
+static dim3 gn_grid(size_t hw, int C, int V, int cap) {
+    size_t b = (hw * (size_t)(C / 4) + 255) / 256;
+    return dim3((unsigned)(b < (size_t)cap ? (b ? b : 1) : cap), V);
+}
+
+extern "C" int mvs_gn_stats_f32(const float* x, int V, size_t hw, int C, double* stats, void* stream) {
+    int rc = gn_check(x, V, hw, C); if (rc) return rc;
+    MVS_CHECK_ARG(stats);
+    gn_reduce_kernel<0><<<gn_grid(hw, C, V, 128), 256, 0, mvs_stream(stream)>>>(x, nullptr, nullptr, nullptr, nullptr, 0.f, 0,
+                                                                                hw, C / 4, stats);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_gn_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
+                                int relu, int V, size_t hw, int C, float* y, void* stream) {
+    int rc = gn_check(x, V, hw, C); if (rc) return rc;
+    MVS_CHECK_ARG(stats && gamma && beta && y);
+    gn_apply_kernel<0><<<gn_grid(hw, C, V, 2048), 256, 0, mvs_stream(stream)>>>(x, nullptr, stats, nullptr, gamma, beta, eps, relu,
+                                                                                hw, C / 4, y);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_gn_bwd_reduce_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
+                                     int relu, const float* g, int V, size_t hw, int C, double* sums, void* stream) {
+    int rc = gn_check(x, V, hw, C); if (rc) return rc;
+    MVS_CHECK_ARG(stats && gamma && beta && g && sums);
+    gn_reduce_kernel<1><<<gn_grid(hw, C, V, 128), 256, 0, mvs_stream(stream)>>>(x, g, stats, gamma, beta, eps, relu, hw, C / 4, sums);
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_gn_bwd_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
+                                    int relu, const float* g, const double* sums, int V, size_t hw, int C, float* dx,
+                                    void* stream) {
+    int rc = gn_check(x, V, hw, C); if (rc) return rc;
+    MVS_CHECK_ARG(stats && gamma && beta && g && sums && dx);
+    gn_apply_kernel<1><<<gn_grid(hw, C, V, 2048), 256, 0, mvs_stream(stream)>>>(x, g, stats, sums, gamma, beta, eps, relu,
+                                                                                hw, C / 4, dx);
     MVS_LAUNCH_RET();
 }

@@ -74,10 +74,55 @@ class UNetDS2GN:
         return unet_forward(self.layers, images.to(self.device))
 
 
-def unet_forward(layers, images):
+class HipGroupNorm(torch.autograd.Function):
+    """GroupNorm(8 channels per group, eps) [+ ReLU] on libmvsnet_hip.so for the training towers: four HBM passes
+    (per-channel float64 sums -> normalise; backward: sums of gz and gz*xhat -> input gradient) instead of
+    torch's group_norm, whose moments kernel alone takes ~0.4 ms per layer on channel-last tensors (12 of the
+    14.5 ms of a 3-view tower forward).  x (V,C,H,W) in channels_last memory."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        from . import _lib
+        lib = _lib.load()
+        x = x.contiguous(memory_format=torch.channels_last)
+        V, C, H, W = x.shape
+        stats = torch.zeros((V, 2, C), device=x.device, dtype=torch.float64)
+        y = torch.empty_like(x)                             # preserves channels_last
+        g_, b_ = gamma.detach().contiguous(), beta.detach().contiguous()
+        _lib.check(lib.mvs_gn_stats_f32(_lib.ptr(x.permute(0, 2, 3, 1)), V, H * W, C, _lib.ptr(stats), _lib.stream_ptr()),
+                   "mvs_gn_stats_f32")
+        _lib.check(lib.mvs_gn_apply_f32(_lib.ptr(x.permute(0, 2, 3, 1)), _lib.ptr(stats), _lib.ptr(g_), _lib.ptr(b_),
+                                        float(eps), int(relu), V, H * W, C, _lib.ptr(y.permute(0, 2, 3, 1)),
+                                        _lib.stream_ptr()), "mvs_gn_apply_f32")
+        ctx.save_for_backward(x, stats, g_, b_)
+        ctx.cfg = (float(eps), int(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        x, stats, gamma, beta = ctx.saved_tensors
+        eps, relu = ctx.cfg
+        V, C, H, W = x.shape
+        g = g.contiguous(memory_format=torch.channels_last)
+        sums = torch.zeros((V, 2, C), device=x.device, dtype=torch.float64)
+        dx = torch.empty_like(x)
+        xp, gp = _lib.ptr(x.permute(0, 2, 3, 1)), _lib.ptr(g.permute(0, 2, 3, 1))
+        _lib.check(lib.mvs_gn_bwd_reduce_f32(xp, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, relu, gp, V, H * W, C,
+                                             _lib.ptr(sums), _lib.stream_ptr()), "mvs_gn_bwd_reduce_f32")
+        _lib.check(lib.mvs_gn_bwd_apply_f32(xp, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, relu, gp, _lib.ptr(sums),
+                                            V, H * W, C, _lib.ptr(dx.permute(0, 2, 3, 1)), _lib.stream_ptr()),
+                   "mvs_gn_bwd_apply_f32")
+        tot = sums.sum(0).to(torch.float32)
+        return dx, tot[1], tot[0], None, None
+
+
+def unet_forward(layers, images, hip_group_norm=False):
     """The tower itself; differentiable (training, SURVEY 8f f4, runs it under torch autograd with the
     layer tensors being views of the trainer's flat parameter buffer).  `layers`: tuples
-    (name, kind, srcs, k, stride, w torch-layout, gamma, beta)."""
+    (name, kind, srcs, k, stride, w torch-layout, gamma, beta).  `hip_group_norm`: GroupNorm(+ReLU) through
+    HipGroupNorm (the trainer's choice) instead of torch's group_norm + relu."""
     x = images.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
     acts = {"data": x}
     for name, kind, srcs, k, stride, w, g, b in layers:
@@ -97,9 +142,12 @@ def unet_forward(layers, images):
                 y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), w, stride=stride)
         if kind != "c":
             C = y.shape[1]
-            y = F.group_norm(y, max(1, C // 8), g, b, eps=1e-5)   # network.py:246-254
-            if kind == "cg":
-                y = F.relu(y)
+            if hip_group_norm and C % 8 == 0:
+                y = HipGroupNorm.apply(y, g, b, 1e-5, kind == "cg")
+            else:
+                y = F.group_norm(y, max(1, C // 8), g, b, eps=1e-5)   # network.py:246-254
+                if kind == "cg":
+                    y = F.relu(y)
         acts[name] = y
     return acts["conv10_2"].permute(0, 2, 3, 1).contiguous()
 

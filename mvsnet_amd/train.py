@@ -156,7 +156,7 @@ class Trainer:
         depth_start, depth_interval = float(cams[0][1][3][0]), float(cams[0][1][3][1])
         depth_num = self.depth_num
         depth_end = float(cams[0][1][3][3])
-        feats = unet_forward(trainable_layers(self.params.group("unet")), images)
+        feats = unet_forward(trainable_layers(self.params.group("unet")), images, hip_group_norm=self.device.type == "cuda")
         if feats.shape[-1] < 32:
             feats = torch.nn.functional.pad(feats, (0, 32 - feats.shape[-1]))      # padded channels: zero cost, zero gradient
         transforms = homography_transforms(cams_t, depth_num, depth_start, depth_interval)

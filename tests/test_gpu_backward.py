@@ -290,3 +290,28 @@ def test_trainer_lite_mode_trains_padded_and_saves_native_shapes(tmp_path):
             assert np.array_equal(na[var][sl], nb[var][sl]), var
     loaded = tf_checkpoint.load_mvsnet_params(prefix, "lite", "3DCNN")       # the inference path reads it back
     assert loaded["regnet"]["3dconv0_1"]["w"].shape == (3, 3, 3, 16, 4)
+
+
+@pytest.mark.parametrize("C,H,W,relu", [(8, 24, 40, True), (16, 12, 20, False), (64, 6, 10, True), (128, 4, 6, True)])
+def test_hip_group_norm_matches_torch_autograd(C, H, W, relu):
+    """GroupNorm(+ReLU) of the training towers (network.py:217-276) against torch's float64 group_norm."""
+    from mvsnet_amd.feature_net import HipGroupNorm
+    rs = np.random.RandomState(C)
+    V = 3
+    x = (rs.randn(V, C, H, W) * 1.3 + 0.2).astype(np.float32)
+    gamma = (1.0 + 0.3 * rs.randn(C)).astype(np.float32); beta = (0.2 * rs.randn(C)).astype(np.float32)
+    g = rs.randn(V, C, H, W).astype(np.float32)
+    xx, gg, bb = d64(x, True), d64(gamma, True), d64(beta, True)
+    y64 = F.group_norm(xx, C // 8, gg, bb, eps=1e-5)
+    if relu:
+        y64 = F.relu(y64)
+    (y64 * d64(g)).sum().backward()
+    xt = t(x).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gt_, bt_ = t(gamma).requires_grad_(True), t(beta).requires_grad_(True)
+    y = HipGroupNorm.apply(xt, gt_, bt_, 1e-5, relu)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert rel_l1(n(y), y64.detach().numpy()) < 1e-6
+    (y * t(g)).sum().backward()
+    assert rel_l1(n(xt.grad), xx.grad.numpy()) < 1e-5
+    assert rel_l1(n(gt_.grad), gg.grad.numpy()) < 1e-5
+    assert rel_l1(n(bt_.grad), bb.grad.numpy()) < 1e-5
