@@ -315,3 +315,57 @@ def test_hip_group_norm_matches_torch_autograd(C, H, W, relu):
     assert rel_l1(n(xt.grad), xx.grad.numpy()) < 1e-5
     assert rel_l1(n(gt_.grad), gg.grad.numpy()) < 1e-5
     assert rel_l1(n(bt_.grad), bb.grad.numpy()) < 1e-5
+
+
+# ---- full-size checks through size-independent properties (train.py's default volume: D=192, 120 x 160) ----------
+FULL = (192, 120, 160)
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize("cin,cout,stride", [(32, 8, 1), (32, 16, 2)])
+def test_full_size_weight_and_input_gradients_are_adjoints_of_the_forward_convolution(cin, cout, stride):
+    """<conv(x, W), g> = <W, wgrad(x, g)> = <x, input_grad(g, W)> with the forward MFMA kernel as the
+    left-hand side: ties both backward routes to the (oracle-checked) forward at the full volume size."""
+    from mvsnet_amd import backward as B
+    from mvsnet_amd.model import conv3d
+    torch.manual_seed(cin + cout)
+    D, H, W = FULL
+    x = torch.randn(D, H, W, cin, device=DEV)
+    w = torch.randn(3, 3, 3, cin, cout, device=DEV) * 0.05
+    y = conv3d(x, w, stride)
+    g = torch.randn_like(y)
+    lhs = _dot(y, g)
+    dw = B.conv3d_wgrad(x, g, stride)
+    assert abs(_dot(dw, w) - lhs) <= 2e-5 * abs(lhs) + 1e-3 * float(dw.abs().double().sum() * 1e-6)
+    gx = (B.conv_s1_input_grad if stride == 1 else B.conv_s2_input_grad)(g, w)
+    assert gx.shape == x.shape
+    assert abs(_dot(gx, x) - lhs) <= 2e-5 * abs(lhs) + 1.0
+
+
+def test_full_size_cost_volume_backward_is_the_directional_derivative():
+    """<grad_f, delta> against a central difference of <cost(f), g> along delta at the full training size.
+    (The cost volume is quadratic in the features where the tap pattern is fixed, so the central difference
+    is exact up to rounding.)"""
+    from mvsnet_amd import backward as B
+    from mvsnet_amd.model import cost_volume
+    from mvsnet_amd.homography_warping import homography_transforms
+    D, H, W = FULL
+    N = 3
+    cams = S.make_cams(N, H, W, D)
+    start, interval = float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1])
+    t8 = homography_transforms(t(cams), D, start, interval)
+    f = t(S.make_features(N, H, W, 32, seed=2))
+    torch.manual_seed(0)
+    g = torch.randn(D, H, W, 32, device=DEV) * 0.1
+    delta = torch.randn_like(f)
+    g_ref, g_src = B.cost_volume_bwd(f[0], f[1:], t8, g)
+    lhs = _dot(torch.cat([g_ref[None], g_src], 0), delta)
+    eps = 0.5
+    cp = cost_volume(f[0] + eps * delta[0], f[1:] + eps * delta[1:], t8, variant="eager")
+    up = _dot(cp, g); del cp
+    cm = cost_volume(f[0] - eps * delta[0], f[1:] - eps * delta[1:], t8, variant="eager")
+    rhs = (up - _dot(cm, g)) / (2 * eps)
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs)) + 1e-2, (lhs, rhs)
