@@ -267,6 +267,17 @@ int run(const float* big, const float* small, int D, int H, int W, int CS, void*
 int dispatch(const float* big, const float* small, int D, int H, int W, int CB, int CS, int stride, void* ws,
              size_t ws_bytes, float* dw, size_t* need, hipStream_t st) {
     if (stride == 2 && ((D | H | W) & 1)) return MVS_E_SHAPE;     // pad_before = 0 holds for even sizes only
+    if (CS == 1 && CB == 8 && stride == 1) {                      // 3dconv6_2: one small channel, VALU kernel (conv3d_c1.hip)
+        int rows, ppw;
+        int rc = mvs_wgrad_c1_plan(D, H, W, CB, &rows, &ppw);
+        if (rc) return rc;
+        const size_t wsz = (size_t)27 * CB, bytes = (size_t)rows * wsz * sizeof(float);
+        if (need) { *need = bytes; return 0; }
+        if (ws_bytes < bytes) return MVS_E_WORKSPACE;
+        if ((rc = mvs_wgrad_c1_launch(big, small, D, H, W, CB, (float*)ws, st))) return rc;
+        wgrad_reduce_kernel<<<mvs_cdiv((long long)wsz, 16), 256, 0, st>>>((const float*)ws, rows, wsz, dw);
+        return (int)hipGetLastError();
+    }
     const int ct = (CS + 15) / 16;
 #define WG_CASE(cb, ctv, s, th) \
     if (CB == cb && ct == ctv && stride == s) return run<cb, ctv, s, th>(big, small, D, H, W, CS, ws, ws_bytes, dw, need, st);
