@@ -304,6 +304,16 @@ int mvs_conv3d_wgrad_f32(const float* big, const float* small, int D, int H, int
 int mvs_cost_volume_bwd_f32(const float* ref, const float* src, const float* transforms,
                             int view_num, int depth_num, int H, int W, int C, const float* g1,
                             const float* g2, float* g_ref, float* g_src, void* stream);
+/* Atomic-free, bit-reproducible variant of mvs_cost_volume_bwd_f32 (C = 32 or 16): stores the per-view
+ * warped-sample gradients in `workspace` (mvs_cost_volume_bwd_workspace_bytes: (N-1)*D*H*W*C floats plus
+ * chunk rows) and gathers them in the source frame through the inverse plane homographies.  g_ref / g_src
+ * are overwritten (no zeroing needed).  Planes that minify a source view more than ~8x fall outside its
+ * candidate search; use the scatter version for such geometry. */
+size_t mvs_cost_volume_bwd_workspace_bytes(int view_num, int depth_num, int H, int W, int C);
+int mvs_cost_volume_bwd_gather_f32(const float* ref, const float* src, const float* transforms,
+                                   int view_num, int depth_num, int H, int W, int C, const float* g1,
+                                   const float* g2, void* workspace, size_t workspace_bytes,
+                                   float* g_ref, float* g_src, void* stream);
 int mvs_rmsprop_step_f32(float* w, const float* g, float* ms, float* mom, size_t n, float lr,
                          float decay, float momentum, float eps, float grad_scale, void* stream);
 /* GroupNorm (+ReLU) of the 2D towers for TRAINING (Network.conv_gn / deconv_gn, network.py:217-276, 350-409:

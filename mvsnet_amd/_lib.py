@@ -62,6 +62,8 @@ SIGNATURES = {
     "mvs_conv3d_wgrad_workspace_bytes": (_sz, [_i] * 6),
     "mvs_conv3d_wgrad_f32": (_i, [_p, _p] + [_i] * 6 + [_p, _sz, _p, _p]),
     "mvs_cost_volume_bwd_f32": (_i, [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _p]),
+    "mvs_cost_volume_bwd_workspace_bytes": (_sz, [_i] * 5),
+    "mvs_cost_volume_bwd_gather_f32": (_i, [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _sz, _p, _p, _p]),
     "mvs_rmsprop_step_f32": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),
     "mvs_gn_stats_f32": (_i, [_p, _i, _sz, _i, _p, _p]),
     "mvs_gn_apply_f32": (_i, [_p, _p, _p, _p, _f, _i, _i, _sz, _i, _p, _p]),

@@ -94,11 +94,26 @@ def conv3d_wgrad(big, small, stride):
     return dw
 
 
-def cost_volume_bwd(ref, src, transforms, g1, g2=None):
-    """Gradient of the warp + variance w.r.t. the feature maps: (g_ref (H,W,C), g_src (N-1,H,W,C))."""
+_CVWS: Dict[torch.device, torch.Tensor] = {}
+
+
+def cost_volume_bwd(ref, src, transforms, g1, g2=None, method="gather"):
+    """Gradient of the warp + variance w.r.t. the feature maps: (g_ref (H,W,C), g_src (N-1,H,W,C)).
+    method "gather": atomic-free two-pass kernels (bit-reproducible, C = 32 / 16); "scatter": float atomics."""
     lib = _lib.load()
     H, W, Cc = ref.shape
     n_src, D = transforms.shape[0], transforms.shape[1]
+    need = lib.mvs_cost_volume_bwd_workspace_bytes(n_src + 1, D, H, W, Cc) if method == "gather" else 0
+    if need:
+        ws = _CVWS.get(ref.device)
+        if ws is None or ws.numel() < need:
+            ws = _CVWS[ref.device] = torch.empty(need, device=ref.device, dtype=torch.uint8)
+        g_ref, g_src = torch.empty_like(ref), torch.empty_like(src)
+        _lib.check(lib.mvs_cost_volume_bwd_gather_f32(
+            _lib.ptr(ref), _lib.ptr(src), _lib.ptr(transforms), n_src + 1, D, H, W, Cc, _lib.ptr(g1), _lib.ptr(g2),
+            C.c_void_p(ws.data_ptr()), ws.numel(), _lib.ptr(g_ref), _lib.ptr(g_src), _lib.stream_ptr()),
+            "mvs_cost_volume_bwd_gather_f32")
+        return g_ref, g_src
     g_ref = torch.zeros_like(ref)
     g_src = torch.zeros_like(src)
     _lib.check(lib.mvs_cost_volume_bwd_f32(_lib.ptr(ref), _lib.ptr(src), _lib.ptr(transforms), n_src + 1, D, H, W, Cc,

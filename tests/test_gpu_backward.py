@@ -144,9 +144,11 @@ def _toy_problem(N=3, D=16, H=16, W=32, C=32):
     return feats, t8, start, interval
 
 
-@pytest.mark.parametrize("shape", [(3, 16, 16, 32, 32), (5, 24, 40, 72, 32), (2, 8, 24, 24, 16)])
-def test_cost_volume_backward_matches_autograd(shape):
-    """2 / 4 / 1 source views, ragged sizes, 32 and 16 channels."""
+@pytest.mark.parametrize("method", ["gather", "scatter"])
+@pytest.mark.parametrize("shape", [(3, 16, 16, 32, 32), (5, 24, 40, 72, 32), (2, 8, 24, 24, 16), (3, 60, 24, 40, 32)])
+def test_cost_volume_backward_matches_autograd(shape, method):
+    """2 / 4 / 1 source views, ragged sizes, 32 and 16 channels, several plane chunks; both the atomic-free
+    gather kernels and the float-atomic scatter kernel."""
     from mvsnet_amd import backward as B
     feats, t8, _, _ = _toy_problem(*shape)
     rs = np.random.RandomState(3)
@@ -156,8 +158,11 @@ def test_cost_volume_backward_matches_autograd(shape):
     cost = TG.cost_volume(f, d64(t8)).permute(1, 2, 3, 0)               # (D,H,W,C)
     (cost * (d64(g1) + d64(g2))).sum().backward()
     ft = t(feats)
-    g_ref, g_src = B.cost_volume_bwd(ft[0], ft[1:], t(t8), t(g1), t(g2))
+    g_ref, g_src = B.cost_volume_bwd(ft[0], ft[1:], t(t8), t(g1), t(g2), method=method)
     got = np.concatenate([n(g_ref)[None], n(g_src)], 0)
+    if method == "gather":                       # bit-reproducible
+        r2, s2 = B.cost_volume_bwd(ft[0], ft[1:], t(t8), t(g1), t(g2), method=method)
+        assert torch.equal(r2, g_ref) and torch.equal(s2, g_src)
     # the warp is piecewise bilinear: fp32 sample coordinates that land within rounding of a pixel boundary
     # may pick the neighbouring cell; the contribution is continuous, so the L1 error stays at rounding level
     assert rel_l1(got, f.grad.numpy()) < 1e-4
