@@ -220,7 +220,9 @@ def main():
                 marks.append(e)
 
     torch.cuda.synchronize()
-    for i in range(args.warmup):
+    # untimed: the requested warm-up steps, topped up to 10 launches so that lazy one-off work (code-object
+    # load, LDS-size attributes, side-stream creation) and the clock ramp never land in the timed region
+    for i in range(max(args.warmup, 10)):
         step(i, False)
     torch.cuda.synchronize()
     # the library brackets the dominant kernel (fused 3dconv0_1 + 3dconv1_0 pass) of every step of
