@@ -234,7 +234,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, True)
+        step(i, False)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -249,6 +249,12 @@ def main():
     pair_ms, pair_n = ctypes.c_double(0.0), ctypes.c_int(0)
     _lib.check(lib.mvs_profile_dominant_ms(ctypes.byref(pair_ms), ctypes.byref(pair_n)), "mvs_profile_dominant_ms")
     _lib.check(lib.mvs_profile_dominant(0), "mvs_profile_dominant")
+    # stage split (warp / conv stack / soft-argmin) for `roofline_kernels`: a separate, untimed pass -- every
+    # event record costs a few microseconds of device idle time, and only the dominant kernel's bracket has to
+    # live inside the timed region
+    for i in range(min(args.steps, 20)):
+        step(i, True)
+    torch.cuda.synchronize()
     # per-kernel device time from the events recorded inside the timed region
     t_warp = np.mean([m[0].elapsed_time(m[1]) for m in marks]) * 1e-3     # includes the tiny homography kernel
     t_conv = np.mean([m[1].elapsed_time(m[2]) for m in marks]) * 1e-3

@@ -146,7 +146,7 @@ class Trainer:
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     # -- one optimisation step ------------------------------------------------------------------------
-    def loss(self, images, cams, depth_image):
+    def loss(self, images, cams, depth_image, depth_num):
         """images (N,H,W,3), cams (N,2,4,4) at the output scale, depth_image (H/4,W/4,1) GT.  Returns
         (loss, less_one, less_three, depth_map) exactly as get_loss (train.py:307-353), batch 1."""
         from .backward import plane_sweep_depth
@@ -154,7 +154,6 @@ class Trainer:
         cams_t = torch.as_tensor(cams, dtype=torch.float32, device=self.device)
         gt = torch.as_tensor(depth_image, dtype=torch.float32, device=self.device)[None]
         depth_start, depth_interval = float(cams[0][1][3][0]), float(cams[0][1][3][1])
-        depth_num = self.depth_num
         depth_end = float(cams[0][1][3][3])
         feats = unet_forward(trainable_layers(self.params.group("unet")), images, hip_group_norm=self.device.type == "cuda")
         if feats.shape[-1] < 32:
@@ -199,16 +198,14 @@ class Trainer:
         self.global_step += 1
 
     def train_step(self, images, cams, depth_image, depth_num):
-        self.depth_num = depth_num
-        loss, l1, l3, _ = self.loss(images, cams, depth_image)
+        loss, l1, l3, _ = self.loss(images, cams, depth_image, depth_num)
         loss.backward()
         self.apply_gradients()
         return loss.detach(), l1.detach(), l3.detach()
 
     @torch.no_grad()
     def validate_step(self, images, cams, depth_image, depth_num):
-        self.depth_num = depth_num
-        loss, l1, l3, _ = self.loss(images, cams, depth_image)
+        loss, l1, l3, _ = self.loss(images, cams, depth_image, depth_num)
         return loss, l1, l3
 
     # -- checkpoints ----------------------------------------------------------------------------------
