@@ -10,17 +10,15 @@
 #include "common.h"
 
 // cell-1 MFMA convolutions (gru_mfma.hip); MVS_E_SHAPE outside their tiling
-int mvs_gru_weight_layout(const float* w, int CT, int COUT, float* out, hipStream_t st);
-int mvs_gru1_gates_mfma(const float* x, const float* h, const float* wprep, const float* bias, int H,
-                        int W, int CA, int F, float* g, double* stats, hipStream_t st);
-int mvs_gru1_out_mfma(const float* x, const float* h, const float* g, const double* g_stats,
-                      const float* r_gamma, const float* r_beta, const float* wprep,
-                      const float* bias, int H, int W, int CA, int F, float* c, double* stats,
-                      hipStream_t st);
-
+int mvs_gru1_split_weights(const float* w_gates, const float* w_out, int CA, int F, float* wx, float* wgh, float* woh,
+                           hipStream_t st);
+int mvs_gru1_xpart_mfma(const float* x, const float* wxg, const float* wxo, const float* bias_g, const float* bias_o,
+                        int H, int W, int planes, float* px, hipStream_t st);
+int mvs_gru1_gates_h_mfma(const float* h, const float* wgh, const float* px, int H, int W, float* g, double* stats,
+                          hipStream_t st);
+int mvs_gru1_out_h_mfma(const float* h, const float* g, const double* g_stats, const float* r_gamma, const float* r_beta,
+                        const float* woh, const float* px, int H, int W, float* c, double* stats, hipStream_t st);
 namespace {
-
-constexpr int MAX_CO = 32;   // largest Cout on the path: gates of cell 1 = 2*16
 
 template <int CO>
 __global__ void __launch_bounds__(256)
@@ -407,7 +405,8 @@ extern "C" int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, i
 
 namespace {
 struct GruWs {
-    float *x, *g[3], *c[3], *rh, *u, *h[3][2], *reg, *max_prob, *exp_sum, *wprep_g, *wprep_o;
+    float *x, *g[3], *c[3], *rh, *u, *h[3][2 * 4], *reg, *max_prob, *exp_sum;   // h: ring of 2*PG states
+    float *px, *wx, *wgh, *woh;        // hoisted x-part of cell 1: (2, XB, H, W, 3*f1) and its prepared weights
     double* stats;     // per plane of a batch: 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
     size_t bytes;
 };
@@ -415,6 +414,8 @@ struct GruWs {
 // come from ONE depth-sweep launch (register tap reuse along depth, cost_volume.hip) into a ring of
 // XB slices, instead of one single-plane launch per step (26 -> ~6 us per plane at 400 x 300).
 constexpr int XB = 16;
+// Planes per synchronisation group of the wavefront (see mvs_gru_wta_f32); the state ring holds 2*PG planes.
+constexpr int PG = 4;
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     size_t hw = (size_t)H * W, off = 0;
@@ -427,28 +428,33 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     // consecutive planes run concurrently (see mvs_gru_wta_f32)
     for (int k = 0; k < 3; ++k) {
         w.g[k] = take(hw * 2 * F[k]); w.c[k] = take(hw * F[k]);
-        w.h[k][0] = take(hw * F[k]); w.h[k][1] = take(hw * F[k]);
+        for (int r = 0; r < 2 * PG; ++r) w.h[k][r] = take(hw * F[k]);
     }
     w.rh = take(hw * fmax); w.u = take(hw * fmax);
     w.reg = take(hw); w.max_prob = take(hw); w.exp_sum = take(hw);
-    w.wprep_g = take((size_t)9 * (C + f1) * 2 * f1); w.wprep_o = take((size_t)9 * (C + f1) * f1);
+    w.px = take((size_t)2 * XB * hw * 3 * f1);
+    w.wx = take((size_t)9 * C * 3 * f1); w.wgh = take((size_t)9 * f1 * 2 * f1); w.woh = take((size_t)9 * f1 * f1);
     w.stats = (double*)(base ? base + off : nullptr); off += align256((size_t)2 * XB * 18 * 8);   // two batches deep
     w.bytes = off;
     return w;
 }
 
-// Two side streams for cells 2 and 3 (created on first use; one host thread per device as elsewhere).
-struct GruStreams { hipStream_t s[2]; hipEvent_t fork, join[2], ready[2][2], read[2][2]; };
+// Side streams for cells 2 and 3 and for the per-batch producer (cost slices + hoisted x-part) (created on first use; one host thread per device as elsewhere).
+struct GruStreams { hipStream_t s[3]; hipEvent_t fork, join[3], ready[2][2], read[2][2], xready[2], xdone[2]; };
 GruStreams* gru_streams() {
     static GruStreams g;
     static int state = 0;
     if (state == 0) {
         state = -1;
         bool ok = !getenv("MVS_GRU_ONE_STREAM");
-        for (int i = 0; ok && i < 2; ++i) ok = hipStreamCreateWithFlags(&g.s[i], hipStreamNonBlocking) == hipSuccess;
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;   // lo = least urgent: the batch producer yields to the cells
+        for (int i = 0; ok && i < 3; ++i)
+            ok = hipStreamCreateWithPriority(&g.s[i], hipStreamNonBlocking, i == 2 ? lo : hi) == hipSuccess;
         auto ev = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
         ev(&g.fork);
-        for (int i = 0; i < 2; ++i) { ev(&g.join[i]); for (int j = 0; j < 2; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
+        for (int i = 0; i < 2; ++i) { ev(&g.xready[i]); ev(&g.xdone[i]); for (int j = 0; j < 2; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
+        for (int i = 0; i < 3; ++i) ev(&g.join[i]);
         if (ok) state = 1;
     }
     return state == 1 ? &g : nullptr;
@@ -483,8 +489,7 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     // cell 1 (90 % of the MACs) runs on the fp32-MFMA kernels when its shape fits their tiling
     bool mfma1 = (mvs_get_conv_impl() != MVS_CONV_IMPL_SCALAR) && C == 32 && f1 == 16;
     if (mfma1) {
-        if ((rc = mvs_gru_weight_layout(params[0], C + f1, 2 * f1, ws.wprep_g, st))) return rc;
-        if ((rc = mvs_gru_weight_layout(params[6], C + f1, f1, ws.wprep_o, st))) return rc;
+        if ((rc = mvs_gru1_split_weights(params[0], params[6], C, f1, ws.wx, ws.wgh, ws.woh, st))) return rc;
     }
     // which kernels each cell gets; the generic conv + gates route shares rh / u and stays on one stream
     const int cins[3] = {C, f1, f2};
@@ -495,90 +500,130 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
                  : ((ci == 16 && f == 4) || (ci == 4 && f == 2) || (ci == 8 && f == 2) || (ci == 2 && f == 1)) ? 2 : 0;
     }
     // Wavefront over (plane, cell): cell k of plane d needs cell k-1 of plane d and cell k of plane d-1, so
-    // the three cells run on three streams, cell 1 of plane d+1 alongside cell 2 of plane d and cell 3 of
-    // plane d-1.  The small kernels of cells 2 / 3 (launch-latency bound, a few workgroups per CU) then fill
-    // the machine under cell 1's MFMA kernels instead of serialising behind them.  States ping-pong per plane
-    // (h[k][d&1] -> h[k][(d+1)&1]); events: ready[k][d&1] = state k of plane d written, read[k][d&1] = the
-    // consumer cell is done reading it (the producer may overwrite it two planes later).
-    GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2) ? gru_streams() : nullptr;
+    // the three cells run on three streams, cell 1 of the next planes alongside cell 2 of these and cell 3 of
+    // the previous ones; the small kernels of cells 2 / 3 (launch-latency bound, a few workgroups per CU) then
+    // fill the machine under cell 1's kernels instead of serialising behind them.  A cross-stream dependency
+    // costs tens of microseconds of signal latency, as much as a cell's kernels for one plane, so the streams
+    // synchronise per GROUP of PG planes: states live in a ring of 2*PG planes (plane d reads h[k][d % 2PG], writes
+    // h[k][(d+1) % 2PG]); per group j, ready[k][j&1] = cell k has written its states of group j, read[k][j&1] =
+    // cell k+1 is done reading them (cell k may overwrite those ring slots in group j+2).
+    GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2 * PG) ? gru_streams() : nullptr;
     hipStream_t sk[3] = {st, gs ? gs->s[0] : st, gs ? gs->s[1] : st};
     if (gs) {
         if ((e = hipEventRecord(gs->fork, st)) != hipSuccess) return (int)e;
-        for (int i = 0; i < 2; ++i) if ((e = hipStreamWaitEvent(gs->s[i], gs->fork, 0)) != hipSuccess) return (int)e;
+        for (int i = 0; i < 3; ++i) if ((e = hipStreamWaitEvent(gs->s[i], gs->fork, 0)) != hipSuccess) return (int)e;
     }
     const long long hw_ll = (long long)H * W;
-    for (int d = 0; d < depth_num; ++d) {
-        const int slot = d % XB, par = d & 1;
-        double* stats_d = ws.stats + (size_t)(((d / XB) & 1) * XB + slot) * 18;
-        if (slot == 0) {
-            // x = -variance cost of planes d .. d+XB-1 (model.py:680-693,698), LayerNorm sums of the batch
-            // (the other half of the stats ring may still be in use by cells 2 / 3 of the previous planes)
-            const int nb = depth_num - d < XB ? depth_num - d : XB;
-            if ((e = hipMemsetAsync(stats_d, 0, (size_t)XB * 18 * 8, st)) != hipSuccess) return (int)e;
-            rc = mvs_cost_volume_f32(ref, src, transforms, view_num, depth_num, d, nb, H, W, C,
-                                     /*variant*/ 1, /*negate*/ 1, /*border*/ 0, ws.x, stream);
-            if (rc) return rc;
+
+    // start of a batch of XB planes (on cell 1's stream, before its first plane of the batch)
+    auto batch_start = [&](int d) -> int {
+        const int half = (d / XB) & 1;
+        // LayerNorm sums of this batch (the other half of the stats ring may still be in use by cells 2 / 3
+        // of the previous planes: they lag cell 1 by at most 4 groups = 16 planes)
+        if ((e = hipMemsetAsync(ws.stats + (size_t)half * XB * 18, 0, (size_t)XB * 18 * 8, st)) != hipSuccess) return (int)e;
+        // Per batch: x = -variance cost slices (model.py:680-693,698) and, for the MFMA cell 1, the x halves of
+        // its two convolutions for the whole batch (gru_mfma.hip: x-part hoisting).
+        auto produce = [&](int d0, hipStream_t s) -> int {
+            const int nb = depth_num - d0 < XB ? depth_num - d0 : XB;
+            int r = mvs_cost_volume_f32(ref, src, transforms, view_num, depth_num, d0, nb, H, W, C, /*variant*/ 1,
+                                        /*negate*/ 1, /*border*/ 0, ws.x, s);
+            if (r || !mfma1) return r;
+            return mvs_gru1_xpart_mfma(ws.x, ws.wx, ws.wx + (size_t)9 * C * 2 * f1, params[1], params[7], H, W, nb,
+                                       ws.px + (size_t)((d0 / XB) & 1) * XB * hw * 3 * f1, s);
+        };
+        if (!(gs && mfma1)) return produce(d, st);
+        // the producer runs one batch ahead on its own (low-priority) stream: 2/3 of cell 1's MACs leave the
+        // recurrent chain
+        hipStream_t sx = gs->s[2];
+        int r;
+        if (d == 0) {
+            if ((r = produce(0, sx))) return r;
+            if ((e = hipEventRecord(gs->xready[0], sx)) != hipSuccess) return (int)e;
         }
-        const float* xin = ws.x + (size_t)slot * hw * C;
-        for (int k = 0; k < 3; ++k) {
-            const float* const* p = params + 10 * k;
-            hipStream_t s = sk[k];
-            double* sg = stats_d + 6 * k;
-            double* so = sg + 4;
-            const float* hp = ws.h[k][par];
-            float* hn = gs ? ws.h[k][par ^ 1] : ws.h[k][par];        // one stream: in place, h[k][0] throughout
-            if (!gs) hp = hn = ws.h[k][0];
-            const int cin = cins[k];
-            if (gs && k > 0 && (e = hipStreamWaitEvent(s, gs->ready[k - 1][par], 0)) != hipSuccess) return (int)e;
-            if (route[k] == 1) {
-                if ((rc = mvs_gru1_gates_mfma(xin, hp, ws.wprep_g, p[1], H, W, C, f1, ws.g[k], sg, s))) return rc;
-                if ((rc = mvs_gru1_out_mfma(xin, hp, ws.g[k], sg, p[2], p[3], ws.wprep_o, p[7], H, W, C, f1, ws.c[k], so, s))) return rc;
-            } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
-            } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
-            } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
-            } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
-            } else {
-                rc = launch_conv2d(xin, cin, hp, F[k], p[0], p[1], H, W, 2 * F[k], ws.g[k], sg, 2, s);
-                if (rc) return rc;
-                rc = mvs_gru_gates_f32(ws.g[k], sg, p[2], p[3], p[4], p[5], hp, H, W, F[k], ws.rh, ws.u, s);
-                if (rc) return rc;
-                rc = launch_conv2d(xin, cin, ws.rh, F[k], p[6], p[7], H, W, F[k], ws.c[k], so, 1, s);
-                if (rc) return rc;
-            }
-            if (gs && k > 0 && (e = hipEventRecord(gs->read[k - 1][par], s)) != hipSuccess) return (int)e;   // x of plane d consumed
-            // the blend overwrites the state buffer cell k+1 read two planes ago
-            if (gs && k < 2 && d >= 2 && (e = hipStreamWaitEvent(s, gs->read[k][par], 0)) != hipSuccess) return (int)e;
-            if (F[k] % 4 == 0)
-                gru_blend_fused_kernel<4><<<mvs_cdiv(hw_ll * F[k] / 4, 256), 256, 0, s>>>(
-                    ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
-            else if (F[k] % 2 == 0)
-                gru_blend_fused_kernel<2><<<mvs_cdiv(hw_ll * F[k] / 2, 256), 256, 0, s>>>(
-                    ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
-            else
-                gru_blend_fused_kernel<1><<<mvs_cdiv(hw_ll * F[k], 256), 256, 0, s>>>(
-                    ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
-            if ((rc = (int)hipGetLastError())) return rc;
-            if (gs && k < 2 && (e = hipEventRecord(gs->ready[k][par], s)) != hipSuccess) return (int)e;
-            xin = hn;
+        if ((e = hipStreamWaitEvent(st, gs->xready[half], 0)) != hipSuccess) return (int)e;
+        if (d + XB < depth_num) {                     // next batch into the other half, once its readers are done
+            if (d >= XB && (e = hipStreamWaitEvent(sx, gs->xdone[half ^ 1], 0)) != hipSuccess) return (int)e;
+            if ((r = produce(d + XB, sx))) return r;
+            if ((e = hipEventRecord(gs->xready[half ^ 1], sx)) != hipSuccess) return (int)e;
         }
+        return 0;
+    };
+
+    // cell k of plane d on stream s: gate conv, candidate conv, blend (+ prob / WTA after cell 3)
+    auto cell_plane = [&](int k, int d, hipStream_t s) -> int {
+        const int slot = d % XB, half = (d / XB) & 1;
+        const float* const* p = params + 10 * k;
+        double* sg = ws.stats + (size_t)(half * XB + slot) * 18 + 6 * k;
+        double* so = sg + 4;
+        const float* hp = ws.h[k][d % (2 * PG)];
+        float* hn = ws.h[k][(d + 1) % (2 * PG)];
+        const float* xin = k == 0 ? ws.x + (size_t)slot * hw * C : ws.h[k - 1][(d + 1) % (2 * PG)];
+        const float* px_d = ws.px + ((size_t)half * XB + slot) * hw * 3 * f1;
+        const int cin = cins[k];
+        int r;
+        if (route[k] == 1) {
+            if ((r = mvs_gru1_gates_h_mfma(hp, ws.wgh, px_d, H, W, ws.g[k], sg, s))) return r;
+            if ((r = mvs_gru1_out_h_mfma(hp, ws.g[k], sg, p[2], p[3], ws.woh, px_d, H, W, ws.c[k], so, s))) return r;
+            if (gs && (slot == XB - 1 || d == depth_num - 1) && (e = hipEventRecord(gs->xdone[half], s)) != hipSuccess) return (int)e;
+        } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
+        } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
+        } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
+        } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
+        } else {
+            if ((r = launch_conv2d(xin, cin, hp, F[k], p[0], p[1], H, W, 2 * F[k], ws.g[k], sg, 2, s))) return r;
+            if ((r = mvs_gru_gates_f32(ws.g[k], sg, p[2], p[3], p[4], p[5], hp, H, W, F[k], ws.rh, ws.u, s))) return r;
+            if ((r = launch_conv2d(xin, cin, ws.rh, F[k], p[6], p[7], H, W, F[k], ws.c[k], so, 1, s))) return r;
+        }
+        if (F[k] % 4 == 0)
+            gru_blend_fused_kernel<4><<<mvs_cdiv(hw_ll * F[k] / 4, 256), 256, 0, s>>>(
+                ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
+        else if (F[k] % 2 == 0)
+            gru_blend_fused_kernel<2><<<mvs_cdiv(hw_ll * F[k] / 2, 256), 256, 0, s>>>(
+                ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
+        else
+            gru_blend_fused_kernel<1><<<mvs_cdiv(hw_ll * F[k], 256), 256, 0, s>>>(
+                ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
+        if ((r = (int)hipGetLastError())) return r;
+        if (k < 2) return 0;
         // prob_conv + exp + winner-take-all update (model.py:701-731)
         const int grid = mvs_cdiv(hw_ll, 256);
-        hipStream_t s3 = sk[2];
-        const float* h3 = xin;
         switch (f3) {
-            case 1: prob_wta_kernel<1><<<grid, 256, 0, s3>>>(h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
-            case 2: prob_wta_kernel<2><<<grid, 256, 0, s3>>>(h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
-            case 4: prob_wta_kernel<4><<<grid, 256, 0, s3>>>(h3, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+            case 1: prob_wta_kernel<1><<<grid, 256, 0, s>>>(hn, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+            case 2: prob_wta_kernel<2><<<grid, 256, 0, s>>>(hn, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+            case 4: prob_wta_kernel<4><<<grid, 256, 0, s>>>(hn, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
             default:
-                rc = launch_conv2d(h3, f3, nullptr, 0, params[30], params[31], H, W, 1, ws.reg, nullptr, 1, s3);
-                if (rc) return rc;
-                rc = mvs_wta_update_f32(ws.reg, depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum, s3);
-                if (rc) return rc;
+                if ((r = launch_conv2d(hn, f3, nullptr, 0, params[30], params[31], H, W, 1, ws.reg, nullptr, 1, s))) return r;
+                if ((r = mvs_wta_update_f32(ws.reg, depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum, s))) return r;
         }
-        if ((rc = (int)hipGetLastError())) return rc;
+        return (int)hipGetLastError();
+    };
+
+    if (!gs) {
+        // one stream: planes in order, cells in order
+        for (int d = 0; d < depth_num; ++d) {
+            if (d % XB == 0 && (rc = batch_start(d))) return rc;
+            for (int k = 0; k < 3; ++k) if ((rc = cell_plane(k, d, st))) return rc;
+        }
+    } else {
+        for (int j = 0, d0 = 0; d0 < depth_num; ++j, d0 += PG) {
+            const int d1 = d0 + PG < depth_num ? d0 + PG : depth_num, jp = j & 1;
+            for (int k = 0; k < 3; ++k) {
+                hipStream_t s = sk[k];
+                // the states cell k wrote in this group ...
+                if (k > 0 && (e = hipStreamWaitEvent(s, gs->ready[k - 1][jp], 0)) != hipSuccess) return (int)e;
+                // ... and the ring slots this cell is about to overwrite were read by cell k+1 two groups ago
+                if (k < 2 && j >= 2 && (e = hipStreamWaitEvent(s, gs->read[k][jp], 0)) != hipSuccess) return (int)e;
+                for (int d = d0; d < d1; ++d) {
+                    if (k == 0 && d % XB == 0 && (rc = batch_start(d))) return rc;
+                    if ((rc = cell_plane(k, d, s))) return rc;
+                }
+                if (k < 2 && (e = hipEventRecord(gs->ready[k][jp], s)) != hipSuccess) return (int)e;
+                if (k > 0 && (e = hipEventRecord(gs->read[k - 1][jp], s)) != hipSuccess) return (int)e;
+            }
+        }
     }
     if (gs)
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             if ((e = hipEventRecord(gs->join[i], gs->s[i])) != hipSuccess) return (int)e;
             if ((e = hipStreamWaitEvent(st, gs->join[i], 0)) != hipSuccess) return (int)e;
         }

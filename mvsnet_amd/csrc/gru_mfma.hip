@@ -9,6 +9,12 @@
 // MODE 1 fuses the reset gate into the staging of xb:  xb = sigmoid(LayerNorm(g_r)) * h
 // (convgru.py:97,101,107), so r*h is never materialised.  LayerNorm moments of the output are
 // accumulated per row tile (tile 0 = reset | tile 1 = update for the gate convolution).
+//
+// x-part hoisting.  Both convolutions are linear in the concatenation, conv([x | h]) = conv_x(x) + conv_h(h), and
+// only the h halves sit on the recurrence: the x halves of BOTH convolutions (32 -> 32 + 16 channels, 2/3 of the
+// cell's MACs) are evaluated for a whole batch of planes by one launch (BATCH: tiles run over planes too) on a
+// side stream, and the per-plane kernels on the critical path only convolve the 16 state channels (CA = 0) and
+// add the precomputed part in their epilogue (ADD).  See mvs_gru_wta_f32.
 #include "conv_common.h"
 
 namespace {
@@ -20,15 +26,21 @@ struct Gru2dArgs {
     const double* g_stats;      // MODE 1: (2,2) [sum,sumsq] of reset | update groups
     const float* r_gamma; const float* r_beta;     // MODE 1
     const float* wprep;         // [tap9][(CA+CB)/4][COUT][4]
-    const float* bias;          // (COUT)
+    const float* bias;          // (COUT) or the first `bias_split` channels when bias2 is given
     float* y;                   // (H,W,COUT)
     double* stats;              // (COUT/16 groups, 2) [sum, sumsq]
     int H, W, tiles_h, tiles_w;
+    const float* bias2;         // bias of channels >= bias_split (the x-part launch carries two convolutions)
+    int bias_split;
+    const float* yadd;          // ADD: precomputed part, pixel stride yadd_stride floats, first channel yadd_off
+    int yadd_stride, yadd_off;
+    int planes;                 // BATCH: xa is (planes,H,W,CA), y is (planes,H,W,y_stride)
+    int y_stride, y_off;        // pixel stride / first channel of y (0: COUT, 0)
 };
 
 constexpr int TH2 = 8, TW2 = 16, PW2 = TW2 + 2;
 
-template <int CA, int CB, int COUT, int MODE>
+template <int CA, int CB, int COUT, int MODE, bool ADD, bool BATCH>
 __global__ void __launch_bounds__(256, 1)
 conv2d_cat_mfma_kernel(Gru2dArgs a) {
     constexpr int CT = CA + CB;
@@ -45,10 +57,14 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;
     float* slab = smem + W_FLOATS;                  // [2][NPOS][S]
+    // The per-plane kernels sit on the recurrent chain and share their CUs with the batched x-part launch of
+    // the next planes (another stream): their waves take issue priority, the batch launch fills the gaps.
+    if (!BATCH) __builtin_amdgcn_s_setprio(3);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
-    const int ntiles = a.tiles_h * a.tiles_w;
+    const int tiles_pp = a.tiles_h * a.tiles_w;                  // tiles per plane
+    const int ntiles = tiles_pp * (BATCH ? a.planes : 1);
 
     copy_weights_to_lds(wl, a.wprep, W_FLOATS);      // prepared layout, eight loads in flight per thread
 
@@ -60,9 +76,11 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     // the horizontal wrap needs a test.
     constexpr int CQB = CB / 4;
     constexpr int NFA = NPOS * CQA, NFB = NPOS * CQB;
-    constexpr int NA = (NFA + 255) / 256, NB = (NFB + 255) / 256, NIT = NA + NB;
-    static_assert(256 % CQA == 0 && 256 % CQB == 0 && NFA >= 256 && NFB >= 256, "staging map");
-    const int qb = tid % CQB;                        // this thread's channel quad in the xb pieces
+    constexpr int NA = (NFA + 255) / 256, NB = (NFB + 255) / 256, NIT = NA + NB;      // either family may be empty
+    static_assert((CA == 0 || (256 % CQA == 0 && NFA >= 256)) && (CB == 0 || (256 % CQB == 0 && NFB >= 256)), "staging map");
+    static_assert(MODE == 0 || CB > 0, "the reset gate applies to the xb family");
+    static_assert(!BATCH || (CB == 0 && MODE == 0 && !ADD), "only the x-part launch is batched over planes");
+    const int qb = tid % (CQB ? CQB : 1);            // this thread's channel quad in the xb pieces
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;      // MODE 1: LayerNorm affine of the reset gate
     if (MODE == 1) {
         const double cnt = (double)a.H * a.W * CB;
@@ -78,20 +96,21 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         ra = make_float4(s[0], s[1], s[2], s[3]); rb = make_float4(t[0], t[1], t[2], t[3]);
     }
     const int bytes_a = a.H * a.W * CA * 4, bytes_b = a.H * a.W * CB * 4;
-    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.xa, 0, bytes_a, 0x00020000);
+    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.xa, 0, bytes_a * (BATCH ? a.planes : 1), 0x00020000);
     const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.xb, 0, bytes_b, 0x00020000);
     const auto rsrc_g = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 1 ? a.g : a.xb), 0, MODE == 1 ? 2 * bytes_b : bytes_b, 0x00020000);
     // per piece: byte offset relative to the tile's (h0-1, w0-1) pixel, staged column, LDS float offset
-    int poff[NIT], pcol[NIT], loff[NIT];
+    int poff[NIT], pcol[NIT], loff[NIT], prow[BATCH ? NIT : 1];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         const bool isb = i >= NA;
-        const int cq = isb ? CQB : CQA, nf = isb ? NFB : NFA;
+        const int cq = isb ? (CQB ? CQB : 1) : (CQA ? CQA : 1), nf = isb ? NFB : NFA;
         int f = tid + 256 * (isb ? i - NA : i);
         if (f >= nf) f -= 256;                       // spare threads of a family's last piece redo their previous one
         const int pos = f / cq, q = f % cq;
         const int r = pos / PW2, c = pos - r * PW2;
         pcol[i] = c;
+        if (BATCH) prow[i] = r;
         poff[i] = ((r * a.W + c) * (isb ? CB : CA) + 4 * q) * 4;
         loff[i] = pos * S + (isb ? CA : 0) + 4 * q;
     }
@@ -102,11 +121,18 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     };
     float4 pre[NIT], preg[MODE == 1 ? NB : 1];
     auto load_piece = [&](int i, int tile) __attribute__((always_inline)) {
-        const int tl = tile < ntiles ? tile : 0;     // past the end: a harmless reload of tile 0
+        const int tg = tile < ntiles ? tile : 0;     // past the end: a harmless reload of tile 0
+        const int plane = BATCH ? tg / tiles_pp : 0, tl = BATCH ? tg - plane * tiles_pp : tg;
         const int th = tl / a.tiles_w, h0 = th * TH2, w0 = (tl - th * a.tiles_w) * TW2;
         const int base = (h0 - 1) * a.W + (w0 - 1);  // may be negative: such offsets are out of range as unsigned
-        const bool ok = (unsigned)(w0 - 1 + pcol[i]) < (unsigned)a.W;
-        if (i < NA) pre[i] = ldb(rsrc_a, ok ? base * (CA * 4) + poff[i] : (int)0x80000000);
+        bool ok = (unsigned)(w0 - 1 + pcol[i]) < (unsigned)a.W;
+        // batched planes are contiguous in one buffer: the rows above / below a plane are its neighbours' rows
+        if (BATCH) ok = ok && (unsigned)(h0 - 1 + prow[i]) < (unsigned)a.H;
+        if (i < NA) {
+            u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? base * (CA * 4) + poff[i] : (int)0x80000000,
+                                                               BATCH ? plane * bytes_a : 0, 0);
+            pre[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
         else {
             pre[i] = ldb(rsrc_b, ok ? base * (CB * 4) + poff[i] : (int)0x80000000);
             // the reset gate is channels [0, CB) of the (H, W, 2*CB) gate tensor: pixel stride doubles
@@ -132,7 +158,10 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bias4[m][k] = a.bias ? a.bias[m * 16 + 4 * kq + k] : 0.f;
+        for (int k = 0; k < 4; ++k) {
+            const int co = m * 16 + 4 * kq + k;
+            bias4[m][k] = (a.bias2 && co >= a.bias_split) ? a.bias2[co - a.bias_split] : (a.bias ? a.bias[co] : 0.f);
+        }
     float st_s[MT], st_q[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { st_s[m] = 0.f; st_q[m] = 0.f; }
@@ -159,6 +188,17 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[m][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 padd[ADD ? MT : 1][V];                // the precomputed part of this tile's outputs, requested now
+        if (ADD) {
+            const int th = tile / a.tiles_w, h0 = th * TH2, w0 = (tile - th * a.tiles_w) * TW2;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int h = min(h0 + V * wave + v, a.H - 1), w = min(w0 + n, a.W - 1);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    padd[m][v] = *(const float4*)(a.yadd + ((size_t)h * a.W + w) * a.yadd_stride + a.yadd_off + m * 16 + 4 * kq);
+            }
+        }
         {   // operand reads of group g+1 are issued before the MFMAs of group g (register double buffer)
             constexpr int NG = 9 * (CT / 16);
             f32x4 bv[2][V], av[2][MT];
@@ -192,7 +232,10 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         }
         // store (+bias) and LayerNorm moments
         {
-            const int th = tile / a.tiles_w, h0 = th * TH2, w0 = (tile - th * a.tiles_w) * TW2;
+            const int plane = BATCH ? tile / tiles_pp : 0, tl = BATCH ? tile - plane * tiles_pp : tile;
+            const int th = tl / a.tiles_w, h0 = th * TH2, w0 = (tl - th * a.tiles_w) * TW2;
+            const int ys = a.y_stride ? a.y_stride : COUT;
+            float* yp = a.y + (size_t)plane * a.H * a.W * ys + a.y_off;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 int h = h0 + V * wave + v, w = w0 + n;
@@ -201,7 +244,8 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
                     for (int m = 0; m < MT; ++m) {
                         f32x4 r = acc[m][v];
                         float4 o = make_float4(r[0] + bias4[m][0], r[1] + bias4[m][1], r[2] + bias4[m][2], r[3] + bias4[m][3]);
-                        *(float4*)(a.y + ((size_t)h * a.W + w) * COUT + m * 16 + 4 * kq) = o;
+                        if (ADD) { o.x += padd[m][v].x; o.y += padd[m][v].y; o.z += padd[m][v].z; o.w += padd[m][v].w; }
+                        *(float4*)(yp + ((size_t)h * a.W + w) * ys + m * 16 + 4 * kq) = o;
                         st_s[m] += (o.x + o.y) + (o.z + o.w);
                         st_q[m] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
                     }
@@ -228,58 +272,87 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     }
 }
 
-// TensorFlow conv2d kernel (3,3,CT,COUT) -> [tap9][CT/4][COUT][4]
-__global__ void gru_weight_layout_kernel(const float* __restrict__ w, int CT, int COUT, float* __restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 9 * CT * COUT) return;
-    int j = i & 3, r = i >> 2;
-    int co = r % COUT; r /= COUT;
-    int CQ = CT / 4;
-    int ciq = r % CQ, tap = r / CQ;
-    out[i] = w[((size_t)tap * CT + ciq * 4 + j) * COUT + co];
-}
-
-template <int CA, int CB, int COUT, int MODE>
+template <int CA, int CB, int COUT, int MODE, bool ADD = false, bool BATCH = false>
 int launch_gru2d(const Gru2dArgs& a0, hipStream_t st) {
     Gru2dArgs a = a0;
     a.tiles_h = (a.H + TH2 - 1) / TH2;
     a.tiles_w = (a.W + TW2 - 1) / TW2;
-    const int ntiles = a.tiles_h * a.tiles_w;
+    const int ntiles = a.tiles_h * a.tiles_w * (BATCH ? a.planes : 1);
     const int grid = ntiles < 256 ? ntiles : 256;
     constexpr int CT = CA + CB;
     size_t smem = (size_t)(9 * CT * COUT + 2 * (TH2 + 2) * PW2 * (CT + 8)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv2d_cat_mfma_kernel<CA, CB, COUT, MODE>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv2d_cat_mfma_kernel<CA, CB, COUT, MODE, ADD, BATCH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv2d_cat_mfma_kernel<CA, CB, COUT, MODE><<<grid, 256, smem, st>>>(a);
+    conv2d_cat_mfma_kernel<CA, CB, COUT, MODE, ADD, BATCH><<<grid, 256, smem, st>>>(a);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
-int mvs_gru_weight_layout(const float* w, int CT, int COUT, float* out, hipStream_t st) {
-    gru_weight_layout_kernel<<<mvs_cdiv(9 * CT * COUT, 256), 256, 0, st>>>(w, CT, COUT, out);
+namespace {
+// input channels [ci0, ci0+CI) of a TensorFlow kernel (3,3,CTOT,COUT) -> out[tap9][CI/4][COUT_OUT][4] at output
+// channel offset co_off (two kernels can share one prepared array: the x-part launch)
+__global__ void gru_weight_slice_kernel(const float* __restrict__ w, int CTOT, int ci0, int CI, int COUT, int COUT_OUT,
+                                        int co_off, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * CI * COUT) return;
+    int j = i & 3, r = i >> 2;
+    int co = r % COUT; r /= COUT;
+    int CQ = CI / 4;
+    int ciq = r % CQ, tap = r / CQ;
+    out[(((size_t)tap * CQ + ciq) * COUT_OUT + co_off + co) * 4 + j] = w[((size_t)tap * CTOT + ci0 + ciq * 4 + j) * COUT + co];
+}
+}  // namespace
+
+// prepared weights of the hoisted formulation (cell 1, CA = 32, F = 16): x-part of the gate convolution (9*32*32 floats)
+// followed by the x-part of the candidate convolution (9*32*16), h-part of the gates (9*16*32), h-part of the candidate (9*16*16)
+int mvs_gru1_split_weights(const float* w_gates, const float* w_out, int CA, int F, float* wx, float* wgh, float* woh,
+                           hipStream_t st) {
+    if (!(CA == 32 && F == 16)) return MVS_E_SHAPE;
+    const int CT = CA + F;
+    auto go = [&](const float* w, int ci0, int CI, int COUT, int COUT_OUT, int co_off, float* out) {
+        gru_weight_slice_kernel<<<mvs_cdiv(9 * CI * COUT, 256), 256, 0, st>>>(w, CT, ci0, CI, COUT, COUT_OUT, co_off, out);
+    };
+    go(w_gates, 0, CA, 2 * F, 2 * F, 0, wx);                           // wx = [gate x-part | candidate x-part]
+    go(w_out, 0, CA, F, F, 0, wx + (size_t)9 * CA * 2 * F);
+    go(w_gates, CA, F, 2 * F, 2 * F, 0, wgh);
+    go(w_out, CA, F, F, F, 0, woh);
     return (int)hipGetLastError();
 }
 
-// gate convolution of cell 1: [x | h] -> 2F raw gates (+bias), LayerNorm moments of reset | update
-int mvs_gru1_gates_mfma(const float* x, const float* h, const float* wprep, const float* bias, int H,
-                        int W, int CA, int F, float* g, double* stats, hipStream_t st) {
-    if (!(CA == 32 && F == 16)) return MVS_E_SHAPE;
-    Gru2dArgs a{x, h, nullptr, nullptr, nullptr, nullptr, wprep, bias, g, stats, H, W, 0, 0};
-    return launch_gru2d<32, 16, 32, 0>(a, st);
+// x-part of both convolutions of cell 1 for `planes` consecutive cost slices: px (planes,H,W,48) =
+// [conv(x, Wg_x) + b_g | conv(x, Wo_x) + b_o].  Two launches (32 + 16 output channels): 94 / 76 KB of LDS each, so
+// that a workgroup of the per-plane kernels on the critical path (53 KB) fits on the same CU beside them -- one
+// 48-channel launch (113 KB) shut them out and serialised the two streams.
+int mvs_gru1_xpart_mfma(const float* x, const float* wxg, const float* wxo, const float* bias_g, const float* bias_o,
+                        int H, int W, int planes, float* px, hipStream_t st) {
+    if ((long long)planes * H * W * 48 * 4 >= (1LL << 31)) return MVS_E_SHAPE;
+    Gru2dArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, wxg, bias_g, px, nullptr, H, W, 0, 0,
+                nullptr, 0, nullptr, 0, 0, planes, 48, 0};
+    int rc = launch_gru2d<32, 0, 32, 0, false, true>(a, st);
+    if (rc) return rc;
+    Gru2dArgs b{x, nullptr, nullptr, nullptr, nullptr, nullptr, wxo, bias_o, px, nullptr, H, W, 0, 0,
+                nullptr, 0, nullptr, 0, 0, planes, 48, 32};
+    return launch_gru2d<32, 0, 16, 0, false, true>(b, st);
 }
 
-// candidate convolution of cell 1: [x | sigmoid(LN(g_r)) * h] -> F (+bias), LayerNorm moments
-int mvs_gru1_out_mfma(const float* x, const float* h, const float* g, const double* g_stats,
-                      const float* r_gamma, const float* r_beta, const float* wprep,
-                      const float* bias, int H, int W, int CA, int F, float* c, double* stats,
-                      hipStream_t st) {
-    if (!(CA == 32 && F == 16)) return MVS_E_SHAPE;
-    Gru2dArgs a{x, h, g, g_stats, r_gamma, r_beta, wprep, bias, c, stats, H, W, 0, 0};
-    return launch_gru2d<32, 16, 16, 1>(a, st);
+// h-part of the gate convolution + precomputed x-part (px, pixel stride 48): raw gates, LayerNorm moments
+int mvs_gru1_gates_h_mfma(const float* h, const float* wgh, const float* px, int H, int W, float* g, double* stats,
+                          hipStream_t st) {
+    Gru2dArgs a{nullptr, h, nullptr, nullptr, nullptr, nullptr, wgh, nullptr, g, stats, H, W, 0, 0,
+                nullptr, 0, px, 48, 0, 1, 0, 0};
+    return launch_gru2d<0, 16, 32, 0, true, false>(a, st);
+}
+
+// h-part of the candidate convolution on sigmoid(LN(g_r)) * h + precomputed x-part (channels 32..47 of px)
+int mvs_gru1_out_h_mfma(const float* h, const float* g, const double* g_stats, const float* r_gamma, const float* r_beta,
+                        const float* woh, const float* px, int H, int W, float* c, double* stats, hipStream_t st) {
+    Gru2dArgs a{nullptr, h, g, g_stats, r_gamma, r_beta, woh, nullptr, c, stats, H, W, 0, 0,
+                nullptr, 0, px, 48, 32, 1, 0, 0};
+    return launch_gru2d<0, 16, 16, 1, true, false>(a, st);
 }
