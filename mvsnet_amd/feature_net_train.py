@@ -1,0 +1,211 @@
+"""UNetDS2GN towers for TRAINING as one autograd node (SURVEY 8f f2 + f4; mvsnet/cnn_wrapper/mvsnetworks.py:53-115,
+the towers of `inference`, mvsnet/model.py:270-292, differentiated by TensorFlow in the reference).
+
+Forward: exactly the inference extractor (`feature_net_hip.HipUNetDS2GN`): one `mvs_conv2d_gn_f32` /
+`mvs_deconv2d_gn_f32` launch per layer with the producer's GroupNorm (+ReLU) folded into the consumer's load; the raw
+layer outputs it keeps anyway are what the backward needs.  (~0.7 ms for 3 x 480 x 640 against ~3.5 ms for the
+MIOpen convolutions + separate GroupNorm passes.)
+
+Backward, per layer in reverse: GroupNorm(+ReLU) backward on the HIP library (`mvs_gn_*_f32`), then the convolution's
+input / weight gradients through ATen's `convolution_backward` (MIOpen) on the materialised normalised inputs -- the
+2D convolution backward kernels stay PyTorch-ROCm glue as north_star has it for the towers.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .feature_net import UNET_LAYERS, _same_pad
+
+GN_EPS = 1e-5
+
+
+def _cl(t):
+    """(V,H,W,C) contiguous -> the (V,C,H,W) channels_last view ATen wants (no copy)."""
+    return t.permute(0, 3, 1, 2)
+
+
+def flatten_unet_params(params) -> List[torch.Tensor]:
+    flat = []
+    for name, kind, *_ in UNET_LAYERS:
+        flat.append(params[name]["w"])
+        if kind != "c":
+            flat += [params[name]["gamma"], params[name]["beta"]]
+    return flat
+
+
+class HipTowers(torch.autograd.Function):
+    """images (V,H,W,3) + the tower variables in TensorFlow layouts -> features (V,H/4,W/4,32)."""
+
+    @staticmethod
+    def forward(ctx, images, *flat):
+        lib = _lib.load()
+        dev = images.device
+        V, H, W, _ = images.shape
+        if H % 16 or W % 16:
+            raise ValueError("UNetDS2GN needs image sizes divisible by 16")
+        slots = lib.mvs_gn_stat_slots()
+        st = _lib.stream_ptr()
+        data = torch.zeros((V, H, W, 4), dtype=torch.float32, device=dev)       # image padded 3 -> 4 channels
+        data[..., :3] = images.detach()
+        P, i = {}, 0
+        for name, kind, *_ in UNET_LAYERS:
+            P[name] = {"w": flat[i].detach()}; i += 1
+            if kind != "c":
+                P[name]["gamma"], P[name]["beta"] = flat[i].detach().contiguous(), flat[i + 1].detach().contiguous(); i += 2
+        acts: Dict[str, torch.Tensor] = {}
+        src_of = {"data": (data, None, None, None, 0)}                           # tensor, stats, gamma, beta, relu
+        chans = {"data": 4}
+        shapes = {"data": (H, W)}
+        for name, kind, srcs, k, _mult, stride in UNET_LAYERS:
+            w = P[name]["w"]
+            h, wd_ = shapes[srcs[0]]
+            cins = [chans[s] for s in srcs]
+            if kind == "dg":
+                cout = w.shape[2]
+                ho, wo = 2 * h, 2 * wd_
+            else:
+                cout = w.shape[3]
+                ho, wo = -(-h // stride), -(-wd_ // stride)
+            y = torch.empty((V, ho, wo, cout), dtype=torch.float32, device=dev)
+            so = torch.zeros(V * (cout // 8) * 2 * slots, dtype=torch.float64, device=dev) if kind != "c" else None
+            a = src_of[srcs[0]]
+            if kind == "dg":
+                wraw = w.contiguous()
+                n = lib.mvs_deconv2d_prepared_floats(cins[0], cout)
+                prep = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+                if n:
+                    _lib.check(lib.mvs_deconv2d_prepare_f32(_lib.ptr(wraw), cins[0], cout, _lib.ptr(prep), st), "mvs_deconv2d_prepare_f32")
+                _lib.check(lib.mvs_deconv2d_gn_f32(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]), cins[0], a[4],
+                                                   _lib.ptr(wraw), _lib.ptr(prep) if n else None, V, h, wd_, cout, _lib.ptr(y),
+                                                   _lib.ptr(so), st), "mvs_deconv2d_gn_f32")
+            else:
+                wt = w
+                if srcs == ("data",):                                            # zero kernel for the padding channel
+                    wt = torch.cat([w, torch.zeros(w.shape[:2] + (1, cout), device=dev)], dim=2)
+                wt = wt.contiguous()
+                c1, c2 = cins[0], (cins[1] if len(cins) > 1 else 0)
+                prep = torch.empty(lib.mvs_conv2d_prepared_floats(k, c1, c2, cout), dtype=torch.float32, device=dev)
+                _lib.check(lib.mvs_conv2d_prepare_f32(_lib.ptr(wt), k, c1, c2, cout, _lib.ptr(prep), st), "mvs_conv2d_prepare_f32")
+                b = src_of[srcs[1]] if len(srcs) > 1 else (None, None, None, None, 0)
+                _lib.check(lib.mvs_conv2d_gn_f32(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]), c1, a[4],
+                                                 _lib.ptr(b[0]), _lib.ptr(b[1]), _lib.ptr(b[2]), _lib.ptr(b[3]), c2, b[4],
+                                                 _lib.ptr(prep), V, h, wd_, cout, k, stride, _lib.ptr(y), _lib.ptr(so), st),
+                           "mvs_conv2d_gn_f32")
+            acts[name] = y
+            chans[name], shapes[name] = cout, (ho, wo)
+            src_of[name] = (y, so, P[name].get("gamma"), P[name].get("beta"), 1 if kind == "cg" else 0)
+        ctx.saved = (data, acts, P)
+        return acts["conv10_2"].clone()
+
+    @staticmethod
+    def backward(ctx, g_feat):
+        lib = _lib.load()
+        data, acts, P = ctx.saved
+        dev = data.device
+        st = _lib.stream_ptr()
+        kinds = {name: kind for name, kind, *_ in UNET_LAYERS}
+
+        chan_stats: Dict[str, torch.Tensor] = {}                                # per-channel (V,2,C) float64 sums of raw y
+
+        def stats_of(name):
+            if name not in chan_stats:
+                y = acts[name]
+                V, h, w, c = y.shape
+                s = torch.zeros((V, 2, c), dtype=torch.float64, device=dev)
+                _lib.check(lib.mvs_gn_stats_f32(_lib.ptr(y), V, h * w, c, _lib.ptr(s), st), "mvs_gn_stats_f32")
+                chan_stats[name] = s
+            return chan_stats[name]
+
+        norm_cache: Dict[str, torch.Tensor] = {}
+
+        def normalised(name):
+            """what the consumers of `name` saw: GroupNorm(+ReLU) of the raw output (the padded image for 'data')"""
+            if name == "data":
+                return data
+            if name not in norm_cache:
+                y = acts[name]
+                V, h, w, c = y.shape
+                out = torch.empty_like(y)
+                _lib.check(lib.mvs_gn_apply_f32(_lib.ptr(y), _lib.ptr(stats_of(name)), _lib.ptr(P[name]["gamma"]),
+                                                _lib.ptr(P[name]["beta"]), GN_EPS, 1 if kinds[name] == "cg" else 0, V, h * w, c,
+                                                _lib.ptr(out), st), "mvs_gn_apply_f32")
+                norm_cache[name] = out
+            return norm_cache[name]
+
+        g_act: Dict[str, torch.Tensor] = {}                                     # gradient w.r.t. the normalised output
+
+        def add_grad(name, g):
+            if name == "data":
+                return
+            g_act[name] = g if name not in g_act else g_act[name] + g
+
+        grads: Dict[str, Dict[str, torch.Tensor]] = {}
+        for name, kind, srcs, k, _mult, stride in reversed(UNET_LAYERS):
+            y = acts[name]
+            V, ho, wo, cout = y.shape
+            if kind == "c":
+                g_y = g_feat.contiguous()
+                grads[name] = {}
+            else:
+                g_a = g_act.pop(name).contiguous()
+                sums = torch.zeros((V, 2, cout), dtype=torch.float64, device=dev)
+                relu = 1 if kind == "cg" else 0
+                args = (_lib.ptr(y), _lib.ptr(stats_of(name)), _lib.ptr(P[name]["gamma"]), _lib.ptr(P[name]["beta"]), GN_EPS, relu,
+                        _lib.ptr(g_a))
+                _lib.check(lib.mvs_gn_bwd_reduce_f32(*args, V, ho * wo, cout, _lib.ptr(sums), st), "mvs_gn_bwd_reduce_f32")
+                g_y = torch.empty_like(y)
+                _lib.check(lib.mvs_gn_bwd_apply_f32(*args, _lib.ptr(sums), V, ho * wo, cout, _lib.ptr(g_y), st), "mvs_gn_bwd_apply_f32")
+                tot = sums.sum(0).to(torch.float32)
+                grads[name] = {"gamma": tot[1], "beta": tot[0]}
+            # convolution backward on the materialised normalised inputs (ATen / MIOpen)
+            xs = [normalised(s) for s in srcs]
+            x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=3)
+            w_tf = P[name]["w"]
+            if srcs == ("data",):
+                w_tf = torch.cat([w_tf, torch.zeros(w_tf.shape[:2] + (1, cout), device=dev)], dim=2)
+            w_t = w_tf.permute(3, 2, 0, 1).contiguous()            # conv (Cout,Cin,k,k); transposed conv (Cin,Cout,k,k)
+            xin, gy = _cl(x), _cl(g_y)
+            if kind == "dg":
+                n_h, n_w = x.shape[1], x.shape[2]
+                pb_h = _same_pad(n_h * stride, k, stride)[0]
+                pb_w = _same_pad(n_w * stride, k, stride)[0]
+                full_h, full_w = stride * (n_h - 1) + k, stride * (n_w - 1) + k
+                gfull = F.pad(gy, (pb_w, full_w - pb_w - wo, pb_h, full_h - pb_h - ho))
+                g_x, g_w, _ = torch.ops.aten.convolution_backward(gfull, xin, w_t, None, [stride, stride], [0, 0], [1, 1], True,
+                                                                  [0, 0], 1, [True, True, False])
+            else:
+                ph, pw = _same_pad(x.shape[1], k, stride), _same_pad(x.shape[2], k, stride)
+                if ph[0] == ph[1] and pw[0] == pw[1]:
+                    g_x, g_w, _ = torch.ops.aten.convolution_backward(gy, xin, w_t, None, [stride, stride], [ph[0], pw[0]], [1, 1],
+                                                                      False, [0, 0], 1, [True, True, False])
+                else:
+                    xp = F.pad(xin, (pw[0], pw[1], ph[0], ph[1]))
+                    g_xp, g_w, _ = torch.ops.aten.convolution_backward(gy, xp, w_t, None, [stride, stride], [0, 0], [1, 1], False,
+                                                                       [0, 0], 1, [True, True, False])
+                    g_x = g_xp[:, :, ph[0]:ph[0] + x.shape[1], pw[0]:pw[0] + x.shape[2]]
+            g_wtf = g_w.permute(2, 3, 1, 0)                           # back to the TensorFlow layout
+            if srcs == ("data",):
+                g_wtf = g_wtf[:, :, :3]
+            grads[name]["w"] = g_wtf.contiguous()
+            g_x = g_x.permute(0, 2, 3, 1)                             # (V,H,W,Cin) view
+            c0 = 0
+            for s_name, xs_ in zip(srcs, xs):
+                c = xs_.shape[3]
+                add_grad(s_name, g_x[..., c0:c0 + c])
+                c0 += c
+        ctx.saved = None
+        flat = []
+        for name, kind, *_ in UNET_LAYERS:
+            flat.append(grads[name]["w"])
+            if kind != "c":
+                flat += [grads[name]["gamma"], grads[name]["beta"]]
+        return (None,) + tuple(flat)
+
+
+def hip_towers(images, params):
+    """images (V,H,W,3) device tensor, params[name] = {'w','gamma','beta'} leaves in TF layouts -> (V,H/4,W/4,32)."""
+    return HipTowers.apply(images, *flatten_unet_params(params))

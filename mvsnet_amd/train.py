@@ -155,7 +155,12 @@ class Trainer:
         gt = torch.as_tensor(depth_image, dtype=torch.float32, device=self.device)[None]
         depth_start, depth_interval = float(cams[0][1][3][0]), float(cams[0][1][3][1])
         depth_end = float(cams[0][1][3][3])
-        feats = unet_forward(trainable_layers(self.params.group("unet")), images, hip_group_norm=self.device.type == "cuda")
+        if self.device.type == "cuda" and self.network_mode == "normal":
+            from .feature_net_train import hip_towers       # HIP forward / GroupNorm backward, ATen convolution backward
+            feats = hip_towers(images, self.params.group("unet"))
+        else:                                               # narrower towers (channel counts below the HIP kernels' tiling)
+            feats = unet_forward(trainable_layers(self.params.group("unet")), images,
+                                 hip_group_norm=self.device.type == "cuda")
         if feats.shape[-1] < 32:
             feats = torch.nn.functional.pad(feats, (0, 32 - feats.shape[-1]))      # padded channels: zero cost, zero gradient
         transforms = homography_transforms(cams_t, depth_num, depth_start, depth_interval)

@@ -374,3 +374,32 @@ def test_full_size_cost_volume_backward_is_the_directional_derivative():
     cm = cost_volume(f[0] - eps * delta[0], f[1:] - eps * delta[1:], t8, variant="eager")
     rhs = (up - _dot(cm, g)) / (2 * eps)
     assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs)) + 1e-2, (lhs, rhs)
+
+
+def test_hip_towers_match_the_torch_towers_forward_and_backward():
+    """UNetDS2GN for training as one autograd node (HIP forward with folded GroupNorm, HIP GroupNorm backward,
+    ATen convolution backward) against the plain PyTorch towers under autograd."""
+    from mvsnet_amd.feature_net import trainable_layers, unet_forward
+    from mvsnet_amd.feature_net_train import hip_towers
+    params = S.make_unet_params("normal", seed=3)
+    rs = np.random.RandomState(1)
+    for name in params:                                   # non-trivial GroupNorm affines
+        if "gamma" in params[name]:
+            params[name]["gamma"] = (1.0 + 0.2 * rs.randn(*params[name]["gamma"].shape)).astype(np.float32)
+            params[name]["beta"] = (0.1 * rs.randn(*params[name]["beta"].shape)).astype(np.float32)
+    images = t(S.make_images(2, 32, 48, seed=4))
+    g = t(rs.randn(2, 8, 12, 32).astype(np.float32))
+    mk = lambda: {k: {kk: t(vv).requires_grad_(True) for kk, vv in v.items()} for k, v in params.items()}
+    pa, pb = mk(), mk()
+    fa = unet_forward(trainable_layers(pa), images)
+    (fa * g).sum().backward()
+    fb = hip_towers(images, pb)
+    assert rel_l1(n(fb), n(fa)) < 1e-5
+    (fb * g).sum().backward()
+    worst = 0.0
+    for name in pa:
+        for key in pa[name]:
+            e = rel_l1(n(pb[name][key].grad), n(pa[name][key].grad))
+            worst = max(worst, e)
+            assert e < 2e-3, (name, key, e)
+    print("worst tower gradient rel-L1:", worst)

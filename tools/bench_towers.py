@@ -8,11 +8,16 @@ from mvsnet_amd.feature_net import trainable_layers, unet_forward
 N, H, W = 3, 480, 640
 tr = T.Trainer("normal", "cuda")
 images = torch.as_tensor(S.make_images(N, H, W)).cuda()
+from mvsnet_amd.feature_net_train import hip_towers
+mode = sys.argv[1] if len(sys.argv) > 1 else "hip"
 def step():
-    f = unet_forward(trainable_layers(tr.params.group("unet")), images)
+    if mode == "hip":
+        f = hip_towers(images, tr.params.group("unet"))
+    else:
+        f = unet_forward(trainable_layers(tr.params.group("unet")), images, hip_group_norm=(mode == "torch+hipgn"))
     f.sum().backward()
 for _ in range(3): step()
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(10): step()
 torch.cuda.synchronize()
-print({"towers_fwd_bwd_ms": round((time.time() - t0) / 10 * 1e3, 2)})
+print({"mode": mode, "towers_fwd_bwd_ms": round((time.time() - t0) / 10 * 1e3, 2)})
