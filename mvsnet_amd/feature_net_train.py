@@ -6,9 +6,10 @@ Forward: exactly the inference extractor (`feature_net_hip.HipUNetDS2GN`): one `
 layer outputs it keeps anyway are what the backward needs.  (~0.7 ms for 3 x 480 x 640 against ~3.5 ms for the
 MIOpen convolutions + separate GroupNorm passes.)
 
-Backward, per layer in reverse: GroupNorm(+ReLU) backward on the HIP library (`mvs_gn_*_f32`), then the convolution's
-input / weight gradients through ATen's `convolution_backward` (MIOpen) on the materialised normalised inputs -- the
-2D convolution backward kernels stay PyTorch-ROCm glue as north_star has it for the towers.
+Backward, per layer in reverse: GroupNorm(+ReLU) backward on the HIP library (`mvs_gn_*_f32`); input gradients of the
+3x3 layers on the forward HIP convolution kernels (flipped kernel / conv <-> transposed conv with the same array);
+weight gradients (and the two 5x5 stride-2 layers) through ATen's `convolution_backward` (MIOpen) on the materialised
+normalised inputs -- the remaining PyTorch-ROCm glue in the towers.
 """
 from __future__ import annotations
 
@@ -161,7 +162,10 @@ class HipTowers(torch.autograd.Function):
                 _lib.check(lib.mvs_gn_bwd_apply_f32(*args, _lib.ptr(sums), V, ho * wo, cout, _lib.ptr(g_y), st), "mvs_gn_bwd_apply_f32")
                 tot = sums.sum(0).to(torch.float32)
                 grads[name] = {"gamma": tot[1], "beta": tot[0]}
-            # convolution backward on the materialised normalised inputs (ATen / MIOpen)
+            # convolution backward on the materialised normalised inputs.  Weight gradient: ATen / MIOpen.  Input
+            # gradient: the forward HIP kernels -- a stride-1 convolution's is the convolution with the flipped,
+            # transposed kernel, a stride-2 convolution's IS the transposed convolution with the same kernel array
+            # and vice versa (as for the 3D layers, backward.py); the 5x5 stride-2 layers stay on ATen.
             xs = [normalised(s) for s in srcs]
             x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=3)
             w_tf = P[name]["w"]
@@ -169,34 +173,68 @@ class HipTowers(torch.autograd.Function):
                 w_tf = torch.cat([w_tf, torch.zeros(w_tf.shape[:2] + (1, cout), device=dev)], dim=2)
             w_t = w_tf.permute(3, 2, 0, 1).contiguous()            # conv (Cout,Cin,k,k); transposed conv (Cin,Cout,k,k)
             xin, gy = _cl(x), _cl(g_y)
+            cin_tot = x.shape[3]
+            need_gx = srcs != ("data",)
+            g_x = None
+            hip_gx = need_gx and k == 3 and cin_tot % 8 == 0
+            if hip_gx:
+                gxt = torch.empty((V, x.shape[1], x.shape[2], cin_tot), dtype=torch.float32, device=dev)
+                if kind == "dg":                                       # conv stride 2 with the same array (3,3,Cout,Cin)
+                    wc = w_tf.contiguous()
+                    prep = torch.empty(lib.mvs_conv2d_prepared_floats(3, cout, 0, cin_tot), dtype=torch.float32, device=dev)
+                    _lib.check(lib.mvs_conv2d_prepare_f32(_lib.ptr(wc), 3, cout, 0, cin_tot, _lib.ptr(prep), st), "mvs_conv2d_prepare_f32")
+                    _lib.check(lib.mvs_conv2d_gn_f32(_lib.ptr(g_y), None, None, None, cout, 0, None, None, None, None, 0, 0,
+                                                     _lib.ptr(prep), V, ho, wo, cin_tot, 3, 2, _lib.ptr(gxt), None, st),
+                               "mvs_conv2d_gn_f32")
+                elif stride == 1:                                       # conv with flip(w)^T: (3,3,Cout,Cin)
+                    wc = w_tf.flip(0, 1).permute(0, 1, 3, 2).contiguous()
+                    prep = torch.empty(lib.mvs_conv2d_prepared_floats(3, cout, 0, cin_tot), dtype=torch.float32, device=dev)
+                    _lib.check(lib.mvs_conv2d_prepare_f32(_lib.ptr(wc), 3, cout, 0, cin_tot, _lib.ptr(prep), st), "mvs_conv2d_prepare_f32")
+                    _lib.check(lib.mvs_conv2d_gn_f32(_lib.ptr(g_y), None, None, None, cout, 0, None, None, None, None, 0, 0,
+                                                     _lib.ptr(prep), V, ho, wo, cin_tot, 3, 1, _lib.ptr(gxt), None, st),
+                               "mvs_conv2d_gn_f32")
+                else:                                                   # transposed conv with the same array (3,3,Cin,Cout)
+                    wc = w_tf.contiguous()
+                    n = lib.mvs_deconv2d_prepared_floats(cout, cin_tot)
+                    prep = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+                    if n:
+                        _lib.check(lib.mvs_deconv2d_prepare_f32(_lib.ptr(wc), cout, cin_tot, _lib.ptr(prep), st), "mvs_deconv2d_prepare_f32")
+                    _lib.check(lib.mvs_deconv2d_gn_f32(_lib.ptr(g_y), None, None, None, cout, 0, _lib.ptr(wc), _lib.ptr(prep) if n else None,
+                                                       V, ho, wo, cin_tot, _lib.ptr(gxt), None, st), "mvs_deconv2d_gn_f32")
+                g_x = _cl(gxt)
+            mask = [need_gx and not hip_gx, True, False]
             if kind == "dg":
                 n_h, n_w = x.shape[1], x.shape[2]
                 pb_h = _same_pad(n_h * stride, k, stride)[0]
                 pb_w = _same_pad(n_w * stride, k, stride)[0]
                 full_h, full_w = stride * (n_h - 1) + k, stride * (n_w - 1) + k
                 gfull = F.pad(gy, (pb_w, full_w - pb_w - wo, pb_h, full_h - pb_h - ho))
-                g_x, g_w, _ = torch.ops.aten.convolution_backward(gfull, xin, w_t, None, [stride, stride], [0, 0], [1, 1], True,
-                                                                  [0, 0], 1, [True, True, False])
+                gx_a, g_w, _ = torch.ops.aten.convolution_backward(gfull, xin, w_t, None, [stride, stride], [0, 0], [1, 1], True,
+                                                                   [0, 0], 1, mask)
             else:
                 ph, pw = _same_pad(x.shape[1], k, stride), _same_pad(x.shape[2], k, stride)
                 if ph[0] == ph[1] and pw[0] == pw[1]:
-                    g_x, g_w, _ = torch.ops.aten.convolution_backward(gy, xin, w_t, None, [stride, stride], [ph[0], pw[0]], [1, 1],
-                                                                      False, [0, 0], 1, [True, True, False])
+                    gx_a, g_w, _ = torch.ops.aten.convolution_backward(gy, xin, w_t, None, [stride, stride], [ph[0], pw[0]], [1, 1],
+                                                                       False, [0, 0], 1, mask)
                 else:
                     xp = F.pad(xin, (pw[0], pw[1], ph[0], ph[1]))
-                    g_xp, g_w, _ = torch.ops.aten.convolution_backward(gy, xp, w_t, None, [stride, stride], [0, 0], [1, 1], False,
-                                                                       [0, 0], 1, [True, True, False])
-                    g_x = g_xp[:, :, ph[0]:ph[0] + x.shape[1], pw[0]:pw[0] + x.shape[2]]
+                    gx_a, g_w, _ = torch.ops.aten.convolution_backward(gy, xp, w_t, None, [stride, stride], [0, 0], [1, 1], False,
+                                                                       [0, 0], 1, mask)
+                    if mask[0]:
+                        gx_a = gx_a[:, :, ph[0]:ph[0] + x.shape[1], pw[0]:pw[0] + x.shape[2]]
+            if mask[0]:
+                g_x = gx_a
             g_wtf = g_w.permute(2, 3, 1, 0)                           # back to the TensorFlow layout
             if srcs == ("data",):
                 g_wtf = g_wtf[:, :, :3]
             grads[name]["w"] = g_wtf.contiguous()
-            g_x = g_x.permute(0, 2, 3, 1)                             # (V,H,W,Cin) view
-            c0 = 0
-            for s_name, xs_ in zip(srcs, xs):
-                c = xs_.shape[3]
-                add_grad(s_name, g_x[..., c0:c0 + c])
-                c0 += c
+            if g_x is not None:
+                g_x = g_x.permute(0, 2, 3, 1)                         # (V,H,W,Cin) view
+                c0 = 0
+                for s_name, xs_ in zip(srcs, xs):
+                    c = xs_.shape[3]
+                    add_grad(s_name, g_x[..., c0:c0 + c])
+                    c0 += c
         ctx.saved = None
         flat = []
         for name, kind, *_ in UNET_LAYERS:
