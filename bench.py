@@ -170,16 +170,25 @@ def main():
     if args.regularization == "GRU":
         gp = S.make_gru_params(args.network_mode, seed=2, in_channels=w.channels)
         gw = MVSNetWeights.from_numpy(args.network_mode, gru=gp, device=dev)
-        gplan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, gw, "GRU", dev)
         from mvsnet_amd.model import wta_depth_values
         dv = wta_depth_values(w.depth_num, w.depth_start, w.depth_end, False)
-        gplan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
-        for _ in range(args.warmup):
-            gplan.run_gru(feats, dv)
+        ns = max(1, args.streams)                       # sweeps of different reference views in flight
+        gplans = [DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, gw, "GRU", dev) for _ in range(ns)]
+        gstreams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+        for pl, s_ in zip(gplans, gstreams):
+            with torch.cuda.stream(s_):
+                pl.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
+
+        def gstep(i):
+            with torch.cuda.stream(gstreams[i % ns]):
+                gplans[i % ns].run_gru(feats, dv)
+        torch.cuda.synchronize()
+        for i in range(max(args.warmup, 2 * ns)):
+            gstep(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            gplan.run_gru(feats, dv)
+        for i in range(args.steps):
+            gstep(i)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         flops = 2.0 * 23238 * w.depth_num * w.height * w.width
@@ -188,7 +197,7 @@ def main():
                           "ms_per_step": el / args.steps * 1e3, "ms_per_plane": el / args.steps / w.depth_num * 1e3,
                           "achieved_tflops": flops * args.steps / el / 1e12, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "%s: GRU sweep, N=%d, D=%d, %dx%d" % (
-                              w.name, w.view_num, w.depth_num, w.width, w.height)}}), flush=True)
+                              w.name, w.view_num, w.depth_num, w.width, w.height), "streams_per_gpu": ns}}), flush=True)
         return
     n_streams = max(1, args.streams)
     plans = [DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", dev)

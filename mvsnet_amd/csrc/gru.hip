@@ -441,23 +441,31 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
 
 // Side streams for cells 2 and 3 and for the per-batch producer (cost slices + hoisted x-part) (created on first use; one host thread per device as elsewhere).
 struct GruStreams { hipStream_t s[3]; hipEvent_t fork, join[3], ready[2][2], read[2][2], xready[2], xdone[2]; };
-GruStreams* gru_streams() {
-    static GruStreams g;
-    static int state = 0;
-    if (state == 0) {
-        state = -1;
-        bool ok = !getenv("MVS_GRU_ONE_STREAM");
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;   // lo = least urgent: the batch producer yields to the cells
-        for (int i = 0; ok && i < 3; ++i)
-            ok = hipStreamCreateWithPriority(&g.s[i], hipStreamNonBlocking, i == 2 ? lo : hi) == hipSuccess;
-        auto ev = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
-        ev(&g.fork);
-        for (int i = 0; i < 2; ++i) { ev(&g.xready[i]); ev(&g.xdone[i]); for (int j = 0; j < 2; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
-        for (int i = 0; i < 3; ++i) ev(&g.join[i]);
-        if (ok) state = 1;
-    }
-    return state == 1 ? &g : nullptr;
+// One set per caller stream (up to 4: sweeps of different reference views in flight on different streams
+// must not share side streams, or they would serialise behind each other); created on first use.
+GruStreams* gru_streams(hipStream_t caller) {
+    struct Slot { hipStream_t caller; GruStreams g; int state; };
+    static Slot slots[4];
+    static int used = 0;
+    static const bool disabled = getenv("MVS_GRU_ONE_STREAM") != nullptr;
+    if (disabled) return nullptr;
+    for (int i = 0; i < used; ++i)
+        if (slots[i].caller == caller) return slots[i].state == 1 ? &slots[i].g : nullptr;
+    if (used == 4) return nullptr;                       // further caller streams run the one-stream sweep
+    Slot& sl = slots[used++];
+    sl.caller = caller; sl.state = -1;
+    GruStreams& g = sl.g;
+    bool ok = true;
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;   // lo = least urgent: the batch producer yields to the cells
+    for (int i = 0; ok && i < 3; ++i)
+        ok = hipStreamCreateWithPriority(&g.s[i], hipStreamNonBlocking, i == 2 ? lo : hi) == hipSuccess;
+    auto ev = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
+    ev(&g.fork);
+    for (int i = 0; i < 2; ++i) { ev(&g.xready[i]); ev(&g.xdone[i]); for (int j = 0; j < 2; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
+    for (int i = 0; i < 3; ++i) ev(&g.join[i]);
+    if (ok) sl.state = 1;
+    return ok ? &g : nullptr;
 }
 }  // namespace
 
@@ -507,7 +515,7 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     // synchronise per GROUP of PG planes: states live in a ring of 2*PG planes (plane d reads h[k][d % 2PG], writes
     // h[k][(d+1) % 2PG]); per group j, ready[k][j&1] = cell k has written its states of group j, read[k][j&1] =
     // cell k+1 is done reading them (cell k may overwrite those ring slots in group j+2).
-    GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2 * PG) ? gru_streams() : nullptr;
+    GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2 * PG) ? gru_streams(st) : nullptr;
     hipStream_t sk[3] = {st, gs ? gs->s[0] : st, gs ? gs->s[1] : st};
     if (gs) {
         if ((e = hipEventRecord(gs->fork, st)) != hipSuccess) return (int)e;
