@@ -223,7 +223,9 @@ def regnet_backward(saved, p, g_reg):
     g_s5 = deconv_input_grad(g_y, p["3dconv6_0"]["w"])
     # 3dconv0_1: conv 32 -> 8 on the cost volume
     g_y = bn_bwd("3dconv0_1", g_s6)
-    G["3dconv0_1"]["w"] = conv3d_wgrad(cost, g_y, 1)
+    # roles swapped (rows = the 8-channel gradient with its taps, columns = the 32 volume channels): the kernel packs 8
+    # taps per MFMA row tile; R(tap, c8, c32) = dW(2 - tap, c32, c8)
+    G["3dconv0_1"]["w"] = conv3d_wgrad(g_y, cost, 1).flip(0, 1, 2).permute(0, 1, 2, 4, 3).contiguous()
     g_cost_a = conv_s1_input_grad(g_y, p["3dconv0_1"]["w"])
     del g_s6
     # 3dconv5_0: deconv 32 -> 16 on  s4 = a(4_0) + a(2_1)

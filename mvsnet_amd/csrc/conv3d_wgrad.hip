@@ -200,6 +200,134 @@ wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Stride-1 variant with taps packed ACROSS kd ("small-stationary"): the workgroup marches over small planes with
+// the three big planes a small plane pairs with resident in a ring, so a row's tap may sit in any of them and the
+// 27 taps pack into ceil(27 / TPG) operand groups instead of 3 * ceil(9 / TPG).  That pays when the row tensor is
+// narrow: for 3dconv0_1 the roles are swapped (rows = the 8-channel output gradient with its taps, columns = the 32
+// cost-volume channels: R(tap, c8, c32) = sum_o g(o + tap - 1, c8) * cost(o, c32) = dW(2 - tap, c32, c8)), 8 taps
+// per group -> 4 groups x 2 column tiles = 32 MFMAs per 4 voxels instead of 60, every tile full.
+template <int CB, int CT, int TH>
+__global__ void __launch_bounds__(256)
+wgrad_flat_kernel(WgradArgs a) {
+    constexpr int QB = CB / 4, TPG = 16 / QB, NGRP = (27 + TPG - 1) / TPG;
+    constexpr int GPW = (NGRP + 3) / 4;
+    constexpr int BH = TH + 2, BW = TW + 2, SB = CB + 4, SS = (CT == 1) ? 16 : 16 * CT + 16;
+    constexpr int BIG_FLOATS = BH * BW * SB, SMALL_FLOATS = TH * TW * SS, NSTEP = TH * TW / 4;
+    static_assert(GPW * 4 * CT <= 32, "accumulator budget");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bigl = lds;                               // ring of 3 planes
+    float* smalll = lds + 3 * BIG_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    const int tiles_w = (a.Ws + TW - 1) / TW;
+    const int tile_h = blockIdx.x / tiles_w, tile_w = blockIdx.x - tile_h * tiles_w;
+    const int oh0 = tile_h * TH, ow0 = tile_w * TW;
+    const int od0 = blockIdx.z * a.planes_per_wg, od1 = min(od0 + a.planes_per_wg, a.Ds);
+
+    for (int i = tid; i < SMALL_FLOATS; i += 256) smalll[i] = 0.f;        // channels CS .. 16*CT-1 stay zero
+
+    const int m_lo = m % QB, m_hi = m / QB;
+    int a_tap[GPW], a_kd[GPW];
+#pragma unroll
+    for (int sl = 0; sl < GPW; ++sl) {
+        int t27 = (sl * 4 + wave) * TPG + m_hi; if (t27 > 26) t27 = 26;    // rows past tap 26 repeat it; never stored
+        const int kd = t27 / 9, t9 = t27 - 9 * kd, kh = t9 / 3, kw = t9 - 3 * kh;
+        a_kd[sl] = kd;
+        a_tap[sl] = (kh * BW + kw + kq) * SB + 4 * m_lo;
+    }
+    const int b_off = kq * SS + m;
+    f32x4 acc[GPW][4][CT];
+#pragma unroll
+    for (int sl = 0; sl < GPW; ++sl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[sl][j][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NFB = BH * BW * QB, NITB = (NFB + 255) / 256;
+    int gofb[NITB], lofb[NITB];
+#pragma unroll
+    for (int i = 0; i < NITB; ++i) {
+        const int f = tid + 256 * i;
+        const int pos = f / QB, c4 = f - pos * QB;
+        const int r = pos / BW, c = pos - r * BW;
+        const int gh = oh0 - 1 + r, gw = ow0 - 1 + c;
+        const bool inb = f < NFB && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        gofb[i] = inb ? ((gh * a.W + gw) * CB + 4 * c4) * 4 : OOB;
+        lofb[i] = f < NFB ? pos * SB + 4 * c4 : -1;
+    }
+    const int big_plane_bytes = a.H * a.W * CB * 4;
+    const auto brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.big, 0, a.D * big_plane_bytes, 0x00020000);
+    const int csq = (a.CS + 3) / 4, nfs = TH * TW * csq;
+    const size_t small_plane = (size_t)a.Hs * a.Ws * a.CS;
+
+    auto stage_big = [&](int q) {                      // plane q -> ring slot (q + 3) % 3 (zeros outside the volume)
+        const bool plane_ok = q >= 0 && q < a.D;
+        float* dst = bigl + ((q + 3) % 3) * BIG_FLOATS;
+        u32x4_t v[NITB];
+#pragma unroll
+        for (int i = 0; i < NITB; ++i)
+            v[i] = __builtin_amdgcn_raw_buffer_load_b128(brsrc, gofb[i] | (plane_ok ? 0 : OOB), plane_ok ? q * big_plane_bytes : 0, 0);
+#pragma unroll
+        for (int i = 0; i < NITB; ++i)
+            if (lofb[i] >= 0) *(u32x4_t*)(dst + lofb[i]) = v[i];
+    };
+    stage_big(od0 - 1);
+    stage_big(od0);
+    for (int od = od0; od < od1; ++od) {
+        __syncthreads();                                // the previous plane's reads are done
+        stage_big(od + 1);
+        {
+            const float* gp = a.small + (size_t)od * small_plane;
+            for (int f = tid; f < nfs; f += 256) {
+                const int pos = f / csq, c4 = f - pos * csq;
+                const int r = pos / TW, c = pos - r * TW;
+                const int oh = oh0 + r, ow = ow0 + c;
+                const bool inb = oh < a.Hs && ow < a.Ws;
+                const float* p = gp + ((size_t)oh * a.Ws + ow) * a.CS + 4 * c4;
+                *(float4*)(smalll + pos * SS + 4 * c4) = inb ? *(const float4*)p : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < GPW; ++sl) {
+            if ((sl * 4 + wave) * TPG > 26) continue;   // wave-uniform: this slot has no taps
+            const float* ap = bigl + ((od + a_kd[sl] - 1 + 3) % 3) * BIG_FLOATS + a_tap[sl];
+            const float* bp = smalll + b_off;
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                constexpr int SPR = TW / 4;
+                const int oh = st / SPR, owb = 4 * (st % SPR);
+                const f32x4 av = *(const f32x4*)(ap + (oh * BW + owb) * SB);
+                float bv[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) bv[ct] = bp[(oh * TW + owb) * SS + 16 * ct];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[sl][j][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[ct], acc[sl][j][ct], 0, 0, 0);
+            }
+        }
+    }
+    const size_t wsz = (size_t)27 * CB * a.CS;
+    float* out = a.partial + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * wsz;
+#pragma unroll
+    for (int sl = 0; sl < GPW; ++sl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * kq + r;
+                    const int t27 = (sl * 4 + wave) * TPG + row / QB, cb = 4 * (row % QB) + j, cs = 16 * ct + m;
+                    if (t27 < 27 && cs < a.CS) out[((size_t)t27 * CB + cb) * a.CS + cs] = acc[sl][j][ct][r];
+                }
+}
+
 // dW[i] = sum_p partial[p][i] in float64, fixed order: a workgroup owns 16 consecutive elements, its 16
 // "p lanes" walk the partials 16 apart (64-byte segments per row), then fold through LDS in lane order.
 __global__ void __launch_bounds__(256)
@@ -276,6 +404,26 @@ int dispatch(const float* big, const float* small, int D, int H, int W, int CB, 
         if (ws_bytes < bytes) return MVS_E_WORKSPACE;
         if ((rc = mvs_wgrad_c1_launch(big, small, D, H, W, CB, (float*)ws, st))) return rc;
         wgrad_reduce_kernel<<<mvs_cdiv((long long)wsz, 16), 256, 0, st>>>((const float*)ws, rows, wsz, dw);
+        return (int)hipGetLastError();
+    }
+    if (CB == 8 && CS == 32 && stride == 1) {                     // swapped 3dconv0_1: taps packed across kd
+        constexpr int TH = 8, CTF = 2;
+        const int tiles = ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+        long long want = 1024 / tiles;
+        int chunks = (int)(want < 1 ? 1 : want);
+        if (chunks > (D / 2 > 0 ? D / 2 : 1)) chunks = D / 2 > 0 ? D / 2 : 1;
+        const int ppw = (D + chunks - 1) / chunks; chunks = (D + ppw - 1) / ppw;
+        const size_t wsz = (size_t)27 * CB * CS, bytes = (size_t)tiles * chunks * wsz * sizeof(float);
+        if (need) { *need = bytes; return 0; }
+        if (ws_bytes < bytes) return MVS_E_WORKSPACE;
+        if ((long long)D * H * W * CB * 4 >= (1LL << 31)) return MVS_E_SHAPE;
+        WgradArgs a{big, small, (float*)ws, D, H, W, D, H, W, CS, ppw};
+        constexpr int SSF = 16 * CTF + 16;
+        const size_t lds = (size_t)(3 * (TH + 2) * (TW + 2) * (8 + 4) + TH * TW * SSF) * sizeof(float);
+        wgrad_flat_kernel<8, CTF, TH><<<dim3(tiles, 1, chunks), 256, lds, st>>>(a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        wgrad_reduce_kernel<<<mvs_cdiv((long long)wsz, 16), 256, 0, st>>>((const float*)ws, tiles * chunks, wsz, dw);
         return (int)hipGetLastError();
     }
     const int ct = (CS + 15) / 16;

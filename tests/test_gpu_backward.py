@@ -84,7 +84,7 @@ def test_bn_relu_and_its_backward_match_autograd(C, two):
 
 
 # (Cbig, Csmall, stride, kind): every layer shape of RegNetUS0 'normal'
-WGRAD_CASES = [(32, 8, 1, "conv"), (16, 16, 1, "conv"), (32, 32, 1, "conv"), (64, 64, 1, "conv"), (8, 1, 1, "conv"),
+WGRAD_CASES = [(32, 8, 1, "conv"), (8, 32, 1, "conv"), (16, 16, 1, "conv"), (32, 32, 1, "conv"), (64, 64, 1, "conv"), (8, 1, 1, "conv"),
                (32, 16, 2, "conv"), (16, 32, 2, "conv"), (32, 64, 2, "conv"),
                (32, 64, 2, "deconv"), (16, 32, 2, "deconv"), (8, 16, 2, "deconv")]
 
