@@ -403,3 +403,25 @@ def test_hip_towers_match_the_torch_towers_forward_and_backward():
             worst = max(worst, e)
             assert e < 2e-3, (name, key, e)
     print("worst tower gradient rel-L1:", worst)
+
+
+def test_train_cli_runs_on_a_synthetic_dataset(tmp_path, capsys):
+    """python -m mvsnet_amd.train end to end (train.py:412-535): train/ + val/ session folders -> generator ->
+    trainer -> TensorFlow-format checkpoint, two steps."""
+    from test_data_and_sharding import make_session
+    from test_train_host import add_depths
+    from mvsnet_amd import train as T
+    from mvsnet_amd import tf_checkpoint
+    for mode in ("train", "val"):
+        s = make_session(str(tmp_path / "data" / mode / "s0"), n_images=4, h=64, w=96, seed=3)
+        add_depths(s, n_images=4, h=64, w=96, seed=3)
+    out = tmp_path / "model"
+    T.main(["--train_data_root", str(tmp_path / "data"), "--model_dir", str(out), "--network_mode", "normal",
+            "--view_num", "3", "--max_d", "16", "--width", "96", "--height", "64", "--base_image_size", "32",
+            "--epoch", "1", "--max_steps_per_epoch", "2", "--snapshot", "1", "--train_steps_per_val", "2",
+            "--val_batch_size", "1"])
+    text = capsys.readouterr().out
+    assert "total_step 2" in text and "Saving model to" in text and "VAL STEP COMPLETED" in text
+    prefix = tf_checkpoint.model_path(tf_checkpoint.ckpt_path(str(out), "3DCNN", "normal"), 2)
+    names = {nm for nm, _s, _d in tf_checkpoint.list_variables(prefix)}
+    assert "3dconv6_2/kernel" in names and "global_step" in names
