@@ -16,7 +16,7 @@ flipped / transposed kernel).
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import torch
 

@@ -10,7 +10,7 @@ streams and the 2D feature extractor.
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, Optional
 
 import numpy as np
@@ -18,8 +18,6 @@ import torch
 
 from . import _lib
 from .feature_net import UNetDS2GN
-from .homography_warping import homography_transforms
-from .synthetic import base_filter, gru_filters
 
 REGNET_ORDER = ("3dconv1_0", "3dconv2_0", "3dconv3_0", "3dconv0_1", "3dconv1_1", "3dconv2_1",
                 "3dconv3_1", "3dconv4_0", "3dconv5_0", "3dconv6_0", "3dconv6_2")

@@ -36,10 +36,10 @@ import numpy as np
 import torch
 
 from . import _lib, tf_checkpoint
-from .feature_net import UNET_LAYERS, trainable_layers, unet_forward
+from .feature_net import trainable_layers, unet_forward
 from .homography_warping import homography_transforms
 from .loss import mvsnet_regression_loss
-from .synthetic import base_filter, make_regnet_params, make_unet_params
+from .synthetic import make_regnet_params, make_unet_params
 
 
 def glorot_uniform_like(params, seed=0):
