@@ -342,6 +342,29 @@ def test_convgru_cell_stages_match_oracle():
     np.testing.assert_allclose(n(dh), exp, rtol=1e-4, atol=2e-5)
 
 
+def test_gru_wta_pipelined_sweep_with_ragged_depth_matches_oracle():
+    """D = 37 planes: three cost-volume batches (16 + 16 + 5), nine full synchronisation groups + one plane,
+    several wraps of the 8-plane state ring -- the multi-stream wavefront (toy's D = 8 runs on one stream)."""
+    from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
+    w = S.make_workload("toy")
+    D = 37
+    cams = w.cams.copy()
+    interval = 12.0
+    cams[:, 1, 3, 1] = interval; cams[:, 1, 3, 2] = D; cams[:, 1, 3, 3] = w.depth_start + interval * D
+    end = w.depth_start + (D - 1) * interval
+    gp = S.make_gru_params("normal", seed=5, in_channels=w.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
+    depth, prob = inference_winner_take_all(None, t(cams)[None], D, w.depth_start, end, weights=weights, features=t(w.features))
+    ed, ep = O.inference_winner_take_all_from_features(w.features, cams, D, w.depth_start, end, gp, False, np.float64)
+    depth, prob = n(depth)[0, :, :, 0], n(prob)[0, :, :, 0]
+    same = np.abs(depth - ed) <= 1e-6 * np.abs(ed)
+    assert same.mean() > 0.97, same.mean()
+    np.testing.assert_allclose(prob[same], ep[same], rtol=5e-4)
+    # and it is reproducible run to run
+    d2, p2 = inference_winner_take_all(None, t(cams)[None], D, w.depth_start, end, weights=weights, features=t(w.features))
+    assert np.array_equal(n(d2)[0, :, :, 0], depth) and np.array_equal(n(p2)[0, :, :, 0], prob)
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 def test_gru_wta_matches_oracle(inverse):
     from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
