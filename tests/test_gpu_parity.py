@@ -365,12 +365,13 @@ def test_gru_wta_pipelined_sweep_with_ragged_depth_matches_oracle():
     assert np.array_equal(n(d2)[0, :, :, 0], depth) and np.array_equal(n(p2)[0, :, :, 0], prob)
 
 
-@pytest.mark.parametrize("inverse", [False, True])
-def test_gru_wta_matches_oracle(inverse):
+@pytest.mark.parametrize("inverse,mode", [(False, "normal"), (True, "normal"), (False, "lite")])
+def test_gru_wta_matches_oracle(inverse, mode):
+    """'lite' (16-channel features, GRU filters 8 / 2 / 1) takes the shape-generic conv + gate kernels for cell 1."""
     from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
-    w = S.make_workload("toy")
-    gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
-    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
+    w = S.make_workload("toy", network_mode=mode)
+    gp = S.make_gru_params(mode, seed=2, in_channels=w.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy(mode, gru=gp, device=DEV)
     depth, prob = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end,
                                             inverse_depth=inverse, weights=weights, features=t(w.features))
     ed, ep = O.inference_winner_take_all_from_features(w.features, w.cams, w.depth_num, w.depth_start,
