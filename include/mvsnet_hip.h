@@ -246,6 +246,9 @@ int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, int H, int W
  *            out_w, out_b, out_gamma, out_beta   (10 each), then prob_w, prob_b
  *   depth_values [host] depth_num floats (depth of plane d, model.py:706-715)
  *   filters (f1,f2,f3): ConvGRU filter counts (16,4,2 for 'normal')
+ * The sweep is a wavefront over (plane, cell) on library-owned side streams forked from / joined to `stream`
+ * (one set per caller stream, created on first use); the workspace holds a batch of 16 cost slices, two batches of
+ * the hoisted x-part of cell 1 and 8-plane state rings: ~1.0 GB at 400 x 300, C = 32 (mvs_gru_workspace_bytes).
  */
 size_t mvs_gru_workspace_bytes(int H, int W, int C, int f1, int f2, int f3);
 int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms, int view_num,
