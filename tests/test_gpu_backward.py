@@ -408,8 +408,7 @@ def test_hip_towers_match_the_torch_towers_forward_and_backward():
 def test_train_cli_runs_on_a_synthetic_dataset(tmp_path, capsys):
     """python -m mvsnet_amd.train end to end (train.py:412-535): train/ + val/ session folders -> generator ->
     trainer -> TensorFlow-format checkpoint, two steps."""
-    from test_data_and_sharding import make_session
-    from test_train_host import add_depths
+    from _helpers import add_depths, make_session
     from mvsnet_amd import train as T
     from mvsnet_amd import tf_checkpoint
     for mode in ("train", "val"):

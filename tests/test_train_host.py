@@ -12,18 +12,9 @@ import numpy as np
 import pytest
 import torch
 
-from test_data_and_sharding import make_session
+from _helpers import add_depths, make_session
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def add_depths(session, n_images=4, h=48, w=64, seed=0):
-    from PIL import Image
-    rs = np.random.RandomState(seed + 100)
-    os.makedirs(os.path.join(session, "depths"))
-    for i in range(n_images):
-        d = rs.randint(300, 1000, size=(h, w)).astype(np.uint16)           # some values fall outside (400, 900]
-        Image.fromarray(d).save(os.path.join(session, "depths", "%d.png" % i))
 
 
 def test_generator_train_and_val_modes(tmp_path):
