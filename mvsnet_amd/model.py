@@ -115,12 +115,17 @@ class MVSNetWeights:
         """`extractor`: "hip" = the 2D towers on the HIP library (feature_net_hip.HipUNetDS2GN, SURVEY 8f
         f2, ~12x the PyTorch/MIOpen module at 5 x 512 x 640), "torch" = feature_net.UNetDS2GN."""
         from .refine import RefineNet
-        if extractor == "hip":
-            from .feature_net_hip import HipUNetDS2GN as Extractor
-        elif extractor == "torch":
-            Extractor = UNetDS2GN
-        else:
+        if extractor not in ("hip", "torch"):
             raise ValueError("extractor must be 'hip' or 'torch'")
+        Extractor = UNetDS2GN
+        if extractor == "hip":
+            # the HIP towers tile output channels in 8s (base_filter 8 = 'normal' and wider); the narrower modes'
+            # 4- and 2-channel layers also have GroupNorm groups smaller than 8 channels, which zero-padding would
+            # change, so they stay on the PyTorch module
+            narrow = unet is not None and any(np.asarray(p["w"]).shape[-1] % 8 for name, p in unet.items()
+                                              if name in ("2dconv0_1", "2dconv1_0"))
+            if not narrow:
+                from .feature_net_hip import HipUNetDS2GN as Extractor
         return cls(network_mode,
                    Extractor(unet, device) if unet is not None else None,
                    RegNetWeights(regnet, device) if regnet is not None else None,

@@ -134,3 +134,28 @@ def test_plan_runs_under_hipgraph_capture(lib_built):
     g.replay()
     torch.cuda.synchronize()
     assert torch.allclose(plan.depth, eager, rtol=1e-6, atol=1e-4)
+
+
+def test_lite_mode_from_images_runs_padded_regulariser_and_torch_towers():
+    """network_mode 'lite' end to end: narrow towers stay on the PyTorch module (GroupNorm groups < 8 channels),
+    the regulariser runs zero-padded on the MFMA shapes; checked against the oracle composition."""
+    import numpy as np
+    import torch
+    from oracle import mvsnet_oracle as O
+    from mvsnet_amd import synthetic as S
+    from mvsnet_amd.model import MVSNetWeights, inference_mem
+    from mvsnet_amd.feature_net import UNetDS2GN
+    mode = "lite"
+    up, rp = S.make_unet_params(mode, seed=3), S.make_regnet_params(mode, seed=1, random_affine=True)
+    weights = MVSNetWeights.from_numpy(mode, unet=up, regnet=rp, device="cuda")
+    assert isinstance(weights.unet, UNetDS2GN) and weights.regnet.cin == 32 and weights.regnet.cin_native == 16
+    N, H, W, D = 3, 64, 64, 8
+    images = S.make_images(N, H, W, seed=2)
+    cams = S.make_cams(N, H // 4, W // 4, D, interval=40.0)
+    start, interval = float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1])
+    depth, prob = inference_mem(torch.as_tensor(images).cuda()[None], torch.as_tensor(cams).cuda()[None], D, start, interval,
+                                mode, weights=weights, view_num=N)
+    feats = np.stack([O.unet_ds2gn(images[v], up, np.float64) for v in range(N)])
+    ed, _ep = O.inference_mem_from_features(feats, cams, D, start, interval, rp, False, np.float64)
+    d = depth.cpu().numpy()[0, :, :, 0]
+    assert float(np.mean(np.abs(d - ed) / ed)) < 1e-3
