@@ -48,8 +48,12 @@ class UNetDS2GN:
     (numpy or torch): conv 'w' (k,k,Cin,Cout), transposed conv 'w' (k,k,Cout,Cin), 'gamma',
     'beta' (Cout,)."""
 
-    def __init__(self, params, device="cuda", dtype=torch.float32):
+    def __init__(self, params, device="cuda", dtype=torch.float32, hip_group_norm=False):
+        """`hip_group_norm`: GroupNorm of the layers with >= 8 channels through HipGroupNorm (the narrow-mode
+        fallback of MVSNetWeights: torch's group_norm is 10x slower on channel-last tensors); off by default so that
+        this module stays an independent cross-check of the HIP extractor."""
         self.device = torch.device(device)
+        self.hip_group_norm = bool(hip_group_norm) and torch.device(device).type == "cuda"
         self.layers = []
         for name, kind, srcs, k, _mult, stride in UNET_LAYERS:
             p = params[name]
@@ -71,7 +75,7 @@ class UNetDS2GN:
         """images (V,H,W,3) channel-last float32 -> features (V,H/4,W/4,C) contiguous.
         Each view is normalised independently (GroupNorm is per sample), so running the V
         towers of mvsnet/model.py:392-406 as one batch is equivalent."""
-        return unet_forward(self.layers, images.to(self.device))
+        return unet_forward(self.layers, images.to(self.device), hip_group_norm=self.hip_group_norm)
 
 
 class HipGroupNorm(torch.autograd.Function):

@@ -126,6 +126,8 @@ class MVSNetWeights:
                                               if name in ("2dconv0_1", "2dconv1_0"))
             if not narrow:
                 from .feature_net_hip import HipUNetDS2GN as Extractor
+            else:
+                Extractor = lambda p, d: UNetDS2GN(p, d, hip_group_norm=True)
         return cls(network_mode,
                    Extractor(unet, device) if unet is not None else None,
                    RegNetWeights(regnet, device) if regnet is not None else None,
