@@ -61,6 +61,11 @@ struct FuseArgs {
     const float* w2;      // stride-2 weights, TensorFlow layout (3,3,3,32,16)
     float* y2;            // (D/2, H/2, W/2, 16) raw output
     double* stats2;       // (2,16) float64 sums or null
+    // The 240 workgroups of a metric-size launch (one per CU) all finish together: their float64 atomics on the 48
+    // sum addresses serialised into a ~19 us tail.  With slots they go to (slots, 2, C) partial rows that the
+    // consumers' bn_affine4 adds up (regnet.hip: 8 rows for 3dconv0_1, 4 for 3dconv1_0 -- what fits the layer's
+    // 128-double statistics slab).
+    int slots1, slots2;
 };
 
 // Developer build (-DC8_PROF): workgroup 0 records s_memtime at 5 points of every plane
@@ -391,15 +396,18 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
                 if (n == 0) {
-                    atomicAdd(&fa.stats2[4 * kq + k], (double)sv);
-                    atomicAdd(&fa.stats2[COUT2 + 4 * kq + k], (double)qv);
+                    double* s2p = fa.stats2 + (size_t)((blockIdx.x + gridDim.x * blockIdx.z) % fa.slots2) * 2 * COUT2;
+                    atomicAdd(&s2p[4 * kq + k], (double)sv);
+                    atomicAdd(&s2p[COUT2 + 4 * kq + k], (double)qv);
                 }
             }
         }
     }
 
     // every lane's st_* are the sums of channels 4*(kq&1) .. +3: fold lanes l and l^32
-    if (a.stats) stats_commit<COUT>(st_s, st_q, true, slab, a.stats, a.cout_total, 0);
+    if (a.stats) stats_commit<COUT>(st_s, st_q, true, slab,
+                                    a.stats + (size_t)((blockIdx.x + gridDim.x * blockIdx.z) % (FUSE ? fa.slots1 : 1)) * 2 * COUT,
+                                    a.cout_total, 0);
 #ifdef C8_PROF
     { const int t = 0; C8_STAMP(7); }
 #endif
@@ -460,12 +468,13 @@ int launch_c8(const ConvArgs& a0, const FuseArgs& fa, hipStream_t st) {
 
 int mvs_conv3d_c8_launch(const ConvArgs& a, hipStream_t st) {
     if (a.x2 || a.cout_total != COUT) return MVS_E_SHAPE;
-    return launch_c8<false>(a, FuseArgs{nullptr, nullptr, nullptr}, st);
+    return launch_c8<false>(a, FuseArgs{nullptr, nullptr, nullptr, 1, 1}, st);
 }
 
 // Both consumers of a 32-channel volume in one pass: y = conv3d(x, w 32->8, stride 1) as above and
 // y2 = conv3d(x, w2 32->16, stride 2).  Even D, H, W only (SAME pads nothing in front).
-int mvs_conv3d_c8_s2_launch(const ConvArgs& a, const float* w2, float* y2, double* stats2, hipStream_t st) {
+int mvs_conv3d_c8_s2_launch(const ConvArgs& a, const float* w2, float* y2, double* stats2, hipStream_t st,
+                            int slots1, int slots2) {
     if (a.x2 || a.cout_total != COUT || (a.D & 1) || (a.H & 1) || (a.W & 1)) return MVS_E_SHAPE;
-    return launch_c8<true>(a, FuseArgs{w2, y2, stats2}, st);
+    return launch_c8<true>(a, FuseArgs{w2, y2, stats2, slots1 > 1 ? slots1 : 1, slots2 > 1 ? slots2 : 1}, st);
 }

@@ -12,14 +12,17 @@ struct BnSrc {
     const double* stats;      // (2,C) [sum, sum of squares] or null
     const float* gamma; const float* beta;
     double count; float eps; int C;
+    int nslot;                // stats is (nslot, 2, C): partial rows the consumer adds up (0 / 1: a single row)
 };
 
 __device__ __forceinline__ void bn_affine4(const BnSrc& b, int c0, float4& sc, float4& sh) {
     float s[4], t[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        double mean = b.stats[c0 + k] / b.count;
-        double var = b.stats[b.C + c0 + k] / b.count - mean * mean;
+        double s1 = b.stats[c0 + k], s2 = b.stats[b.C + c0 + k];
+        for (int sl = 1; sl < b.nslot; ++sl) { s1 += b.stats[sl * 2 * b.C + c0 + k]; s2 += b.stats[sl * 2 * b.C + b.C + c0 + k]; }
+        double mean = s1 / b.count;
+        double var = s2 / b.count - mean * mean;
         if (var < 0.0) var = 0.0;
         double inv = (double)b.gamma[c0 + k] / sqrt(var + (double)b.eps);
         s[k] = (float)inv;
@@ -154,7 +157,9 @@ int mvs_wgrad_c1_launch(const float* big, const float* small, int D, int H, int 
 int mvs_deconv3d_c8_launch(const ConvArgs& a, int Cin, int Cout, hipStream_t st);   // 8 couts per workgroup, packed tiles
 int mvs_conv3d_c8_launch(const ConvArgs& a, hipStream_t st);      // 32 -> 8 stride 1 (conv3d_c8.hip)
 // same + the 32 -> 16 stride-2 consumer of the same input in one pass
-int mvs_conv3d_c8_s2_launch(const ConvArgs& a, const float* w2, float* y2, double* stats2, hipStream_t st);
+// slots1 / slots2 > 1: the BatchNorm sums go to (slots, 2, C) partial rows (workgroup id modulo slots), see BnSrc::nslot
+int mvs_conv3d_c8_s2_launch(const ConvArgs& a, const float* w2, float* y2, double* stats2, hipStream_t st,
+                            int slots1 = 1, int slots2 = 1);
 // opt-in split-precision stride-1 path (conv3d_bf16x3.hip)
 bool mvs_conv3d_bf16x3_supported(int Cin, int Cout);
 int mvs_conv3d_s1_bf16x3(const ConvArgs& a, int Cin, int Cout, hipStream_t st);

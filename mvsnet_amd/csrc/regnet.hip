@@ -238,9 +238,14 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
     const double cnt[N_BN] = {v1, v2, v3, v0, v1, v2, v3, v2, v1, v0};
     auto st = [&](int i) { return ws.stats + (size_t)i * 2 * cmax; };
     bool finalised[N_BN] = {false};
+    bool pair_done = false;
+    // the fused pass over the cost volume spreads its sums over partial rows (conv3d_c8.hip, FuseArgs): as many as
+    // fit the layer's 2*cmax-double slab
+    const int slots01 = (2 * cmax) / (2 * b) < 8 ? (2 * cmax) / (2 * b) : 8, slots10 = (2 * cmax) / (4 * b) < 8 ? (2 * cmax) / (4 * b) : 8;
     auto bn_of = [&](int i) {      // producer i's raw BatchNorm sums (i < 0: raw input, no BN)
-        BnSrc s{nullptr, nullptr, nullptr, 1.0, eps, 0};
-        if (i >= 0) s = BnSrc{st(i), gammas[i], betas[i], cnt[i], eps, ch[i]};
+        BnSrc s{nullptr, nullptr, nullptr, 1.0, eps, 0, 1};
+        if (i >= 0) s = BnSrc{st(i), gammas[i], betas[i], cnt[i], eps, ch[i],
+                              pair_done ? (i == L01 ? slots01 : i == L10 ? slots10 : 1) : 1};
         return s;
     };
     auto ensure_final = [&](int i) -> int {
@@ -275,7 +280,6 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
 #define HIP_RUN(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return (int)e__; } while (0)
     // encoder on the raw cost volume (mvsnetworks.py:130-136).  3dconv1_0 and 3dconv0_1 read the same
     // volume: one fused pass when the shape is the one conv3d_c8.hip is built for.
-    bool pair_done = false;
     if ((g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA) && cin == 32 && b == 8 &&
         !getenv("MVS_NO_PAIR_FUSION")) {
         ConvArgs a{cost, nullptr, nullptr, nullptr, nullptr, nullptr, weights[L01], ws.y[L01], st(L01), D, H, W, b,
@@ -289,7 +293,7 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
             }
         }
         if (slot >= 0) HIP_RUN(hipEventRecord(g_prof.ev[slot][0], hs));
-        rc = mvs_conv3d_c8_s2_launch(a, weights[L10], ws.y[L10], st(L10), hs);
+        rc = mvs_conv3d_c8_s2_launch(a, weights[L10], ws.y[L10], st(L10), hs, slots01, slots10);
         if (slot >= 0 && rc == 0) { HIP_RUN(hipEventRecord(g_prof.ev[slot][1], hs)); g_prof.used = slot + 1; }
         if (rc == 0) pair_done = true;
         else if (rc != MVS_E_SHAPE) return rc;
