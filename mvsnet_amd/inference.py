@@ -83,10 +83,28 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
     # re-used by all the reference views that list the image as a source.
     feature_cache = {}
     done = 0
-    for c in mine:
+    # Host pipeline: like the reference, whose generator runs in a tf.data thread with a prefetch buffer
+    # (predictlib.py:48-51), image loading / resizing of the next clusters and the file writes of the previous ones run
+    # on worker threads (numpy / PIL / file IO release the GIL); this thread only drives the GPU.
+    from concurrent.futures import ThreadPoolExecutor
+    loader, writer = ThreadPoolExecutor(max_workers=2), ThreadPoolExecutor(max_workers=2)
+    pending, writes = [], []
+    ahead = 3
+
+    def submit_next(it):
+        for c_ in it:
+            pending.append((c_, loader.submit(gen.prepare, c_)))
+            return
+
+    it = iter(mine)
+    for _ in range(ahead):
+        submit_next(it)
+    while pending:
+        c, fut = pending.pop(0)
+        submit_next(it)
         start = time.time()
         try:
-            out_images, in_images, out_cams, full_cams, index = gen.prepare(c)
+            out_images, in_images, out_cams, full_cams, index = fut.result()
         except Exception as e:                        # skip-and-log per reference view
             logger.warning("skipping cluster %s/%d: %s", c.session_dir, c.ref_index, e)
             continue
@@ -112,14 +130,18 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
         d, p, _ = pl.get_depth_and_prob_map(None, cams, depth_start, depth_interval, config, weights,
                                             depth_num=depth_num, depth_end=depth_end, features=features,
                                             ref_image=ref_image)
+        d_np, p_np = d.cpu().numpy(), p.cpu().numpy()
         if config.refinement and config.upsample_before_refinement:      # full-size outputs (predictlib.py:107-115)
-            pl.write_output_slice(output_dir, d.cpu().numpy(), p.cpu().numpy(), in_images[0], full_cams[0],
-                                  index, config.visualize, prob_upsample=1.0 / config.sample_scale)
+            writes.append(writer.submit(pl.write_output_slice, output_dir, d_np, p_np, in_images[0], full_cams[0],
+                                        index, config.visualize, 1.0 / config.sample_scale))
         else:
-            pl.write_output_slice(output_dir, d.cpu().numpy(), p.cpu().numpy(), out_images[0], out_cams[0],
-                                  index, config.visualize)
+            writes.append(writer.submit(pl.write_output_slice, output_dir, d_np, p_np, out_images[0], out_cams[0],
+                                        index, config.visualize))
         done += 1
         logger.info("Depth inference %d/%d finished. (%.3f sec/step)", done, len(mine), time.time() - start)
+    for w_ in writes:
+        w_.result()                                   # surfaces write errors; all files are on disk on return
+    loader.shutdown(); writer.shutdown()
     return done
 
 

@@ -98,3 +98,16 @@ def test_png_quantisation():
     from mvsnet_amd import preprocess as P
     assert list(P.depth_to_uint16(np.array([-3.0, 12.7, 70000.0]))) == [0, 12, 65535]
     assert list(P.confidence_to_uint16(np.array([0.0, 0.5, 1.5]))) == [0, 32767, 65535]
+
+
+def test_every_package_module_imports_without_a_gpu():
+    """Import-time errors (syntax, missing names) in modules that only run on the GPU box must show up here."""
+    import importlib
+    import pkgutil
+    import mvsnet_amd
+    names = sorted(m.name for m in pkgutil.iter_modules(mvsnet_amd.__path__))
+    assert {"inference", "train", "backward", "feature_net_train", "model", "test"} <= set(names)
+    for name in names:
+        importlib.import_module("mvsnet_amd." + name)
+    for extra in ("bench", "__graft_entry__"):
+        importlib.import_module(extra)
