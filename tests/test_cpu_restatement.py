@@ -50,3 +50,22 @@ def test_golden_fixture_reproduces():
                                                              w.depth_end, gp, False, np.float64)
         np.testing.assert_allclose(d, g["depth"], rtol=1e-9)
         np.testing.assert_allclose(p, g["prob"], rtol=1e-7, atol=1e-9)
+
+
+def test_gradient_golden_fixture_reproduces():
+    """tests/golden/toy_grad.npz: float64 autograd of the torch restatement (oracle/torch_grad.py), the checker of the
+    training backward."""
+    import torch
+    from oracle import torch_grad as TG
+    g = np.load(os.path.join(GOLDEN, "toy_grad.npz"))
+    w = S.make_workload("toy")
+    rp = S.make_regnet_params("normal", seed=1, random_affine=True)
+    d64 = lambda a, req=False: torch.tensor(np.asarray(a, np.float64)).requires_grad_(req)
+    f64 = d64(w.features[:3], True)
+    p64 = {k: {kk: d64(vv, True) for kk, vv in v.items()} for k, v in rp.items()}
+    depth = TG.depth_from_features(f64, d64(g["t8"]), w.depth_start, w.depth_interval, p64)
+    (depth * d64(g["g"])).sum().backward()
+    np.testing.assert_allclose(depth.detach().numpy(), g["depth"], rtol=1e-10)
+    np.testing.assert_allclose(f64.grad.numpy(), g["g_features"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(p64["3dconv0_1"]["w"].grad.numpy(), g["g_w01"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(p64["3dconv6_2"]["w"].grad.numpy(), g["g_w62"], rtol=1e-7, atol=1e-10)

@@ -424,3 +424,21 @@ def test_train_cli_runs_on_a_synthetic_dataset(tmp_path, capsys):
     prefix = tf_checkpoint.model_path(tf_checkpoint.ckpt_path(str(out), "3DCNN", "normal"), 2)
     names = {nm for nm, _s, _d in tf_checkpoint.list_variables(prefix)}
     assert "3dconv6_2/kernel" in names and "global_step" in names
+
+
+def test_device_gradients_match_the_committed_golden_fixture():
+    """tests/golden/toy_grad.npz (float64 autograd of the restatement; generator committed beside it)."""
+    from mvsnet_amd import backward as B
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "toy_grad.npz"))
+    w = S.make_workload("toy")
+    rp = S.make_regnet_params("normal", seed=1, random_affine=True)
+    ft = t(w.features[:3]).requires_grad_(True)
+    pt = {k: {kk: t(vv).requires_grad_(True) for kk, vv in v.items()} for k, v in rp.items()}
+    depth, _ = B.plane_sweep_depth(ft, t(g["t8"]), w.depth_start, w.depth_interval, pt)
+    (depth * t(g["g"])).sum().backward()
+    assert rel_l1(n(depth), g["depth"]) < 1e-5
+    assert rel_l1(n(ft.grad), g["g_features"]) < 2e-3
+    assert rel_l1(n(pt["3dconv0_1"]["w"].grad), g["g_w01"]) < 2e-3
+    assert rel_l1(n(pt["3dconv6_2"]["w"].grad), g["g_w62"]) < 2e-3
+    assert rel_l1(n(pt["3dconv3_0"]["gamma"].grad), g["g_gamma30"]) < 2e-3
+    assert rel_l1(n(pt["3dconv6_0"]["beta"].grad), g["g_beta60"]) < 2e-3
