@@ -116,10 +116,11 @@ def test_conv3d_weight_gradient_matches_autograd(cb, cs, stride, kind, dims):
 @pytest.mark.parametrize("cin,cout,kind", [(32, 8, "s1"), (16, 16, "s1"), (8, 1, "s1"), (64, 64, "s1"),
                                            (32, 16, "s2"), (16, 32, "s2"), (32, 64, "s2"),
                                            (64, 32, "deconv"), (32, 16, "deconv"), (16, 8, "deconv")])
-def test_conv3d_input_gradients_match_autograd(cin, cout, kind):
+@pytest.mark.parametrize("dims", [(8, 8, 16), (6, 12, 40)])
+def test_conv3d_input_gradients_match_autograd(cin, cout, kind, dims):
     from mvsnet_amd import backward as B
     rs = np.random.RandomState(cin + 3 * cout)
-    D, H, W = 8, 8, 16
+    D, H, W = dims
     x = d64(rs.randn(D, H, W, cin), True)
     if kind == "deconv":
         w = rs.randn(3, 3, 3, cout, cin).astype(np.float32) * 0.1
