@@ -16,7 +16,7 @@ flipped / transposed kernel).
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 
@@ -53,23 +53,57 @@ def bn_relu(y, affine=None, y2=None, affine2=None):
     return out
 
 
-def bn_relu_bwd(y, stats, affine, gamma, g1, g2=None, eps=BN_EPSILON):
-    """BatchNorm(batch statistics)+ReLU backward (network.py:492-509).  Returns (g_y, g_gamma, g_beta)."""
+class SyncBN:
+    """Cross-replica BatchNorm for data-parallel training (SURVEY 8f f4 lists it as an addition; the reference's
+    towers keep per-GPU statistics): the float64 per-channel sums of every BatchNorm layer -- forward [sum, sumsq],
+    backward [sum gz, sum gz*xhat] -- are summed over the ranks and the voxel count is multiplied by the world size,
+    exactly as if the replicas' volumes were one batch.  Per-variable gradients stay local (the flat-buffer
+    all-reduce averages them afterwards).  RCCL reduces the tiny buffers in place; under gloo (CPU tests) they are
+    staged through host memory."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.direct = dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+    def all_reduce(self, t):
+        if self.world == 1:
+            return t
+        if self.direct:
+            self.dist.all_reduce(t, group=self.group)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        return t
+
+
+def bn_relu_bwd(y, stats, affine, gamma, g1, g2=None, eps=BN_EPSILON, sync: Optional[SyncBN] = None):
+    """BatchNorm(batch statistics)+ReLU backward (network.py:492-509).  Returns (g_y, g_gamma, g_beta).
+    `stats` are the sums the forward normalised with (global ones under `sync`)."""
     lib = _lib.load()
     Cn = y.shape[-1]
     vox = y.numel() // Cn
+    world = sync.world if sync is not None else 1
     sums = torch.zeros((lib.mvs_bn_bwd_sum_slots(), 2, Cn), device=y.device, dtype=torch.float64)
     s, t = affine
-    _lib.check(lib.mvs_bn_bwd_reduce_f32(_lib.ptr(y), _lib.ptr(stats), float(vox), float(eps), _lib.ptr(s), _lib.ptr(t),
+    _lib.check(lib.mvs_bn_bwd_reduce_f32(_lib.ptr(y), _lib.ptr(stats), float(vox * world), float(eps), _lib.ptr(s), _lib.ptr(t),
                                          _lib.ptr(g1), _lib.ptr(g2), vox, Cn, _lib.ptr(sums), _lib.stream_ptr()),
                "mvs_bn_bwd_reduce_f32")
     g_y = torch.empty_like(y)
     g_gamma = torch.empty(Cn, device=y.device, dtype=torch.float32)
     g_beta = torch.empty_like(g_gamma)
-    _lib.check(lib.mvs_bn_bwd_apply_f32(_lib.ptr(y), _lib.ptr(stats), float(vox), float(eps), _lib.ptr(s), _lib.ptr(t),
+    local = None
+    if world > 1:                                      # the variables' gradients are this replica's own sums
+        local = sums.sum(0).to(torch.float32)
+        sync.all_reduce(sums)
+    _lib.check(lib.mvs_bn_bwd_apply_f32(_lib.ptr(y), _lib.ptr(stats), float(vox * world), float(eps), _lib.ptr(s), _lib.ptr(t),
                                         _lib.ptr(gamma), _lib.ptr(g1), _lib.ptr(g2), _lib.ptr(sums), vox, Cn,
                                         _lib.ptr(g_y), _lib.ptr(g_gamma), _lib.ptr(g_beta), _lib.stream_ptr()),
                "mvs_bn_bwd_apply_f32")
+    if local is not None:
+        g_gamma, g_beta = local[1].contiguous(), local[0].contiguous()
     return g_y, g_gamma, g_beta
 
 
@@ -159,17 +193,21 @@ def deconv_input_grad(g_y, w):
 # RegNetUS0 with saved activations
 # ------------------------------------------------------------------------------------------------
 
-def regnet_forward_train(cost, p: Dict[str, Dict[str, torch.Tensor]]):
-    """cost (D,H,W,32); p[name] = {'w', 'gamma', 'beta'}.  Returns (reg (D,H,W), saved)."""
+def regnet_forward_train(cost, p: Dict[str, Dict[str, torch.Tensor]], sync: Optional[SyncBN] = None):
+    """cost (D,H,W,32); p[name] = {'w', 'gamma', 'beta'}.  Returns (reg (D,H,W), saved).  `sync`: cross-replica
+    BatchNorm statistics (SyncBN)."""
     dev = cost.device
     y, st, aff = {}, {}, {}
+    world = sync.world if sync is not None else 1
 
     def layer(name, x, stride=1, x_aff=None, skip=None, skip_aff=None, transpose=False):
         cout = p[name]["w"].shape[3] if transpose else p[name]["w"].shape[4]
         s = torch.zeros((2, cout), device=dev, dtype=torch.float64)
         out = conv3d(x, p[name]["w"], stride, x_aff, skip, skip_aff, s, transpose)
+        if world > 1:
+            sync.all_reduce(s)
         y[name], st[name] = out, s
-        aff[name] = bn_finalize(s, out.numel() // cout, p[name]["gamma"], p[name]["beta"])
+        aff[name] = bn_finalize(s, (out.numel() // cout) * world, p[name]["gamma"], p[name]["beta"])
 
     if cost.shape[3] == 32 and p["3dconv0_1"]["w"].shape[4] == 8 and not (cost.shape[0] | cost.shape[1] | cost.shape[2]) & 1:
         # both consumers of the cost volume in one pass over it (mvs_conv3d_pair_f32)
@@ -177,8 +215,10 @@ def regnet_forward_train(cost, p: Dict[str, Dict[str, torch.Tensor]]):
         s10 = torch.zeros((2, 16), device=dev, dtype=torch.float64)
         y["3dconv0_1"], y["3dconv1_0"] = conv3d_pair(cost, p["3dconv0_1"]["w"], p["3dconv1_0"]["w"], s01, s10)
         for nm, s in (("3dconv0_1", s01), ("3dconv1_0", s10)):
+            if world > 1:
+                sync.all_reduce(s)
             st[nm] = s
-            aff[nm] = bn_finalize(s, y[nm].numel() // y[nm].shape[3], p[nm]["gamma"], p[nm]["beta"])
+            aff[nm] = bn_finalize(s, (y[nm].numel() // y[nm].shape[3]) * world, p[nm]["gamma"], p[nm]["beta"])
         fused = True
     else:
         fused = False
@@ -194,19 +234,19 @@ def regnet_forward_train(cost, p: Dict[str, Dict[str, torch.Tensor]]):
     layer("3dconv5_0", y["3dconv4_0"], 2, aff["3dconv4_0"], y["3dconv2_1"], aff["3dconv2_1"], transpose=True)
     layer("3dconv6_0", y["3dconv5_0"], 2, aff["3dconv5_0"], y["3dconv1_1"], aff["3dconv1_1"], transpose=True)
     reg = conv3d(y["3dconv6_0"], p["3dconv6_2"]["w"], 1, aff["3dconv6_0"], y["3dconv0_1"], aff["3dconv0_1"])
-    return reg[..., 0], (cost, y, st, aff)
+    return reg[..., 0], (cost, y, st, aff, sync)
 
 
 def regnet_backward(saved, p, g_reg):
     """g_reg (D,H,W) -> (grads {name: {'w','gamma','beta'}}, g_cost_a, g_cost_b): the cost volume has two
     consumers (3dconv0_1, 3dconv1_0); their input gradients are returned separately and summed on load by
     the cost-volume backward."""
-    cost, y, st, aff = saved
+    cost, y, st, aff, sync = saved
     G: Dict[str, Dict[str, torch.Tensor]] = {}
     g_reg = g_reg.contiguous()[..., None]
 
     def bn_bwd(name, g1, g2=None):
-        g_y, gg, gb = bn_relu_bwd(y[name], st[name], aff[name], p[name]["gamma"], g1, g2)
+        g_y, gg, gb = bn_relu_bwd(y[name], st[name], aff[name], p[name]["gamma"], g1, g2, sync=sync)
         G[name] = {"gamma": gg, "beta": gb}
         return g_y
 
@@ -294,12 +334,12 @@ class PlaneSweepDepth(torch.autograd.Function):
     of any training loss (train.py:314-356 uses the depth maps only) and is returned detached."""
 
     @staticmethod
-    def forward(ctx, features, transforms, depth_start, depth_interval, inverse_depth, *flat):
+    def forward(ctx, features, transforms, depth_start, depth_interval, inverse_depth, sync, *flat):
         from .model import softargmin_prob
         p = unflatten_params([t.detach() for t in flat])
         features = features.detach().contiguous()
         cost = cost_volume(features[0], features[1:], transforms, variant="eager")      # model.py:330-332
-        reg, saved = regnet_forward_train(cost, p)
+        reg, saved = regnet_forward_train(cost, p, sync)
         depth, prob = softargmin_prob(reg, depth_start, depth_interval, inverse_depth)
         ctx.saved = (features, transforms, reg, saved, p)
         ctx.scalars = (float(depth_start), float(depth_interval), bool(inverse_depth))
@@ -320,9 +360,10 @@ class PlaneSweepDepth(torch.autograd.Function):
             if n in BN_LAYERS:
                 flat += [G[n]["gamma"], G[n]["beta"]]
         ctx.saved = None
-        return (g_feat, None, None, None, None) + tuple(flat)
+        return (g_feat, None, None, None, None, None) + tuple(flat)
 
 
-def plane_sweep_depth(features, transforms, depth_start, depth_interval, params, inverse_depth=False):
-    return PlaneSweepDepth.apply(features, transforms, depth_start, depth_interval, inverse_depth,
+def plane_sweep_depth(features, transforms, depth_start, depth_interval, params, inverse_depth=False, sync=None):
+    """`sync`: a SyncBN for cross-replica BatchNorm statistics under torch.distributed (default: per-replica)."""
+    return PlaneSweepDepth.apply(features, transforms, depth_start, depth_interval, inverse_depth, sync,
                                  *flatten_params(params))

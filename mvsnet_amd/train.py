@@ -111,7 +111,8 @@ class FlatParameters:
 
 class Trainer:
     def __init__(self, network_mode="normal", device="cuda", optimizer="rmsprop", base_lr=1e-3, stepvalue=70000,
-                 gamma=0.5, loss_type="power", alpha=0.25, beta=0.0, eta=0.02, grad_loss=True, init=None, seed=0):
+                 gamma=0.5, loss_type="power", alpha=0.25, beta=0.0, eta=0.02, grad_loss=True, init=None, seed=0,
+                 sync_bn=False):
         if optimizer not in OPTIMIZER_SLOTS:
             raise NotImplementedError("Optimizer %s is not implemented" % optimizer)       # train.py:268-271
         self.network_mode, self.device = network_mode, torch.device(device)
@@ -144,6 +145,10 @@ class Trainer:
                       for i in range(len(OPTIMIZER_SLOTS[optimizer]))]
         self.global_step = 0
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.sync = None
+        if sync_bn and self.world > 1:
+            from .backward import SyncBN
+            self.sync = SyncBN()
 
     # -- one optimisation step ------------------------------------------------------------------------
     def loss(self, images, cams, depth_image, depth_num):
@@ -164,7 +169,8 @@ class Trainer:
         if feats.shape[-1] < 32:
             feats = torch.nn.functional.pad(feats, (0, 32 - feats.shape[-1]))      # padded channels: zero cost, zero gradient
         transforms = homography_transforms(cams_t, depth_num, depth_start, depth_interval)
-        depth, _prob = plane_sweep_depth(feats, transforms, depth_start, depth_interval, self.params.group("regnet"))
+        depth, _prob = plane_sweep_depth(feats, transforms, depth_start, depth_interval, self.params.group("regnet"),
+                                         sync=self.sync)
         est = depth[None, :, :, None]
         ds = torch.tensor([depth_start], device=self.device)
         de = torch.tensor([depth_end], device=self.device)
@@ -281,6 +287,7 @@ def build_parser():
     a("--loss_type", default="power"); a("--alpha", type=float, default=0.25); a("--beta", type=float, default=0.0)
     a("--eta", type=float, default=0.02); a("--no_grad_loss", action="store_true")
     a("--seed", type=int, default=0)
+    a("--sync_bn", action="store_true", help="BatchNorm statistics over all replicas (not in the reference)")
     return p
 
 
@@ -297,7 +304,7 @@ def train(args):
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     tr = Trainer(args.network_mode, "cuda", args.optimizer, args.base_lr, args.stepvalue, args.gamma, args.loss_type,
-                 args.alpha, args.beta, args.eta, not args.no_grad_loss, seed=args.seed)
+                 args.alpha, args.beta, args.eta, not args.no_grad_loss, seed=args.seed, sync_bn=args.sync_bn)
     if args.ckpt_step:
         ck = tf_checkpoint.ckpt_path(args.model_load_dir or args.model_dir, args.regularization, args.network_mode)
         tr.restore(tf_checkpoint.model_path(ck, args.ckpt_step))

@@ -66,8 +66,11 @@ def _bn_relu(x, p, eps=1e-5):
 
 
 def regnet_us0(cost, p):
-    """cost (C,D,H,W) -> (D,H,W); p[name] = {'w','gamma','beta'} tensors in the TensorFlow layouts."""
-    x = cost[None]
+    """cost (C,D,H,W) -> (D,H,W), or a batch (B,C,D,H,W) -> (B,D,H,W) whose BatchNorm statistics run over the whole
+    batch (what cross-replica BatchNorm computes with one sample per replica); p[name] = {'w','gamma','beta'} tensors
+    in the TensorFlow layouts."""
+    batched = cost.dim() == 5
+    x = cost if batched else cost[None]
     cb = lambda t, n, s: _bn_relu(_conv(t, p[n]["w"], s), p[n])
     db = lambda t, n: _bn_relu(_deconv(t, p[n]["w"]), p[n])
     c1_0 = cb(x, "3dconv1_0", 2); c2_0 = cb(c1_0, "3dconv2_0", 2); c3_0 = cb(c2_0, "3dconv3_0", 2)
@@ -76,7 +79,8 @@ def regnet_us0(cost, p):
     c4 = db(c3_1, "3dconv4_0") + c2_1
     c5 = db(c4, "3dconv5_0") + c1_1
     c6 = db(c5, "3dconv6_0") + c0_1
-    return _conv(c6, p["3dconv6_2"]["w"], 1)[0, 0]
+    out = _conv(c6, p["3dconv6_2"]["w"], 1)[:, 0]
+    return out if batched else out[0]
 
 
 def soft_argmin(reg, depth_start, depth_interval):

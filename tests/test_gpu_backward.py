@@ -443,3 +443,67 @@ def test_device_gradients_match_the_committed_golden_fixture():
     assert rel_l1(n(pt["3dconv6_2"]["w"].grad), g["g_w62"]) < 2e-3
     assert rel_l1(n(pt["3dconv3_0"]["gamma"].grad), g["g_gamma30"]) < 2e-3
     assert rel_l1(n(pt["3dconv6_0"]["beta"].grad), g["g_beta60"]) < 2e-3
+
+
+_SYNC_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from mvsnet_amd import shard as sh, synthetic as S, backward as B
+dist = sh.init_process_group("gloo")
+rank, _local, world = sh.rank_world()
+torch.cuda.set_device(0)                                  # both replicas share the box's one GPU
+d = np.load(%(inp)r)
+t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+params = S.make_regnet_params("normal", seed=1, random_affine=True)
+ft = t(d["feats"][rank]).requires_grad_(True)
+pt = {k: {kk: t(vv).requires_grad_(True) for kk, vv in v.items()} for k, v in params.items()}
+depth, _ = B.plane_sweep_depth(ft, t(d["t8"]), float(d["start"]), float(d["interval"]), pt, sync=B.SyncBN())
+(depth * t(d["g"][rank])).sum().backward()
+torch.cuda.synchronize()
+out = {"depth": depth.detach().cpu().numpy(), "g_features": ft.grad.cpu().numpy()}
+for k in pt:
+    for kk in pt[k]:
+        out["%%s/%%s" %% (k, kk)] = pt[k][kk].grad.cpu().numpy()
+np.savez(%(out)r %% rank, **out)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_sync_batchnorm_two_replicas_match_a_batch_of_two(tmp_path):
+    """Cross-replica BatchNorm (backward.SyncBN): two processes, one sample each, against float64 autograd of the
+    restatement on the batch of two (BatchNorm statistics over both volumes).  The replicas' variable gradients
+    add up to the batch's; each replica's feature gradient is its sample's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f0, t8, start, interval = _toy_problem()
+    f1 = S.make_features(3, 16, 32, 32, seed=9)
+    rs = np.random.RandomState(21)
+    g = rs.randn(2, 16, 32).astype(np.float32)
+    inp = str(tmp_path / "in.npz")
+    np.savez(inp, feats=np.stack([f0, f1]), t8=t8, start=start, interval=interval, g=g)
+    outp = str(tmp_path / "rank%d.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, "-c", _SYNC_WORKER % {"root": root, "inp": inp, "out": outp}],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = [np.load(outp % r) for r in range(2)]
+    # checker: the batch of two through the restatement
+    params = S.make_regnet_params("normal", seed=1, random_affine=True)
+    p64 = {k: {kk: d64(vv, True) for kk, vv in v.items()} for k, v in params.items()}
+    f64 = [d64(f0, True), d64(f1, True)]
+    costs = torch.stack([TG.cost_volume(f, d64(t8)) for f in f64])
+    reg = TG.regnet_us0(costs, p64)
+    depth = torch.stack([TG.soft_argmin(reg[b], start, interval) for b in range(2)])
+    (depth * d64(g)).sum().backward()
+    for r in range(2):
+        assert rel_l1(got[r]["depth"].astype(np.float64), depth[r].detach().numpy()) < 1e-5
+        assert rel_l1(got[r]["g_features"].astype(np.float64), f64[r].grad.numpy()) < 2e-3
+    for k in p64:
+        for kk in p64[k]:
+            tot = got[0]["%s/%s" % (k, kk)].astype(np.float64) + got[1]["%s/%s" % (k, kk)].astype(np.float64)
+            assert rel_l1(tot, p64[k][kk].grad.numpy()) < 2e-3, (k, kk)
