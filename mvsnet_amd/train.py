@@ -184,7 +184,13 @@ class Trainer:
         """average_gradients (train.py:155-187): ONE sum all-reduce of the flat gradient buffer (RCCL on the
         GPUs, gloo in the CPU tests); returns the 1/world factor the update kernel applies."""
         if self.world > 1:
-            torch.distributed.all_reduce(self.params.grad)
+            g = self.params.grad
+            if g.is_cuda and torch.distributed.get_backend() != "nccl":      # rehearsals over gloo: stage through the host
+                h = g.cpu()
+                torch.distributed.all_reduce(h)
+                g.copy_(h)
+            else:
+                torch.distributed.all_reduce(g)
         return 1.0 / self.world
 
     def apply_gradients(self):

@@ -507,3 +507,45 @@ def test_sync_batchnorm_two_replicas_match_a_batch_of_two(tmp_path):
         for kk in p64[k]:
             tot = got[0]["%s/%s" % (k, kk)].astype(np.float64) + got[1]["%s/%s" % (k, kk)].astype(np.float64)
             assert rel_l1(tot, p64[k][kk].grad.numpy()) < 2e-3, (k, kk)
+
+
+_DP_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from mvsnet_amd import shard as sh, synthetic as S, train as T
+dist = sh.init_process_group("gloo")
+rank, _local, world = sh.rank_world()
+torch.cuda.set_device(0)
+tr = T.Trainer("normal", "cuda", seed=0, sync_bn=%(sync)s)       # same seed: identical replicas
+N, H, W, D = 3, 64, 96, 16
+images = S.make_images(N, H, W, seed=10 + rank)                  # every rank its own sample
+cams = S.make_cams(N, H // 4, W // 4, D)
+start, interval = float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1])
+gt = np.full((H // 4, W // 4, 1), start + interval * D * (0.4 + 0.2 * rank), np.float32)
+losses = [float(tr.train_step(images, cams, gt, D)[0]) for _ in range(3)]
+ck = torch.tensor([float(tr.params.data.double().sum()), float(tr.params.data.double().abs().sum())], dtype=torch.float64)
+lo, hi = ck.clone(), ck.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+if rank == 0:
+    print(json.dumps({"losses": losses, "equal": bool(torch.equal(lo, hi)), "steps": tr.global_step}))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("sync", [False, True])
+def test_data_parallel_training_keeps_two_replicas_identical(sync):
+    """Two processes (sharing the box's GPU, collectives over gloo) train on different samples: after the flat
+    gradient all-reduce + optimiser step the replicas must hold bit-identical parameters."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563" if sync else "29565", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, "-c", _DP_WORKER % {"root": root, "sync": sync}],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=400) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert res["equal"] and res["steps"] == 3 and all(np.isfinite(res["losses"]))
