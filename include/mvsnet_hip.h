@@ -264,7 +264,9 @@ int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms,
  * kernel array, a transposed convolution's is mvs_conv3d_f32 (stride 2) with the same array, and a
  * stride-1 convolution's is mvs_conv3d_f32 with the kernel flipped along kd,kh,kw and Cin/Cout swapped.
  *
- * mvs_softargmin_bwd_f32   g_reg(d) = -g_depth * P_d * (z_d - depth), P = softmax(-reg) (model.py:343-366)
+ * mvs_softargmin_bwd_f32   g_reg(d) = -g_depth * P_d * (z_d - depth) - g_prob * P_d * (m_d - prob), P = softmax(-reg),
+ *                          m_d = number of the four probability buckets equal to plane d (model.py:343-366, 45-144;
+ *                          the bucket indices carry no gradient); g_depth or g_prob may be NULL
  * mvs_bn_relu_f32          out = act(y*scale+shift) [+ act(y2*scale2+shift2)], act = ReLU when the scale
  *                          is given: the normalised layer input the forward kernels form on load
  * mvs_bn_bwd_reduce_f32    BatchNorm(batch statistics)+ReLU backward, pass 1: sums (S,2,C) float64 (zeroed
@@ -286,7 +288,7 @@ int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms,
  *                          ms += (g^2-ms)(1-decay); mom = momentum*mom + lr*g/sqrt(ms+eps); w -= mom,
  *                          g = grad * grad_scale (1/world_size after a sum all-reduce)
  */
-int mvs_softargmin_bwd_f32(const float* reg, const float* g_depth, int D, int H, int W,
+int mvs_softargmin_bwd_f32(const float* reg, const float* g_depth, const float* g_prob, int D, int H, int W,
                            float depth_start, float depth_interval, int inverse_depth,
                            float* g_reg, void* stream);
 int mvs_bn_relu_f32(const float* y, const float* scale, const float* shift, const float* y2,

@@ -54,7 +54,7 @@ SIGNATURES = {
     "mvs_wta_update_f32": (_i, [_p, _f, _i, _i, _p, _p, _p, _p]),
     "mvs_wta_finish_f32": (_i, [_p, _p, _i, _i, _p, _p]),
     "mvs_gru_workspace_bytes": (_sz, [_i] * 6),
-    "mvs_softargmin_bwd_f32": (_i, [_p, _p, _i, _i, _i, _f, _f, _i, _p, _p]),
+    "mvs_softargmin_bwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _i, _p, _p]),
     "mvs_bn_relu_f32": (_i, [_p] * 6 + [_sz, _i, _p, _p]),
     "mvs_bn_bwd_sum_slots": (_i, []),
     "mvs_bn_bwd_reduce_f32": (_i, [_p, _p, C.c_double, _f, _p, _p, _p, _p, _sz, _i, _p, _p]),

@@ -30,12 +30,14 @@ BN_LAYERS = REGNET_ORDER[:-1]
 # single-op wrappers
 # ------------------------------------------------------------------------------------------------
 
-def softargmin_bwd(reg, g_depth, depth_start, depth_interval, inverse_depth=False):
-    """reg (D,H,W), g_depth (H,W) -> g_reg (D,H,W)   (model.py:343-366)"""
+def softargmin_bwd(reg, g_depth, depth_start, depth_interval, inverse_depth=False, g_prob=None):
+    """reg (D,H,W), g_depth (H,W) [, g_prob (H,W)] -> g_reg (D,H,W)   (model.py:343-366, 45-144)"""
     lib = _lib.load()
     D, H, W = reg.shape
     g = torch.empty_like(reg)
-    _lib.check(lib.mvs_softargmin_bwd_f32(_lib.ptr(reg), _lib.ptr(_lib.f32(g_depth.contiguous())), D, H, W,
+    gd = _lib.f32(g_depth.contiguous()) if g_depth is not None else None
+    gp = _lib.f32(g_prob.contiguous()) if g_prob is not None else None
+    _lib.check(lib.mvs_softargmin_bwd_f32(_lib.ptr(reg), _lib.ptr(gd), _lib.ptr(gp), D, H, W,
                                           float(depth_start), float(depth_interval), int(bool(inverse_depth)),
                                           _lib.ptr(g), _lib.stream_ptr()), "mvs_softargmin_bwd_f32")
     return g
@@ -330,8 +332,8 @@ def unflatten_params(flat) -> Dict[str, Dict[str, torch.Tensor]]:
 
 class PlaneSweepDepth(torch.autograd.Function):
     """features (N,H,W,C) [view 0 = reference], transforms (N-1,D,8) -> depth map (H,W); differentiable
-    w.r.t. the features and the RegNetUS0 parameters (cameras are data).  The probability map is not part
-    of any training loss (train.py:314-356 uses the depth maps only) and is returned detached."""
+    w.r.t. the features and the RegNetUS0 parameters (cameras are data).  The probability map carries a gradient too
+    (it is an input channel of the refinement network, model.py:753-811); its bucket indices do not."""
 
     @staticmethod
     def forward(ctx, features, transforms, depth_start, depth_interval, inverse_depth, sync, *flat):
@@ -343,14 +345,13 @@ class PlaneSweepDepth(torch.autograd.Function):
         depth, prob = softargmin_prob(reg, depth_start, depth_interval, inverse_depth)
         ctx.saved = (features, transforms, reg, saved, p)
         ctx.scalars = (float(depth_start), float(depth_interval), bool(inverse_depth))
-        ctx.mark_non_differentiable(prob)
         return depth, prob
 
     @staticmethod
-    def backward(ctx, g_depth, _g_prob):
+    def backward(ctx, g_depth, g_prob):
         features, transforms, reg, saved, p = ctx.saved
         start, interval, inverse = ctx.scalars
-        g_reg = softargmin_bwd(reg, g_depth, start, interval, inverse)
+        g_reg = softargmin_bwd(reg, g_depth, start, interval, inverse, g_prob)
         G, ga, gb = regnet_backward(saved, p, g_reg)
         g_ref, g_src = cost_volume_bwd(features[0], features[1:], transforms, ga, gb)
         g_feat = torch.cat([g_ref[None], g_src], 0)

@@ -24,9 +24,14 @@ __device__ __forceinline__ float depth_at(int d, int D, float start, float inter
 }
 
 // depth = sum_d P_d z_d, P = softmax(-reg)  =>  d depth / d reg_d = -P_d (z_d - depth).
+// The 4-bucket probability map prob = P[l0] + P[r0] + P[l1] + P[r1] (model.py:45-144; the bucket indices come from
+// floor / ceil of the depth and carry no gradient, exactly as in TensorFlow) adds, when a gradient for it is given
+// (training through the refinement network, which takes the map as an input channel),
+//   d prob / d reg_d = -P_d (m_d - prob),  m_d = how many of the four buckets are plane d.
 // One lane per pixel, three coalesced sweeps over depth (max, sums, write).
 __global__ void __launch_bounds__(256)
-softargmin_bwd_kernel(const float* __restrict__ reg, const float* __restrict__ g_depth, int D, int HW,
+softargmin_bwd_kernel(const float* __restrict__ reg, const float* __restrict__ g_depth,
+                      const float* __restrict__ g_prob, int D, int HW,
                       float start, float interval, int inverse, float* __restrict__ g_reg) {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= HW) return;
@@ -38,10 +43,34 @@ softargmin_bwd_kernel(const float* __restrict__ reg, const float* __restrict__ g
         float e = __expf(-col[(size_t)d * HW] - m);
         se += e; sz += e * depth_at(d, D, start, interval, inverse);
     }
-    const float depth = sz / se, g = g_depth[pix] / se;
+    const float depth = sz / se, g = (g_depth ? g_depth[pix] : 0.f) / se;
+    int l0 = 0, r0 = 0, l1 = 0, r1 = 0;
+    float gp = 0.f, prob = 0.f;
+    if (g_prob) {                                              // bucket indices as in softargmin.hip
+        if (inverse) {
+            float end = start + ((float)D - 1.0f) * interval;
+            float inv_s = 1.0f / start, inv_e = 1.0f / end;
+            float inv_int = (inv_s - inv_e) / ((float)D - 1.0f);
+            float idx = (1.0f / depth - inv_e) / inv_int;
+            l0 = D - (int)ceilf(idx) - 1; r0 = D - (int)floorf(idx) - 1;
+        } else {
+            float idx = (depth - start) / interval;
+            l0 = (int)floorf(idx); r0 = (int)ceilf(idx);
+        }
+        l0 = min(max(l0, 0), D - 1); r0 = min(max(r0, 0), D - 1);
+        l1 = min(max(l0 - 1, 0), D - 1); r1 = min(max(r0 + 1, 0), D - 1);
+        auto P = [&](int d) { return __expf(-col[(size_t)d * HW] - m) / se; };
+        prob = (P(l0) + P(r0)) + (P(l1) + P(r1));
+        gp = g_prob[pix] / se;
+    }
     for (int d = 0; d < D; ++d) {
         float e = __expf(-col[(size_t)d * HW] - m);
-        g_reg[(size_t)d * HW + pix] = -g * e * (depth_at(d, D, start, interval, inverse) - depth);
+        float v = -g * e * (depth_at(d, D, start, interval, inverse) - depth);
+        if (g_prob) {
+            const float md = (float)((d == l0) + (d == r0) + (d == l1) + (d == r1));
+            v -= gp * e * (md - prob);
+        }
+        g_reg[(size_t)d * HW + pix] = v;
     }
 }
 
@@ -593,13 +622,13 @@ inline int grid_for(size_t n4) { size_t b = (n4 + 255) / 256; return (int)(b < 4
 
 }  // namespace
 
-extern "C" int mvs_softargmin_bwd_f32(const float* reg, const float* g_depth, int D, int H, int W,
+extern "C" int mvs_softargmin_bwd_f32(const float* reg, const float* g_depth, const float* g_prob, int D, int H, int W,
                                       float depth_start, float depth_interval, int inverse_depth,
                                       float* g_reg, void* stream) {
-    MVS_CHECK_ARG(reg && g_depth && g_reg && D > 0 && H > 0 && W > 0);
+    MVS_CHECK_ARG(reg && (g_depth || g_prob) && g_reg && D > 0 && H > 0 && W > 0);
     const int HW = H * W;
     softargmin_bwd_kernel<<<mvs_cdiv(HW, 256), 256, 0, mvs_stream(stream)>>>(
-        reg, g_depth, D, HW, depth_start, depth_interval, inverse_depth, g_reg);
+        reg, g_depth, g_prob, D, HW, depth_start, depth_interval, inverse_depth, g_reg);
     MVS_LAUNCH_RET();
 }
 

@@ -54,6 +54,19 @@ def test_softargmin_backward_matches_autograd():
     (TG.soft_argmin(x, 425.0, 2.5) * d64(g)).sum().backward()
     got = n(B.softargmin_bwd(t(reg), t(g), 425.0, 2.5))
     assert rel_l1(got, x.grad.numpy()) < 1e-5
+    # with a gradient for the 4-bucket probability map as well (bucket indices are constants, as in TensorFlow)
+    gp = rs.randn(H, W).astype(np.float32)
+    x2 = d64(reg, True)
+    P = torch.softmax(-x2, dim=0)
+    depth = TG.soft_argmin(x2, 425.0, 2.5)
+    idx = ((depth - 425.0) / 2.5).detach()
+    l0 = idx.floor().long().clamp(0, D - 1); r0 = idx.ceil().long().clamp(0, D - 1)
+    l1 = (l0 - 1).clamp(0, D - 1); r1 = (r0 + 1).clamp(0, D - 1)
+    pick = lambda i: torch.gather(P, 0, i[None])[0]
+    prob = pick(l0) + pick(r0) + pick(l1) + pick(r1)
+    ((depth * d64(g)).sum() + (prob * d64(gp)).sum()).backward()
+    got2 = n(B.softargmin_bwd(t(reg), t(g), 425.0, 2.5, g_prob=t(gp)))
+    assert rel_l1(got2, x2.grad.numpy()) < 1e-4
 
 
 @pytest.mark.parametrize("C,two", [(8, True), (16, False), (64, True)])
