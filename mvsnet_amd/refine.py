@@ -106,18 +106,33 @@ class RefineNet:
     @torch.no_grad()
     def __call__(self, color_image, depth_image):
         """color_image (B,H,W,3), depth_image (B,H,W,1|2) channel-last -> (B,H,W,1)."""
-        x = torch.cat([color_image, depth_image], dim=3).to(self.device).permute(0, 3, 1, 2).contiguous()
-        acts = {"concat_image": x}
-        for name, kind, srcs, stride, relu, w, b in self.layers:
-            x = acts[srcs[0]] if len(srcs) == 1 else torch.cat([acts[s] for s in srcs], dim=1)
-            if kind == "d":
-                n_h, n_w = x.shape[2], x.shape[3]
-                y = F.conv_transpose2d(x, w, stride=stride)[:, :, :n_h * stride, :n_w * stride] + b[None, :, None, None]
-            else:
-                ph, pw = _same_pad(x.shape[2], 3, stride), _same_pad(x.shape[3], 3, stride)
-                y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), w, b, stride=stride)
-            acts[name] = F.relu(y) if relu else y
-        return acts[self.table[-1][0]].permute(0, 2, 3, 1).contiguous()
+        return refine_forward(self.table, self.layers, color_image.to(self.device), depth_image.to(self.device))
+
+
+def refine_forward(table, layers, color_image, depth_image):
+    """The tower itself; differentiable (the trainer runs it under torch autograd).  `layers`: tuples
+    (name, kind, srcs, stride, relu, w torch-layout, b)."""
+    x = torch.cat([color_image, depth_image], dim=3).permute(0, 3, 1, 2).contiguous()
+    acts = {"concat_image": x}
+    for name, kind, srcs, stride, relu, w, b in layers:
+        x = acts[srcs[0]] if len(srcs) == 1 else torch.cat([acts[s] for s in srcs], dim=1)
+        if kind == "d":
+            n_h, n_w = x.shape[2], x.shape[3]
+            y = F.conv_transpose2d(x, w, stride=stride)[:, :, :n_h * stride, :n_w * stride] + b[None, :, None, None]
+        else:
+            ph, pw = _same_pad(x.shape[2], 3, stride), _same_pad(x.shape[3], 3, stride)
+            y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), w, b, stride=stride)
+        acts[name] = F.relu(y) if relu else y
+    return acts[table[-1][0]].permute(0, 2, 3, 1).contiguous()
+
+
+def trainable_refine_layers(params, network_type):
+    """`params[name]` = {'w', 'b'} torch tensors in the TensorFlow layouts (leaves that require grad) -> (table, layers)
+    for refine_forward."""
+    table, _ = refine_layers(network_type)
+    layers = [(name, kind, srcs, stride, relu, params[name]["w"].permute(3, 2, 0, 1), params[name]["b"])
+              for name, kind, srcs, _mult, stride, relu in table]
+    return table, layers
 
 
 def depth_refine(init_depth_map, image, prob_map, depth_num, depth_start, depth_interval, refine_net,

@@ -21,8 +21,10 @@ The forward / backward of the hot path run in libmvsnet_hip.so (backward.py); th
 feature_net.unet_forward under torch autograd (north_star keeps them on PyTorch-ROCm).
 network_mode: 'normal' natively; 'semilite' / 'lite' (the reference's default) / 'ultralite' zero-padded to the
 'normal' shapes (padded entries provably stay zero); wider modes raise NotImplementedError.
-Not built: GRU training (the reference's GRU branch has arity bugs, train.py:355-364 vs model.py:505) and
-training through the refinement network (train.py:317-349): both raise NotImplementedError.
+Training through the refinement network (`--refinement`, train.py:317-349: all / refine_only / main_only; the towers of
+refine.py under torch autograd, the probability-map gradient through mvs_softargmin_bwd_f32).
+Not built: GRU training (the reference's GRU branch has arity bugs, train.py:355-364 vs model.py:505) and the stereo
+partner of the refinement network (`refine_with_stereo`).
 """
 from __future__ import annotations
 
@@ -72,9 +74,9 @@ class FlatParameters:
     names; `grad` is a second flat buffer the leaves' .grad tensors are views of, so one all-reduce and one
     optimiser launch cover the whole model."""
 
-    def __init__(self, unet, regnet, network_mode, device):
-        self.names = tf_checkpoint.variable_names(network_mode, "3DCNN")
-        src = {"unet": unet, "regnet": regnet}
+    def __init__(self, unet, regnet, network_mode, device, refine=None, refinement=None):
+        self.names = tf_checkpoint.variable_names(network_mode, "3DCNN", refinement if refine is not None else None)
+        src = {"unet": unet, "regnet": regnet, "refine": refine}
         self.index = []                                   # (key, var_name, offset, shape)
         off = 0
         for key in sorted(self.names, key=lambda k: self.names[k]):
@@ -112,7 +114,8 @@ class FlatParameters:
 class Trainer:
     def __init__(self, network_mode="normal", device="cuda", optimizer="rmsprop", base_lr=1e-3, stepvalue=70000,
                  gamma=0.5, loss_type="power", alpha=0.25, beta=0.0, eta=0.02, grad_loss=True, init=None, seed=0,
-                 sync_bn=False):
+                 sync_bn=False, refinement=False, refinement_network="unet", upsample_before_refinement=True,
+                 refine_with_confidence=True, refinement_train_mode="all"):
         if optimizer not in OPTIMIZER_SLOTS:
             raise NotImplementedError("Optimizer %s is not implemented" % optimizer)       # train.py:268-271
         self.network_mode, self.device = network_mode, torch.device(device)
@@ -138,7 +141,20 @@ class Trainer:
             regnet = padded
         elif np.asarray(regnet["3dconv1_0"]["w"]).shape[3] > 32:
             raise NotImplementedError("network_mode %r: no weight-gradient kernels for these channel counts" % network_mode)
-        self.params = FlatParameters(init["unet"], regnet, network_mode, self.device)
+        # depth refinement (train.py:317-349): the refinement tower's variables join the flat buffer
+        self.refinement = bool(refinement)
+        self.refine_cfg = (refinement_network, bool(upsample_before_refinement), bool(refine_with_confidence), refinement_train_mode)
+        if refinement_train_mode not in ("all", "refine_only", "main_only"):
+            raise ValueError("refinement_train_mode must be all, refine_only or main_only")
+        refine = None
+        if self.refinement:
+            from .refine import make_refine_params
+            refine = init.get("refine")
+            if refine is None:
+                tmpl = make_refine_params(refinement_network, network_mode, in_channels=5 if refine_with_confidence else 4)
+                g = glorot_uniform_like(tmpl, seed + 2)
+                refine = {k: {"w": g[k]["w"], "b": np.zeros_like(np.asarray(tmpl[k]["b"], np.float32))} for k in tmpl}   # tf.layers: zero biases
+        self.params = FlatParameters(init["unet"], regnet, network_mode, self.device, refine, refinement_network)
         n = self.params.numel
         ones = optimizer == "rmsprop"                    # TF's RMSProp `rms` slot starts at one
         self.slots = [torch.ones(n, device=self.device) if (ones and i == 0) else torch.zeros(n, device=self.device)
@@ -151,7 +167,7 @@ class Trainer:
             self.sync = SyncBN()
 
     # -- one optimisation step ------------------------------------------------------------------------
-    def loss(self, images, cams, depth_image, depth_num):
+    def loss(self, images, cams, depth_image, depth_num, full_depth=None):
         """images (N,H,W,3), cams (N,2,4,4) at the output scale, depth_image (H/4,W/4,1) GT.  Returns
         (loss, less_one, less_three, depth_map) exactly as get_loss (train.py:307-353), batch 1."""
         from .backward import plane_sweep_depth
@@ -175,6 +191,28 @@ class Trainer:
         ds = torch.tensor([depth_start], device=self.device)
         de = torch.tensor([depth_end], device=self.device)
         loss, l1, l3, _dbg = mvsnet_regression_loss(est, gt, ds, de, **self.loss_args)
+        if self.refinement:                               # train.py:317-349
+            from .refine import depth_refine, refine_forward, trainable_refine_layers
+            net, upsample, conf, mode = self.refine_cfg
+            table, layers = trainable_refine_layers(self.params.group("refine"), net)
+            refined, _residual = depth_refine(est, images[0:1], _prob[None, :, :, None], depth_num, depth_start, depth_interval,
+                                              lambda c, d: refine_forward(table, layers, c, d), upsample_depth=upsample,
+                                              refine_with_confidence=conf)
+            if upsample:
+                if full_depth is None:
+                    raise ValueError("upsample_before_refinement needs the full-resolution ground truth")
+                target = torch.as_tensor(full_depth, dtype=torch.float32, device=self.device)[None]
+            else:
+                target = gt
+            loss1, l1r, l3r, _ = mvsnet_regression_loss(refined, target, ds, de, **self.loss_args)
+            if mode == "refine_only":
+                loss = loss1 + 1e-9 * loss
+                l1, l3 = l1r, l3r
+            elif mode == "main_only":
+                loss = loss + 1e-12 * loss1
+            else:
+                loss = (loss + loss1) / 2
+                l1, l3 = l1r, l3r
         return loss, l1, l3, depth
 
     def learning_rate(self):
@@ -214,15 +252,19 @@ class Trainer:
         g.zero_()
         self.global_step += 1
 
-    def train_step(self, images, cams, depth_image, depth_num):
-        loss, l1, l3, _ = self.loss(images, cams, depth_image, depth_num)
+    def train_step(self, images, cams, depth_image, depth_num, full_depth=None):
+        loss, l1, l3, _ = self.loss(images, cams, depth_image, depth_num, full_depth)
         loss.backward()
+        if self.refinement and self.refine_cfg[3] == "refine_only":     # the main network's variables are not trainable
+            for (group, _l, _f), _v, o, shape in self.params.index:
+                if group != "refine":
+                    self.params.grad[o:o + int(np.prod(shape))].zero_()
         self.apply_gradients()
         return loss.detach(), l1.detach(), l3.detach()
 
     @torch.no_grad()
-    def validate_step(self, images, cams, depth_image, depth_num):
-        loss, l1, l3, _ = self.loss(images, cams, depth_image, depth_num)
+    def validate_step(self, images, cams, depth_image, depth_num, full_depth=None):
+        loss, l1, l3, _ = self.loss(images, cams, depth_image, depth_num, full_depth)
         return loss, l1, l3
 
     # -- checkpoints ----------------------------------------------------------------------------------
@@ -285,6 +327,8 @@ def build_parser():
     a("--base_image_size", type=int, default=8)
     a("--regularization", default="3DCNN"); a("--optimizer", default="rmsprop")
     a("--refinement", action="store_true"); a("--network_mode", default="lite")
+    a("--refinement_network", default="unet"); a("--refinement_train_mode", default="all")
+    a("--no_upsample_before_refinement", action="store_true"); a("--no_refine_with_confidence", action="store_true")
     a("--epoch", type=int, default=1); a("--max_steps_per_epoch", type=int, default=None)
     a("--base_lr", type=float, default=0.001); a("--display", type=int, default=1)
     a("--stepvalue", type=int, default=70000); a("--snapshot", type=int, default=5000)
@@ -302,15 +346,15 @@ def train(args):
     from .shard import shard_indices
     if args.regularization != "3DCNN":
         raise NotImplementedError("only the 3DCNN regulariser trains here (the reference's GRU branch is broken)")
-    if args.refinement:
-        raise NotImplementedError("training through the refinement network is not built")
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     tr = Trainer(args.network_mode, "cuda", args.optimizer, args.base_lr, args.stepvalue, args.gamma, args.loss_type,
-                 args.alpha, args.beta, args.eta, not args.no_grad_loss, seed=args.seed, sync_bn=args.sync_bn)
+                 args.alpha, args.beta, args.eta, not args.no_grad_loss, seed=args.seed, sync_bn=args.sync_bn, refinement=args.refinement,
+                 refinement_network=args.refinement_network, upsample_before_refinement=not args.no_upsample_before_refinement,
+                 refine_with_confidence=not args.no_refine_with_confidence, refinement_train_mode=args.refinement_train_mode)
     if args.ckpt_step:
         ck = tf_checkpoint.ckpt_path(args.model_load_dir or args.model_dir, args.regularization, args.network_mode)
         tr.restore(tf_checkpoint.model_path(ck, args.ckpt_step))
@@ -333,7 +377,7 @@ def train(args):
                 if world > 1:
                     raise                              # a skipped step would desynchronise the all-reduce
                 continue
-            loss, l1, l3 = tr.train_step(images, cams, depth, args.max_d)
+            loss, l1, l3 = tr.train_step(images, cams, depth, args.max_d, _full)
             if step % args.display == 0 and rank == 0:
                 print("epoch, %d, step %d, total_step %d, loss = %.4f, (< 1px) = %.4f, (< 3px) = %.4f (%.3f sec/step)"
                       % (epoch, step, tr.global_step, float(loss), float(l1), float(l3), time.time() - t0), flush=True)
@@ -345,10 +389,10 @@ def train(args):
                 vals = []
                 for k, vc in enumerate(val_gen.clusters[:args.val_batch_size]):
                     try:
-                        vi, vcam, vd, _ = val_gen.prepare_training(vc)
+                        vi, vcam, vd, _vf = val_gen.prepare_training(vc)
                     except (OSError, ValueError, KeyError):
                         continue
-                    vals.append([float(x) for x in tr.validate_step(vi, vcam, vd, args.max_d)])
+                    vals.append([float(x) for x in tr.validate_step(vi, vcam, vd, args.max_d, _vf)])
                 if vals:
                     m = np.mean(np.asarray(vals), axis=0)
                     print("VAL STEP COMPLETED. Average loss: %g, Average less one: %g, Average less three: %g"

@@ -562,3 +562,34 @@ def test_data_parallel_training_keeps_two_replicas_identical(sync):
     assert all(p.returncode == 0 for p in procs), outs
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["equal"] and res["steps"] == 3 and all(np.isfinite(res["losses"]))
+
+
+@pytest.mark.parametrize("mode,network", [("all", "unet"), ("refine_only", "original"), ("main_only", "unet")])
+def test_trainer_with_refinement(tmp_path, mode, network):
+    """Training through the refinement network (train.py:317-349): the refinement tower's variables are in the flat
+    buffer and the checkpoint; refine_only leaves the main network untouched."""
+    from mvsnet_amd import train as T
+    from mvsnet_amd import tf_checkpoint
+    images, cams, gt, D = _train_batch()
+    H, W = images.shape[1], images.shape[2]
+    full = np.repeat(np.repeat(gt, 4, axis=0), 4, axis=1).astype(np.float32)
+    assert full.shape == (H, W, 1)
+    tr = T.Trainer("normal", DEV, seed=0, refinement=True, refinement_network=network, refinement_train_mode=mode)
+    before = tr.params.data.clone()
+    losses = [float(tr.train_step(images, cams, gt, D, full)[0]) for _ in range(4)]
+    assert all(np.isfinite(losses)), losses
+    moved = {}
+    for (group, _l, _f), _v, o, shape in tr.params.index:
+        nel = int(np.prod(shape))
+        moved[group] = moved.get(group, 0.0) + float((tr.params.data[o:o + nel] - before[o:o + nel]).abs().sum())
+    assert moved["refine"] > 0
+    if mode == "refine_only":
+        assert moved["regnet"] == 0.0 and moved["unet"] == 0.0
+    else:
+        assert moved["regnet"] > 0 and moved["unet"] > 0
+    prefix = tr.save(str(tmp_path))
+    names = {nm for nm, _s, _d in tf_checkpoint.list_variables(prefix)}
+    first = "refine_conv0" if network == "original" else "2dconv1_0_refine"
+    assert first + "/kernel" in names and first + "/bias" in names
+    loaded = tf_checkpoint.load_mvsnet_params(prefix, "normal", "3DCNN", refinement=network)
+    assert loaded["refine"][first]["w"].shape[-2] == 5                      # image + depth + confidence
