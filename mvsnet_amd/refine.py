@@ -136,9 +136,10 @@ def trainable_refine_layers(params, network_type):
 
 
 def depth_refine(init_depth_map, image, prob_map, depth_num, depth_start, depth_interval, refine_net,
-                 upsample_depth=False, refine_with_confidence=False, residual_refinement=True):
+                 upsample_depth=False, refine_with_confidence=False, residual_refinement=True, stereo_image=None):
     """model.py:753-811.  init_depth_map, prob_map (B,h,w,1); image (B,H,W,3), the centred reference
-    image.  Returns (refined_depth_map, residual_depth_map)."""
+    image; stereo_image (B,H,W,3) the optional stereo partner (:777-789, training only in the reference).
+    Returns (refined_depth_map, residual_depth_map)."""
     depth_start = float(depth_start); depth_interval = float(depth_interval)
     depth_scale = (depth_start + (float(depth_num) - 1.0) * depth_interval) - depth_start
     norm = (init_depth_map - depth_start) / depth_scale
@@ -150,7 +151,11 @@ def depth_refine(init_depth_map, image, prob_map, depth_num, depth_start, depth_
             prob_map = resize_bilinear_tf1(prob_map, H, W)
     else:
         image = resize_bilinear_tf1(image, init_depth_map.shape[1], init_depth_map.shape[2])
+        if stereo_image is not None:
+            stereo_image = resize_bilinear_tf1(stereo_image, init_depth_map.shape[1], init_depth_map.shape[2])
     data = torch.cat([norm, prob_map], dim=3) if refine_with_confidence else norm
+    if stereo_image is not None:
+        data = torch.cat([data, stereo_image], dim=3)
     residual = refine_net(image, data) * depth_scale
     refined = residual + init_depth_map if residual_refinement else residual
     return refined, residual

@@ -23,8 +23,7 @@ network_mode: 'normal' natively; 'semilite' / 'lite' (the reference's default) /
 'normal' shapes (padded entries provably stay zero); wider modes raise NotImplementedError.
 Training through the refinement network (`--refinement`, train.py:317-349: all / refine_only / main_only; the towers of
 refine.py under torch autograd, the probability-map gradient through mvs_softargmin_bwd_f32).
-Not built: GRU training (the reference's GRU branch has arity bugs, train.py:355-364 vs model.py:505) and the stereo
-partner of the refinement network (`refine_with_stereo`).
+Not built: GRU training (the reference's GRU branch has arity bugs, train.py:355-364 vs model.py:505).
 """
 from __future__ import annotations
 
@@ -115,7 +114,7 @@ class Trainer:
     def __init__(self, network_mode="normal", device="cuda", optimizer="rmsprop", base_lr=1e-3, stepvalue=70000,
                  gamma=0.5, loss_type="power", alpha=0.25, beta=0.0, eta=0.02, grad_loss=True, init=None, seed=0,
                  sync_bn=False, refinement=False, refinement_network="unet", upsample_before_refinement=True,
-                 refine_with_confidence=True, refinement_train_mode="all"):
+                 refine_with_confidence=True, refinement_train_mode="all", refine_with_stereo=False):
         if optimizer not in OPTIMIZER_SLOTS:
             raise NotImplementedError("Optimizer %s is not implemented" % optimizer)       # train.py:268-271
         self.network_mode, self.device = network_mode, torch.device(device)
@@ -144,6 +143,7 @@ class Trainer:
         # depth refinement (train.py:317-349): the refinement tower's variables join the flat buffer
         self.refinement = bool(refinement)
         self.refine_cfg = (refinement_network, bool(upsample_before_refinement), bool(refine_with_confidence), refinement_train_mode)
+        self.refine_with_stereo = bool(refine_with_stereo)
         if refinement_train_mode not in ("all", "refine_only", "main_only"):
             raise ValueError("refinement_train_mode must be all, refine_only or main_only")
         refine = None
@@ -151,7 +151,7 @@ class Trainer:
             from .refine import make_refine_params
             refine = init.get("refine")
             if refine is None:
-                tmpl = make_refine_params(refinement_network, network_mode, in_channels=5 if refine_with_confidence else 4)
+                tmpl = make_refine_params(refinement_network, network_mode, in_channels=(5 if refine_with_confidence else 4) + (3 if refine_with_stereo else 0))
                 g = glorot_uniform_like(tmpl, seed + 2)
                 refine = {k: {"w": g[k]["w"], "b": np.zeros_like(np.asarray(tmpl[k]["b"], np.float32))} for k in tmpl}   # tf.layers: zero biases
         self.params = FlatParameters(init["unet"], regnet, network_mode, self.device, refine, refinement_network)
@@ -197,7 +197,8 @@ class Trainer:
             table, layers = trainable_refine_layers(self.params.group("refine"), net)
             refined, _residual = depth_refine(est, images[0:1], _prob[None, :, :, None], depth_num, depth_start, depth_interval,
                                               lambda c, d: refine_forward(table, layers, c, d), upsample_depth=upsample,
-                                              refine_with_confidence=conf)
+                                              refine_with_confidence=conf,
+                                              stereo_image=images[1:2] if (self.refine_with_stereo and images.shape[0] > 1) else None)
             if upsample:
                 if full_depth is None:
                     raise ValueError("upsample_before_refinement needs the full-resolution ground truth")
@@ -329,6 +330,7 @@ def build_parser():
     a("--refinement", action="store_true"); a("--network_mode", default="lite")
     a("--refinement_network", default="unet"); a("--refinement_train_mode", default="all")
     a("--no_upsample_before_refinement", action="store_true"); a("--no_refine_with_confidence", action="store_true")
+    a("--refine_with_stereo", action="store_true")
     a("--epoch", type=int, default=1); a("--max_steps_per_epoch", type=int, default=None)
     a("--base_lr", type=float, default=0.001); a("--display", type=int, default=1)
     a("--stepvalue", type=int, default=70000); a("--snapshot", type=int, default=5000)
@@ -354,7 +356,8 @@ def train(args):
     tr = Trainer(args.network_mode, "cuda", args.optimizer, args.base_lr, args.stepvalue, args.gamma, args.loss_type,
                  args.alpha, args.beta, args.eta, not args.no_grad_loss, seed=args.seed, sync_bn=args.sync_bn, refinement=args.refinement,
                  refinement_network=args.refinement_network, upsample_before_refinement=not args.no_upsample_before_refinement,
-                 refine_with_confidence=not args.no_refine_with_confidence, refinement_train_mode=args.refinement_train_mode)
+                 refine_with_confidence=not args.no_refine_with_confidence, refinement_train_mode=args.refinement_train_mode,
+                 refine_with_stereo=args.refine_with_stereo)
     if args.ckpt_step:
         ck = tf_checkpoint.ckpt_path(args.model_load_dir or args.model_dir, args.regularization, args.network_mode)
         tr.restore(tf_checkpoint.model_path(ck, args.ckpt_step))

@@ -701,8 +701,9 @@ def refine_net(color_image, depth_image, params, network_type="original", dtype=
 
 def depth_refine(init_depth_map, image, prob_map, depth_num, depth_start, depth_interval, params,
                  network_type="original", upsample_depth=False, refine_with_confidence=False,
-                 residual_refinement=True, dtype=np.float32):
-    """model.py:753-811 for one sample: init_depth_map, prob_map (h,w,1); image (H,W,3)."""
+                 residual_refinement=True, dtype=np.float32, stereo_image=None):
+    """model.py:753-811 for one sample: init_depth_map, prob_map (h,w,1); image (H,W,3); stereo_image (H,W,3) is the
+    optional stereo partner concatenated after the confidence (:777-789)."""
     d = np.asarray(init_depth_map, dtype)
     scale = dtype((depth_start + (float(depth_num) - 1.0) * depth_interval) - depth_start)
     norm = (d - dtype(depth_start)) / scale
@@ -714,7 +715,11 @@ def depth_refine(init_depth_map, image, prob_map, depth_num, depth_start, depth_
             prob_map = resize_bilinear_tf1(prob_map, H, W, dtype)
     else:
         image = resize_bilinear_tf1(image, d.shape[0], d.shape[1], dtype)
+        if stereo_image is not None:
+            stereo_image = resize_bilinear_tf1(np.asarray(stereo_image, dtype), d.shape[0], d.shape[1], dtype)
     data = np.concatenate([norm, prob_map], -1) if refine_with_confidence else norm
+    if stereo_image is not None:
+        data = np.concatenate([data, np.asarray(stereo_image, dtype)], -1)
     residual = refine_net(image, data, params, network_type, dtype) * scale
     return (residual + d if residual_refinement else residual), residual
 

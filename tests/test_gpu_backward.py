@@ -564,8 +564,9 @@ def test_data_parallel_training_keeps_two_replicas_identical(sync):
     assert res["equal"] and res["steps"] == 3 and all(np.isfinite(res["losses"]))
 
 
-@pytest.mark.parametrize("mode,network", [("all", "unet"), ("refine_only", "original"), ("main_only", "unet")])
-def test_trainer_with_refinement(tmp_path, mode, network):
+@pytest.mark.parametrize("mode,network,stereo", [("all", "unet", False), ("refine_only", "original", False),
+                                                 ("main_only", "unet", False), ("all", "original", True)])
+def test_trainer_with_refinement(tmp_path, mode, network, stereo):
     """Training through the refinement network (train.py:317-349): the refinement tower's variables are in the flat
     buffer and the checkpoint; refine_only leaves the main network untouched."""
     from mvsnet_amd import train as T
@@ -574,7 +575,8 @@ def test_trainer_with_refinement(tmp_path, mode, network):
     H, W = images.shape[1], images.shape[2]
     full = np.repeat(np.repeat(gt, 4, axis=0), 4, axis=1).astype(np.float32)
     assert full.shape == (H, W, 1)
-    tr = T.Trainer("normal", DEV, seed=0, refinement=True, refinement_network=network, refinement_train_mode=mode)
+    tr = T.Trainer("normal", DEV, seed=0, refinement=True, refinement_network=network, refinement_train_mode=mode,
+                   refine_with_stereo=stereo)
     before = tr.params.data.clone()
     losses = [float(tr.train_step(images, cams, gt, D, full)[0]) for _ in range(4)]
     assert all(np.isfinite(losses)), losses
@@ -592,4 +594,4 @@ def test_trainer_with_refinement(tmp_path, mode, network):
     first = "refine_conv0" if network == "original" else "2dconv1_0_refine"
     assert first + "/kernel" in names and first + "/bias" in names
     loaded = tf_checkpoint.load_mvsnet_params(prefix, "normal", "3DCNN", refinement=network)
-    assert loaded["refine"][first]["w"].shape[-2] == 5                      # image + depth + confidence
+    assert loaded["refine"][first]["w"].shape[-2] == (8 if stereo else 5)   # image + depth + confidence (+ stereo partner)

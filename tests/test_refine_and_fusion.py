@@ -35,19 +35,22 @@ def test_refine_tables_match_reference_topology():
     assert sorted(R.REFINE_UNET) == sorted(O.REFINE_UNET) and len(R.REFINE_UNET) == 28
 
 
-def _case(network_type, conf, upsample, seed):
+def _case(network_type, conf, upsample, seed, stereo=False):
     from mvsnet_amd import refine as R
     rs = np.random.RandomState(seed)
     h, w, H, W = 16, 16, 32, 32                         # unet: 4 stride-2 levels need /16 at the tower's resolution
     depth = (425 + 500 * rs.rand(1, h, w, 1)).astype(np.float32)
     prob = rs.rand(1, h, w, 1).astype(np.float32)
     image = rs.standard_normal((1, H, W, 3)).astype(np.float32)
-    params = R.make_refine_params(network_type, "normal", 3 + 1 + int(conf), seed)
+    partner = rs.standard_normal((1, H, W, 3)).astype(np.float32) if stereo else None
+    params = R.make_refine_params(network_type, "normal", 3 + 1 + int(conf) + (3 if stereo else 0), seed)
     net = R.RefineNet(params, network_type, "cpu")
     got, got_res = R.depth_refine(torch.as_tensor(depth), torch.as_tensor(image), torch.as_tensor(prob), 192, 425.0, 2.65,
-                                  net, upsample_depth=upsample, refine_with_confidence=conf)
+                                  net, upsample_depth=upsample, refine_with_confidence=conf,
+                                  stereo_image=torch.as_tensor(partner) if stereo else None)
     exp, exp_res = O.depth_refine(depth[0], image[0], prob[0], 192, 425.0, 2.65, params, network_type,
-                                  upsample_depth=upsample, refine_with_confidence=conf, dtype=np.float64)
+                                  upsample_depth=upsample, refine_with_confidence=conf, dtype=np.float64,
+                                  stereo_image=partner[0] if stereo else None)
     assert got.shape == (1,) + exp.shape
     np.testing.assert_allclose(got_res[0].numpy(), exp_res, rtol=2e-4, atol=2e-3 * np.abs(exp_res).max())
     np.testing.assert_allclose(got[0].numpy(), exp, rtol=2e-4, atol=2e-3 * np.abs(exp_res).max())
@@ -61,6 +64,12 @@ def test_depth_refine_original_matches_oracle():
 def test_depth_refine_unet_matches_oracle():
     _case("unet", True, False, 3)
     _case("unet", False, True, 4)
+
+
+def test_depth_refine_with_stereo_partner_matches_oracle():
+    """model.py:777-789: the stereo partner is resized with the image (no up-sampling) or used at full size."""
+    _case("original", True, False, 5, stereo=True)
+    _case("unet", True, True, 6, stereo=True)
 
 
 def test_probability_filter_and_gipuma_export(tmp_path):
