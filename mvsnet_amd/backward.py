@@ -174,7 +174,7 @@ def _pad_channels(x, w, axis, to=16):
 def conv_s1_input_grad(g_y, w):
     """Input gradient of y = conv3d(x, w (3,3,3,Cin,Cout), stride 1): conv3d(g_y, flip(w)^T)."""
     wt = w.flip(0, 1, 2).permute(0, 1, 2, 4, 3).contiguous()          # (3,3,3,Cout,Cin) read as Cin'=Cout, Cout'=Cin
-    if g_y.shape[-1] == 8:
+    if g_y.shape[-1] == 8 and wt.shape[4] != 32:          # 8 -> 32 has its own kernel (conv3d_k8.hip: taps paired along w)
         g_y, wt = _pad_channels(g_y, wt, 3)
     return conv3d(g_y, wt, 1)
 

@@ -337,6 +337,7 @@ static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t
     if (stride == 1) {
         if (Cout == 1) return mvs_conv3d_out_launch(a, Cin, st);
         if (Cin == 1) return mvs_conv3d_in1_launch(a, Cout, st);     // input gradient of the one-channel output layer
+        if (Cin == 8) return mvs_conv3d_k8_launch(a, Cout, st);      // input gradient of 3dconv0_1 (8 -> 32)
         if (a.wprep_bf && mvs_conv3d_bf16x3_supported(Cin, Cout)) return mvs_conv3d_s1_bf16x3(a, Cin, Cout, st);
         if (Cin == 32 && Cout == 8 && !a.x2 && !g_generic_c8) {
             int rc = mvs_conv3d_c8_launch(a, st);

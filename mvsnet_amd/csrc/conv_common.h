@@ -152,6 +152,7 @@ int mvs_deconv3d_mfma_launch(const ConvArgs& a, int Cin, int Cout, hipStream_t s
 int mvs_conv3d_out_launch(const ConvArgs& a, int Cin, hipStream_t st);
 // one-channel side layers of the training path (conv3d_c1.hip)
 int mvs_conv3d_in1_launch(const ConvArgs& a, int Cout, hipStream_t st);
+int mvs_conv3d_k8_launch(const ConvArgs& a, int Cout, hipStream_t st);       // 8 -> 32, taps paired along w (conv3d_k8.hip)
 int mvs_wgrad_c1_plan(int D, int H, int W, int CB, int* rows, int* planes_per_wg);
 int mvs_wgrad_c1_launch(const float* big, const float* small, int D, int H, int W, int CB, float* partial, hipStream_t st);
 int mvs_deconv3d_c8_launch(const ConvArgs& a, int Cin, int Cout, hipStream_t st);   // 8 couts per workgroup, packed tiles
