@@ -1,0 +1,146 @@
+"""Training of the recurrent (ConvGRU) regulariser: `inference_prob_recurrent` (mvsnet/model.py:505-599) and
+`mvsnet_classification_loss` (mvsnet/loss.py:223-267), SURVEY 8f row f4.
+
+The reference's branch does not run as shipped (get_loss returns three values where its caller unpacks four,
+train.py:355-364 vs :428; `non_zero_mean_absolute_diff` is not defined anywhere in loss.py): what is built here is
+what that branch states, with the arity made consistent (loss, less_one, less_three, depth map — as the 3DCNN branch).
+
+Where the work runs
+  * warp + variance of ALL planes and its backward w.r.t. the feature maps: libmvsnet_hip.so
+    (`mvs_cost_volume_f32` / `mvs_cost_volume_bwd_gather_f32`), as on the 3D-CNN training path;
+  * the three ConvGRU cells + prob_conv: PyTorch-ROCm autograd (ATen / MIOpen convolutions) — back-propagation
+    through time over `depth_num` planes.  The sweep is restructured the way the inference kernels are
+    (DESIGN §4.4): a cell's convolution over concat([x, h]) is split into an x part and an h part, and the x part of
+    every plane is ONE batched convolution (planes as the batch dimension), cell by cell; only the h part, the
+    LayerNorms and the gates walk the planes.  The inference-only HIP sweep (`mvs_gru_wta_f32`) keeps no
+    activations and is not used here.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .loss import less_one_percentage, less_three_percentage, original_loss
+
+LN_EPSILON = 1e-12          # tf.contrib.layers.layer_norm's variance_epsilon (convgru.py:30-31)
+
+
+class VarianceCostVolume(torch.autograd.Function):
+    """features (N,H,W,C) [view 0 = reference], transforms (N-1,D,8) -> cost (D,H,W,C) = E[f^2] - E[f]^2 over the
+    views (model.py:566-581), both directions on the HIP library."""
+
+    @staticmethod
+    def forward(ctx, features, transforms):
+        from .model import cost_volume
+        features = features.detach().contiguous()
+        ctx.saved = (features, transforms)
+        return cost_volume(features[0], features[1:], transforms, variant="eager")
+
+    @staticmethod
+    def backward(ctx, g_cost):
+        from .backward import cost_volume_bwd
+        features, transforms = ctx.saved
+        g_ref, g_src = cost_volume_bwd(features[0], features[1:], transforms, g_cost.contiguous())
+        ctx.saved = None
+        return torch.cat([g_ref[None], g_src], 0), None
+
+
+def _layer_norm(x, gamma, beta):
+    """tf.contrib.layers.layer_norm on one sample: moments over (H,W,C), per-channel gamma / beta."""
+    var, mean = torch.var_mean(x, unbiased=False)
+    return (x - mean) * torch.rsqrt(var + LN_EPSILON) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+
+
+def conv_gru_sweep(x_all, p):
+    """One ConvGRUCell (convgru.py:82-122) over all planes: x_all (D,Cin,H,W) -> states (D,F,H,W), zero initial state
+    (model.py:546-551)."""
+    Fn = p["out_b"].shape[0]
+    D, Cin = x_all.shape[0], x_all.shape[1]
+    wg = p["gates_w"].permute(3, 2, 0, 1)                       # TF (3,3,Cin+F,2F) -> (2F,Cin+F,3,3)
+    wo = p["out_w"].permute(3, 2, 0, 1)
+    gx = F.conv2d(x_all, wg[:, :Cin], p["gates_b"], padding=1)  # x parts of every plane, batched
+    ox = F.conv2d(x_all, wo[:, :Cin], p["out_b"], padding=1)
+    wgh, woh = wg[:, Cin:].contiguous(), wo[:, Cin:].contiguous()
+    h = x_all.new_zeros((1, Fn) + tuple(x_all.shape[2:]))
+    states = []
+    for d in range(D):
+        g = gx[d:d + 1] + F.conv2d(h, wgh, padding=1)           # :89-94
+        r = torch.sigmoid(_layer_norm(g[:, :Fn], p["reset_gamma"], p["reset_beta"]))       # :97,101
+        u = torch.sigmoid(_layer_norm(g[:, Fn:], p["update_gamma"], p["update_beta"]))     # :98,102
+        c = ox[d:d + 1] + F.conv2d(r * h, woh, padding=1)       # :107-111
+        y = torch.tanh(_layer_norm(c, p["out_gamma"], p["out_beta"]))                      # :114-117
+        h = u * h + (1.0 - u) * y                               # :120
+        states.append(h)
+    return torch.cat(states, 0)
+
+
+def recurrent_regularisation(features, transforms, gru):
+    """features (N,H,W,C), transforms (N-1,D,8), gru = {'gru1','gru2','gru3': cell tensors, 'prob_w','prob_b'} ->
+    regularised cost `reg` (D,H,W) (model.py:563-592, before the softmax)."""
+    cin = int(gru["gru1"]["gates_w"].shape[2]) - int(gru["gru1"]["out_b"].shape[0])
+    feats = features
+    if feats.shape[-1] not in (16, 32):                         # channel counts the HIP gather kernels tile
+        feats = F.pad(feats, (0, (16 if feats.shape[-1] < 16 else 32) - feats.shape[-1]))
+    cost = VarianceCostVolume.apply(feats, transforms)          # (D,H,W,C)
+    x = (-cost[..., :cin]).permute(0, 3, 1, 2)                  # the cells see -cost (model.py:584)
+    s1 = conv_gru_sweep(x, gru["gru1"])
+    s2 = conv_gru_sweep(s1, gru["gru2"])
+    s3 = conv_gru_sweep(s2, gru["gru3"])
+    reg = F.conv2d(s3, gru["prob_w"].permute(3, 2, 0, 1), gru["prob_b"], padding=1)        # :587-588
+    return reg[:, 0]
+
+
+def inference_prob_recurrent(features, transforms, gru):
+    """prob_volume (D,H,W) = softmax over the planes of the regularised cost (model.py:591-592).  The feature
+    towers are the caller's (as everywhere in this package: model.inference_mem takes features or images)."""
+    return torch.softmax(recurrent_regularisation(features, transforms, gru), dim=0)
+
+
+def mvsnet_classification_loss(prob_volume, gt_depth_image, depth_num, depth_start, depth_interval):
+    """loss.py:223-267 for one sample.  prob_volume (D,H,W), gt_depth_image (1,H,W,1).
+    Returns (masked_cross_entropy, masked_mae, less_one_accuracy, less_three_accuracy, wta_depth_map (1,H,W,1))."""
+    gt = gt_depth_image
+    dt, dev = gt.dtype, gt.device
+    start = torch.as_tensor(depth_start, dtype=dt, device=dev).reshape(-1, 1, 1, 1)
+    interval = torch.as_tensor(depth_interval, dtype=dt, device=dev).reshape(-1, 1, 1, 1)
+    mask = (gt != 0).to(dt)
+    valid = mask.sum() + 1e-7
+    index = torch.round(mask * ((gt - start) / interval)).to(torch.int64)[0, :, :, 0]      # tf.round: half to even
+    inside = ((index >= 0) & (index < depth_num)).to(dt)       # tf.one_hot: an index outside [0, D) is an all-zero row
+    picked = torch.gather(prob_volume, 0, index.clamp(0, depth_num - 1)[None])[0]
+    cross_entropy = -(inside * torch.log(picked))
+    loss = (mask[0, :, :, 0] * cross_entropy).sum() / valid
+    wta = torch.argmax(prob_volume, dim=0).to(dt)[None, :, :, None] * interval + start
+    step = interval.abs().reshape(-1)
+    # `non_zero_mean_absolute_diff` is not defined in the reference's loss.py; it is the paper's masked mean absolute
+    # error in units of the interval, which loss.py keeps as original_loss (:14-27)
+    mae = original_loss(gt, wta, step)
+    return loss, mae, less_one_percentage(gt, wta, step), less_three_percentage(gt, wta, step), wta
+
+
+def glorot_gru_params(template, seed=0):
+    """tf.layers.conv2d defaults (glorot_uniform kernels, zero biases) and layer_norm's gamma = 1, beta = 0."""
+    rs = np.random.RandomState(seed)
+
+    def kernel(w):
+        w = np.asarray(w)
+        rf = int(np.prod(w.shape[:-2]))
+        limit = math.sqrt(6.0 / (rf * w.shape[-2] + rf * w.shape[-1]))
+        return rs.uniform(-limit, limit, w.shape).astype(np.float32)
+
+    out: Dict[str, object] = {}
+    for name in ("gru1", "gru2", "gru3"):
+        p = template[name]
+        q = {"gates_w": kernel(p["gates_w"]), "out_w": kernel(p["out_w"])}
+        for k in ("gates_b", "out_b", "reset_beta", "update_beta", "out_beta"):
+            q[k] = np.zeros_like(np.asarray(p[k], np.float32))
+        for k in ("reset_gamma", "update_gamma", "out_gamma"):
+            q[k] = np.ones_like(np.asarray(p[k], np.float32))
+        out[name] = q
+    out["prob_w"] = kernel(template["prob_w"])
+    out["prob_b"] = np.zeros_like(np.asarray(template["prob_b"], np.float32))
+    return out

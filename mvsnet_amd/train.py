@@ -1,4 +1,4 @@
-"""Training of MVSNet (3D-CNN regulariser) on MI355X: host-side mirror of mvsnet/train.py.
+"""Training of MVSNet (3D-CNN or recurrent regulariser) on MI355X: host-side mirror of mvsnet/train.py.
 
     python -m mvsnet_amd.train --train_data_root <root with train/ and val/ session folders> --model_dir <out>
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m mvsnet_amd.train ...
@@ -23,7 +23,9 @@ network_mode: 'normal' natively; 'semilite' / 'lite' (the reference's default) /
 'normal' shapes (padded entries provably stay zero); wider modes raise NotImplementedError.
 Training through the refinement network (`--refinement`, train.py:317-349: all / refine_only / main_only; the towers of
 refine.py under torch autograd, the probability-map gradient through mvs_softargmin_bwd_f32).
-Not built: GRU training (the reference's GRU branch has arity bugs, train.py:355-364 vs model.py:505).
+`--regularization GRU` (train.py:355-364): gru_train.py — cost volume forward / backward on the HIP library, the
+ConvGRU cells under torch autograd, classification loss; the generator then also yields every cluster with the depth
+sweep reversed (flip_cams, train.py:194-203).
 """
 from __future__ import annotations
 
@@ -40,7 +42,7 @@ from . import _lib, tf_checkpoint
 from .feature_net import trainable_layers, unet_forward
 from .homography_warping import homography_transforms
 from .loss import mvsnet_regression_loss
-from .synthetic import make_regnet_params, make_unet_params
+from .synthetic import base_filter, make_regnet_params, make_unet_params
 
 
 def glorot_uniform_like(params, seed=0):
@@ -73,14 +75,17 @@ class FlatParameters:
     names; `grad` is a second flat buffer the leaves' .grad tensors are views of, so one all-reduce and one
     optimiser launch cover the whole model."""
 
-    def __init__(self, unet, regnet, network_mode, device, refine=None, refinement=None):
-        self.names = tf_checkpoint.variable_names(network_mode, "3DCNN", refinement if refine is not None else None)
-        src = {"unet": unet, "regnet": regnet, "refine": refine}
+    def __init__(self, unet, regnet, network_mode, device, refine=None, refinement=None, gru=None):
+        self.names = tf_checkpoint.variable_names(network_mode, "GRU" if gru is not None else "3DCNN",
+                                                  refinement if refine is not None else None)
+        groups = {"unet": unet, "regnet": regnet, "refine": refine, "gru": gru}
+        # prob_conv sits beside the cells in the GRU dictionary: key ("gru", None, "prob_w")
+        lookup = lambda g, layer, field: groups[g][field] if layer is None else groups[g][layer][field]
         self.index = []                                   # (key, var_name, offset, shape)
         off = 0
         for key in sorted(self.names, key=lambda k: self.names[k]):
             group, layer, field = key
-            a = np.asarray(src[group][layer][field], np.float32)
+            a = np.asarray(lookup(group, layer, field), np.float32)
             self.index.append((key, self.names[key], off, a.shape))
             off += a.size
         self.numel = off
@@ -89,7 +94,7 @@ class FlatParameters:
         host = np.empty(off, np.float32)
         for key, _v, o, shape in self.index:
             group, layer, field = key
-            host[o:o + int(np.prod(shape))] = np.asarray(src[group][layer][field], np.float32).ravel()
+            host[o:o + int(np.prod(shape))] = np.asarray(lookup(group, layer, field), np.float32).ravel()
         self.data.copy_(torch.from_numpy(host))
         self.leaves: Dict[tuple, torch.Tensor] = {}
         for key, _v, o, shape in self.index:
@@ -101,7 +106,9 @@ class FlatParameters:
     def group(self, group):
         out: Dict[str, Dict[str, torch.Tensor]] = {}
         for (g, layer, field), leaf in self.leaves.items():
-            if g == group:
+            if g == group and layer is None:
+                out[field] = leaf
+            elif g == group:
                 out.setdefault(layer, {})[field] = leaf
         return out
 
@@ -114,15 +121,33 @@ class Trainer:
     def __init__(self, network_mode="normal", device="cuda", optimizer="rmsprop", base_lr=1e-3, stepvalue=70000,
                  gamma=0.5, loss_type="power", alpha=0.25, beta=0.0, eta=0.02, grad_loss=True, init=None, seed=0,
                  sync_bn=False, refinement=False, refinement_network="unet", upsample_before_refinement=True,
-                 refine_with_confidence=True, refinement_train_mode="all", refine_with_stereo=False):
+                 refine_with_confidence=True, refinement_train_mode="all", refine_with_stereo=False,
+                 regularization="3DCNN"):
+        if regularization not in ("3DCNN", "GRU"):
+            raise NotImplementedError("regularization %r" % regularization)
+        if regularization == "GRU" and refinement:
+            raise NotImplementedError("refinement is only applicable with the 3DCNN regulariser (train.py:77-79)")
+        self.regularization = regularization
         if optimizer not in OPTIMIZER_SLOTS:
             raise NotImplementedError("Optimizer %s is not implemented" % optimizer)       # train.py:268-271
         self.network_mode, self.device = network_mode, torch.device(device)
         self.optimizer, self.base_lr, self.stepvalue, self.gamma = optimizer, base_lr, stepvalue, gamma
         self.loss_args = dict(loss_type=loss_type, alpha=alpha, beta=beta, eta=eta, grad_loss=grad_loss)
         if init is None:
-            init = {"unet": glorot_uniform_like(make_unet_params(network_mode), seed),
-                    "regnet": glorot_uniform_like(make_regnet_params(network_mode), seed + 1)}
+            init = {"unet": glorot_uniform_like(make_unet_params(network_mode), seed)}
+            if regularization == "GRU":
+                from .gru_train import glorot_gru_params
+                from .synthetic import make_gru_params
+                init["gru"] = glorot_gru_params(make_gru_params(network_mode, in_channels=4 * base_filter(network_mode)), seed + 1)
+            else:
+                init["regnet"] = glorot_uniform_like(make_regnet_params(network_mode), seed + 1)
+        self.refinement = False
+        self.sync = None
+        self.native_shapes = {}
+        if regularization == "GRU":                     # no BatchNorm, no refinement, no padding on this branch
+            self.params = FlatParameters(init["unet"], None, network_mode, self.device, gru=init["gru"])
+            self._finish_init(optimizer)
+            return
         # narrower modes ('lite' is the reference's default, train.py:82) train zero-padded to the shapes the
         # MFMA kernels tile (model.pad_regnet_params): padded kernels / gamma / beta receive exactly zero
         # gradients (their inputs or their BN scale are zero), so they stay zero; checkpoints hold the native shapes
@@ -155,16 +180,18 @@ class Trainer:
                 g = glorot_uniform_like(tmpl, seed + 2)
                 refine = {k: {"w": g[k]["w"], "b": np.zeros_like(np.asarray(tmpl[k]["b"], np.float32))} for k in tmpl}   # tf.layers: zero biases
         self.params = FlatParameters(init["unet"], regnet, network_mode, self.device, refine, refinement_network)
+        self._finish_init(optimizer)
+        if sync_bn and self.world > 1:
+            from .backward import SyncBN
+            self.sync = SyncBN()
+
+    def _finish_init(self, optimizer):
         n = self.params.numel
         ones = optimizer == "rmsprop"                    # TF's RMSProp `rms` slot starts at one
         self.slots = [torch.ones(n, device=self.device) if (ones and i == 0) else torch.zeros(n, device=self.device)
                       for i in range(len(OPTIMIZER_SLOTS[optimizer]))]
         self.global_step = 0
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        self.sync = None
-        if sync_bn and self.world > 1:
-            from .backward import SyncBN
-            self.sync = SyncBN()
 
     # -- one optimisation step ------------------------------------------------------------------------
     def loss(self, images, cams, depth_image, depth_num, full_depth=None):
@@ -182,9 +209,14 @@ class Trainer:
         else:                                               # narrower towers (channel counts below the HIP kernels' tiling)
             feats = unet_forward(trainable_layers(self.params.group("unet")), images,
                                  hip_group_norm=self.device.type == "cuda")
+        transforms = homography_transforms(cams_t, depth_num, depth_start, depth_interval)
+        if self.regularization == "GRU":                  # train.py:355-364
+            from .gru_train import inference_prob_recurrent, mvsnet_classification_loss
+            prob_volume = inference_prob_recurrent(feats, transforms, self.params.group("gru"))
+            loss, _mae, l1, l3, wta = mvsnet_classification_loss(prob_volume, gt, depth_num, [depth_start], [depth_interval])
+            return loss, l1, l3, wta[0, :, :, 0]
         if feats.shape[-1] < 32:
             feats = torch.nn.functional.pad(feats, (0, 32 - feats.shape[-1]))      # padded channels: zero cost, zero gradient
-        transforms = homography_transforms(cams_t, depth_num, depth_start, depth_interval)
         depth, _prob = plane_sweep_depth(feats, transforms, depth_start, depth_interval, self.params.group("regnet"),
                                          sync=self.sync)
         est = depth[None, :, :, None]
@@ -269,9 +301,9 @@ class Trainer:
         return loss, l1, l3
 
     # -- checkpoints ----------------------------------------------------------------------------------
-    def save(self, model_dir, regularization="3DCNN"):
+    def save(self, model_dir, regularization=None):
         """train.py:360-365: <model_dir>/<regularization>/<network_mode>/model.ckpt-<global step>."""
-        ck = tf_checkpoint.ckpt_path(model_dir, regularization, self.network_mode)
+        ck = tf_checkpoint.ckpt_path(model_dir, regularization or self.regularization, self.network_mode)
         os.makedirs(os.path.dirname(ck), exist_ok=True)
         prefix = tf_checkpoint.model_path(ck, self.global_step)
         def native(arrays):                           # padded regulariser variables back to their own shapes
@@ -318,7 +350,7 @@ class Trainer:
 # ------------------------------------------------------------------------------------------------
 
 def build_parser():
-    p = argparse.ArgumentParser(description="Train MVSNet (3D-CNN regulariser) on MI355X")
+    p = argparse.ArgumentParser(description="Train MVSNet on MI355X")
     a = p.add_argument
     a("--train_data_root", required=True); a("--model_dir", required=True)
     a("--model_load_dir", default=None); a("--ckpt_step", type=int, default=None)
@@ -346,8 +378,6 @@ def build_parser():
 def train(args):
     from .mvs_data_generation import ClusterGenerator
     from .shard import shard_indices
-    if args.regularization != "3DCNN":
-        raise NotImplementedError("only the 3DCNN regulariser trains here (the reference's GRU branch is broken)")
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -357,14 +387,14 @@ def train(args):
                  args.alpha, args.beta, args.eta, not args.no_grad_loss, seed=args.seed, sync_bn=args.sync_bn, refinement=args.refinement,
                  refinement_network=args.refinement_network, upsample_before_refinement=not args.no_upsample_before_refinement,
                  refine_with_confidence=not args.no_refine_with_confidence, refinement_train_mode=args.refinement_train_mode,
-                 refine_with_stereo=args.refine_with_stereo)
+                 refine_with_stereo=args.refine_with_stereo, regularization=args.regularization)
     if args.ckpt_step:
         ck = tf_checkpoint.ckpt_path(args.model_load_dir or args.model_dir, args.regularization, args.network_mode)
         tr.restore(tf_checkpoint.model_path(ck, args.ckpt_step))
     mk = lambda mode: ClusterGenerator(args.train_data_root, args.view_num, args.width, args.height, args.max_d,
                                        args.interval_scale, args.base_image_size, mode=mode,
                                        output_scale=args.sample_scale, sessions_frac=args.dataset_fraction,
-                                       seed=args.seed)
+                                       seed=args.seed, flip_cams=args.regularization == "GRU")     # train.py:194-196
     train_gen, val_gen = mk("train"), mk("val")
     mine = shard_indices(len(train_gen.clusters), rank, world)
     steps = len(mine) if args.max_steps_per_epoch is None else min(len(mine), args.max_steps_per_epoch)
@@ -381,6 +411,9 @@ def train(args):
                     raise                              # a skipped step would desynchronise the all-reduce
                 continue
             loss, l1, l3 = tr.train_step(images, cams, depth, args.max_d, _full)
+            if args.regularization == "GRU":           # the same cluster with the sweep reversed (cluster_generator.py:303-304)
+                from .mvs_data_generation import flip_cams
+                loss, l1, l3 = tr.train_step(images, flip_cams(cams, args.max_d), depth, args.max_d, _full)
             if step % args.display == 0 and rank == 0:
                 print("epoch, %d, step %d, total_step %d, loss = %.4f, (< 1px) = %.4f, (< 3px) = %.4f (%.3f sec/step)"
                       % (epoch, step, tr.global_step, float(loss), float(l1), float(l3), time.time() - t0), flush=True)

@@ -93,3 +93,57 @@ def soft_argmin(reg, depth_start, depth_interval):
 def depth_from_features(features, t8, depth_start, depth_interval, p):
     """features (N,H,W,C), t8 (N-1,D,8) -> depth (H,W), differentiable in features and p."""
     return soft_argmin(regnet_us0(cost_volume(features, t8), p), depth_start, depth_interval)
+
+
+# ---- recurrent regulariser (model.py:505-599) and classification loss (loss.py:223-267) ------------------------
+
+def _conv2d_same(x, w, b):
+    """x (1,C,H,W), w TF layout (3,3,Cin,Cout): tf.layers.conv2d(padding='same')."""
+    return F.conv2d(x, w.permute(3, 2, 0, 1), b, padding=1)
+
+
+def _layer_norm(x, gamma, beta, eps=1e-12):
+    """tf.contrib.layers.layer_norm on one sample (convgru.py:30-31): moments over (C,H,W)."""
+    mean = x.mean()
+    var = ((x - mean) ** 2).mean()
+    return (x - mean) / torch.sqrt(var + eps) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+
+
+def conv_gru_cell(x, h, p):
+    """ConvGRUCell.__call__ (convgru.py:82-122) in its own shape: concatenate, convolve, split."""
+    Fn = h.shape[1]
+    g = _conv2d_same(torch.cat([x, h], 1), p["gates_w"], p["gates_b"])
+    r = torch.sigmoid(_layer_norm(g[:, :Fn], p["reset_gamma"], p["reset_beta"]))
+    u = torch.sigmoid(_layer_norm(g[:, Fn:], p["update_gamma"], p["update_beta"]))
+    c = _conv2d_same(torch.cat([x, r * h], 1), p["out_w"], p["out_b"])
+    y = torch.tanh(_layer_norm(c, p["out_gamma"], p["out_beta"]))
+    return u * h + (1.0 - u) * y
+
+
+def recurrent_reg(features, t8, gp):
+    """features (N,H,W,C), t8 (N-1,D,8) -> regularised cost (D,H,W), plane by plane (model.py:563-589)."""
+    cost = cost_volume(features, t8)                              # (C,D,H,W)
+    _C, D, H, W = cost.shape
+    f = [int(gp[k]["out_b"].shape[0]) for k in ("gru1", "gru2", "gru3")]
+    s = [torch.zeros((1, n, H, W), dtype=cost.dtype) for n in f]
+    planes = []
+    for d in range(D):
+        s[0] = conv_gru_cell(-cost[:, d][None], s[0], gp["gru1"])
+        s[1] = conv_gru_cell(s[0], s[1], gp["gru2"])
+        s[2] = conv_gru_cell(s[1], s[2], gp["gru3"])
+        planes.append(_conv2d_same(s[2], gp["prob_w"], gp["prob_b"])[0, 0])
+    return torch.stack(planes, 0)
+
+
+def classification_loss(reg, gt, depth_start, depth_interval):
+    """loss.py:223-247 on one sample: reg (D,H,W) -> softmax over planes -> masked cross entropy against the
+    one-hot of round((gt - start) / interval); gt (H,W), zeros = invalid."""
+    D = reg.shape[0]
+    prob = torch.softmax(reg, 0)
+    mask = (gt != 0).to(reg.dtype)
+    index = torch.round(mask * (gt - depth_start) / depth_interval).to(torch.int64)
+    onehot = torch.zeros_like(prob)
+    inside = (index >= 0) & (index < D)
+    onehot.scatter_(0, index.clamp(0, D - 1)[None], inside[None].to(reg.dtype))
+    ce = -(onehot * torch.log(prob)).sum(0)
+    return (mask * ce).sum() / (mask.sum() + 1e-7)

@@ -595,3 +595,98 @@ def test_trainer_with_refinement(tmp_path, mode, network, stereo):
     assert first + "/kernel" in names and first + "/bias" in names
     loaded = tf_checkpoint.load_mvsnet_params(prefix, "normal", "3DCNN", refinement=network)
     assert loaded["refine"][first]["w"].shape[-2] == (8 if stereo else 5)   # image + depth + confidence (+ stereo partner)
+
+
+# ---- recurrent regulariser (model.py:505-599, loss.py:223-267) -------------------------------------------------
+
+def _gru_t(params, grad=True):
+    return {k: ({kk: t(vv).requires_grad_(grad) for kk, vv in v.items()} if isinstance(v, dict) else t(v).requires_grad_(grad))
+            for k, v in params.items()}
+
+
+def _gru_64(params):
+    return {k: ({kk: d64(vv, True) for kk, vv in v.items()} if isinstance(v, dict) else d64(v, True))
+            for k, v in params.items()}
+
+
+@pytest.mark.parametrize("mode,C", [("normal", 32), ("lite", 16)])
+def test_recurrent_regularisation_gradients_match_autograd(mode, C):
+    """features -> cost volume (HIP, both directions) -> 3 ConvGRU cells + prob_conv (x parts hoisted, torch autograd)
+    -> classification loss: value, feature gradient and every cell parameter gradient against the float64
+    plane-by-plane checker."""
+    from mvsnet_amd import gru_train as G
+    feats, t8, start, interval = _toy_problem(N=3, D=8, H=16, W=32, C=C)
+    gp = S.make_gru_params(mode, in_channels=C, random_affine=True)
+    rs = np.random.RandomState(4)
+    gt = (start + interval * rs.uniform(0, 7, feats.shape[1:3])).astype(np.float32)
+    gt[:2, :5] = 0.0
+    f64, p64 = d64(feats, True), _gru_64(gp)
+    reg64 = TG.recurrent_reg(f64, d64(t8), p64)
+    loss64 = TG.classification_loss(reg64, d64(gt), start, interval)
+    loss64.backward()
+    ft, pt = t(feats).requires_grad_(True), _gru_t(gp)
+    reg = G.recurrent_regularisation(ft, t(t8), pt)
+    assert rel_l1(n(reg), reg64.detach().numpy()) < 1e-5
+    loss = G.mvsnet_classification_loss(torch.softmax(reg, 0), t(gt)[None, :, :, None], 8, [start], [interval])[0]
+    assert abs(float(loss.detach()) - float(loss64.detach())) < 1e-5 * abs(float(loss64.detach()))
+    loss.backward()
+    assert rel_l1(n(ft.grad), f64.grad.numpy()) < 2e-3
+    for cell in ("gru1", "gru2", "gru3"):
+        for key in p64[cell]:
+            ref, got = p64[cell][key].grad.numpy(), n(pt[cell][key].grad)
+            # (a bias / beta in front of a one-channel LayerNorm has a true gradient of zero: absolute floor)
+            assert rel_l1(got, ref) < 2e-3 or np.abs(got - ref).max() < 1e-7, (cell, key, rel_l1(got, ref))
+    assert rel_l1(n(pt["prob_w"].grad), p64["prob_w"].grad.numpy()) < 2e-3
+    # a softmax over the planes does not see a bias shared by all planes: the true gradient of prob_conv/bias is zero
+    assert abs(float(p64["prob_b"].grad)) < 1e-12 and abs(float(pt["prob_b"].grad)) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["normal", "lite"])
+def test_gru_trainer_reduces_the_loss_and_round_trips_its_checkpoint(tmp_path, mode):
+    from mvsnet_amd import model as M
+    from mvsnet_amd import tf_checkpoint
+    from mvsnet_amd import train as T
+    from mvsnet_amd.mvs_data_generation import flip_cams
+    images, cams, gt, D = _train_batch()
+    tr = T.Trainer(mode, DEV, regularization="GRU", base_lr=2e-3, seed=0)
+    losses = []
+    for _ in range(6):                                  # the cluster and its reversed sweep, as the generator yields them
+        losses.append(float(tr.train_step(images, cams, gt, D)[0]))
+        losses.append(float(tr.train_step(images, flip_cams(cams, D), gt, D)[0]))
+    assert all(np.isfinite(losses)) and min(losses[-2:]) < losses[0], losses
+    assert abs(losses[0] - np.log(D)) < 0.5             # an untrained softmax over D planes: cross entropy ~ log D
+    prefix = tr.save(str(tmp_path))
+    assert prefix.endswith(os.path.join("GRU", mode, "model.ckpt-12"))
+    names = {nm for nm, _s, _d in tf_checkpoint.list_variables(prefix)}
+    assert {"conv_gru1/Gates/conv/kernel", "conv_gru2/Output/LayerNorm/gamma/RMSProp", "prob_conv/bias", "global_step"} <= names
+    tr2 = T.Trainer(mode, DEV, regularization="GRU", seed=77)
+    tr2.restore(prefix)
+    assert tr2.global_step == 12 and torch.equal(tr2.params.data, tr.params.data)
+    assert all(torch.equal(a, b) for a, b in zip(tr2.slots, tr.slots))
+    # the winner-take-all inference sweep (HIP) runs on what training wrote and agrees with the trainer's own argmax
+    loaded = tf_checkpoint.load_mvsnet_params(prefix, mode, "GRU")
+    weights = M.MVSNetWeights.from_numpy(mode, unet=loaded["unet"], gru=loaded["gru"], device=DEV)
+    start, interval = float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1])
+    depth, _prob = M.inference_winner_take_all(t(images)[None], t(cams)[None], D, start, start + (D - 1) * interval, weights=weights)
+    with torch.no_grad():
+        _l, _a, _b, wta = tr.loss(images, cams, gt, D)
+    agree = float((torch.abs(depth.reshape(wta.shape) - wta) < 0.5 * interval).float().mean())
+    assert agree > 0.9, agree
+
+
+def test_train_cli_gru_branch(tmp_path, capsys):
+    from _helpers import add_depths, make_session
+    from mvsnet_amd import train as T
+    from mvsnet_amd import tf_checkpoint
+    for mode in ("train", "val"):
+        s = make_session(str(tmp_path / "data" / mode / "s0"), n_images=4, h=64, w=96, seed=3)
+        add_depths(s, n_images=4, h=64, w=96, seed=3)
+    out = tmp_path / "model"
+    T.main(["--train_data_root", str(tmp_path / "data"), "--model_dir", str(out), "--network_mode", "lite",
+            "--regularization", "GRU", "--view_num", "3", "--max_d", "16", "--width", "96", "--height", "64",
+            "--base_image_size", "32", "--epoch", "1", "--max_steps_per_epoch", "2", "--snapshot", "2",
+            "--train_steps_per_val", "2", "--val_batch_size", "1"])
+    text = capsys.readouterr().out
+    assert "total_step 4" in text and "Saving model to" in text and "VAL STEP COMPLETED" in text   # 2 clusters x 2 sweeps
+    prefix = tf_checkpoint.model_path(tf_checkpoint.ckpt_path(str(out), "GRU", "lite"), 4)
+    assert "prob_conv/kernel" in {nm for nm, _s, _d in tf_checkpoint.list_variables(prefix)}

@@ -26,11 +26,26 @@ def main():
     ap.add_argument("--views", type=int, default=3); ap.add_argument("--depth", type=int, default=192)
     ap.add_argument("--height", type=int, default=480); ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--regularization", default="3DCNN")
     a = ap.parse_args()
     N, D, H, W = a.views, a.depth, a.height, a.width
     images = S.make_images(N, H, W); cams = S.make_cams(N, H // 4, W // 4, D)
     start, interval = float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1])
     gt = np.full((H // 4, W // 4, 1), start + interval * D * 0.5, np.float32)
+    if a.regularization == "GRU":
+        tr = T.Trainer("normal", "cuda", regularization="GRU")
+        tr.train_step(images, cams, gt, D)
+        step = timed(lambda: tr.train_step(images, cams, gt, D), a.iters)
+        torch.cuda.reset_peak_memory_stats()
+
+        def fwd():
+            with torch.no_grad():
+                tr.loss(images, cams, gt, D)
+        fwd(); hf = timed(fwd, a.iters)
+        print({"gru_train_step_ms": round(step, 1), "gru_forward_ms": round(hf, 1),
+               "peak_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+               "config": dict(views=N, depth=D, height=H, width=W)})
+        return
     tr = T.Trainer("normal", "cuda")
     for _ in range(2):
         tr.train_step(images, cams, gt, D)
