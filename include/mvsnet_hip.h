@@ -345,6 +345,26 @@ int mvs_momentum_step_f32(float* w, const float* g, float* accum, size_t n, floa
 int mvs_adam_step_f32(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1,
                       float beta2, float eps, float grad_scale, void* stream);
 
+/* Training of the recurrent regulariser (inference_prob_recurrent, mvsnet/model.py:505-599; ConvGRUCell,
+ * mvsnet/convgru.py:82-122): the plane-sequential part of back-propagation through time of ONE cell over all D
+ * planes (csrc/gru_train.hip).  px (D,H,W,3F) holds the x parts of the cell's two convolutions with their biases,
+ * channels [reset | update | candidate]; wgh (3,3,F,2F) / woh (3,3,F,F) are the h parts of the two kernels;
+ * ln (6,F) = reset gamma, reset beta, update gamma, update beta, candidate gamma, candidate beta.
+ * Forward keeps g (D,H,W,2F), c (D,H,W,F) (raw convolutions), rh (D,H,W,F) = r*h, h (D+1,H,W,F) with h[0] the initial
+ * state set by the caller, and the LayerNorm moments stats (D, forward_slots, 6) float64, zeroed by the caller.
+ * Backward takes gh (D,H,W,F), the gradient reaching every state from outside the recurrence, the flipped /
+ * transposed kernels wgh_t (3,3,2F,F), woh_t (3,3,F,F), and returns gpx (D,H,W,3F), the gradient w.r.t. px (from
+ * which the host forms every input, weight and bias gradient with batched convolutions), and
+ * part (D,3,backward_slots,2,F) float64 (zeroed by the caller): per plane and LayerNorm the sums over pixels of
+ * dz and dz*xhat, i.e. the gradients of beta and gamma once summed over planes and slots.
+ * scratch: 5*H*W*F floats, zeroed by the caller.  F in {16, 8, 4, 2, 1}. */
+int mvs_gru_train_slots(int* forward_slots, int* backward_slots);
+int mvs_gru_train_cell_fwd_f32(const float* px, const float* wgh, const float* woh, const float* ln, int D, int H,
+                               int W, int F, float* g, float* c, float* rh, float* h, double* stats, void* stream);
+int mvs_gru_train_cell_bwd_f32(const float* gh, const float* g, const float* c, const float* h, const double* stats,
+                               const float* wgh_t, const float* woh_t, const float* ln, int D, int H, int W, int F,
+                               float* gpx, double* part, float* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

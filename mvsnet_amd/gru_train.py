@@ -8,12 +8,16 @@ what that branch states, with the arity made consistent (loss, less_one, less_th
 Where the work runs
   * warp + variance of ALL planes and its backward w.r.t. the feature maps: libmvsnet_hip.so
     (`mvs_cost_volume_f32` / `mvs_cost_volume_bwd_gather_f32`), as on the 3D-CNN training path;
-  * the three ConvGRU cells + prob_conv: PyTorch-ROCm autograd (ATen / MIOpen convolutions) — back-propagation
-    through time over `depth_num` planes.  The sweep is restructured the way the inference kernels are
-    (DESIGN §4.4): a cell's convolution over concat([x, h]) is split into an x part and an h part, and the x part of
-    every plane is ONE batched convolution (planes as the batch dimension), cell by cell; only the h part, the
-    LayerNorms and the gates walk the planes.  The inference-only HIP sweep (`mvs_gru_wta_f32`) keeps no
-    activations and is not used here.
+  * the three ConvGRU cells: back-propagation through time over `depth_num` planes, restructured the way the
+    inference kernels are: a cell's convolution over concat([x, h]) is split into an x part and an h
+    part, and the network is walked cell by cell instead of plane by plane.  The x part of every plane is then ONE
+    batched convolution (planes as the batch dimension), and so are the x-part input gradients and ALL weight / bias
+    gradients in the backward pass (ATen / MIOpen, as for the 2D towers).  What is sequential in the plane index —
+    the h-part convolutions, LayerNorms, gates, and their backward — runs in libmvsnet_hip.so
+    (`mvs_gru_train_cell_fwd_f32` / `_bwd_f32`, csrc/gru_train.hip): three launches per plane and direction.
+    `conv_gru_sweep` is the same sweep written with torch ops only (used for filter counts the kernels are not
+    built for, and as the mid-level checker in the tests).  The inference-only HIP sweep (`mvs_gru_wta_f32`) keeps
+    no activations and is not used here.
 """
 from __future__ import annotations
 
@@ -24,6 +28,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import _lib
 from .loss import less_one_percentage, less_three_percentage, original_loss
 
 LN_EPSILON = 1e-12          # tf.contrib.layers.layer_norm's variance_epsilon (convgru.py:30-31)
@@ -78,6 +83,77 @@ def conv_gru_sweep(x_all, p):
     return torch.cat(states, 0)
 
 
+HIP_FILTERS = (16, 8, 4, 2, 1)     # instances of csrc/gru_train.hip
+
+
+class ConvGRUSweep(torch.autograd.Function):
+    """One ConvGRUCell over all planes on the HIP library: x (D,H,W,Cin) -> states (D,H,W,F), zero initial state."""
+
+    @staticmethod
+    def forward(ctx, x, gates_w, gates_b, out_w, out_b, rg, rb, ug, ub, og, ob):
+        lib = _lib.load()
+        P, dev = _lib.ptr, x.device
+        D, H, W, Cin = x.shape
+        Fn = int(out_b.shape[0])
+        x = x.detach().contiguous()
+        gates_w, out_w = gates_w.detach(), out_w.detach()
+        # x parts of both convolutions for every plane: one batched convolution, channels [reset | update | candidate]
+        wx = torch.cat([gates_w[:, :, :Cin, :], out_w[:, :, :Cin, :]], 3).permute(3, 2, 0, 1).contiguous()
+        px = F.conv2d(x.permute(0, 3, 1, 2), wx, torch.cat([gates_b.detach(), out_b.detach()]), padding=1)
+        px = px.permute(0, 2, 3, 1).contiguous()
+        wgh, woh = gates_w[:, :, Cin:, :].contiguous(), out_w[:, :, Cin:, :].contiguous()
+        ln = torch.stack([t.detach() for t in (rg, rb, ug, ub, og, ob)]).contiguous()
+        sf, sb = _lib.C.c_int(), _lib.C.c_int()
+        lib.mvs_gru_train_slots(_lib.C.byref(sf), _lib.C.byref(sb))
+        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        g, c, rh, h = new(D, H, W, 2 * Fn), new(D, H, W, Fn), new(D, H, W, Fn), new(D + 1, H, W, Fn)
+        h[0].zero_()                                                          # model.py:546-551
+        stats = torch.zeros((D, sf.value, 6), device=dev, dtype=torch.float64)
+        _lib.check(lib.mvs_gru_train_cell_fwd_f32(P(px), P(wgh), P(woh), P(ln), D, H, W, Fn, P(g), P(c), P(rh), P(h),
+                                                  P(stats), _lib.stream_ptr()), "mvs_gru_train_cell_fwd_f32")
+        ctx.saved = (x, wx, wgh, woh, ln, g, c, rh, h, stats, sb.value)
+        return h[1:]
+
+    @staticmethod
+    def backward(ctx, gh):
+        lib = _lib.load()
+        P = _lib.ptr
+        x, wx, wgh, woh, ln, g, c, rh, h, stats, slots = ctx.saved
+        ctx.saved = None
+        D, H, W, Cin = x.shape
+        Fn = c.shape[-1]
+        dev = x.device
+        gh = gh.contiguous()
+        flip_t = lambda w: w.flip(0, 1).permute(0, 1, 3, 2).contiguous()      # the kernel of the input gradient
+        wgh_t, woh_t = flip_t(wgh), flip_t(woh)
+        gpx = torch.empty((D, H, W, 3 * Fn), device=dev, dtype=torch.float32)
+        part = torch.zeros((D, 3, slots, 2, Fn), device=dev, dtype=torch.float64)
+        scratch = torch.zeros((5, H, W, Fn), device=dev, dtype=torch.float32)
+        _lib.check(lib.mvs_gru_train_cell_bwd_f32(P(gh), P(g), P(c), P(h), P(stats), P(wgh_t), P(woh_t), P(ln), D, H, W, Fn,
+                                                  P(gpx), P(part), P(scratch), _lib.stream_ptr()), "mvs_gru_train_cell_bwd_f32")
+        # everything that is not sequential: batched convolutions over the planes
+        cb = torch.ops.aten.convolution_backward
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        tf_w = lambda t: t.permute(2, 3, 1, 0)                                # (Cout,Cin,3,3) -> (3,3,Cin,Cout)
+        args = ([1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+        gp = nchw(gpx)
+        g_x, g_wx, g_b = cb(gp, nchw(x), wx, [3 * Fn], *args, [ctx.needs_input_grad[0], True, True])
+        _n, g_wgh, _n2 = cb(gp[:, :2 * Fn], nchw(h[:D]), wgh.permute(3, 2, 0, 1),
+                            None, *args, [False, True, False])
+        _n, g_woh, _n2 = cb(gp[:, 2 * Fn:], nchw(rh), woh.permute(3, 2, 0, 1), None, *args, [False, True, False])
+        g_wx, g_wgh, g_woh = tf_w(g_wx), tf_w(g_wgh), tf_w(g_woh)
+        g_gates_w = torch.cat([g_wx[..., :2 * Fn], g_wgh], 2)
+        g_out_w = torch.cat([g_wx[..., 2 * Fn:], g_woh], 2)
+        sums = part.sum((0, 2)).to(torch.float32)                             # (3 LayerNorms, [d beta, d gamma], F)
+        return (g_x.permute(0, 2, 3, 1) if g_x is not None else None, g_gates_w, g_b[:2 * Fn], g_out_w, g_b[2 * Fn:],
+                sums[0, 1], sums[0, 0], sums[1, 1], sums[1, 0], sums[2, 1], sums[2, 0])
+
+
+def conv_gru_sweep_hip(x_nhwc, p):
+    return ConvGRUSweep.apply(x_nhwc, p["gates_w"], p["gates_b"], p["out_w"], p["out_b"], p["reset_gamma"], p["reset_beta"],
+                              p["update_gamma"], p["update_beta"], p["out_gamma"], p["out_beta"])
+
+
 def recurrent_regularisation(features, transforms, gru):
     """features (N,H,W,C), transforms (N-1,D,8), gru = {'gru1','gru2','gru3': cell tensors, 'prob_w','prob_b'} ->
     regularised cost `reg` (D,H,W) (model.py:563-592, before the softmax)."""
@@ -86,11 +162,13 @@ def recurrent_regularisation(features, transforms, gru):
     if feats.shape[-1] not in (16, 32):                         # channel counts the HIP gather kernels tile
         feats = F.pad(feats, (0, (16 if feats.shape[-1] < 16 else 32) - feats.shape[-1]))
     cost = VarianceCostVolume.apply(feats, transforms)          # (D,H,W,C)
-    x = (-cost[..., :cin]).permute(0, 3, 1, 2)                  # the cells see -cost (model.py:584)
-    s1 = conv_gru_sweep(x, gru["gru1"])
-    s2 = conv_gru_sweep(s1, gru["gru2"])
-    s3 = conv_gru_sweep(s2, gru["gru3"])
-    reg = F.conv2d(s3, gru["prob_w"].permute(3, 2, 0, 1), gru["prob_b"], padding=1)        # :587-588
+    s = -cost[..., :cin]                                        # the cells see -cost (model.py:584)
+    for cell in ("gru1", "gru2", "gru3"):
+        if int(gru[cell]["out_b"].shape[0]) in HIP_FILTERS:
+            s = conv_gru_sweep_hip(s, gru[cell])
+        else:
+            s = conv_gru_sweep(s.permute(0, 3, 1, 2), gru[cell]).permute(0, 2, 3, 1)
+    reg = F.conv2d(s.permute(0, 3, 1, 2), gru["prob_w"].permute(3, 2, 0, 1), gru["prob_b"], padding=1)   # :587-588
     return reg[:, 0]
 
 

@@ -690,3 +690,43 @@ def test_train_cli_gru_branch(tmp_path, capsys):
     assert "total_step 4" in text and "Saving model to" in text and "VAL STEP COMPLETED" in text   # 2 clusters x 2 sweeps
     prefix = tf_checkpoint.model_path(tf_checkpoint.ckpt_path(str(out), "GRU", "lite"), 4)
     assert "prob_conv/kernel" in {nm for nm, _s, _d in tf_checkpoint.list_variables(prefix)}
+
+
+@pytest.mark.parametrize("Cin,Fn,dims", [(32, 16, (5, 21, 37)), (16, 8, (4, 16, 32)), (16, 4, (6, 9, 50)), (4, 2, (5, 33, 17)),
+                                         (2, 1, (4, 18, 20)), (8, 16, (3, 40, 16))])
+def test_hip_conv_gru_sweep_matches_the_float64_cell_chain(Cin, Fn, dims):
+    """mvs_gru_train_cell_fwd_f32 / _bwd_f32 (+ the host's batched convolutions): states and every gradient of one
+    ConvGRU cell over all planes against the plane-by-plane concatenated cell of the checker, ragged tile sizes."""
+    from mvsnet_amd import gru_train as G
+    D, H, W = dims
+    rs = np.random.RandomState(Cin * 100 + Fn)
+    c = Cin + Fn
+    p = {"gates_w": (rs.randn(3, 3, c, 2 * Fn) * (1.5 / np.sqrt(9 * c))).astype(np.float32),
+         "out_w": (rs.randn(3, 3, c, Fn) * (1.5 / np.sqrt(9 * c))).astype(np.float32),
+         "gates_b": (0.1 * rs.randn(2 * Fn)).astype(np.float32), "out_b": (0.1 * rs.randn(Fn)).astype(np.float32)}
+    for nm in ("reset", "update", "out"):
+        p[nm + "_gamma"] = (1 + 0.3 * rs.randn(Fn)).astype(np.float32)
+        p[nm + "_beta"] = (0.2 * rs.randn(Fn)).astype(np.float32)
+    x = rs.randn(D, H, W, Cin).astype(np.float32)
+    gh = rs.randn(D, H, W, Fn).astype(np.float32)
+    # checker
+    x64 = d64(x, True)
+    p64 = {k: d64(v, True) for k, v in p.items()}
+    h = torch.zeros((1, Fn, H, W), dtype=torch.float64)
+    states = []
+    for d in range(D):
+        h = TG.conv_gru_cell(x64[d].permute(2, 0, 1)[None], h, p64)
+        states.append(h[0].permute(1, 2, 0))
+    want = torch.stack(states, 0)
+    (want * d64(gh)).sum().backward()
+    # device
+    xt = t(x).requires_grad_(True)
+    pt = {k: t(v).requires_grad_(True) for k, v in p.items()}
+    got = G.conv_gru_sweep_hip(xt, pt)
+    assert tuple(got.shape) == (D, H, W, Fn)
+    assert rel_l1(n(got), want.detach().numpy()) < 2e-6
+    (got * t(gh)).sum().backward()
+    assert rel_l1(n(xt.grad), x64.grad.numpy()) < 1e-4
+    for k in p:
+        ref, dev = p64[k].grad.numpy(), n(pt[k].grad)
+        assert rel_l1(dev, ref) < 1e-4 or np.abs(dev - ref).max() < 1e-5, (k, rel_l1(dev, ref))
