@@ -357,7 +357,7 @@ int mvs_adam_step_f32(float* w, const float* g, float* m, float* v, size_t n, fl
  * which the host forms every input, weight and bias gradient with batched convolutions), and
  * part (D,3,backward_slots,2,F) float64 (zeroed by the caller): per plane and LayerNorm the sums over pixels of
  * dz and dz*xhat, i.e. the gradients of beta and gamma once summed over planes and slots.
- * scratch: 5*H*W*F floats, zeroed by the caller.  F in {16, 8, 4, 2, 1}. */
+ * scratch: 6*H*W*F floats, zeroed by the caller.  F in {16, 8, 4, 2, 1}. */
 int mvs_gru_train_slots(int* forward_slots, int* backward_slots);
 int mvs_gru_train_cell_fwd_f32(const float* px, const float* wgh, const float* woh, const float* ln, int D, int H,
                                int W, int F, float* g, float* c, float* rh, float* h, double* stats, void* stream);

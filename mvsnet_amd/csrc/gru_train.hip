@@ -7,10 +7,11 @@
 //     g = px_g + conv3x3(h, Wgh)                      + LayerNorm moments of g_r, g_u           gt_gates_kernel
 //     c = px_c + conv3x3(r*h, Woh), r = sigmoid(LN g_r) + moments of c, r*h kept                gt_out_kernel
 //     h' = u*h + (1-u)*tanh(LN c),  u = sigmoid(LN g_u)                                         gt_blend_kernel
-// and three backward (plane D-1 down to 0), with every activation recomputed from the kept raw convolutions g, c:
+// (the blend is folded into the staging of the next plane's gate convolution: two launches per plane) and three backward (plane D-1 down to 0), with every activation recomputed from the kept raw convolutions g, c:
 //     dz_c, dz_u, dh = dh'*u                          + per-channel sums of the two LayerNorms  gt_bwd_blend_kernel
 //     dc = LN'(dz_c) [kept: gradient of px_c]; d(rh) = conv3x3(dc, Woh^T); dh += d(rh)*r; dz_r  gt_bwd_out_kernel
 //     dg = LN'(dz_r | dz_u) [kept: gradient of px_g]; dh += conv3x3(dg, Wgh^T)                  gt_bwd_gates_kernel
+// (the blend backward of plane d-1 is folded into the epilogue of plane d's gate kernel: two launches per plane).
 // LN'(dz) = inv_std * (gamma*dz - mean(gamma*dz) - xhat * mean(gamma*dz*xhat)), the means over all H*W*F elements of
 // the plane; the per-channel sums A[f] = sum dz, B[f] = sum dz*xhat are kept per plane (they are the gradients of beta
 // and gamma).  Everything that is NOT sequential -- x-part input gradients, all weight and bias gradients -- is a
@@ -32,7 +33,9 @@ template <int F> struct Geo {
 };
 template <int CIN> constexpr int lds_stride() { return CIN >= 8 ? CIN + 4 : CIN; }
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// hardware exp / reciprocal (1 ulp): forward and backward evaluate the gates with the same expressions
+__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
 
 template <int N>
 __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&o)[N]) {
@@ -95,23 +98,66 @@ __device__ __forceinline__ TileIdx tile_index(int H, int W) {
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------
+// Staging is dealt out in (position, channel quad) units over all 256 threads; the LayerNorm parameters sit in LDS.
+template <int F> struct Unit { static constexpr int Q = F >= 4 ? 4 : F, NQ = F / Q; };
+
+template <int F>
+__device__ __forceinline__ void stage_ln(const float* __restrict__ ln, float* lnl) {
+    if (threadIdx.x < 6 * F) lnl[threadIdx.x] = ln[threadIdx.x];
+    __syncthreads();
+}
+
 template <int F>
 __global__ void __launch_bounds__(256)
-gt_gates_kernel(const float* __restrict__ px, const float* __restrict__ hprev, const float* __restrict__ wgh,
-                int H, int W, float* __restrict__ g, double* __restrict__ stats) {
+gt_gates_kernel(const float* __restrict__ px, const float* __restrict__ hsrc, const float* __restrict__ cprev,
+                const float* __restrict__ gprev, const double* __restrict__ stats_prev, const float* __restrict__ ln,
+                const float* __restrict__ wgh, int H, int W, float* __restrict__ hcur, float* __restrict__ g,
+                double* __restrict__ stats) {
     using G = Geo<F>;
-    constexpr int CO = 2 * F, CPT = CO / G::NS, LC = lds_stride<F>();
+    using U = Unit<F>;
+    constexpr int CO = 2 * F, CPT = CO / G::NS, LC = lds_stride<F>(), Q = U::Q, NQ = U::NQ;
     __shared__ __attribute__((aligned(16))) float tile[G::PH * PW * LC];
+    __shared__ float lnl[6 * F];
     __shared__ float red[4][4];
     const TileIdx t = tile_index<F>(H, W);
-    for (int f = threadIdx.x; f < G::PH * PW; f += 256) {
+    // the state entering this plane is the previous plane's blend h = u*h' + (1-u)*tanh(LN c) (convgru.py:98,102,
+    // 114-120), evaluated while staging (halo positions are recomputed by the neighbouring tiles; the tile's own
+    // pixels are written out: the candidate convolution and the backward pass read them).  Plane 0: hcur is given.
+    float mu = 0.f, isu = 0.f, mc = 0.f, isc = 0.f;
+    if (cprev) {
+        ln_moments(stats_prev, 1, (double)H * W * F, mu, isu);
+        ln_moments(stats_prev, 2, (double)H * W * F, mc, isc);
+    }
+    stage_ln<F>(ln, lnl);
+    for (int ui = threadIdx.x; ui < G::PH * PW * NQ; ui += 256) {
+        const int f = ui / NQ, ch0 = (ui - f * NQ) * Q;
         const int r = f / PW, c = f - r * PW, gy = t.y0 - 1 + r, gx = t.x0 - 1 + c;
-        float v[F];
+        float v[Q];
 #pragma unroll
-        for (int i = 0; i < F; ++i) v[i] = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) load_vec<F>(hprev + ((size_t)gy * W + gx) * F, v);
+        for (int i = 0; i < Q; ++i) v[i] = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t q = (size_t)gy * W + gx;
+            if (cprev) {
+                float cv[Q], gu[Q];
+                load_vec<Q>(hsrc + q * F + ch0, v);
+                load_vec<Q>(cprev + q * F + ch0, cv);
+                load_vec<Q>(gprev + q * 2 * F + F + ch0, gu);
 #pragma unroll
-        for (int i = 0; i < F; ++i) tile[f * LC + i] = v[i];
+                for (int i = 0; i < Q; ++i) {
+                    const float u = sigm(lnl[2 * F + ch0 + i] * ((gu[i] - mu) * isu) + lnl[3 * F + ch0 + i]);
+                    const float y = tanh_fast(lnl[4 * F + ch0 + i] * ((cv[i] - mc) * isc) + lnl[5 * F + ch0 + i]);
+                    v[i] = u * v[i] + (1.0f - u) * y;
+                }
+                if (r >= 1 && r <= G::TH && c >= 1 && c <= TW) {
+#pragma unroll
+                    for (int i = 0; i < Q; ++i) hcur[q * F + ch0 + i] = v[i];
+                }
+            } else {
+                load_vec<Q>(hcur + q * F + ch0, v);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < Q; ++i) tile[f * LC + ch0 + i] = v[i];
     }
     __syncthreads();
     const int co0 = t.co_group * CPT;
@@ -144,31 +190,35 @@ gt_out_kernel(const float* __restrict__ px, const float* __restrict__ hprev, con
               double* __restrict__ stats, const float* __restrict__ woh, const float* __restrict__ ln,
               int H, int W, float* __restrict__ rh, float* __restrict__ c) {
     using G = Geo<F>;
-    constexpr int CPT = F / G::NS, LC = lds_stride<F>();
+    using U = Unit<F>;
+    constexpr int CPT = F / G::NS, LC = lds_stride<F>(), Q = U::Q, NQ = U::NQ;
     __shared__ __attribute__((aligned(16))) float tile[G::PH * PW * LC];
+    __shared__ float lnl[6 * F];
     __shared__ float red[4][2];
     const TileIdx t = tile_index<F>(H, W);
     float mean, is;
     ln_moments(stats, 0, (double)H * W * F, mean, is);
-    for (int f = threadIdx.x; f < G::PH * PW; f += 256) {
+    stage_ln<F>(ln, lnl);
+    for (int ui = threadIdx.x; ui < G::PH * PW * NQ; ui += 256) {
+        const int f = ui / NQ, ch0 = (ui - f * NQ) * Q;
         const int r = f / PW, cc = f - r * PW, gy = t.y0 - 1 + r, gx = t.x0 - 1 + cc;
-        float v[F];
+        float v[Q];
 #pragma unroll
-        for (int i = 0; i < F; ++i) v[i] = 0.f;
+        for (int i = 0; i < Q; ++i) v[i] = 0.f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
             const size_t q = (size_t)gy * W + gx;
-            float gr[F];
-            load_vec<F>(hprev + q * F, v);
-            load_vec<F>(g + q * 2 * F, gr);
+            float gr[Q];
+            load_vec<Q>(hprev + q * F + ch0, v);
+            load_vec<Q>(g + q * 2 * F + ch0, gr);
 #pragma unroll
-            for (int i = 0; i < F; ++i) v[i] *= sigm(ln[i] * ((gr[i] - mean) * is) + ln[F + i]);   // convgru.py:97,101,107
+            for (int i = 0; i < Q; ++i) v[i] *= sigm(lnl[ch0 + i] * ((gr[i] - mean) * is) + lnl[F + ch0 + i]);   // convgru.py:97,101,107
             if (r >= 1 && r <= G::TH && cc >= 1 && cc <= TW) {
 #pragma unroll
-                for (int i = 0; i < F; ++i) rh[q * F + i] = v[i];
+                for (int i = 0; i < Q; ++i) rh[q * F + ch0 + i] = v[i];
             }
         }
 #pragma unroll
-        for (int i = 0; i < F; ++i) tile[f * LC + i] = v[i];
+        for (int i = 0; i < Q; ++i) tile[f * LC + ch0 + i] = v[i];
     }
     __syncthreads();
     const int co0 = t.co_group * CPT;
@@ -202,7 +252,7 @@ gt_blend_kernel(const float* __restrict__ c, const float* __restrict__ g, const 
     ln_moments(stats, 1, (double)HW * F, mu, isu);
     ln_moments(stats, 2, (double)HW * F, mc, isc);
     const float u = sigm(ln[2 * F + f] * ((g[(size_t)pix * 2 * F + F + f] - mu) * isu) + ln[3 * F + f]);   // :98,102
-    const float y = tanhf(ln[4 * F + f] * ((c[i] - mc) * isc) + ln[5 * F + f]);                            // :114,117
+    const float y = tanh_fast(ln[4 * F + f] * ((c[i] - mc) * isc) + ln[5 * F + f]);                            // :114,117
     hout[i] = u * hprev[i] + (1.0f - u) * y;                                                               // :120
 }
 
@@ -231,7 +281,7 @@ gt_bwd_blend_kernel(const float* __restrict__ gh, const float* __restrict__ dh_r
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW * F; i += gridDim.x * 256) {
         const int pix = i / F;
         const float gn = (g[(size_t)pix * 2 * F + F + f] - mu) * isu, cn = (c[i] - mc) * isc;
-        const float u = sigm(gu_ * gn + bu_), y = tanhf(gc_ * cn + bc_);
+        const float u = sigm(gu_ * gn + bu_), y = tanh_fast(gc_ * cn + bc_);
         const float d = dh_rec[i] + gh[i];
         const float vc = d * (1.0f - u) * (1.0f - y * y);
         const float vu = d * (hprev[i] - y) * u * (1.0f - u);
@@ -277,8 +327,10 @@ gt_bwd_out_kernel(const float* __restrict__ dzc, const float* __restrict__ c, co
                   const float* __restrict__ woh_t, const float* __restrict__ ln, int H, int W,
                   float* __restrict__ gpx, float* __restrict__ dh_next, float* __restrict__ dzr) {
     using G = Geo<F>;
-    constexpr int CPT = F / G::NS, LC = lds_stride<F>();
+    using U = Unit<F>;
+    constexpr int CPT = F / G::NS, LC = lds_stride<F>(), Q = U::Q, NQ = U::NQ;
     __shared__ __attribute__((aligned(16))) float tile[G::PH * PW * LC];
+    __shared__ float lnl[6 * F];
     __shared__ double fold[2 * F];
     __shared__ float red[4][2][CPT];
     const TileIdx t = tile_index<F>(H, W);
@@ -287,25 +339,27 @@ gt_bwd_out_kernel(const float* __restrict__ dzc, const float* __restrict__ c, co
     ln_moments(stats, 0, n, mr, isr);
     ln_moments(stats, 2, n, mc, isc);
     ln_bwd_means<F>(part, 2, ln + 4 * F, n, fold, m1, m2);
-    for (int f = threadIdx.x; f < G::PH * PW; f += 256) {
+    stage_ln<F>(ln, lnl);
+    for (int ui = threadIdx.x; ui < G::PH * PW * NQ; ui += 256) {
+        const int f = ui / NQ, ch0 = (ui - f * NQ) * Q;
         const int r = f / PW, cc = f - r * PW, gy = t.y0 - 1 + r, gx = t.x0 - 1 + cc;
-        float v[F];
+        float v[Q];
 #pragma unroll
-        for (int i = 0; i < F; ++i) v[i] = 0.f;
+        for (int i = 0; i < Q; ++i) v[i] = 0.f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
             const size_t q = (size_t)gy * W + gx;
-            float cv[F];
-            load_vec<F>(dzc + q * F, v);
-            load_vec<F>(c + q * F, cv);
+            float cv[Q];
+            load_vec<Q>(dzc + q * F + ch0, v);
+            load_vec<Q>(c + q * F + ch0, cv);
 #pragma unroll
-            for (int i = 0; i < F; ++i) v[i] = isc * (ln[4 * F + i] * v[i] - m1 - (cv[i] - mc) * isc * m2);
+            for (int i = 0; i < Q; ++i) v[i] = isc * (lnl[4 * F + ch0 + i] * v[i] - m1 - (cv[i] - mc) * isc * m2);
             if (r >= 1 && r <= G::TH && cc >= 1 && cc <= TW) {
 #pragma unroll
-                for (int i = 0; i < F; ++i) gpx[q * 3 * F + 2 * F + i] = v[i];
+                for (int i = 0; i < Q; ++i) gpx[q * 3 * F + 2 * F + ch0 + i] = v[i];
             }
         }
 #pragma unroll
-        for (int i = 0; i < F; ++i) tile[f * LC + i] = v[i];
+        for (int i = 0; i < Q; ++i) tile[f * LC + ch0 + i] = v[i];
     }
     __syncthreads();
     const int co0 = t.co_group * CPT;
@@ -322,7 +376,7 @@ gt_bwd_out_kernel(const float* __restrict__ dzc, const float* __restrict__ c, co
         for (int j = 0; j < CPT; ++j) {
             const int f = co0 + j;
             const float gn = (g[p * 2 * F + f] - mr) * isr;
-            const float r = sigm(ln[f] * gn + ln[F + f]);
+            const float r = sigm(lnl[f] * gn + lnl[F + f]);
             dh_next[p * F + f] += acc[j] * r;
             const float vz = acc[j] * hprev[p * F + f] * r * (1.0f - r);
             dzr[p * F + f] = vz;
@@ -352,10 +406,16 @@ __global__ void __launch_bounds__(256)
 gt_bwd_gates_kernel(const float* __restrict__ dzr, const float* __restrict__ dzu, const float* __restrict__ g,
                     const double* __restrict__ stats, const double* __restrict__ part,
                     const float* __restrict__ wgh_t, const float* __restrict__ ln, int H, int W,
-                    float* __restrict__ gpx, float* __restrict__ dh_next) {
+                    float* __restrict__ gpx, const float* __restrict__ dh_next,
+                    // blend backward of the plane below (null gh_p on plane 0): its inputs, and where its results go
+                    const float* __restrict__ gh_p, const float* __restrict__ c_p, const float* __restrict__ g_p,
+                    const float* __restrict__ h_pp, const double* __restrict__ stats_p, double* __restrict__ part_p,
+                    float* __restrict__ dzc_o, float* __restrict__ dzu_o, float* __restrict__ dh_o) {
     using G = Geo<F>;
-    constexpr int CIN = 2 * F, CPT = F / G::NS, LC = lds_stride<CIN>();
+    using U = Unit<F>;
+    constexpr int CIN = 2 * F, CPT = F / G::NS, LC = lds_stride<CIN>(), Q = U::Q, NQ = U::NQ;
     __shared__ __attribute__((aligned(16))) float tile[G::PH * PW * LC];
+    __shared__ float lnl[6 * F];
     __shared__ double fold[2 * F];
     const TileIdx t = tile_index<F>(H, W);
     const double n = (double)H * W * F;
@@ -364,29 +424,28 @@ gt_bwd_gates_kernel(const float* __restrict__ dzr, const float* __restrict__ dzu
     ln_moments(stats, 1, n, mu, isu);
     ln_bwd_means<F>(part, 0, ln, n, fold, m1r, m2r);
     ln_bwd_means<F>(part, 1, ln + 2 * F, n, fold, m1u, m2u);
-    for (int f = threadIdx.x; f < G::PH * PW; f += 256) {
+    stage_ln<F>(ln, lnl);
+    for (int ui = threadIdx.x; ui < G::PH * PW * 2 * NQ; ui += 256) {
+        const int f = ui / (2 * NQ), qd = ui - f * 2 * NQ, half = qd / NQ, ch0 = (qd - half * NQ) * Q;
         const int r = f / PW, cc = f - r * PW, gy = t.y0 - 1 + r, gx = t.x0 - 1 + cc;
-        float v[CIN];
+        float v[Q];
 #pragma unroll
-        for (int i = 0; i < CIN; ++i) v[i] = 0.f;
+        for (int i = 0; i < Q; ++i) v[i] = 0.f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
             const size_t q = (size_t)gy * W + gx;
-            float zr[F], zu[F], gv[CIN];
-            load_vec<F>(dzr + q * F, zr);
-            load_vec<F>(dzu + q * F, zu);
-            load_vec<CIN>(g + q * CIN, gv);
+            const float mean = half ? mu : mr, is = half ? isu : isr, m1 = half ? m1u : m1r, m2 = half ? m2u : m2r;
+            float gv[Q];
+            load_vec<Q>((half ? dzu : dzr) + q * F + ch0, v);
+            load_vec<Q>(g + q * CIN + half * F + ch0, gv);
 #pragma unroll
-            for (int i = 0; i < F; ++i) {
-                v[i] = isr * (ln[i] * zr[i] - m1r - (gv[i] - mr) * isr * m2r);
-                v[F + i] = isu * (ln[2 * F + i] * zu[i] - m1u - (gv[F + i] - mu) * isu * m2u);
-            }
+            for (int i = 0; i < Q; ++i) v[i] = is * (lnl[half * 2 * F + ch0 + i] * v[i] - m1 - (gv[i] - mean) * is * m2);
             if (r >= 1 && r <= G::TH && cc >= 1 && cc <= TW) {
 #pragma unroll
-                for (int i = 0; i < CIN; ++i) gpx[q * 3 * F + i] = v[i];
+                for (int i = 0; i < Q; ++i) gpx[q * 3 * F + half * F + ch0 + i] = v[i];
             }
         }
 #pragma unroll
-        for (int i = 0; i < CIN; ++i) tile[f * LC + i] = v[i];
+        for (int i = 0; i < Q; ++i) tile[f * LC + half * F + ch0 + i] = v[i];
     }
     __syncthreads();
     const int co0 = t.co_group * CPT;
@@ -394,10 +453,48 @@ gt_bwd_gates_kernel(const float* __restrict__ dzr, const float* __restrict__ dzu
 #pragma unroll
     for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
     conv_taps<CIN, F, CPT>(tile, t.ly, t.lx, (cfloat*)wgh_t, co0, acc);
+    if (!gh_p) return;                                              // plane 0: nothing below consumes the state gradient
+    // acc + dh_next is the complete gradient of the state entering this plane = leaving the plane below: run that
+    // plane's blend backward right here (same arithmetic as gt_bwd_blend_kernel), one launch less per plane
+    __shared__ float red[4][4][CPT];
+    float mc, isc;
+    ln_moments(stats_p, 1, n, mu, isu);                             // from here on: the moments of the plane below
+    ln_moments(stats_p, 2, n, mc, isc);
+    float s4[4][CPT];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) s4[k][j] = 0.f;
     if (t.valid) {
         const size_t p = (size_t)t.py * W + t.px;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) dh_next[p * F + co0 + j] += acc[j];
+        for (int j = 0; j < CPT; ++j) {
+            const int f = co0 + j;
+            const size_t i = p * F + f;
+            const float gn = (g_p[p * 2 * F + F + f] - mu) * isu, cn = (c_p[i] - mc) * isc;
+            const float u = sigm(lnl[2 * F + f] * gn + lnl[3 * F + f]), y = tanh_fast(lnl[4 * F + f] * cn + lnl[5 * F + f]);
+            const float d = dh_next[i] + acc[j] + gh_p[i];
+            const float vc = d * (1.0f - u) * (1.0f - y * y);
+            const float vu = d * (h_pp[i] - y) * u * (1.0f - u);
+            dh_o[i] = d * u;
+            dzc_o[i] = vc; dzu_o[i] = vu;
+            s4[0][j] = vc; s4[1][j] = vc * cn; s4[2][j] = vu; s4[3][j] = vu * gn;
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { const float v = wave_sum(s4[k][j]); if (lane == 0) red[wv][k][j] = v; }
+    __syncthreads();
+    if (threadIdx.x < 4 * F) {
+        const int k = threadIdx.x / F, f = threadIdx.x % F, grp = f / CPT, j = f % CPT;
+        constexpr int WPG = 4 / G::NS;
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < WPG; ++w) tot += (double)red[grp * WPG + w][k][j];
+        const int norm = k < 2 ? 2 : 1, ab = k & 1;
+        atomicAdd(&part_p[((size_t)(norm * SLOTS_B + blockIdx.x % SLOTS_B) * 2 + ab) * F + f], tot);
     }
 }
 
@@ -410,14 +507,20 @@ int cell_fwd(const float* px, const float* wgh, const float* woh, const float* l
     const int eb = mvs_cdiv((long long)hw * F, 256);
     for (int d = 0; d < D; ++d) {
         const float* pxd = px + d * hw * 3 * F;
-        const float* hp = h + d * hw * F;
+        float* hp = h + d * hw * F;
         float* gd = g + d * hw * 2 * F;
         float* cd = c + d * hw * F;
         double* sd = stats + (size_t)d * SLOTS_F * 6;
-        gt_gates_kernel<F><<<tiles, 256, 0, st>>>(pxd, hp, wgh, H, W, gd, sd);
+        // h[d] = blend of plane d-1, formed inside the gate convolution's staging (h[0] is the caller's)
+        if (d == 0)
+            gt_gates_kernel<F><<<tiles, 256, 0, st>>>(pxd, nullptr, nullptr, nullptr, nullptr, ln, wgh, H, W, h, gd, sd);
+        else
+            gt_gates_kernel<F><<<tiles, 256, 0, st>>>(pxd, h + (d - 1) * hw * F, c + (d - 1) * hw * F, g + (d - 1) * hw * 2 * F,
+                                                      sd - SLOTS_F * 6, ln, wgh, H, W, h + d * hw * F, gd, sd);
         gt_out_kernel<F><<<tiles, 256, 0, st>>>(pxd, hp, gd, sd, woh, ln, H, W, rh + d * hw * F, cd);
-        gt_blend_kernel<F><<<eb, 256, 0, st>>>(cd, gd, hp, sd, ln, (int)hw, h + (d + 1) * hw * F);
     }
+    gt_blend_kernel<F><<<eb, 256, 0, st>>>(c + (D - 1) * hw * F, g + (D - 1) * hw * 2 * F, h + (D - 1) * hw * F,
+                                           stats + (size_t)(D - 1) * SLOTS_F * 6, ln, (int)hw, h + D * hw * F);
     return (int)hipGetLastError();
 }
 
@@ -430,19 +533,35 @@ int cell_bwd(const float* gh, const float* g, const float* c, const float* h, co
     const int tiles = ((H + G::TH - 1) / G::TH) * ((W + TW - 1) / TW);
     int eb = mvs_cdiv((long long)pf, 256 * 8);                      // ~8 elements per thread
     if (eb < 1) eb = 1;
-    float *dzc = scratch, *dzu = scratch + pf, *dzr = scratch + 2 * pf, *dh[2] = {scratch + 3 * pf, scratch + 4 * pf};
+    float *dzc = scratch, *dzr = scratch + pf, *dzu[2] = {scratch + 2 * pf, scratch + 3 * pf},
+          *dh[2] = {scratch + 4 * pf, scratch + 5 * pf};
+    const size_t pstride = (size_t)3 * SLOTS_B * 2 * F;
+    // the state gradient entering plane d from above sits in dh[d & 1]; a plane's blend backward leaves dh'*u in the
+    // other buffer, the two convolution kernels add their parts to it.  dz_u alternates as well: the gate kernel of
+    // plane d still stages plane d's while its epilogue writes plane d-1's.
+    {
+        const int d = D - 1;
+        gt_bwd_blend_kernel<F><<<eb, 256, 0, st>>>(gh + d * pf, dh[d & 1], c + d * pf, g + d * hw * 2 * F, h + d * pf,
+                                                   stats + (size_t)d * SLOTS_F * 6, ln, (int)hw, dzc, dzu[d & 1],
+                                                   dh[(d + 1) & 1], part + d * pstride);
+    }
     for (int d = D - 1; d >= 0; --d) {
         const float* gd = g + d * hw * 2 * F;
-        const float* cd = c + d * hw * F;
+        const float* cd = c + d * pf;
         const float* hp = h + d * pf;
         const double* sd = stats + (size_t)d * SLOTS_F * 6;
-        double* pd = part + (size_t)d * 3 * SLOTS_B * 2 * F;
+        double* pd = part + d * pstride;
         float* gpd = gpx + d * hw * 3 * F;
-        float* rec = dh[d & 1];
         float* nxt = dh[(d + 1) & 1];
-        gt_bwd_blend_kernel<F><<<eb, 256, 0, st>>>(gh + d * pf, rec, cd, gd, hp, sd, ln, (int)hw, dzc, dzu, nxt, pd);
         gt_bwd_out_kernel<F><<<tiles, 256, 0, st>>>(dzc, cd, gd, hp, sd, pd, woh_t, ln, H, W, gpd, nxt, dzr);
-        gt_bwd_gates_kernel<F><<<tiles, 256, 0, st>>>(dzr, dzu, gd, sd, pd, wgh_t, ln, H, W, gpd, nxt);
+        if (d > 0)
+            gt_bwd_gates_kernel<F><<<tiles, 256, 0, st>>>(dzr, dzu[d & 1], gd, sd, pd, wgh_t, ln, H, W, gpd, nxt,
+                                                          gh + (d - 1) * pf, c + (d - 1) * pf, g + (d - 1) * hw * 2 * F,
+                                                          h + (d - 1) * pf, sd - SLOTS_F * 6, pd - pstride,
+                                                          dzc, dzu[(d - 1) & 1], dh[d & 1]);
+        else
+            gt_bwd_gates_kernel<F><<<tiles, 256, 0, st>>>(dzr, dzu[0], gd, sd, pd, wgh_t, ln, H, W, gpd, nxt, nullptr, nullptr,
+                                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     }
     return (int)hipGetLastError();
 }

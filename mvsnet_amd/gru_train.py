@@ -14,7 +14,7 @@ Where the work runs
     batched convolution (planes as the batch dimension), and so are the x-part input gradients and ALL weight / bias
     gradients in the backward pass (ATen / MIOpen, as for the 2D towers).  What is sequential in the plane index —
     the h-part convolutions, LayerNorms, gates, and their backward — runs in libmvsnet_hip.so
-    (`mvs_gru_train_cell_fwd_f32` / `_bwd_f32`, csrc/gru_train.hip): three launches per plane and direction.
+    (`mvs_gru_train_cell_fwd_f32` / `_bwd_f32`, csrc/gru_train.hip): two launches per plane and direction.
     `conv_gru_sweep` is the same sweep written with torch ops only (used for filter counts the kernels are not
     built for, and as the mid-level checker in the tests).  The inference-only HIP sweep (`mvs_gru_wta_f32`) keeps
     no activations and is not used here.
@@ -128,7 +128,7 @@ class ConvGRUSweep(torch.autograd.Function):
         wgh_t, woh_t = flip_t(wgh), flip_t(woh)
         gpx = torch.empty((D, H, W, 3 * Fn), device=dev, dtype=torch.float32)
         part = torch.zeros((D, 3, slots, 2, Fn), device=dev, dtype=torch.float64)
-        scratch = torch.zeros((5, H, W, Fn), device=dev, dtype=torch.float32)
+        scratch = torch.zeros((6, H, W, Fn), device=dev, dtype=torch.float32)
         _lib.check(lib.mvs_gru_train_cell_bwd_f32(P(gh), P(g), P(c), P(h), P(stats), P(wgh_t), P(woh_t), P(ln), D, H, W, Fn,
                                                   P(gpx), P(part), P(scratch), _lib.stream_ptr()), "mvs_gru_train_cell_bwd_f32")
         # everything that is not sequential: batched convolutions over the planes
