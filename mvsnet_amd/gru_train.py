@@ -86,72 +86,87 @@ def conv_gru_sweep(x_all, p):
 HIP_FILTERS = (16, 8, 4, 2, 1)     # instances of csrc/gru_train.hip
 
 
+CELL_FIELDS = ("gates_w", "gates_b", "out_w", "out_b", "reset_gamma", "reset_beta", "update_gamma", "update_beta",
+               "out_gamma", "out_beta")
+
+
+def _cell_forward(x, gates_w, gates_b, out_w, out_b, rg, rb, ug, ub, og, ob):
+    """x (D,H,W,Cin) -> (states (D,H,W,F) [a view of the kept (D+1,H,W,F) buffer], what the backward needs)."""
+    lib = _lib.load()
+    P, dev = _lib.ptr, x.device
+    D, H, W, Cin = x.shape
+    Fn = int(out_b.shape[0])
+    x = x.detach().contiguous()
+    gates_w, out_w = gates_w.detach(), out_w.detach()
+    # x parts of both convolutions for every plane: one batched convolution, channels [reset | update | candidate]
+    wx = torch.cat([gates_w[:, :, :Cin, :], out_w[:, :, :Cin, :]], 3).permute(3, 2, 0, 1).contiguous()
+    px = F.conv2d(x.permute(0, 3, 1, 2), wx, torch.cat([gates_b.detach(), out_b.detach()]), padding=1)
+    px = px.permute(0, 2, 3, 1).contiguous()
+    wgh, woh = gates_w[:, :, Cin:, :].contiguous(), out_w[:, :, Cin:, :].contiguous()
+    ln = torch.stack([t.detach() for t in (rg, rb, ug, ub, og, ob)]).contiguous()
+    sf, sb = _lib.C.c_int(), _lib.C.c_int()
+    lib.mvs_gru_train_slots(_lib.C.byref(sf), _lib.C.byref(sb))
+    new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    g, c, rh, h = new(D, H, W, 2 * Fn), new(D, H, W, Fn), new(D, H, W, Fn), new(D + 1, H, W, Fn)
+    h[0].zero_()                                                          # model.py:546-551
+    stats = torch.zeros((D, sf.value, 6), device=dev, dtype=torch.float64)
+    _lib.check(lib.mvs_gru_train_cell_fwd_f32(P(px), P(wgh), P(woh), P(ln), D, H, W, Fn, P(g), P(c), P(rh), P(h),
+                                              P(stats), _lib.stream_ptr()), "mvs_gru_train_cell_fwd_f32")
+    return h[1:], (x, wx, wgh, woh, ln, g, c, rh, h, stats, sb.value)
+
+
+def _cell_backward(saved, gh, need_x_grad=True):
+    """gh (D,H,W,F): gradient reaching every state from outside the recurrence.  Returns (g_x or None, the ten
+    parameter gradients in CELL_FIELDS order).  (Putting the batched weight gradients on a second stream, under the
+    launch-latency-bound sweep of the next cell down, was measured: no gain, the convolution's workgroups fill the
+    CUs and the sweep's launches queue behind them.)"""
+    lib = _lib.load()
+    P = _lib.ptr
+    x, wx, wgh, woh, ln, g, c, rh, h, stats, slots = saved
+    D, H, W, Cin = x.shape
+    Fn = c.shape[-1]
+    dev = x.device
+    gh = gh.contiguous()
+    flip_t = lambda w: w.flip(0, 1).permute(0, 1, 3, 2).contiguous()      # the kernel of the input gradient
+    wgh_t, woh_t = flip_t(wgh), flip_t(woh)
+    gpx = torch.empty((D, H, W, 3 * Fn), device=dev, dtype=torch.float32)
+    part = torch.zeros((D, 3, slots, 2, Fn), device=dev, dtype=torch.float64)
+    scratch = torch.zeros((6, H, W, Fn), device=dev, dtype=torch.float32)
+    _lib.check(lib.mvs_gru_train_cell_bwd_f32(P(gh), P(g), P(c), P(h), P(stats), P(wgh_t), P(woh_t), P(ln), D, H, W, Fn,
+                                              P(gpx), P(part), P(scratch), _lib.stream_ptr()), "mvs_gru_train_cell_bwd_f32")
+    # everything that is not sequential: batched convolutions over the planes
+    cb = torch.ops.aten.convolution_backward
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    tf_w = lambda t: t.permute(2, 3, 1, 0)                                # (Cout,Cin,3,3) -> (3,3,Cin,Cout)
+    args = ([1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+    gp = nchw(gpx)
+    g_x, g_wx, g_b = cb(gp, nchw(x), wx, [3 * Fn], *args, [need_x_grad, True, True])
+    g_wgh = cb(gp[:, :2 * Fn], nchw(h[:D]), wgh.permute(3, 2, 0, 1), None, *args, [False, True, False])[1]
+    g_woh = cb(gp[:, 2 * Fn:], nchw(rh), woh.permute(3, 2, 0, 1), None, *args, [False, True, False])[1]
+    g_wx, g_wgh, g_woh = tf_w(g_wx), tf_w(g_wgh), tf_w(g_woh)
+    sums = part.sum((0, 2)).to(torch.float32)                             # (3 LayerNorms, [d beta, d gamma], F)
+    grads = (torch.cat([g_wx[..., :2 * Fn], g_wgh], 2), g_b[:2 * Fn], torch.cat([g_wx[..., 2 * Fn:], g_woh], 2),
+             g_b[2 * Fn:], sums[0, 1], sums[0, 0], sums[1, 1], sums[1, 0], sums[2, 1], sums[2, 0])
+    return (g_x.permute(0, 2, 3, 1) if g_x is not None else None), grads
+
+
 class ConvGRUSweep(torch.autograd.Function):
     """One ConvGRUCell over all planes on the HIP library: x (D,H,W,Cin) -> states (D,H,W,F), zero initial state."""
 
     @staticmethod
-    def forward(ctx, x, gates_w, gates_b, out_w, out_b, rg, rb, ug, ub, og, ob):
-        lib = _lib.load()
-        P, dev = _lib.ptr, x.device
-        D, H, W, Cin = x.shape
-        Fn = int(out_b.shape[0])
-        x = x.detach().contiguous()
-        gates_w, out_w = gates_w.detach(), out_w.detach()
-        # x parts of both convolutions for every plane: one batched convolution, channels [reset | update | candidate]
-        wx = torch.cat([gates_w[:, :, :Cin, :], out_w[:, :, :Cin, :]], 3).permute(3, 2, 0, 1).contiguous()
-        px = F.conv2d(x.permute(0, 3, 1, 2), wx, torch.cat([gates_b.detach(), out_b.detach()]), padding=1)
-        px = px.permute(0, 2, 3, 1).contiguous()
-        wgh, woh = gates_w[:, :, Cin:, :].contiguous(), out_w[:, :, Cin:, :].contiguous()
-        ln = torch.stack([t.detach() for t in (rg, rb, ug, ub, og, ob)]).contiguous()
-        sf, sb = _lib.C.c_int(), _lib.C.c_int()
-        lib.mvs_gru_train_slots(_lib.C.byref(sf), _lib.C.byref(sb))
-        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
-        g, c, rh, h = new(D, H, W, 2 * Fn), new(D, H, W, Fn), new(D, H, W, Fn), new(D + 1, H, W, Fn)
-        h[0].zero_()                                                          # model.py:546-551
-        stats = torch.zeros((D, sf.value, 6), device=dev, dtype=torch.float64)
-        _lib.check(lib.mvs_gru_train_cell_fwd_f32(P(px), P(wgh), P(woh), P(ln), D, H, W, Fn, P(g), P(c), P(rh), P(h),
-                                                  P(stats), _lib.stream_ptr()), "mvs_gru_train_cell_fwd_f32")
-        ctx.saved = (x, wx, wgh, woh, ln, g, c, rh, h, stats, sb.value)
-        return h[1:]
+    def forward(ctx, x, *params):
+        out, ctx.saved = _cell_forward(x, *params)
+        return out
 
     @staticmethod
     def backward(ctx, gh):
-        lib = _lib.load()
-        P = _lib.ptr
-        x, wx, wgh, woh, ln, g, c, rh, h, stats, slots = ctx.saved
-        ctx.saved = None
-        D, H, W, Cin = x.shape
-        Fn = c.shape[-1]
-        dev = x.device
-        gh = gh.contiguous()
-        flip_t = lambda w: w.flip(0, 1).permute(0, 1, 3, 2).contiguous()      # the kernel of the input gradient
-        wgh_t, woh_t = flip_t(wgh), flip_t(woh)
-        gpx = torch.empty((D, H, W, 3 * Fn), device=dev, dtype=torch.float32)
-        part = torch.zeros((D, 3, slots, 2, Fn), device=dev, dtype=torch.float64)
-        scratch = torch.zeros((6, H, W, Fn), device=dev, dtype=torch.float32)
-        _lib.check(lib.mvs_gru_train_cell_bwd_f32(P(gh), P(g), P(c), P(h), P(stats), P(wgh_t), P(woh_t), P(ln), D, H, W, Fn,
-                                                  P(gpx), P(part), P(scratch), _lib.stream_ptr()), "mvs_gru_train_cell_bwd_f32")
-        # everything that is not sequential: batched convolutions over the planes
-        cb = torch.ops.aten.convolution_backward
-        nchw = lambda t: t.permute(0, 3, 1, 2)
-        tf_w = lambda t: t.permute(2, 3, 1, 0)                                # (Cout,Cin,3,3) -> (3,3,Cin,Cout)
-        args = ([1, 1], [1, 1], [1, 1], False, [0, 0], 1)
-        gp = nchw(gpx)
-        g_x, g_wx, g_b = cb(gp, nchw(x), wx, [3 * Fn], *args, [ctx.needs_input_grad[0], True, True])
-        _n, g_wgh, _n2 = cb(gp[:, :2 * Fn], nchw(h[:D]), wgh.permute(3, 2, 0, 1),
-                            None, *args, [False, True, False])
-        _n, g_woh, _n2 = cb(gp[:, 2 * Fn:], nchw(rh), woh.permute(3, 2, 0, 1), None, *args, [False, True, False])
-        g_wx, g_wgh, g_woh = tf_w(g_wx), tf_w(g_wgh), tf_w(g_woh)
-        g_gates_w = torch.cat([g_wx[..., :2 * Fn], g_wgh], 2)
-        g_out_w = torch.cat([g_wx[..., 2 * Fn:], g_woh], 2)
-        sums = part.sum((0, 2)).to(torch.float32)                             # (3 LayerNorms, [d beta, d gamma], F)
-        return (g_x.permute(0, 2, 3, 1) if g_x is not None else None, g_gates_w, g_b[:2 * Fn], g_out_w, g_b[2 * Fn:],
-                sums[0, 1], sums[0, 0], sums[1, 1], sums[1, 0], sums[2, 1], sums[2, 0])
+        saved, ctx.saved = ctx.saved, None
+        g_x, grads = _cell_backward(saved, gh, ctx.needs_input_grad[0])
+        return (g_x,) + grads
 
 
 def conv_gru_sweep_hip(x_nhwc, p):
-    return ConvGRUSweep.apply(x_nhwc, p["gates_w"], p["gates_b"], p["out_w"], p["out_b"], p["reset_gamma"], p["reset_beta"],
-                              p["update_gamma"], p["update_beta"], p["out_gamma"], p["out_beta"])
+    return ConvGRUSweep.apply(x_nhwc, *[p[k] for k in CELL_FIELDS])
 
 
 def recurrent_regularisation(features, transforms, gru):
@@ -166,7 +181,7 @@ def recurrent_regularisation(features, transforms, gru):
     for cell in ("gru1", "gru2", "gru3"):
         if int(gru[cell]["out_b"].shape[0]) in HIP_FILTERS:
             s = conv_gru_sweep_hip(s, gru[cell])
-        else:
+        else:                                                   # filter counts without a kernel instance ('fat' modes)
             s = conv_gru_sweep(s.permute(0, 3, 1, 2), gru[cell]).permute(0, 2, 3, 1)
     reg = F.conv2d(s.permute(0, 3, 1, 2), gru["prob_w"].permute(3, 2, 0, 1), gru["prob_b"], padding=1)   # :587-588
     return reg[:, 0]
