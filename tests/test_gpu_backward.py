@@ -530,7 +530,7 @@ from mvsnet_amd import shard as sh, synthetic as S, train as T
 dist = sh.init_process_group("gloo")
 rank, _local, world = sh.rank_world()
 torch.cuda.set_device(0)
-tr = T.Trainer("normal", "cuda", seed=0, sync_bn=%(sync)s)       # same seed: identical replicas
+tr = T.Trainer("normal", "cuda", seed=0, sync_bn=%(sync)s, regularization=%(reg)r)       # same seed: identical replicas
 N, H, W, D = 3, 64, 96, 16
 images = S.make_images(N, H, W, seed=10 + rank)                  # every rank its own sample
 cams = S.make_cams(N, H // 4, W // 4, D)
@@ -546,16 +546,16 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("sync", [False, True])
-def test_data_parallel_training_keeps_two_replicas_identical(sync):
+@pytest.mark.parametrize("sync,reg", [(False, "3DCNN"), (True, "3DCNN"), (False, "GRU")])
+def test_data_parallel_training_keeps_two_replicas_identical(sync, reg):
     """Two processes (sharing the box's GPU, collectives over gloo) train on different samples: after the flat
     gradient all-reduce + optimiser step the replicas must hold bit-identical parameters."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563" if sync else "29565", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, "-c", _DP_WORKER % {"root": root, "sync": sync}],
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563" if sync else ("29565" if reg == "3DCNN" else "29567"), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, "-c", _DP_WORKER % {"root": root, "sync": sync, "reg": reg}],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=400) for p in procs]
