@@ -730,3 +730,38 @@ def test_hip_conv_gru_sweep_matches_the_float64_cell_chain(Cin, Fn, dims):
     for k in p:
         ref, dev = p64[k].grad.numpy(), n(pt[k].grad)
         assert rel_l1(dev, ref) < 1e-4 or np.abs(dev - ref).max() < 1e-5, (k, rel_l1(dev, ref))
+
+
+def test_full_size_conv_gru_sweep_backward_is_the_directional_derivative():
+    """Size-independent property at train.py's full sizes (D = 192 planes of 120 x 160, cell 1: 32 -> 16): the
+    gradient the HIP sweep returns for its input and for a kernel is the directional derivative of the forward,
+    d/de <f(x + e v), w> = <grad_x, v>, central differences in float64 accumulation over the fp32 forward."""
+    from mvsnet_amd import gru_train as G
+    D, H, W, Cin, Fn = 192, 120, 160, 32, 16
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    rnd = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    c = Cin + Fn
+    p = {"gates_w": rnd(3, 3, c, 2 * Fn) / np.sqrt(9 * c), "out_w": rnd(3, 3, c, Fn) / np.sqrt(9 * c),
+         "gates_b": 0.1 * rnd(2 * Fn), "out_b": 0.1 * rnd(Fn)}
+    for nm in ("reset", "update", "out"):
+        p[nm + "_gamma"] = 1 + 0.2 * rnd(Fn)
+        p[nm + "_beta"] = 0.1 * rnd(Fn)
+    x, v, w = rnd(D, H, W, Cin), rnd(D, H, W, Cin), rnd(D, H, W, Fn)
+    w[: D - 8] = 0                                        # weight the last planes: the longest back-propagation chains
+    xt = x.clone().requires_grad_(True)
+    pt = {k: t_.clone().requires_grad_(True) for k, t_ in p.items()}
+    out = G.conv_gru_sweep_hip(xt, pt)
+    assert torch.isfinite(out).all()
+    (out.double() * w.double()).sum().backward()
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    with torch.no_grad():
+        f = lambda xx, pp: dot(G.conv_gru_sweep_hip(xx, pp), w)
+        eps = 1e-2
+        num_x = (f(x + eps * v, p) - f(x - eps * v, p)) / (2 * eps)
+        vw = rnd(3, 3, c, 2 * Fn) / np.sqrt(9 * c)
+        pp, pm = dict(p), dict(p)
+        pp["gates_w"], pm["gates_w"] = p["gates_w"] + eps * vw, p["gates_w"] - eps * vw
+        num_w = (f(x, pp) - f(x, pm)) / (2 * eps)
+    ana_x, ana_w = dot(xt.grad, v), dot(pt["gates_w"].grad, vw)
+    assert abs(num_x - ana_x) < 2e-2 * max(abs(ana_x), 1.0), (num_x, ana_x)
+    assert abs(num_w - ana_w) < 2e-2 * max(abs(ana_w), 1.0), (num_w, ana_w)
