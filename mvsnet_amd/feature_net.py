@@ -146,7 +146,7 @@ def unet_forward(layers, images, hip_group_norm=False):
                 y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), w, stride=stride)
         if kind != "c":
             C = y.shape[1]
-            if hip_group_norm and C % 8 == 0:
+            if hip_group_norm and C % 8 == 0 and 256 % (C // 4) == 0:     # the shapes mvs_gn_*_f32 tile
                 y = HipGroupNorm.apply(y, g, b, 1e-5, kind == "cg")
             else:
                 y = F.group_norm(y, max(1, C // 8), g, b, eps=1e-5)   # network.py:246-254
