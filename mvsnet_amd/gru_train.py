@@ -4,6 +4,11 @@
 The reference's branch does not run as shipped (get_loss returns three values where its caller unpacks four,
 train.py:355-364 vs :428; `non_zero_mean_absolute_diff` is not defined anywhere in loss.py): what is built here is
 what that branch states, with the arity made consistent (loss, less_one, less_three, depth map — as the 3DCNN branch).
+One more deliberate difference: the reference unrolls the sweep in Python (model.py:563) and calls
+`tf.contrib.layers.layer_norm` without a scope, so TensorFlow uniquifies the default name per call (LayerNorm,
+LayerNorm_1, … LayerNorm_{2D-1}): its training graph gives every plane its own gamma / beta, of which the inference
+graph (a while_loop body traced once: LayerNorm, LayerNorm_1 | LayerNorm) can only ever load plane 0's.
+Here the LayerNorm parameters are shared by all planes — the variables the inference sweep reads.
 
 Where the work runs
   * warp + variance of ALL planes and its backward w.r.t. the feature maps: libmvsnet_hip.so
