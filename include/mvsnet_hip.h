@@ -357,13 +357,19 @@ int mvs_adam_step_f32(float* w, const float* g, float* m, float* v, size_t n, fl
  * which the host forms every input, weight and bias gradient with batched convolutions), and
  * part (D,3,backward_slots,2,F) float64 (zeroed by the caller): per plane and LayerNorm the sums over pixels of
  * dz and dz*xhat, i.e. the gradients of beta and gamma once summed over planes and slots.
- * scratch: 6*H*W*F floats, zeroed by the caller.  F in {16, 8, 4, 2, 1}. */
+ * scratch: 6*H*W*F floats.  dh_in (H,W,F): gradient w.r.t. the state LEAVING the last plane that arrives from
+ * planes above this call's range (null: none, and then the caller zeroes `scratch`); dh_out (H,W,F), optional:
+ * receives the gradient w.r.t. h[0], the state entering plane 0 -- so a sweep can be run in chunks of planes (forward
+ * in ascending chunks with h carried through the (D+1)-plane buffer, backward in descending chunks with dh_out of
+ * one call as dh_in of the next), which is what lets the three cells run as a wavefront on three streams.
+ * F in {16, 8, 4, 2, 1}. */
 int mvs_gru_train_slots(int* forward_slots, int* backward_slots);
 int mvs_gru_train_cell_fwd_f32(const float* px, const float* wgh, const float* woh, const float* ln, int D, int H,
                                int W, int F, float* g, float* c, float* rh, float* h, double* stats, void* stream);
 int mvs_gru_train_cell_bwd_f32(const float* gh, const float* g, const float* c, const float* h, const double* stats,
                                const float* wgh_t, const float* woh_t, const float* ln, int D, int H, int W, int F,
-                               float* gpx, double* part, float* scratch, void* stream);
+                               float* gpx, double* part, float* scratch, const float* dh_in, float* dh_out,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -453,7 +453,14 @@ gt_bwd_gates_kernel(const float* __restrict__ dzr, const float* __restrict__ dzu
 #pragma unroll
     for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
     conv_taps<CIN, F, CPT>(tile, t.ly, t.lx, (cfloat*)wgh_t, co0, acc);
-    if (!gh_p) return;                                              // plane 0: nothing below consumes the state gradient
+    if (!gh_p) {                                                    // plane 0 of the call: hand the state gradient out
+        if (dh_o && t.valid) {
+            const size_t p = (size_t)t.py * W + t.px;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) dh_o[p * F + co0 + j] = dh_next[p * F + co0 + j] + acc[j];
+        }
+        return;
+    }
     // acc + dh_next is the complete gradient of the state entering this plane = leaving the plane below: run that
     // plane's blend backward right here (same arithmetic as gt_bwd_blend_kernel), one launch less per plane
     __shared__ float red[4][4][CPT];
@@ -527,7 +534,7 @@ int cell_fwd(const float* px, const float* wgh, const float* woh, const float* l
 template <int F>
 int cell_bwd(const float* gh, const float* g, const float* c, const float* h, const double* stats, const float* wgh_t,
              const float* woh_t, const float* ln, int D, int H, int W, float* gpx, double* part, float* scratch,
-             hipStream_t st) {
+             const float* dh_in, float* dh_out, hipStream_t st) {
     using G = Geo<F>;
     const size_t hw = (size_t)H * W, pf = hw * F;
     const int tiles = ((H + G::TH - 1) / G::TH) * ((W + TW - 1) / TW);
@@ -541,7 +548,7 @@ int cell_bwd(const float* gh, const float* g, const float* c, const float* h, co
     // plane d still stages plane d's while its epilogue writes plane d-1's.
     {
         const int d = D - 1;
-        gt_bwd_blend_kernel<F><<<eb, 256, 0, st>>>(gh + d * pf, dh[d & 1], c + d * pf, g + d * hw * 2 * F, h + d * pf,
+        gt_bwd_blend_kernel<F><<<eb, 256, 0, st>>>(gh + d * pf, dh_in ? dh_in : dh[d & 1], c + d * pf, g + d * hw * 2 * F, h + d * pf,
                                                    stats + (size_t)d * SLOTS_F * 6, ln, (int)hw, dzc, dzu[d & 1],
                                                    dh[(d + 1) & 1], part + d * pstride);
     }
@@ -561,7 +568,7 @@ int cell_bwd(const float* gh, const float* g, const float* c, const float* h, co
                                                           dzc, dzu[(d - 1) & 1], dh[d & 1]);
         else
             gt_bwd_gates_kernel<F><<<tiles, 256, 0, st>>>(dzr, dzu[0], gd, sd, pd, wgh_t, ln, H, W, gpd, nxt, nullptr, nullptr,
-                                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dh_out);
     }
     return (int)hipGetLastError();
 }
@@ -593,15 +600,15 @@ extern "C" int mvs_gru_train_cell_fwd_f32(const float* px, const float* wgh, con
 extern "C" int mvs_gru_train_cell_bwd_f32(const float* gh, const float* g, const float* c, const float* h,
                                           const double* stats, const float* wgh_t, const float* woh_t, const float* ln,
                                           int D, int H, int W, int F, float* gpx, double* part, float* scratch,
-                                          void* stream) {
+                                          const float* dh_in, float* dh_out, void* stream) {
     MVS_CHECK_ARG(gh && g && c && h && stats && wgh_t && woh_t && ln && gpx && part && scratch && D > 0 && H > 0 && W > 0);
     hipStream_t st = mvs_stream(stream);
     switch (F) {
-        case 16: return cell_bwd<16>(gh, g, c, h, stats, wgh_t, woh_t, ln, D, H, W, gpx, part, scratch, st);
-        case 8: return cell_bwd<8>(gh, g, c, h, stats, wgh_t, woh_t, ln, D, H, W, gpx, part, scratch, st);
-        case 4: return cell_bwd<4>(gh, g, c, h, stats, wgh_t, woh_t, ln, D, H, W, gpx, part, scratch, st);
-        case 2: return cell_bwd<2>(gh, g, c, h, stats, wgh_t, woh_t, ln, D, H, W, gpx, part, scratch, st);
-        case 1: return cell_bwd<1>(gh, g, c, h, stats, wgh_t, woh_t, ln, D, H, W, gpx, part, scratch, st);
+        case 16: return cell_bwd<16>(gh, g, c, h, stats, wgh_t, woh_t, ln, D, H, W, gpx, part, scratch, dh_in, dh_out, st);
+        case 8: return cell_bwd<8>(gh, g, c, h, stats, wgh_t, woh_t, ln, D, H, W, gpx, part, scratch, dh_in, dh_out, st);
+        case 4: return cell_bwd<4>(gh, g, c, h, stats, wgh_t, woh_t, ln, D, H, W, gpx, part, scratch, dh_in, dh_out, st);
+        case 2: return cell_bwd<2>(gh, g, c, h, stats, wgh_t, woh_t, ln, D, H, W, gpx, part, scratch, dh_in, dh_out, st);
+        case 1: return cell_bwd<1>(gh, g, c, h, stats, wgh_t, woh_t, ln, D, H, W, gpx, part, scratch, dh_in, dh_out, st);
         default: return MVS_E_SHAPE;
     }
 }

@@ -27,6 +27,7 @@ Where the work runs
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict
 
 import numpy as np
@@ -138,7 +139,7 @@ def _cell_backward(saved, gh, need_x_grad=True):
     part = torch.zeros((D, 3, slots, 2, Fn), device=dev, dtype=torch.float64)
     scratch = torch.zeros((6, H, W, Fn), device=dev, dtype=torch.float32)
     _lib.check(lib.mvs_gru_train_cell_bwd_f32(P(gh), P(g), P(c), P(h), P(stats), P(wgh_t), P(woh_t), P(ln), D, H, W, Fn,
-                                              P(gpx), P(part), P(scratch), _lib.stream_ptr()), "mvs_gru_train_cell_bwd_f32")
+                                              P(gpx), P(part), P(scratch), None, None, _lib.stream_ptr()), "mvs_gru_train_cell_bwd_f32")
     # everything that is not sequential: batched convolutions over the planes
     cb = torch.ops.aten.convolution_backward
     nchw = lambda t: t.permute(0, 3, 1, 2)
@@ -174,6 +175,135 @@ def conv_gru_sweep_hip(x_nhwc, p):
     return ConvGRUSweep.apply(x_nhwc, *[p[k] for k in CELL_FIELDS])
 
 
+# ---- the three cells as a wavefront on three streams ------------------------------------------------------------
+CHUNK = int(os.environ.get("MVS_GRU_TRAIN_CHUNK", "32"))     # planes per hand-over between the cells
+_STREAMS = {}
+
+
+def _cell_streams(dev):
+    st = _STREAMS.get(dev)
+    if st is None:
+        st = _STREAMS[dev] = [torch.cuda.Stream(dev) for _ in range(3)]
+    return st
+
+
+class RecurrentCells(torch.autograd.Function):
+    """conv_gru1 -> conv_gru2 -> conv_gru3 over all planes: x (D,H,W,C) -> states of cell 3 (D,H,W,F3).
+
+    Walking the network cell by cell leaves the GPU to one launch-latency-bound chain at a time.  Here every cell has
+    its own HIP stream and works through the planes in chunks of CHUNK: as soon as cell k has finished a chunk (an
+    event), cell k+1 forms the x parts of that chunk (one batched convolution) and sweeps it while cell k is already
+    in the next chunk -- a wavefront over (chunk, cell), forward; backward the same in reverse (cell 3 first, chunks
+    descending, the state gradient handed from chunk to chunk through dh_out -> dh_in, the x-gradient of a chunk
+    being the next cell down's `gh` of that chunk).  The batched weight / bias gradients follow on the caller's
+    stream once the streams have joined.  (Measured and dropped: a cell's batched x-part convolutions on a stream of
+    their own, ahead of its sweep -- their workgroups fill the CUs and the sweeps' launches queue behind them:
+    38.4 -> 41.2 ms.)"""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        lib = _lib.load()
+        P, dev = _lib.ptr, x.device
+        D, H, W, _ = x.shape
+        x = x.detach().contiguous()
+        main = torch.cuda.current_stream(dev)
+        streams = _cell_streams(dev)
+        chunks = [(a, min(a + CHUNK, D)) for a in range(0, D, CHUNK)]
+        sf, sb = _lib.C.c_int(), _lib.C.c_int()
+        lib.mvs_gru_train_slots(_lib.C.byref(sf), _lib.C.byref(sb))
+        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        cells, inp = [], x
+        for k in range(3):                                  # every long-lived buffer comes from the caller's stream
+            gates_w, gates_b, out_w, out_b, rg, rb, ug, ub, og, ob = [t.detach() for t in params[10 * k:10 * k + 10]]
+            Cin, Fn = int(inp.shape[-1]), int(out_b.shape[0])
+            cl = dict(Cin=Cin, F=Fn, x=inp,
+                      wx=torch.cat([gates_w[:, :, :Cin, :], out_w[:, :, :Cin, :]], 3).permute(3, 2, 0, 1).contiguous(),
+                      bx=torch.cat([gates_b, out_b]), wgh=gates_w[:, :, Cin:, :].contiguous(), woh=out_w[:, :, Cin:, :].contiguous(),
+                      ln=torch.stack([rg, rb, ug, ub, og, ob]).contiguous(),
+                      g=new(D, H, W, 2 * Fn), c=new(D, H, W, Fn), rh=new(D, H, W, Fn), h=new(D + 1, H, W, Fn),
+                      stats=torch.zeros((D, sf.value, 6), device=dev, dtype=torch.float64))
+            cl["h"][0].zero_()                              # model.py:546-551
+            cells.append(cl)
+            inp = cl["h"][1:]
+        start = main.record_event()
+        above = None
+        for k, cl in enumerate(cells):
+            st, done = streams[k], []
+            with torch.cuda.stream(st):
+                st.wait_event(start)
+                for j, (a, b) in enumerate(chunks):
+                    if above is not None:
+                        st.wait_event(above[j])
+                    px = F.conv2d(cl["x"][a:b].permute(0, 3, 1, 2), cl["wx"], cl["bx"], padding=1).permute(0, 2, 3, 1).contiguous()
+                    _lib.check(lib.mvs_gru_train_cell_fwd_f32(
+                        P(px), P(cl["wgh"]), P(cl["woh"]), P(cl["ln"]), b - a, H, W, cl["F"], P(cl["g"][a:b]), P(cl["c"][a:b]),
+                        P(cl["rh"][a:b]), P(cl["h"][a:b + 1]), P(cl["stats"][a:b]), _lib.stream_ptr()), "mvs_gru_train_cell_fwd_f32")
+                    done.append(st.record_event())
+            above = done
+        for st in streams:
+            main.wait_stream(st)
+        ctx.saved = (cells, chunks, sb.value)
+        return cells[2]["h"][1:]
+
+    @staticmethod
+    def backward(ctx, gh3):
+        lib = _lib.load()
+        P, dev = _lib.ptr, gh3.device
+        cells, chunks, slots = ctx.saved
+        ctx.saved = None
+        D, H, W = cells[0]["g"].shape[:3]
+        main = torch.cuda.current_stream(dev)
+        streams = _cell_streams(dev)
+        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        flip_t = lambda w: w.flip(0, 1).permute(0, 1, 3, 2).contiguous()      # the kernel of the input gradient
+        cb = torch.ops.aten.convolution_backward
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        args = ([1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+        need_x = ctx.needs_input_grad[0]
+        for k, cl in enumerate(cells):
+            Fn = cl["F"]
+            cl.update(gh=gh3.contiguous() if k == 2 else new(D, H, W, Fn), gpx=new(D, H, W, 3 * Fn),
+                      part=torch.zeros((D, 3, slots, 2, Fn), device=dev, dtype=torch.float64), scratch=new(6, H, W, Fn),
+                      carry=new(len(chunks) + 1, H, W, Fn), wgh_t=flip_t(cl["wgh"]), woh_t=flip_t(cl["woh"]))
+            cl["carry"][len(chunks)].zero_()                 # nothing arrives at the last plane from beyond the sweep
+        g_x = new(*cells[0]["x"].shape) if need_x else None
+        start = main.record_event()
+        above = None
+        for k in (2, 1, 0):
+            cl, st, done = cells[k], streams[k], [None] * len(chunks)
+            below = cells[k - 1]["gh"] if k > 0 else g_x
+            with torch.cuda.stream(st):
+                st.wait_event(start)
+                for j in reversed(range(len(chunks))):
+                    a, b = chunks[j]
+                    if above is not None:
+                        st.wait_event(above[j])
+                    _lib.check(lib.mvs_gru_train_cell_bwd_f32(
+                        P(cl["gh"][a:b]), P(cl["g"][a:b]), P(cl["c"][a:b]), P(cl["h"][a:b]), P(cl["stats"][a:b]), P(cl["wgh_t"]),
+                        P(cl["woh_t"]), P(cl["ln"]), b - a, H, W, cl["F"], P(cl["gpx"][a:b]), P(cl["part"][a:b]), P(cl["scratch"]),
+                        P(cl["carry"][j + 1]), P(cl["carry"][j]), _lib.stream_ptr()), "mvs_gru_train_cell_bwd_f32")
+                    if below is not None:                    # the x-gradient of this chunk: what the cell below waits for
+                        gx = cb(nchw(cl["gpx"][a:b]), nchw(cl["x"][a:b]), cl["wx"], None, *args, [True, False, False])[0]
+                        below[a:b].copy_(gx.permute(0, 2, 3, 1))
+                    done[j] = st.record_event()
+            above = done
+        for st in streams:
+            main.wait_stream(st)
+        # not sequential and on nobody's critical path: weight / bias gradients, batched over all planes
+        tf_w = lambda t: t.permute(2, 3, 1, 0)                                # (Cout,Cin,3,3) -> (3,3,Cin,Cout)
+        grads = ()
+        for cl in cells:
+            Fn, gp = cl["F"], nchw(cl["gpx"])
+            _n, g_wx, g_b = cb(gp, nchw(cl["x"]), cl["wx"], [3 * Fn], *args, [False, True, True])
+            g_wgh = cb(gp[:, :2 * Fn], nchw(cl["h"][:D]), cl["wgh"].permute(3, 2, 0, 1), None, *args, [False, True, False])[1]
+            g_woh = cb(gp[:, 2 * Fn:], nchw(cl["rh"]), cl["woh"].permute(3, 2, 0, 1), None, *args, [False, True, False])[1]
+            g_wx, g_wgh, g_woh = tf_w(g_wx), tf_w(g_wgh), tf_w(g_woh)
+            sums = cl["part"].sum((0, 2)).to(torch.float32)                   # (3 LayerNorms, [d beta, d gamma], F)
+            grads += (torch.cat([g_wx[..., :2 * Fn], g_wgh], 2), g_b[:2 * Fn], torch.cat([g_wx[..., 2 * Fn:], g_woh], 2),
+                      g_b[2 * Fn:], sums[0, 1], sums[0, 0], sums[1, 1], sums[1, 0], sums[2, 1], sums[2, 0])
+        return (g_x,) + grads
+
+
 def recurrent_regularisation(features, transforms, gru):
     """features (N,H,W,C), transforms (N-1,D,8), gru = {'gru1','gru2','gru3': cell tensors, 'prob_w','prob_b'} ->
     regularised cost `reg` (D,H,W) (model.py:563-592, before the softmax)."""
@@ -183,11 +313,12 @@ def recurrent_regularisation(features, transforms, gru):
         feats = F.pad(feats, (0, (16 if feats.shape[-1] < 16 else 32) - feats.shape[-1]))
     cost = VarianceCostVolume.apply(feats, transforms)          # (D,H,W,C)
     s = -cost[..., :cin]                                        # the cells see -cost (model.py:584)
-    for cell in ("gru1", "gru2", "gru3"):
-        if int(gru[cell]["out_b"].shape[0]) in HIP_FILTERS:
-            s = conv_gru_sweep_hip(s, gru[cell])
-        else:                                                   # filter counts without a kernel instance ('fat' modes)
-            s = conv_gru_sweep(s.permute(0, 3, 1, 2), gru[cell]).permute(0, 2, 3, 1)
+    cells = ("gru1", "gru2", "gru3")
+    if all(int(gru[k]["out_b"].shape[0]) in HIP_FILTERS for k in cells):
+        s = RecurrentCells.apply(s, *[gru[k][f] for k in cells for f in CELL_FIELDS])
+    else:                                                       # filter counts without a kernel instance ('fat' modes)
+        for k in cells:
+            s = conv_gru_sweep(s.permute(0, 3, 1, 2), gru[k]).permute(0, 2, 3, 1)
     reg = F.conv2d(s.permute(0, 3, 1, 2), gru["prob_w"].permute(3, 2, 0, 1), gru["prob_b"], padding=1)   # :587-588
     return reg[:, 0]
 
