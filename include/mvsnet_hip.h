@@ -371,6 +371,16 @@ int mvs_gru_train_cell_bwd_f32(const float* gh, const float* g, const float* c, 
                                float* gpx, double* part, float* scratch, const float* dh_in, float* dh_out,
                                void* stream);
 
+/* Weight gradient of a 3x3 SAME stride-1 2D convolution over a batch of planes (csrc/conv2d_wgrad.hip; in the
+ * reference: TensorFlow's Conv2DBackpropFilter of the tf.layers.conv2d calls of mvsnet/convgru.py:92,110 behind
+ * opt.compute_gradients, train.py:428-429):  dw (3,3,Cin,Cout) = sum over n,y,x of x[n,y+kh-1,x+kw-1,ci] * g[n,y,x,co].
+ * x (N,H,W,Cin); g (N,H,W,g_stride) of which channels [g_off, g_off+Cout) are used (g_stride, g_off multiples of 4).
+ * Deterministic (per-workgroup partials in `workspace`, fixed-order float64 sum).  Built for (Cin, Cout) in
+ * {16,32} x {16,32,48}; anything else returns MVS_E_SHAPE. */
+size_t mvs_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int mvs_conv2d_wgrad_f32(const float* x, const float* g, int g_stride, int g_off, int N, int H, int W, int Cin,
+                         int Cout, void* workspace, size_t workspace_bytes, float* dw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,8 @@ SIGNATURES = {
     "mvs_gru_train_slots": (_i, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mvs_gru_train_cell_fwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "mvs_gru_train_cell_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "mvs_conv2d_wgrad_workspace_bytes": (_sz, [_i] * 5),
+    "mvs_conv2d_wgrad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
     "mvs_gru_wta_f32": (_i, [_p, _p, _p] + [_i] * 8 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
 }
 

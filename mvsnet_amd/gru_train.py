@@ -121,6 +121,40 @@ def _cell_forward(x, gates_w, gates_b, out_w, out_b, rg, rb, ug, ub, og, ob):
     return h[1:], (x, wx, wgh, woh, ln, g, c, rh, h, stats, sb.value)
 
 
+WGRAD_CHANNELS = ((16, 32), (16, 32, 48))     # (Cin, Cout) instances of csrc/conv2d_wgrad.hip
+
+
+def conv2d_wgrad(x, g, g_off, cout):
+    """dW (3,3,Cin,cout) of a 3x3 SAME convolution over the batch of planes: x (N,H,W,Cin), g (N,H,W,Cg) of which the
+    channels [g_off, g_off + cout) are the output gradient.  MFMA kernel where it is built, ATen otherwise."""
+    N, H, W, Cin = x.shape
+    if Cin in WGRAD_CHANNELS[0] and cout in WGRAD_CHANNELS[1] and g.shape[-1] % 4 == 0 and g_off % 4 == 0:
+        lib = _lib.load()
+        need = lib.mvs_conv2d_wgrad_workspace_bytes(N, H, W, Cin, cout)
+        ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+        dw = torch.empty((3, 3, Cin, cout), device=x.device, dtype=torch.float32)
+        _lib.check(lib.mvs_conv2d_wgrad_f32(_lib.ptr(x), _lib.ptr(g), g.shape[-1], g_off, N, H, W, Cin, cout,
+                                            _lib.C.c_void_p(ws.data_ptr()), need, _lib.ptr(dw), _lib.stream_ptr()),
+                   "mvs_conv2d_wgrad_f32")
+        return dw
+    gp = g.permute(0, 3, 1, 2)[:, g_off:g_off + cout]
+    w = x.new_empty((cout, Cin, 3, 3))
+    g_w = torch.ops.aten.convolution_backward(gp, x.permute(0, 3, 1, 2), w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1]
+    return g_w.permute(2, 3, 1, 0)
+
+
+def _weight_grads(x, h_prev, rh, gpx, part, Fn):
+    """The ten parameter gradients of a cell (CELL_FIELDS order) from the kept px-gradients: batched over all planes."""
+    g_wx = conv2d_wgrad(x, gpx, 0, 3 * Fn)
+    g_wgh = conv2d_wgrad(h_prev, gpx, 0, 2 * Fn)
+    g_woh = conv2d_wgrad(rh, gpx, 2 * Fn, Fn)
+    g_b = gpx.sum((0, 1, 2))
+    sums = part.sum((0, 2)).to(torch.float32)                             # (3 LayerNorms, [d beta, d gamma], F)
+    return (torch.cat([g_wx[..., :2 * Fn], g_wgh], 2), g_b[:2 * Fn], torch.cat([g_wx[..., 2 * Fn:], g_woh], 2),
+            g_b[2 * Fn:], sums[0, 1], sums[0, 0], sums[1, 1], sums[1, 0], sums[2, 1], sums[2, 0])
+
+
 def _cell_backward(saved, gh, need_x_grad=True):
     """gh (D,H,W,F): gradient reaching every state from outside the recurrence.  Returns (g_x or None, the ten
     parameter gradients in CELL_FIELDS order).  (Putting the batched weight gradients on a second stream, under the
@@ -141,19 +175,12 @@ def _cell_backward(saved, gh, need_x_grad=True):
     _lib.check(lib.mvs_gru_train_cell_bwd_f32(P(gh), P(g), P(c), P(h), P(stats), P(wgh_t), P(woh_t), P(ln), D, H, W, Fn,
                                               P(gpx), P(part), P(scratch), None, None, _lib.stream_ptr()), "mvs_gru_train_cell_bwd_f32")
     # everything that is not sequential: batched convolutions over the planes
-    cb = torch.ops.aten.convolution_backward
-    nchw = lambda t: t.permute(0, 3, 1, 2)
-    tf_w = lambda t: t.permute(2, 3, 1, 0)                                # (Cout,Cin,3,3) -> (3,3,Cin,Cout)
-    args = ([1, 1], [1, 1], [1, 1], False, [0, 0], 1)
-    gp = nchw(gpx)
-    g_x, g_wx, g_b = cb(gp, nchw(x), wx, [3 * Fn], *args, [need_x_grad, True, True])
-    g_wgh = cb(gp[:, :2 * Fn], nchw(h[:D]), wgh.permute(3, 2, 0, 1), None, *args, [False, True, False])[1]
-    g_woh = cb(gp[:, 2 * Fn:], nchw(rh), woh.permute(3, 2, 0, 1), None, *args, [False, True, False])[1]
-    g_wx, g_wgh, g_woh = tf_w(g_wx), tf_w(g_wgh), tf_w(g_woh)
-    sums = part.sum((0, 2)).to(torch.float32)                             # (3 LayerNorms, [d beta, d gamma], F)
-    grads = (torch.cat([g_wx[..., :2 * Fn], g_wgh], 2), g_b[:2 * Fn], torch.cat([g_wx[..., 2 * Fn:], g_woh], 2),
-             g_b[2 * Fn:], sums[0, 1], sums[0, 0], sums[1, 1], sums[1, 0], sums[2, 1], sums[2, 0])
-    return (g_x.permute(0, 2, 3, 1) if g_x is not None else None), grads
+    g_x = None
+    if need_x_grad:
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        g_x = torch.ops.aten.convolution_backward(nchw(gpx), nchw(x), wx, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                  [True, False, False])[0].permute(0, 2, 3, 1)
+    return g_x, _weight_grads(x, h[:D], rh, gpx, part, Fn)
 
 
 class ConvGRUSweep(torch.autograd.Function):
@@ -290,17 +317,9 @@ class RecurrentCells(torch.autograd.Function):
         for st in streams:
             main.wait_stream(st)
         # not sequential and on nobody's critical path: weight / bias gradients, batched over all planes
-        tf_w = lambda t: t.permute(2, 3, 1, 0)                                # (Cout,Cin,3,3) -> (3,3,Cin,Cout)
         grads = ()
         for cl in cells:
-            Fn, gp = cl["F"], nchw(cl["gpx"])
-            _n, g_wx, g_b = cb(gp, nchw(cl["x"]), cl["wx"], [3 * Fn], *args, [False, True, True])
-            g_wgh = cb(gp[:, :2 * Fn], nchw(cl["h"][:D]), cl["wgh"].permute(3, 2, 0, 1), None, *args, [False, True, False])[1]
-            g_woh = cb(gp[:, 2 * Fn:], nchw(cl["rh"]), cl["woh"].permute(3, 2, 0, 1), None, *args, [False, True, False])[1]
-            g_wx, g_wgh, g_woh = tf_w(g_wx), tf_w(g_wgh), tf_w(g_woh)
-            sums = cl["part"].sum((0, 2)).to(torch.float32)                   # (3 LayerNorms, [d beta, d gamma], F)
-            grads += (torch.cat([g_wx[..., :2 * Fn], g_wgh], 2), g_b[:2 * Fn], torch.cat([g_wx[..., 2 * Fn:], g_woh], 2),
-                      g_b[2 * Fn:], sums[0, 1], sums[0, 0], sums[1, 1], sums[1, 0], sums[2, 1], sums[2, 0])
+            grads += _weight_grads(cl["x"], cl["h"][:D], cl["rh"], cl["gpx"], cl["part"], cl["F"])
         return (g_x,) + grads
 
 

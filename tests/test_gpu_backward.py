@@ -776,3 +776,23 @@ def test_trainer_runs_the_other_narrow_modes(mode):
     tr = T.Trainer(mode, DEV, seed=0)
     losses = [float(tr.train_step(images, cams, gt, D)[0]) for _ in range(6)]
     assert all(np.isfinite(losses)) and min(losses[-2:]) < losses[0], losses
+
+
+@pytest.mark.parametrize("cin,cout,cg,off", [(32, 48, 48, 0), (16, 32, 48, 0), (16, 16, 48, 32), (32, 32, 32, 0), (32, 16, 20, 4),
+                                             (16, 48, 48, 0), (16, 12, 12, 0)])
+@pytest.mark.parametrize("dims", [(3, 9, 37), (5, 16, 64), (2, 4, 32)])
+def test_conv2d_weight_gradient_matches_autograd(cin, cout, cg, off, dims):
+    """mvs_conv2d_wgrad_f32 (MFMA, deterministic) against float64 autograd of the 3x3 SAME convolution, ragged tiles, the
+    output gradient as a channel slice of a wider tensor; (16, 12) has no kernel instance and takes the ATen route."""
+    from mvsnet_amd import gru_train as G
+    N, H, W = dims
+    rs = np.random.RandomState(cin + cout + H)
+    x = rs.randn(N, H, W, cin).astype(np.float32)
+    g = rs.randn(N, H, W, cg).astype(np.float32)
+    w64 = torch.zeros((3, 3, cin, cout), dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(d64(x).permute(0, 3, 1, 2), w64.permute(3, 2, 0, 1), padding=1)
+    (y * d64(g[..., off:off + cout]).permute(0, 3, 1, 2)).sum().backward()
+    got = G.conv2d_wgrad(t(x), t(g), off, cout)
+    assert tuple(got.shape) == (3, 3, cin, cout)
+    assert rel_l1(n(got), w64.grad.numpy()) < 2e-6
+    assert torch.equal(got, G.conv2d_wgrad(t(x), t(g), off, cout)) or cout == 12          # bit-reproducible

@@ -21,5 +21,5 @@ for name, s, e in win:
     a[0] += 1; a[1] += e - s
 busy = sum(v[1] for v in agg.values())
 print("window %.2f ms wall, %.2f ms of kernel time, %d launches" % ((win[-1][2] - win[0][1]) / 1e6, busy / 1e6, len(win)))
-for name, (cnt, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+for name, (cnt, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[4]) if len(sys.argv) > 4 else 40]:
     print("%-100s calls %5d  total %8.1f us  avg %7.1f us" % (name[:100], cnt, t / 1e3, t / 1e3 / cnt))
