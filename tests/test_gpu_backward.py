@@ -796,3 +796,40 @@ def test_conv2d_weight_gradient_matches_autograd(cin, cout, cg, off, dims):
     assert tuple(got.shape) == (3, 3, cin, cout)
     assert rel_l1(n(got), w64.grad.numpy()) < 2e-6
     assert torch.equal(got, G.conv2d_wgrad(t(x), t(g), off, cout)) or cout == 12          # bit-reproducible
+
+
+@pytest.mark.parametrize("chunk", [1, 3, 5])
+def test_recurrent_cells_wavefront_matches_the_cell_by_cell_sweeps(monkeypatch, chunk):
+    """gru_train.RecurrentCells (three streams, planes handed over in chunks, the state gradient carried between chunk
+    calls through dh_out -> dh_in) against the three single-cell sweeps run one after the other, ragged last chunk."""
+    from mvsnet_amd import gru_train as G
+    monkeypatch.setattr(G, "CHUNK", chunk)
+    D, H, W, C = 8, 13, 22, 32
+    rs = np.random.RandomState(chunk)
+    gp = S.make_gru_params("normal", in_channels=C, random_affine=True)
+    x = rs.randn(D, H, W, C).astype(np.float32)
+    gh = rs.randn(D, H, W, 2).astype(np.float32)
+    cells = ("gru1", "gru2", "gru3")
+
+    def run(fn):
+        xt = t(x).requires_grad_(True)
+        pt = {k: {f: t(gp[k][f]).requires_grad_(True) for f in G.CELL_FIELDS} for k in cells}
+        out = fn(xt, pt)
+        (out * t(gh)).sum().backward()
+        return n(out), n(xt.grad), {(k, f): n(pt[k][f].grad) for k in cells for f in G.CELL_FIELDS}
+
+    def wavefront(xt, pt):
+        return G.RecurrentCells.apply(xt, *[pt[k][f] for k in cells for f in G.CELL_FIELDS])
+
+    def one_by_one(xt, pt):
+        s = xt
+        for k in cells:
+            s = G.conv_gru_sweep_hip(s, pt[k])
+        return s
+
+    a, ga, pa = run(wavefront)
+    b, gb, pb = run(one_by_one)
+    assert np.array_equal(a, b)                                   # the forward is the same kernels on the same data
+    assert rel_l1(ga, gb) < 1e-5
+    for key in pa:
+        assert rel_l1(pa[key], pb[key]) < 1e-4 or np.abs(pa[key] - pb[key]).max() < 1e-6, key
