@@ -179,9 +179,11 @@ def main():
             with torch.cuda.stream(s_):
                 pl.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
 
+        last = [None]
+
         def gstep(i):
             with torch.cuda.stream(gstreams[i % ns]):
-                gplans[i % ns].run_gru(feats, dv)
+                last[0] = gplans[i % ns].run_gru(feats, dv)
         torch.cuda.synchronize()
         for i in range(max(args.warmup, 2 * ns)):
             gstep(i)
@@ -196,6 +198,7 @@ def main():
                           "unit": "depth maps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": el / args.steps * 1e3, "ms_per_plane": el / args.steps / w.depth_num * 1e3,
                           "achieved_tflops": flops * args.steps / el / 1e12, "dtype": "f32", "data": "synthetic",
+                          "depth_checksum": float(last[0][0].double().sum()), "prob_checksum": float(last[0][1].double().sum()),
                           "config": {"workload": "%s: GRU sweep, N=%d, D=%d, %dx%d" % (
                               w.name, w.view_num, w.depth_num, w.width, w.height), "streams_per_gpu": ns}}), flush=True)
         return

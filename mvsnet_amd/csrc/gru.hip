@@ -16,6 +16,10 @@ int mvs_gru1_xpart_mfma(const float* x, const float* wxg, const float* wxo, cons
                         int H, int W, int planes, float* px, hipStream_t st);
 int mvs_gru1_gates_h_mfma(const float* h, const float* wgh, const float* px, int H, int W, float* g, double* stats,
                           hipStream_t st);
+int mvs_gru1_gates_h_blend_mfma(const float* h_before, const float* c_prev, const float* g_prev, const double* stats_c,
+                                const double* stats_u, const float* o_gamma, const float* o_beta, const float* u_gamma,
+                                const float* u_beta, float* h_out, const float* wgh, const float* px, int H, int W,
+                                float* g, double* stats, hipStream_t st);
 int mvs_gru1_out_h_mfma(const float* h, const float* g, const double* g_stats, const float* r_gamma, const float* r_beta,
                         const float* woh, const float* px, int H, int W, float* c, double* stats, hipStream_t st);
 namespace {
@@ -166,13 +170,25 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&o)
 // staged once in LDS (MODE 1 folds the reset gate into xb there: xb = sigmoid(LayerNorm(g_r)) * h,
 // convgru.py:97,101,107 -- evaluated once per staged element, not once per tap), every thread then
 // reads its 9 taps from LDS; weights come through the scalar cache.
+// MODE 2: what the previous plane's blend needs, evaluated while staging xb (see conv2d_small_kernel)
+struct BlendIn {
+    const float* c; const float* g;                   // previous plane: raw candidate (H,W,F) and gate (H,W,2F) convolutions
+    const double* stats_c; const double* stats_u;     // their LayerNorm moments [sum, sumsq]
+    const float *og, *ob, *ug, *ub;                   // candidate / update LayerNorm gamma, beta
+    float* h_out;                                     // receives the blended state (the tile's own pixels)
+};
+
+// MODE 2 folds the PREVIOUS plane's blend into the staging of xb: xb holds the state that entered the previous plane
+// and the state entering this one, u*h + (1-u)*tanh(LN c) (convgru.py:98,102,114-120), is formed on load (halo
+// positions are recomputed by the neighbouring tiles), written out for the tile's own pixels -- the candidate
+// convolution, the next cell and the WTA update read it -- and convolved: one launch less per plane and cell.
 template <int CA, int CB, int CO, int MODE>
 __global__ void __launch_bounds__(256)
 conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
                     const float* __restrict__ g, const double* __restrict__ g_stats,
                     const float* __restrict__ r_gamma, const float* __restrict__ r_beta,
                     const float* __restrict__ w, const float* __restrict__ bias, int H, int W,
-                    float* __restrict__ y, double* __restrict__ stats, int groups) {
+                    float* __restrict__ y, double* __restrict__ stats, int groups, BlendIn bl) {
     constexpr int CT = CA + CB;
     constexpr int TS = 16, PS = TS + 2;
     typedef const __attribute__((address_space(4))) float cfloat;      // wave-uniform -> s_load into SGPRs
@@ -189,6 +205,15 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
         for (int f = 0; f < CB; ++f) {
             double inv = (double)r_gamma[f] / sqrt(var + 1e-12);
             ra[f] = (float)inv; rb[f] = (float)((double)r_beta[f] - mean * inv);
+        }
+    }
+    float ua[CB], ub_[CB], ca[CB], cb_[CB];
+    if (MODE == 2) {
+        const double cnt = (double)H * W * CB;
+#pragma unroll
+        for (int f = 0; f < CB; ++f) {
+            ln_affine(bl.stats_u, cnt, bl.ug[f], bl.ub[f], ua[f], ub_[f]);
+            ln_affine(bl.stats_c, cnt, bl.og[f], bl.ob[f], ca[f], cb_[f]);
         }
     }
     const int tiles_x = (W + TS - 1) / TS;
@@ -211,6 +236,20 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
                 load_vec<CB>(g + p * 2 * CB, gr);
 #pragma unroll
                 for (int i = 0; i < CB; ++i) vb[i] *= 1.0f / (1.0f + expf(-(gr[i] * ra[i] + rb[i])));
+            }
+            if (MODE == 2) {
+                float cv[CB], gu[CB];
+                load_vec<CB>(bl.c + p * CB, cv);
+                load_vec<CB>(bl.g + p * 2 * CB + CB, gu);
+#pragma unroll
+                for (int i = 0; i < CB; ++i) {
+                    const float uu = sigmoidf(gu[i] * ua[i] + ub_[i]);
+                    vb[i] = uu * vb[i] + (1.0f - uu) * tanhf(cv[i] * ca[i] + cb_[i]);
+                }
+                if (r >= 1 && r <= TS && c >= 1 && c <= TS) {
+#pragma unroll
+                    for (int i = 0; i < CB; ++i) bl.h_out[p * CB + i] = vb[i];
+                }
             }
         }
         float* d = tile + f * CT;
@@ -267,13 +306,23 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
 }
 
 // cells 2 / 3: gate conv then candidate conv (reset gate folded in); false if the shape has no instance
+// `prev`: the previous plane's blend has not been launched -- its inputs; h then RECEIVES the state entering this plane
+// (formed from h_before, the state that entered the previous plane) in the gate convolution's staging
+struct PrevPlane { const float* h_before; const float* g; const double* sg; const double* so; };
 template <int CA, int F>
-bool launch_small_cell(const float* xin, const float* h, const float* const* p, int H, int W, float* g, float* c,
-                       double* sg, double* so, hipStream_t st) {
+bool launch_small_cell(const float* xin, float* h, const float* const* p, int H, int W, float* g, float* c,
+                       double* sg, double* so, const PrevPlane* prev, hipStream_t st) {
     const int grid = ((H + 15) / 16) * ((W + 15) / 16);           // 16 x 16 pixel tiles
-    conv2d_small_kernel<CA, F, 2 * F, 0><<<grid, 256, 0, st>>>(xin, h, nullptr, nullptr, nullptr, nullptr,
-                                                               p[0], p[1], H, W, g, sg, 2);
-    conv2d_small_kernel<CA, F, F, 1><<<grid, 256, 0, st>>>(xin, h, g, sg, p[2], p[3], p[6], p[7], H, W, c, so, 1);
+    BlendIn none = {};
+    if (prev) {
+        BlendIn bl = {c, prev->g, prev->so, prev->sg + 2, p[8], p[9], p[4], p[5], h};
+        conv2d_small_kernel<CA, F, 2 * F, 2><<<grid, 256, 0, st>>>(xin, prev->h_before, nullptr, nullptr, nullptr, nullptr,
+                                                                   p[0], p[1], H, W, g, sg, 2, bl);
+    } else {
+        conv2d_small_kernel<CA, F, 2 * F, 0><<<grid, 256, 0, st>>>(xin, h, nullptr, nullptr, nullptr, nullptr,
+                                                                   p[0], p[1], H, W, g, sg, 2, none);
+    }
+    conv2d_small_kernel<CA, F, F, 1><<<grid, 256, 0, st>>>(xin, h, g, sg, p[2], p[3], p[6], p[7], H, W, c, so, 1, none);
     return true;
 }
 
@@ -405,7 +454,7 @@ extern "C" int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, i
 
 namespace {
 struct GruWs {
-    float *x, *g[3], *c[3], *rh, *u, *h[3][2 * 4], *reg, *max_prob, *exp_sum;   // h: ring of 2*PG states
+    float *x, *g[3], *g2[3], *c[3], *rh, *u, *h[3][2 * 4], *reg, *max_prob, *exp_sum;   // h: ring of 2*PG states; g2: the gate buffer of odd planes (cells whose blend is folded into the next plane's gate convolution)
     float *px, *wx, *wgh, *woh;        // hoisted x-part of cell 1: (2, XB, H, W, 3*f1) and its prepared weights
     double* stats;     // per plane of a batch: 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
     size_t bytes;
@@ -427,7 +476,7 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     // every cell has its own gate / candidate buffers and a ping-pong state: the three cells of
     // consecutive planes run concurrently (see mvs_gru_wta_f32)
     for (int k = 0; k < 3; ++k) {
-        w.g[k] = take(hw * 2 * F[k]); w.c[k] = take(hw * F[k]);
+        w.g[k] = take(hw * 2 * F[k]); w.g2[k] = take(hw * 2 * F[k]); w.c[k] = take(hw * F[k]);
         for (int r = 0; r < 2 * PG; ++r) w.h[k][r] = take(hw * F[k]);
     }
     w.rh = take(hw * fmax); w.u = take(hw * fmax);
@@ -563,45 +612,73 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
         const float* const* p = params + 10 * k;
         double* sg = ws.stats + (size_t)(half * XB + slot) * 18 + 6 * k;
         double* so = sg + 4;
-        const float* hp = ws.h[k][d % (2 * PG)];
+        float* hp_w = ws.h[k][d % (2 * PG)];
+        const float* hp = hp_w;
         float* hn = ws.h[k][(d + 1) % (2 * PG)];
+        // On the wavefront: the blend of a plane is folded into the NEXT plane's gate convolution (its
+        // staging forms the state it convolves) except at the end of a synchronisation group, where the next cell
+        // (and the WTA update) are about to read the state: 3 of 4 blend launches disappear.  The gate buffer
+        // alternates, a folded gate convolution still reads the previous plane's update gate while it writes its own.
+        const bool fold = route[k] != 0 && gs != nullptr;           // (the MFMA cell 1 folds its blend the same way)
+        const bool fused_in = fold && d % PG != 0;               // plane d-1 left its blend to this plane
+        const bool blend_now = !fold || d % PG == PG - 1 || d == depth_num - 1;
+        float* gcur = (fold && (d & 1)) ? ws.g2[k] : ws.g[k];
+        PrevPlane prev = {nullptr, nullptr, nullptr, nullptr};
+        if (fused_in) {
+            const int dp = d - 1;
+            double* sgp = ws.stats + (size_t)(((dp / XB) & 1) * XB + dp % XB) * 18 + 6 * k;
+            prev = {ws.h[k][dp % (2 * PG)], (dp & 1) ? ws.g2[k] : ws.g[k], sgp, sgp + 4};
+        }
+        const PrevPlane* pv = fused_in ? &prev : nullptr;
         const float* xin = k == 0 ? ws.x + (size_t)slot * hw * C : ws.h[k - 1][(d + 1) % (2 * PG)];
         const float* px_d = ws.px + ((size_t)half * XB + slot) * hw * 3 * f1;
         const int cin = cins[k];
         int r;
         if (route[k] == 1) {
-            if ((r = mvs_gru1_gates_h_mfma(hp, ws.wgh, px_d, H, W, ws.g[k], sg, s))) return r;
-            if ((r = mvs_gru1_out_h_mfma(hp, ws.g[k], sg, p[2], p[3], ws.woh, px_d, H, W, ws.c[k], so, s))) return r;
+            if (fused_in)
+                r = mvs_gru1_gates_h_blend_mfma(prev.h_before, ws.c[k], prev.g, prev.so, prev.sg + 2, p[8], p[9], p[4], p[5], hp_w,
+                                                ws.wgh, px_d, H, W, gcur, sg, s);
+            else
+                r = mvs_gru1_gates_h_mfma(hp, ws.wgh, px_d, H, W, gcur, sg, s);
+            if (r) return r;
+            if ((r = mvs_gru1_out_h_mfma(hp, gcur, sg, p[2], p[3], ws.woh, px_d, H, W, ws.c[k], so, s))) return r;
             if (gs && (slot == XB - 1 || d == depth_num - 1) && (e = hipEventRecord(gs->xdone[half], s)) != hipSuccess) return (int)e;
-        } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
-        } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
-        } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
-        } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hp, p, H, W, ws.g[k], ws.c[k], sg, so, s)) {
+        } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s)) {
+        } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s)) {
+        } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s)) {
+        } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s)) {
         } else {
             if ((r = launch_conv2d(xin, cin, hp, F[k], p[0], p[1], H, W, 2 * F[k], ws.g[k], sg, 2, s))) return r;
             if ((r = mvs_gru_gates_f32(ws.g[k], sg, p[2], p[3], p[4], p[5], hp, H, W, F[k], ws.rh, ws.u, s))) return r;
             if ((r = launch_conv2d(xin, cin, ws.rh, F[k], p[6], p[7], H, W, F[k], ws.c[k], so, 1, s))) return r;
         }
-        if (F[k] % 4 == 0)
-            gru_blend_fused_kernel<4><<<mvs_cdiv(hw_ll * F[k] / 4, 256), 256, 0, s>>>(
-                ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
-        else if (F[k] % 2 == 0)
-            gru_blend_fused_kernel<2><<<mvs_cdiv(hw_ll * F[k] / 2, 256), 256, 0, s>>>(
-                ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
-        else
-            gru_blend_fused_kernel<1><<<mvs_cdiv(hw_ll * F[k], 256), 256, 0, s>>>(
-                ws.c[k], so, p[8], p[9], ws.g[k], sg + 2, p[4], p[5], H * W, F[k], hp, hn);
-        if ((r = (int)hipGetLastError())) return r;
-        if (k < 2) return 0;
-        // prob_conv + exp + winner-take-all update (model.py:701-731)
-        const int grid = mvs_cdiv(hw_ll, 256);
-        switch (f3) {
-            case 1: prob_wta_kernel<1><<<grid, 256, 0, s>>>(hn, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
-            case 2: prob_wta_kernel<2><<<grid, 256, 0, s>>>(hn, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
-            case 4: prob_wta_kernel<4><<<grid, 256, 0, s>>>(hn, params[30], params[31], depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
-            default:
-                if ((r = launch_conv2d(hn, f3, nullptr, 0, params[30], params[31], H, W, 1, ws.reg, nullptr, 1, s))) return r;
-                if ((r = mvs_wta_update_f32(ws.reg, depth_values[d], H, W, ws.max_prob, depth_out, ws.exp_sum, s))) return r;
+        // prob_conv + exp + winner-take-all update (model.py:701-731) of plane `dd`, whose final state is `hs`
+        auto prob_wta = [&](const float* hs, int dd) -> int {
+            const int grid = mvs_cdiv(hw_ll, 256);
+            int r2;
+            switch (f3) {
+                case 1: prob_wta_kernel<1><<<grid, 256, 0, s>>>(hs, params[30], params[31], depth_values[dd], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+                case 2: prob_wta_kernel<2><<<grid, 256, 0, s>>>(hs, params[30], params[31], depth_values[dd], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+                case 4: prob_wta_kernel<4><<<grid, 256, 0, s>>>(hs, params[30], params[31], depth_values[dd], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+                default:
+                    if ((r2 = launch_conv2d(hs, f3, nullptr, 0, params[30], params[31], H, W, 1, ws.reg, nullptr, 1, s))) return r2;
+                    if ((r2 = mvs_wta_update_f32(ws.reg, depth_values[dd], H, W, ws.max_prob, depth_out, ws.exp_sum, s))) return r2;
+            }
+            return (int)hipGetLastError();
+        };
+        if (k == 2 && fused_in && (r = prob_wta(hp, d - 1))) return r;     // plane d-1's state exists since this plane's gate convolution
+        if (blend_now) {
+            if (F[k] % 4 == 0)
+                gru_blend_fused_kernel<4><<<mvs_cdiv(hw_ll * F[k] / 4, 256), 256, 0, s>>>(
+                    ws.c[k], so, p[8], p[9], gcur, sg + 2, p[4], p[5], H * W, F[k], hp, hn);
+            else if (F[k] % 2 == 0)
+                gru_blend_fused_kernel<2><<<mvs_cdiv(hw_ll * F[k] / 2, 256), 256, 0, s>>>(
+                    ws.c[k], so, p[8], p[9], gcur, sg + 2, p[4], p[5], H * W, F[k], hp, hn);
+            else
+                gru_blend_fused_kernel<1><<<mvs_cdiv(hw_ll * F[k], 256), 256, 0, s>>>(
+                    ws.c[k], so, p[8], p[9], gcur, sg + 2, p[4], p[5], H * W, F[k], hp, hn);
+            if ((r = (int)hipGetLastError())) return r;
+            if (k == 2 && (r = prob_wta(hn, d))) return r;
         }
         return (int)hipGetLastError();
     };

@@ -36,6 +36,12 @@ struct Gru2dArgs {
     int yadd_stride, yadd_off;
     int planes;                 // BATCH: xa is (planes,H,W,CA), y is (planes,H,W,y_stride)
     int y_stride, y_off;        // pixel stride / first channel of y (0: COUT, 0)
+    // MODE 2: xb is the state that ENTERED the previous plane; the previous plane's blend is evaluated on load
+    const float* c_prev;        // (H,W,CB) raw candidate convolution of the previous plane
+    const float* g_prev;        // (H,W,2*CB) raw gate convolution of the previous plane (update gate = channels [CB,2CB))
+    const double* stats_c; const double* stats_u;          // their LayerNorm moments [sum, sumsq]
+    const float *o_gamma, *o_beta, *u_gamma, *u_beta;
+    float* h_out;               // (H,W,CB): receives the state entering this plane (the tile's own pixels)
 };
 
 constexpr int TH2 = 8, TW2 = 16, PW2 = TW2 + 2;
@@ -95,12 +101,32 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         }
         ra = make_float4(s[0], s[1], s[2], s[3]); rb = make_float4(t[0], t[1], t[2], t[3]);
     }
+    float4 ua = ra, ub = ra, ca = ra, cb = ra;      // MODE 2: LayerNorm affines of the update gate and the candidate
+    if (MODE == 2) {
+        const double cnt = (double)a.H * a.W * CB;
+        auto affine = [&](const double* st, const float* gamma, const float* beta, float4& sc, float4& sh) {
+            double mean = st[0] / cnt;
+            double var = st[1] / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            float s4[4], t4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double inv = (double)gamma[4 * qb + k] / sqrt(var + 1e-12);
+                s4[k] = (float)inv; t4[k] = (float)((double)beta[4 * qb + k] - mean * inv);
+            }
+            sc = make_float4(s4[0], s4[1], s4[2], s4[3]); sh = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        };
+        affine(a.stats_u, a.u_gamma, a.u_beta, ua, ub);
+        affine(a.stats_c, a.o_gamma, a.o_beta, ca, cb);
+    }
     const int bytes_a = a.H * a.W * CA * 4, bytes_b = a.H * a.W * CB * 4;
     const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.xa, 0, bytes_a * (BATCH ? a.planes : 1), 0x00020000);
     const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.xb, 0, bytes_b, 0x00020000);
-    const auto rsrc_g = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 1 ? a.g : a.xb), 0, MODE == 1 ? 2 * bytes_b : bytes_b, 0x00020000);
+    const auto rsrc_g = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 1 ? a.g : MODE == 2 ? a.g_prev : a.xb), 0,
+                                                          MODE != 0 ? 2 * bytes_b : bytes_b, 0x00020000);
+    const auto rsrc_c = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 2 ? a.c_prev : a.xb), 0, bytes_b, 0x00020000);
     // per piece: byte offset relative to the tile's (h0-1, w0-1) pixel, staged column, LDS float offset
-    int poff[NIT], pcol[NIT], loff[NIT], prow[BATCH ? NIT : 1];
+    int poff[NIT], pcol[NIT], loff[NIT], prow[(BATCH || MODE == 2) ? NIT : 1];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         const bool isb = i >= NA;
@@ -110,7 +136,7 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         const int pos = f / cq, q = f % cq;
         const int r = pos / PW2, c = pos - r * PW2;
         pcol[i] = c;
-        if (BATCH) prow[i] = r;
+        if (BATCH || MODE == 2) prow[i] = r;
         poff[i] = ((r * a.W + c) * (isb ? CB : CA) + 4 * q) * 4;
         loff[i] = pos * S + (isb ? CA : 0) + 4 * q;
     }
@@ -119,7 +145,8 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
         return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     };
-    float4 pre[NIT], preg[MODE == 1 ? NB : 1];
+    float4 pre[NIT], preg[MODE != 0 ? NB : 1], prec[MODE == 2 ? NB : 1];
+    unsigned inside = 0;                             // MODE 2: bit i = piece i's position lies inside the image
     auto load_piece = [&](int i, int tile) __attribute__((always_inline)) {
         const int tg = tile < ntiles ? tile : 0;     // past the end: a harmless reload of tile 0
         const int plane = BATCH ? tg / tiles_pp : 0, tl = BATCH ? tg - plane * tiles_pp : tg;
@@ -137,15 +164,35 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
             pre[i] = ldb(rsrc_b, ok ? base * (CB * 4) + poff[i] : (int)0x80000000);
             // the reset gate is channels [0, CB) of the (H, W, 2*CB) gate tensor: pixel stride doubles
             if (MODE == 1) preg[i - NA] = ldb(rsrc_g, ok ? base * (2 * CB * 4) + 2 * poff[i] - 16 * qb : (int)0x80000000);
+            if (MODE == 2) {                         // the update gate is channels [CB, 2*CB) of the previous plane's gate tensor
+                preg[i - NA] = ldb(rsrc_g, ok ? base * (2 * CB * 4) + 2 * poff[i] - 16 * qb + CB * 4 : (int)0x80000000);
+                prec[i - NA] = ldb(rsrc_c, ok ? base * (CB * 4) + poff[i] : (int)0x80000000);
+                const bool in = ok && (unsigned)(h0 - 1 + prow[i]) < (unsigned)a.H;
+                inside = in ? inside | (1u << i) : inside & ~(1u << i);
+            }
         }
     };
     auto sig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); };
-    auto stage_piece = [&](int i, float* buf) __attribute__((always_inline)) {
+    auto tanh_ = [](float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); };
+    auto stage_piece = [&](int i, float* buf, int tile_of) __attribute__((always_inline)) {
         float4 v = pre[i];                           // zeros outside the image (SAME padding)
         if (MODE == 1 && i >= NA) {                  // xb = sigmoid(LN(g_r)) * h (convgru.py:97,101,107)
             const float4 gq = preg[i - NA];
             v.x *= sig(gq.x * ra.x + rb.x); v.y *= sig(gq.y * ra.y + rb.y);
             v.z *= sig(gq.z * ra.z + rb.z); v.w *= sig(gq.w * ra.w + rb.w);
+        }
+        if (MODE == 2 && i >= NA) {                  // xb = u*h + (1-u)*tanh(LN c) of the previous plane (convgru.py:98,102,114-120)
+            const float4 gq = preg[i - NA], cq = prec[i - NA];
+            const float u0 = sig(gq.x * ua.x + ub.x), u1 = sig(gq.y * ua.y + ub.y), u2 = sig(gq.z * ua.z + ub.z), u3 = sig(gq.w * ua.w + ub.w);
+            v.x = u0 * v.x + (1.0f - u0) * tanh_(cq.x * ca.x + cb.x); v.y = u1 * v.y + (1.0f - u1) * tanh_(cq.y * ca.y + cb.y);
+            v.z = u2 * v.z + (1.0f - u2) * tanh_(cq.z * ca.z + cb.z); v.w = u3 * v.w + (1.0f - u3) * tanh_(cq.w * ca.w + cb.w);
+            if (!((inside >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            // the tile's own pixels keep the state: the candidate convolution, the next cell and later planes read it
+            const int r = prow[i], c = pcol[i];
+            if (tile_of < ntiles && r >= 1 && r <= TH2 && c >= 1 && c <= TW2 && ((inside >> i) & 1u) && tid + 256 * (i - NA) < NFB) {
+                const int th = tile_of / a.tiles_w, h0 = th * TH2, w0 = (tile_of - th * a.tiles_w) * TW2;
+                *(float4*)(a.h_out + ((size_t)(h0 - 1 + r) * a.W + (w0 - 1 + c)) * CB + 4 * qb) = v;
+            }
         }
         *(float4*)(buf + loff[i]) = v;
     };
@@ -174,7 +221,7 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) load_piece(i, tile);
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) stage_piece(i, slab);
+    for (int i = 0; i < NIT; ++i) stage_piece(i, slab, tile);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) load_piece(i, tile + stride);
     __syncthreads();
@@ -217,7 +264,7 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) {
-                    if ((i * (NG / 2)) / NIT == g) stage_piece(i, nxt);
+                    if ((i * (NG / 2)) / NIT == g) stage_piece(i, nxt, tile + stride);
                     if (NG / 2 + (i * (NG - NG / 2)) / NIT == g) load_piece(i, tile + 2 * stride);
                 }
 #pragma unroll
@@ -347,6 +394,17 @@ int mvs_gru1_gates_h_mfma(const float* h, const float* wgh, const float* px, int
     Gru2dArgs a{nullptr, h, nullptr, nullptr, nullptr, nullptr, wgh, nullptr, g, stats, H, W, 0, 0,
                 nullptr, 0, px, 48, 0, 1, 0, 0};
     return launch_gru2d<0, 16, 32, 0, true, false>(a, st);
+}
+
+// The same with the previous plane's blend folded in: h_before = the state that entered the previous plane, c_prev /
+// g_prev / their moments = that plane's raw convolutions; h_out receives the state entering this plane.
+int mvs_gru1_gates_h_blend_mfma(const float* h_before, const float* c_prev, const float* g_prev, const double* stats_c,
+                                const double* stats_u, const float* o_gamma, const float* o_beta, const float* u_gamma,
+                                const float* u_beta, float* h_out, const float* wgh, const float* px, int H, int W,
+                                float* g, double* stats, hipStream_t st) {
+    Gru2dArgs a{nullptr, h_before, nullptr, nullptr, nullptr, nullptr, wgh, nullptr, g, stats, H, W, 0, 0,
+                nullptr, 0, px, 48, 0, 1, 0, 0, c_prev, g_prev, stats_c, stats_u, o_gamma, o_beta, u_gamma, u_beta, h_out};
+    return launch_gru2d<0, 16, 32, 2, true, false>(a, st);
 }
 
 // h-part of the candidate convolution on sigmoid(LN(g_r)) * h + precomputed x-part (channels 32..47 of px)
