@@ -833,3 +833,37 @@ def test_recurrent_cells_wavefront_matches_the_cell_by_cell_sweeps(monkeypatch, 
     assert rel_l1(ga, gb) < 1e-5
     for key in pa:
         assert rel_l1(pa[key], pb[key]) < 1e-4 or np.abs(pa[key] - pb[key]).max() < 1e-6, key
+
+
+def test_new_training_entry_points_report_errors_instead_of_launching():
+    """C ABI error behaviour (include/mvsnet_hip.h): null pointers -> MVS_E_BADARG (-1), shapes without a kernel
+    instance -> MVS_E_SHAPE (-2), a workspace that is too small -> MVS_E_WORKSPACE (-3); nothing is launched."""
+    import ctypes as C
+    from mvsnet_amd import _lib as L
+    lib = L.load()
+    P = L.ptr
+    z = lambda *s: torch.zeros(s, device=DEV)
+    D, H, W, Fn = 2, 8, 16, 3                                     # F = 3 has no instance
+    px, wgh, woh, ln = z(D, H, W, 3 * Fn), z(3, 3, Fn, 2 * Fn), z(3, 3, Fn, Fn), z(6, Fn)
+    g, c, rh, h = z(D, H, W, 2 * Fn), z(D, H, W, Fn), z(D, H, W, Fn), z(D + 1, H, W, Fn)
+    stats = torch.zeros((D, 8, 6), device=DEV, dtype=torch.float64)
+    st = L.stream_ptr()
+    assert lib.mvs_gru_train_cell_fwd_f32(P(px), P(wgh), P(woh), P(ln), D, H, W, Fn, P(g), P(c), P(rh), P(h), P(stats), st) == -2
+    assert lib.mvs_gru_train_cell_fwd_f32(None, P(wgh), P(woh), P(ln), D, H, W, 4, P(g), P(c), P(rh), P(h), P(stats), st) == -1
+    assert lib.mvs_gru_train_cell_fwd_f32(P(px), P(wgh), P(woh), P(ln), 0, H, W, 4, P(g), P(c), P(rh), P(h), P(stats), st) == -1
+    part, scratch = torch.zeros((D, 3, 16, 2, Fn), device=DEV, dtype=torch.float64), z(6, H, W, Fn)
+    assert lib.mvs_gru_train_cell_bwd_f32(P(c), P(g), P(c), P(h), P(stats), P(wgh), P(woh), P(ln), D, H, W, Fn, P(px), P(part),
+                                          P(scratch), None, None, st) == -2
+    assert lib.mvs_gru_train_cell_bwd_f32(P(c), P(g), P(c), P(h), P(stats), P(wgh), P(woh), P(ln), D, H, W, 4, None, P(part),
+                                          P(scratch), None, None, st) == -1
+    x, gg, dw = z(D, H, W, 16), z(D, H, W, 32), z(3, 3, 16, 32)
+    need = lib.mvs_conv2d_wgrad_workspace_bytes(D, H, W, 16, 32)
+    ws = torch.empty(need, device=DEV, dtype=torch.uint8)
+    wp = C.c_void_p(ws.data_ptr())
+    assert lib.mvs_conv2d_wgrad_f32(P(x), P(gg), 32, 0, D, H, W, 16, 32, wp, need, P(dw), st) == 0
+    assert lib.mvs_conv2d_wgrad_f32(P(x), P(gg), 32, 0, D, H, W, 16, 32, wp, need - 1, P(dw), st) == -3
+    assert lib.mvs_conv2d_wgrad_f32(P(x), P(gg), 32, 0, D, H, W, 16, 24, wp, need, P(dw), st) == -2      # no (16, 24) instance
+    assert lib.mvs_conv2d_wgrad_f32(P(x), P(gg), 32, 16, D, H, W, 16, 32, wp, need, P(dw), st) == -1     # slice beyond the tensor
+    assert lib.mvs_conv2d_wgrad_f32(P(x), P(gg), 30, 0, D, H, W, 16, 16, wp, need, P(dw), st) == -2      # stride not a multiple of 4
+    assert lib.mvs_conv2d_wgrad_f32(None, P(gg), 32, 0, D, H, W, 16, 32, wp, need, P(dw), st) == -1
+    torch.cuda.synchronize()
