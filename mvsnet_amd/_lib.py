@@ -121,6 +121,14 @@ def ptr(t):
         raise MvsnetHipError("expected a device tensor (no CPU path exists)")
     if not t.is_contiguous():
         raise MvsnetHipError("expected a contiguous tensor")
+    # Kernels launch on HIP's CURRENT device and on torch's current stream of that device
+    # (stream_ptr): a tensor living on another GPU would be dereferenced across devices (a memory
+    # fault without peer access).  One process drives one GPU: shard.bind_device() selects it.
+    cur = torch.cuda.current_device()
+    if t.device.index != cur:
+        raise MvsnetHipError("tensor is on cuda:%s but the current device is cuda:%d -- call "
+                             "torch.cuda.set_device (mvsnet_amd.shard.bind_device) before any library call"
+                             % (t.device.index, cur))
     return C.c_void_p(t.data_ptr())
 
 
@@ -137,7 +145,7 @@ def stream_ptr():
 def ptr_array(tensors):
     arr = (C.c_void_p * len(tensors))()
     for k, t in enumerate(tensors):
-        arr[k] = t.data_ptr() if t is not None else None
+        arr[k] = ptr(t).value if t is not None else None
     return arr
 
 

@@ -19,7 +19,7 @@ SOURCES = ["homography.hip", "cost_volume.hip", "conv3d_scalar.hip", "conv3d_mfm
            "backward.hip", "conv3d_wgrad.hip", "conv3d_c1.hip", "conv3d_k8.hip", "gru_train.hip", "conv2d_wgrad.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-FLAGS += os.environ.get("MVS_EXTRA_HIPCC_FLAGS", "").split()      # developer builds, e.g. -DC8_PROF
+FLAGS += os.environ.get("MVS_EXTRA_HIPCC_FLAGS", "").split()      # developer builds (tools/README.md)
 
 
 def _stale(out, deps):

@@ -68,17 +68,6 @@ struct FuseArgs {
     int slots1, slots2;
 };
 
-// Developer build (-DC8_PROF): workgroup 0 records s_memtime at 5 points of every plane
-#ifdef C8_PROF
-__device__ long long g_c8_prof[8 * 256];
-#define C8_STAMP(slot) do { if (blockIdx.x == 0 && blockIdx.z == 0 && tid == PROF_TID && t < 256) g_c8_prof[(slot) * 256 + t] = __builtin_readcyclecounter(); } while (0)
-#else
-#define C8_STAMP(slot) do {} while (0)
-#endif
-#ifndef PROF_TID
-#define PROF_TID 64
-#endif
-
 template <bool FUSE, bool AFF>
 __global__ void __launch_bounds__(256, 2)
 conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
@@ -100,9 +89,6 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     const int d1 = min(d0 + a.planes_per_wg, a.D);
     const int T = d1 - d0 + 2;                     // input planes d0-1 .. d1
 
-#ifdef C8_PROF
-    { const int t = 0; C8_STAMP(6); }
-#endif
     if (a.wprep) load_prepared_weights(wl, a.wprep, W_FLOATS);
     else for (int i = tid; i < W_FLOATS; i += 256) {
         int j = i & 3;
@@ -352,11 +338,8 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
             if (G >= 6 && G < 6 + NIT) stage_piece(G - 6, q + 1, nxt);
             if (G >= 14 && G < 14 + NIT) load_piece(G - 14, q + 2);
         };
-        C8_STAMP(0);
         if (FUSE) s2_finish();
-        C8_STAMP(1);
         sweep(Pc, cur_buf, extra);                 // planes outside the volume are staged as zeros
-        C8_STAMP(2);
         if (FUSE && q >= d0) {
             if (q & 1) {
                 if (in_vol) s2_sweep(std::false_type{}, cur_buf);
@@ -376,11 +359,8 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
                 }
             }
         }
-        C8_STAMP(3);
         retire(Pc, q - 1);
-        C8_STAMP(4);
         __syncthreads();
-        C8_STAMP(5);
     };
     for (int t = 0; t < T; t += 3) {
         plane(std::integral_constant<int, 0>{}, t);
@@ -408,9 +388,6 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     if (a.stats) stats_commit<COUT>(st_s, st_q, true, slab,
                                     a.stats + (size_t)((blockIdx.x + gridDim.x * blockIdx.z) % (FUSE ? fa.slots1 : 1)) * 2 * COUT,
                                     a.cout_total, 0);
-#ifdef C8_PROF
-    { const int t = 0; C8_STAMP(7); }
-#endif
 }
 
 template <bool FUSE>
@@ -446,21 +423,6 @@ int launch_c8(const ConvArgs& a0, const FuseArgs& fa, hipStream_t st) {
     }
     if (aff) conv3d_c8_kernel<FUSE, true><<<grid, 256, smem, st>>>(a, fa);
     else conv3d_c8_kernel<FUSE, false><<<grid, 256, smem, st>>>(a, fa);
-#ifdef C8_PROF
-    {
-        static int dumped = 0;
-        if (dumped++ == 3) {
-            static long long h[8 * 256];
-            hipDeviceSynchronize();
-            hipMemcpyFromSymbol(h, HIP_SYMBOL(g_c8_prof), sizeof(h));
-            fprintf(stderr, "c8 prof: planes_per_wg %d; kernel entry -> first plane %lld, last barrier -> exit %lld, entry -> exit %lld\n",
-                    a.planes_per_wg, h[1] - h[6 * 256], h[7 * 256] - h[5 * 256 + a.planes_per_wg + 1], h[7 * 256] - h[6 * 256]);
-            for (int t = 1; t < a.planes_per_wg + 2 && t < 256; ++t)
-                fprintf(stderr, "  t=%3d  %6lld %6lld %6lld %6lld %6lld   total %6lld\n", t, h[256 + t] - h[t], h[512 + t] - h[256 + t],
-                        h[768 + t] - h[512 + t], h[1024 + t] - h[768 + t], h[1280 + t] - h[1024 + t], h[1280 + t] - h[1280 + t - 1]);
-        }
-    }
-#endif
     return (int)hipGetLastError();
 }
 

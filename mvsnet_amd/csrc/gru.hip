@@ -496,8 +496,7 @@ GruStreams* gru_streams(hipStream_t caller) {
     struct Slot { hipStream_t caller; GruStreams g; int state; };
     static Slot slots[4];
     static int used = 0;
-    static const bool disabled = getenv("MVS_GRU_ONE_STREAM") != nullptr;
-    if (disabled) return nullptr;
+    if (getenv("MVS_GRU_ONE_STREAM") != nullptr) return nullptr;     // A/B + test switch, read per sweep
     for (int i = 0; i < used; ++i)
         if (slots[i].caller == caller) return slots[i].state == 1 ? &slots[i].g : nullptr;
     if (used == 4) return nullptr;                       // further caller streams run the one-stream sweep

@@ -67,7 +67,10 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
         setattr(config, k, v)
     rank, local_rank, world = sh.rank_world()
     if device is None:
-        device = torch.device("cuda", local_rank)
+        device = sh.bind_device(local_rank)           # one process drives one GPU
+    else:
+        device = torch.device(device)
+        torch.cuda.set_device(device)                 # library launches go to the current device
     output_dir = pl.setup_output_dir(input_dir, config.output_dir)
     gen = make_generator(input_dir, config.view_num, config.width, config.height, config.max_d,
                            config.interval_scale, config.base_image_size, mode="inference",
@@ -177,7 +180,7 @@ def main(argv=None):
                 if not f.startswith(".") and not f.endswith(".txt")]
     import torch
     rank, local_rank, world = sh.rank_world()
-    device = torch.device("cuda", local_rank)
+    device = sh.bind_device(local_rank)
     weights = build_weights(cfg, device, weights_path, args.model_dir, args.ckpt_step, args.extractor)
     total = 0
     for d in dirs:

@@ -31,11 +31,12 @@ def _dev(a, device):
 
 
 def pad_regnet_params(params):
-    """Zero-pads RegNetUS0 parameters of a narrower network_mode (semilite / lite / ultralite: base_filter
-    6 / 4 / 2, mvsnetworks.py:126-127) to the channel counts of 'normal' (base 8, 32-channel volume), the
+    """Zero-pads RegNetUS0 parameters of a narrower network_mode (lite / ultralite: base_filter 4 / 2,
+    mvsnetworks.py:126-127; also 'semilite-py3', base_filter 6 -- the reference's own 'semilite' is base 8 at
+    run time, synthetic.base_divisor) to the channel counts of 'normal' (base 8, 32-channel volume), the
     shapes the fp32-MFMA kernels tile.  Padded kernels are zero and padded gamma / beta are zero, so the
     extra channels carry exact zeros through conv, BatchNorm (0 * xhat + 0) and ReLU and the real channels
-    see the same sums: same function, ~8x (lite) to ~25x (semilite) faster than the shape-generic VALU
+    see the same sums: same function, ~8x (lite) to ~25x (base_filter 6) faster than the shape-generic VALU
     kernels those modes would otherwise fall back to."""
     from .synthetic import make_regnet_params
     target = make_regnet_params("normal")

@@ -29,9 +29,25 @@ def shard(items: Sequence, rank: int, world: int) -> list:
     return [items[i] for i in shard_indices(len(items), rank, world)]
 
 
+def bind_device(local_rank=None):
+    """Makes GPU `local_rank` (default: LOCAL_RANK) this process's current HIP device and returns its
+    torch.device.  Must run before the first library call: kernels launch on the CURRENT device and
+    the library creates its side streams / events there on first use (`_lib.ptr` refuses tensors of
+    any other device).  Raises when the node has fewer GPUs than ranks instead of silently sharing one."""
+    import torch
+    if local_rank is None:
+        local_rank = rank_world()[1]
+    n = torch.cuda.device_count()
+    if not (0 <= local_rank < n):
+        raise RuntimeError("local rank %d needs cuda:%d but only %d GPU(s) are visible" % (local_rank, local_rank, n))
+    torch.cuda.set_device(local_rank)
+    return torch.device("cuda", local_rank)
+
+
 def init_process_group(backend=None):
     """Initialises torch.distributed when WORLD_SIZE > 1 (rendezvous on 127.0.0.1 by default).
-    Returns the module or None for single-process runs."""
+    Returns the module or None for single-process runs.  With the RCCL backend the process is bound
+    to its GPU first and the group is created with that `device_id`."""
     rank, local_rank, world = rank_world()
     if world <= 1:
         return None
@@ -42,7 +58,10 @@ def init_process_group(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if not dist.is_initialized():
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=bind_device(local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return dist
 
 

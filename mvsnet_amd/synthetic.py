@@ -29,8 +29,15 @@ FOCAL_AT_160 = 361.54    # DTU focal length at 1/4 of a 640-wide image
 
 
 def base_divisor(network_mode: str) -> float:
-    """network_mode -> base_divisor, mvsnet/cnn_wrapper/network.py:75-85."""
-    return {"normal": 1.0, "semilite": 4.0 / 3.0, "lite": 2.0, "ultralite": 4.0,
+    """network_mode -> base_divisor, mvsnet/cnn_wrapper/network.py:75-85.
+
+    'semilite' is written `4/3` there, in a Python 2.7 module without `from __future__ import division`
+    (network.py:9 imports only print_function), so at the reference's run time it is the INTEGER 1:
+    semilite towers and regulariser have the channel counts of 'normal' (base_filter 8), and that is
+    what a reference semilite checkpoint holds.  Only the ConvGRU filter counts differ (model.py:641:
+    halved for every mode but 'normal').  'semilite-py3' (not a reference mode) keeps the true-division
+    reading, base_filter 6: channel counts 6/12/24/48 that exercise the shape-generic kernels."""
+    return {"normal": 1.0, "semilite": 1.0, "semilite-py3": 4.0 / 3.0, "lite": 2.0, "ultralite": 4.0,
             "fat": 0.5, "ultrafat": 0.25}[network_mode]
 
 

@@ -96,7 +96,7 @@ def main(argv=None):
     if cfg.input_dir is None:
         ap.error("--input_dir is required")
     rank, local_rank, _world = sh.rank_world()
-    device = torch.device("cuda", local_rank)
+    device = sh.bind_device(local_rank)
     weights = build_weights(cfg, device, args.weights, args.model_dir, args.ckpt_step, args.extractor)
     dirs = [cfg.input_dir] if os.path.isfile(os.path.join(cfg.input_dir, "covisibility.json")) else \
         [os.path.join(cfg.input_dir, f) for f in sorted(os.listdir(cfg.input_dir)) if not f.startswith(".")]

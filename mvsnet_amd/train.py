@@ -14,12 +14,16 @@ What the reference does (train.py:412-523) and how it maps here:
   * tf.train.exponential_decay(base_lr, global_step, stepvalue, gamma) (train.py:256-257), RMSProp / momentum /
     Adam with TensorFlow's defaults and update formulas (train.py:258-266);
   * checkpoints `<model_dir>/<regularization>/<network_mode>/model.ckpt-<step>` (train.py:360-365) written in
-    TensorFlow's own bundle format with the reference's variable names (tf_checkpoint.py), so that either
-    code base can read them; optimiser slots ride along as `<var>/RMSProp`, `<var>/RMSProp_1`, ... and
-    `global_step`.
+    TensorFlow's own bundle format with the reference's variable names (tf_checkpoint.py); the name set is the
+    reference graph's `tf.global_variables()` (what its `tf.train.Saver` restores, predictlib.py:69-76): the
+    trainable variables, optimiser slots `<var>/RMSProp`, `<var>/RMSProp_1`, ... (Adam: also `beta1_power`,
+    `beta2_power`), `global_step`, and the `<layer>/bn/moving_mean|moving_variance` pairs that
+    tf.layers.batch_normalization creates (network.py:492-509) although `training=True` never reads or updates
+    them (written at their initial zeros / ones).  Export is unpinned: no TensorFlow exists offline to restore one.
 The forward / backward of the hot path run in libmvsnet_hip.so (backward.py); the 2D towers are
 feature_net.unet_forward under torch autograd (north_star keeps them on PyTorch-ROCm).
-network_mode: 'normal' natively; 'semilite' / 'lite' (the reference's default) / 'ultralite' zero-padded to the
+network_mode: 'normal' and 'semilite' (= 'normal' channel counts under the reference's Python 2 division) natively;
+'lite' (the reference's default) / 'ultralite' zero-padded to the
 'normal' shapes (padded entries provably stay zero); wider modes raise NotImplementedError.
 Training through the refinement network (`--refinement`, train.py:317-349: all / refine_only / main_only; the towers of
 refine.py under torch autograd, the probability-map gradient through mvs_softargmin_bwd_f32).
@@ -194,9 +198,11 @@ class Trainer:
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     # -- one optimisation step ------------------------------------------------------------------------
-    def loss(self, images, cams, depth_image, depth_num, full_depth=None):
+    def loss(self, images, cams, depth_image, depth_num, full_depth=None, sync="self"):
         """images (N,H,W,3), cams (N,2,4,4) at the output scale, depth_image (H/4,W/4,1) GT.  Returns
-        (loss, less_one, less_three, depth_map) exactly as get_loss (train.py:307-353), batch 1."""
+        (loss, less_one, less_three, depth_map) exactly as get_loss (train.py:307-353), batch 1.
+        `sync`: the cross-replica BatchNorm reducer; "self" = the trainer's own (None unless --sync_bn)."""
+        sync = self.sync if sync == "self" else sync
         from .backward import plane_sweep_depth
         images = torch.as_tensor(images, dtype=torch.float32, device=self.device)
         cams_t = torch.as_tensor(cams, dtype=torch.float32, device=self.device)
@@ -218,7 +224,7 @@ class Trainer:
         if feats.shape[-1] < 32:
             feats = torch.nn.functional.pad(feats, (0, 32 - feats.shape[-1]))      # padded channels: zero cost, zero gradient
         depth, _prob = plane_sweep_depth(feats, transforms, depth_start, depth_interval, self.params.group("regnet"),
-                                         sync=self.sync)
+                                         sync=sync)
         est = depth[None, :, :, None]
         ds = torch.tensor([depth_start], device=self.device)
         de = torch.tensor([depth_end], device=self.device)
@@ -297,7 +303,10 @@ class Trainer:
 
     @torch.no_grad()
     def validate_step(self, images, cams, depth_image, depth_num, full_depth=None):
-        loss, l1, l3, _ = self.loss(images, cams, depth_image, depth_num, full_depth)
+        """Validation is a per-replica computation (train.py:373-409 runs it on one tower): BatchNorm uses this
+        replica's statistics even under --sync_bn, so a rank validating alone issues NO collective (its peers are
+        already in the next training step, whose BatchNorm all-reduces have the same shapes and would pair up)."""
+        loss, l1, l3, _ = self.loss(images, cams, depth_image, depth_num, full_depth, sync=None)
         return loss, l1, l3
 
     # -- checkpoints ----------------------------------------------------------------------------------
@@ -314,6 +323,13 @@ class Trainer:
             for var, arr in native(self.params.named_arrays(buf)).items():
                 tensors[var + "/" + slot] = arr
         tensors["global_step"] = np.asarray(self.global_step, np.int64)
+        for var in [v for v in tensors if v.endswith("/bn/gamma")]:      # created by tf.layers.batch_normalization, never
+            n = tensors[var].shape                                      # updated (no UPDATE_OPS dependency)
+            tensors[var[:-len("gamma")] + "moving_mean"] = np.zeros(n, np.float32)
+            tensors[var[:-len("gamma")] + "moving_variance"] = np.ones(n, np.float32)
+        if self.optimizer == "adam":                  # tf.train.AdamOptimizer's non-slot accumulators after `global_step` updates
+            tensors["beta1_power"] = np.asarray(0.9 ** (self.global_step + 1), np.float32)
+            tensors["beta2_power"] = np.asarray(0.999 ** (self.global_step + 1), np.float32)
         tf_checkpoint.write_checkpoint(prefix, tensors)
         return prefix
 
@@ -417,7 +433,14 @@ def train(args):
             if step % args.display == 0 and rank == 0:
                 print("epoch, %d, step %d, total_step %d, loss = %.4f, (< 1px) = %.4f, (< 3px) = %.4f (%.3f sec/step)"
                       % (epoch, step, tr.global_step, float(loss), float(l1), float(l3), time.time() - t0), flush=True)
-            if not math.isfinite(float(loss)):
+            bad = not math.isfinite(float(loss))
+            if world > 1:                              # decide together: a rank leaving alone strands its peers in the next all-reduce
+                flag = torch.tensor([1.0 if bad else 0.0], device="cuda")
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+                bad = bool(flag.item() > 0)
+            if bad:
+                if world > 1:
+                    torch.distributed.destroy_process_group()
                 raise SystemExit(1)                    # train.py:486-488
             if rank == 0 and (tr.global_step % args.snapshot == 0 or step == steps - 1):
                 print("Saving model to", tr.save(args.model_dir, args.regularization), flush=True)

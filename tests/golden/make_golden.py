@@ -1,11 +1,18 @@
-"""Writes the golden fixtures tests/golden/toy_*.npz from the float64 CPU oracle.
+"""Writes the golden fixtures from the float64 CPU oracle: tests/golden/toy_*.npz (default) and, with
+--full [M c1 c2 c3], the FULL-SIZE fixtures full_<workload>.npz of the BASELINE.json configurations.
 
 The reference (ubiquity6/MVSNet) holds no fixtures and cannot be executed here (TensorFlow 1.12 /
 python2 absent), so these vectors pin the build's own restatement, which is in turn pinned by the
 hand-computed KATs of tests/test_oracle_kat.py.  Inputs are regenerated from seeds
 (mvsnet_amd/synthetic.py); their SHA-256 is stored so RNG drift is detected.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                 # toy fixtures (strict numpy oracle, seconds)
+    python tests/golden/make_golden.py --full          # M, c1, c2 (3D-CNN) and c3 (ConvGRU sweep): minutes, ~20 GB
+
+Full-size fixtures come from oracle/torch_restatement.py in float64 (the strict numpy oracle's arithmetic,
+held to it at ~1e-15 by tests/test_cpu_restatement.py, on all host cores): depth and probability maps as
+float32 (c3: also the winning plane index as uint8), the SHA-256 of the regenerated inputs, and the distance of
+the float32 CPU restatement from the float64 one (the rounding-noise floor a float32 device path is held to).
 """
 import hashlib
 import os
@@ -20,7 +27,45 @@ from oracle import mvsnet_oracle as O          # noqa: E402
 from mvsnet_amd import synthetic as S          # noqa: E402
 
 
+def abs_rel(a, b):
+    return float(np.mean(np.abs(np.asarray(a, np.float64) - b) / np.abs(b)))
+
+
+def full(names):
+    import time
+    import torch
+    from oracle import torch_restatement as TR
+    for name in names:
+        w = S.make_workload(name)
+        sha = hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest()
+        t0 = time.time()
+        if name != "c3":
+            rp = S.make_regnet_params("normal", seed=1, random_affine=True)
+            d, p = TR.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start, w.depth_interval,
+                                                  rp, torch.float64)
+            d32, p32 = TR.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start,
+                                                      w.depth_interval, rp, torch.float32)
+            extra = dict(f32_cpu_abs_rel=abs_rel(d32, d), f32_cpu_prob_mismatch=float((np.abs(p32 - p) > 1e-3).mean()))
+        else:
+            gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
+            say = lambda a, b: print("  c3 plane %d/%d  %.0f s" % (a, b, time.time() - t0), flush=True)
+            d, p, idx = TR.inference_winner_take_all_from_features(w.features, w.cams, w.depth_num, w.depth_start,
+                                                                   w.depth_end, gp, torch.float64, say)
+            d32, p32, i32 = TR.inference_winner_take_all_from_features(w.features, w.cams, w.depth_num, w.depth_start,
+                                                                       w.depth_end, gp, torch.float32)
+            same = i32 == idx
+            extra = dict(index=idx.astype(np.uint8), f32_cpu_plane_agreement=float(same.mean()),
+                         f32_cpu_prob_rel=float(np.max(np.abs(p32[same] - p[same]) / p[same])))
+        np.savez_compressed(os.path.join(HERE, "full_%s.npz" % name), depth=d.astype(np.float32),
+                            prob=p.astype(np.float32), input_sha256=sha, **extra)
+        print("wrote full_%s.npz in %.0f s: %s" % (name, time.time() - t0,
+                                                  {k: v for k, v in extra.items() if k != "index"}), flush=True)
+
+
 def main():
+    if "--full" in sys.argv:
+        names = [a for a in sys.argv[1:] if a in S.WORKLOADS]
+        return full(names or ["c1", "M", "c2", "c3"])
     w = S.make_workload("toy")
     sha = hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest()
     rp = S.make_regnet_params("normal", seed=1, random_affine=True)

@@ -111,3 +111,38 @@ def test_every_package_module_imports_without_a_gpu():
         importlib.import_module("mvsnet_amd." + name)
     for extra in ("bench", "__graft_entry__"):
         importlib.import_module(extra)
+
+
+def test_ptr_refuses_tensors_of_another_device(monkeypatch):
+    """One process drives one GPU: kernels launch on HIP's current device, so a tensor of any other device must be
+    refused before its pointer reaches a launch (multi-GPU inference never bound its device)."""
+    import torch
+    from mvsnet_amd import _lib
+
+    class FakeDev:
+        index = 1
+
+    class FakeTensor:
+        is_cuda = True
+        device = FakeDev()
+
+        def is_contiguous(self):
+            return True
+
+        def data_ptr(self):
+            return 0x1000
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    with pytest.raises(_lib.MvsnetHipError, match="current device"):
+        _lib.ptr(FakeTensor())
+    with pytest.raises(_lib.MvsnetHipError, match="current device"):
+        _lib.ptr_array([None, FakeTensor()])
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+    assert _lib.ptr(FakeTensor()).value == 0x1000
+
+
+def test_bind_device_refuses_a_rank_without_a_gpu(monkeypatch):
+    import torch
+    from mvsnet_amd import shard
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    with pytest.raises(RuntimeError, match="only 2 GPU"):
+        shard.bind_device(3)

@@ -171,3 +171,17 @@ def test_upstream_pair_txt_project(tmp_path):
     assert np.array_equal(in_images[3], in_images[0]) and np.array_equal(out_cams[4], out_cams[0])
     np.testing.assert_allclose(out_cams[0, 1, 3], [425.0, 2.65, 16, 425.0 + 2.65 * 16])   # 29-word cams + max_d
     np.testing.assert_allclose(out_cams[1, 0, 0, 3], -30.0)
+
+
+def test_semilite_has_the_reference_runtime_channel_counts():
+    """network.py:75-76 writes `self.base_divisor = 4/3` in a Python 2.7 module with no `division` import
+    (network.py:9): integer 1 at run time, so 'semilite' networks are 'normal'-sized (base_filter 8, 32-channel
+    features) and only the ConvGRU filters are halved (model.py:641-645)."""
+    from mvsnet_amd import synthetic as S
+    assert S.base_filter("semilite") == 8 == S.base_filter("normal")
+    assert S.make_workload("toy", "semilite").channels == 32
+    assert S.gru_filters("semilite") == (8, 2, 1) and S.gru_filters("normal") == (16, 4, 2)
+    assert S.base_filter("semilite-py3") == 6 and S.base_filter("lite") == 4 and S.base_filter("fat") == 16
+    a = S.make_regnet_params("semilite", seed=1)
+    b = S.make_regnet_params("normal", seed=1)
+    assert all(a[k]["w"].shape == b[k]["w"].shape for k in b)

@@ -641,7 +641,7 @@ def test_recurrent_regularisation_gradients_match_autograd(mode, C):
     assert abs(float(p64["prob_b"].grad)) < 1e-12 and abs(float(pt["prob_b"].grad)) < 1e-5
 
 
-@pytest.mark.parametrize("mode", ["normal", "lite", "semilite", "ultralite"])
+@pytest.mark.parametrize("mode", ["normal", "lite", "semilite-py3", "ultralite"])
 def test_gru_trainer_reduces_the_loss_and_round_trips_its_checkpoint(tmp_path, mode):
     from mvsnet_amd import model as M
     from mvsnet_amd import tf_checkpoint
@@ -767,9 +767,9 @@ def test_full_size_conv_gru_sweep_backward_is_the_directional_derivative():
     assert abs(num_w - ana_w) < 2e-2 * max(abs(ana_w), 1.0), (num_w, ana_w)
 
 
-@pytest.mark.parametrize("mode", ["semilite", "ultralite"])
+@pytest.mark.parametrize("mode", ["semilite-py3", "ultralite"])
 def test_trainer_runs_the_other_narrow_modes(mode):
-    """network.py:75-85: base_filter 6 ('semilite': channel counts 6 / 12 / 24 / 48, outside the HIP GroupNorm tiling ->
+    """network.py:75-85: base_filter 6 ('semilite-py3': channel counts 6 / 12 / 24 / 48, outside the HIP GroupNorm tiling ->
     torch group_norm) and 2 ('ultralite'); the regulariser trains zero-padded as in 'lite'."""
     from mvsnet_amd import train as T
     images, cams, gt, D = _train_batch()

@@ -120,3 +120,48 @@ def test_gradient_averaging_world_size_2_over_gloo():
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["replicas_equal"]
     assert math.isclose(res["avg"], 1.5) and math.isclose(res["total"], 1.5 * res["n"])
+
+
+def test_saved_checkpoint_holds_the_reference_graphs_global_variables(tmp_path):
+    """predictlib.py:69-76 restores tf.train.Saver(tf.global_variables()): besides the trainable variables that
+    list holds every BatchNorm layer's moving_mean / moving_variance (tf.layers.batch_normalization creates them,
+    network.py:492-509, although training=True never reads them), the optimiser slots, Adam's beta powers and
+    global_step.  Trainer.save must write that whole name set or the reference restore fails with NotFound."""
+    from mvsnet_amd.train import Trainer
+    from mvsnet_amd import tf_checkpoint as ck
+    for opt, slots in (("rmsprop", ("RMSProp", "RMSProp_1")), ("adam", ("Adam", "Adam_1"))):
+        tr = Trainer("normal", "cpu", opt, 1e-3, 10000, 0.9, "l1", 1.0, 1.0, 1.0, True, seed=0)
+        prefix = tr.save(str(tmp_path / opt), "3DCNN")
+        names = {n for n, _s, _d in ck.list_variables(prefix)}
+        trainable = set(ck.variable_names("normal", "3DCNN").values())
+        bn_layers = sorted(v[:-len("/gamma")] for v in trainable if v.endswith("/bn/gamma"))
+        assert len(bn_layers) == 10                                  # RegNetUS0's conv_bn / deconv_bn layers
+        want = set(trainable) | {"global_step"}
+        want |= {v + "/" + s for v in trainable for s in slots}
+        want |= {b + "/moving_mean" for b in bn_layers} | {b + "/moving_variance" for b in bn_layers}
+        if opt == "adam":
+            want |= {"beta1_power", "beta2_power"}
+        assert names == want
+        got = ck.read_checkpoint(prefix, [bn_layers[0] + "/moving_mean", bn_layers[0] + "/moving_variance"])
+        assert np.all(got[bn_layers[0] + "/moving_mean"] == 0) and np.all(got[bn_layers[0] + "/moving_variance"] == 1)
+
+
+def test_validation_never_takes_the_cross_replica_batchnorm_path():
+    """A rank validating alone (train.py:373-409 validates on one tower) must not issue collectives its peers do not
+    match: validate_step passes sync=None whatever --sync_bn configured."""
+    import inspect
+    from mvsnet_amd.train import Trainer
+    src = inspect.getsource(Trainer.validate_step)
+    assert "sync=None" in src
+    seen = {}
+
+    class T(Trainer):
+        def __init__(self):
+            self.sync = object()                                    # stands for an active SyncBN reducer
+
+        def loss(self, *a, sync="self", **k):
+            seen["sync"] = sync
+            z = torch.zeros(())
+            return z, z, z, z
+    T().validate_step(None, None, None, 8)
+    assert seen["sync"] is None
