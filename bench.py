@@ -10,7 +10,10 @@ A step = one features->depth pass of the metric workload (BASELINE.json: N=5 vie
 cost volume -> RegNetUS0 -> soft-argmin + probability map, inputs (feature maps, cameras, weights)
 resident in HBM.  Reference views are independent, so ranks shard them with no
 data-path collective ("scaling": "weak"); value = depth maps of all ranks / max-over-ranks time.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  After the timed region (never inside it) the same process adds informative records
+to that line: the median of repeated blocks of the same K steps, in-pipeline times of every RegNetUS0 layer
+(`roofline_kernels`), and -- single GPU only -- configs[1] (c2, 288x216, D=192) and configs[2] (c3, ConvGRU sweep,
+400x300, D=256) with their rates and their distance from the committed float64 fixtures (tests/golden/full_*.npz).
 """
 from __future__ import annotations
 
@@ -53,6 +56,25 @@ def algorithmic_work(view_num, D, H, W, C, base=8):
     conv_flops = 2.0 * mac * vox
     soft_bytes = vox * 4 + 2 * H * W * 4
     return warp_bytes, conv_flops, soft_bytes
+
+
+# RegNetUS0 layers in the library's weight order (mvs_profile_layers_ms): name, MACs per FULL-resolution voxel
+# in units of base^2 * 27 (see algorithmic_work), i.e. flops = 2 * 27 * factor * voxels
+LAYERS = ["3dconv1_0", "3dconv2_0", "3dconv3_0", "3dconv0_1", "3dconv1_1", "3dconv2_1", "3dconv3_1", "3dconv4_0",
+          "3dconv5_0", "3dconv6_0", "3dconv6_2"]
+
+
+def layer_flops(C, b, vox):
+    mac = {"3dconv0_1": C * b, "3dconv1_0": C * 2 * b / 8, "3dconv1_1": 2 * b * 2 * b / 8, "3dconv2_0": 2 * b * 4 * b / 64,
+           "3dconv2_1": 4 * b * 4 * b / 64, "3dconv3_0": 4 * b * 8 * b / 512, "3dconv3_1": 8 * b * 8 * b / 512,
+           "3dconv4_0": 8 * b * 4 * b / 512, "3dconv5_0": 4 * b * 2 * b / 64, "3dconv6_0": 2 * b * b / 8, "3dconv6_2": b * 1}
+    return {k: 2.0 * 27 * v * vox for k, v in mac.items()}
+
+
+def fixture(name):
+    """tests/golden/full_<name>.npz (float64 CPU oracle outputs, generator committed beside them) or None."""
+    path = os.path.join(ROOT, "tests", "golden", "full_%s.npz" % name)
+    return np.load(path) if os.path.exists(path) else None
 
 
 def pmc_traffic():
@@ -114,6 +136,82 @@ def cpu_baseline(workload, rp, budget_s=20.0, gpu_depth=None):
                       "of the reference; TensorFlow reference not runnable offline) in %.1f s" % (n_done, w.name, el)}
 
 
+def timed_block(step, steps):
+    """One block of `steps` steps, bracketed like the timed region (single process); returns seconds."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i, False)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def extra_config_3dcnn(name, dev, steps=10):
+    """A second 3D-CNN configuration (c2 = BASELINE.json configs[1]) on this GPU: rate + distance from its fixture.
+    Weights are the fixture's (seed 1, random BatchNorm affine); speed does not depend on their values."""
+    from mvsnet_amd import synthetic as S
+    from mvsnet_amd.model import DepthPlan, MVSNetWeights
+    w = S.make_workload(name)
+    weights = MVSNetWeights.from_numpy("normal", regnet=S.make_regnet_params("normal", seed=1, random_affine=True), device=dev)
+    feats, cams = torch.as_tensor(w.features).to(dev), torch.as_tensor(w.cams).to(dev)
+    plan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", dev)
+
+    def step(i, _r):
+        plan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
+        plan.run_3dcnn(feats, w.depth_start, w.depth_interval)
+    for i in range(3):
+        step(i, False)
+    el = timed_block(step, steps)
+    out = {"workload": "%s: N=%d, D=%d, %dx%d, 3D-CNN" % (name, w.view_num, w.depth_num, w.width, w.height),
+           "depth_maps_per_s": steps / el, "ms_per_depth_map": el / steps * 1e3, "steps": steps}
+    g = fixture(name)
+    if g is not None:
+        d = plan.depth.cpu().numpy().astype(np.float64)
+        p = plan.prob.cpu().numpy().astype(np.float64)
+        out["abs_rel_vs_fixture"] = float(np.mean(np.abs(d - g["depth"]) / g["depth"]))
+        out["prob_mismatch_vs_fixture"] = float((np.abs(p - g["prob"]) > 1e-3).mean())
+        out["fixture"] = "tests/golden/full_%s.npz (float64 CPU oracle; float32 CPU restatement lands at %.2e)" % (
+            name, float(g["f32_cpu_abs_rel"]))
+    del plan
+    torch.cuda.empty_cache()
+    return out
+
+
+def extra_config_gru(name, dev, steps=5):
+    """configs[2] (c3): the ConvGRU + winner-take-all sweep: rate, time per plane, agreement with its fixture."""
+    from mvsnet_amd import synthetic as S
+    from mvsnet_amd.model import DepthPlan, MVSNetWeights, wta_depth_values
+    w = S.make_workload(name)
+    gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=dev)
+    feats, cams = torch.as_tensor(w.features).to(dev), torch.as_tensor(w.cams).to(dev)
+    dv = wta_depth_values(w.depth_num, w.depth_start, w.depth_end, False)
+    plan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "GRU", dev)
+
+    def step(i, _r):
+        plan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
+        plan.run_gru(feats, dv)
+    for i in range(2):
+        step(i, False)
+    el = timed_block(step, steps)
+    flops = 2.0 * 23238 * w.depth_num * w.height * w.width          # SURVEY 8a R9: 23 238 MAC per pixel and plane
+    out = {"workload": "%s: N=%d, D=%d, %dx%d, ConvGRU sweep + winner-take-all" % (name, w.view_num, w.depth_num, w.width, w.height),
+           "depth_maps_per_s": steps / el, "ms_per_depth_map": el / steps * 1e3, "ms_per_plane": el / steps / w.depth_num * 1e3,
+           "achieved_tflops": flops * steps / el / 1e12, "steps": steps}
+    g = fixture(name)
+    if g is not None:
+        d = plan.depth.cpu().numpy()
+        p = plan.prob.cpu().numpy().astype(np.float64)
+        same = np.abs(d - g["depth"]) <= 1e-6 * g["depth"]
+        out["plane_agreement_vs_fixture"] = float(same.mean())
+        out["prob_rel_max_on_agreeing_pixels"] = float(np.max(np.abs(p[same] - g["prob"][same]) / g["prob"][same]))
+        out["fixture"] = "tests/golden/full_%s.npz (float64 CPU oracle; float32 CPU restatement: agreement %.5f, prob rel max %.1e)" % (
+            name, float(g["f32_cpu_plane_agreement"]), float(g["f32_cpu_prob_rel"]))
+    del plan
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +227,9 @@ def main():
     ap.add_argument("--regularization", default="3DCNN", choices=["3DCNN", "GRU"],
                     help="GRU = R-MVSNet recurrent sweep (config 3); reported as an extra, not the metric")
     ap.add_argument("--extractor", choices=("hip", "torch"), default="hip", help="2D towers for --with-images")
-    ap.add_argument("--no-extra", action="store_true", help="skip the informative two-stream pass")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the informative records (repeated blocks, two-stream pass, c2 / c3 configurations)")
+    ap.add_argument("--blocks", type=int, default=5, help="repeated blocks of --steps steps after the timed region")
     ap.add_argument("--with-images", action="store_true",
                     help="also time images->depth (adds the PyTorch UNetDS2GN towers)")
     args = ap.parse_args()
@@ -142,6 +242,11 @@ def main():
     # one rank per GPU; MVS_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the
     # multi-process path on a 1-GPU box (ranks then share device 0)
     ndev = torch.cuda.device_count()
+    if world > 1 and os.environ.get("MVS_DIST_BACKEND", "nccl") == "nccl" and ndev < world:
+        raise SystemExit("bench.py --gpus %d over RCCL needs %d GPUs on this node, found %d (one rank per GPU; "
+                         "MVS_DIST_BACKEND=gloo rehearses the multi-process path on fewer)" % (args.gpus, world, ndev))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch N ranks with torch.distributed.run" % (args.gpus, world))
     dev_index = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -252,8 +357,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rank_rates = [args.steps / elapsed]
     if dist:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)                          # per-rank times: stragglers show in the record
+        rank_rates = [args.steps / float(e.item()) for e in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -274,6 +383,28 @@ def main():
     warp_bytes, conv_flops, soft_bytes = algorithmic_work(w.view_num, w.depth_num, w.height, w.width,
                                                          w.channels, S.base_filter(args.network_mode))
     depth_np = plan.depth.cpu().numpy()
+    # every RegNetUS0 layer inside a depth map (untimed pass; the library brackets each launch with HIP events on the
+    # stream it goes to)
+    layer_ms = (ctypes.c_double * 11)()
+    layer_n = ctypes.c_int(0)
+    _lib.check(lib.mvs_profile_layers(1), "mvs_profile_layers")
+    for i in range(min(args.steps, 20)):
+        step(i, False)
+    torch.cuda.synchronize()
+    _lib.check(lib.mvs_profile_layers_ms(layer_ms, ctypes.byref(layer_n)), "mvs_profile_layers_ms")
+    _lib.check(lib.mvs_profile_layers(0), "mvs_profile_layers")
+    # the same K steps again, several times: the headline is one sample of a noisy quantity (clock ramps, DVFS)
+    block_rates = []
+    if not args.no_extra and args.blocks > 0:
+        for _ in range(args.blocks):
+            if dist:
+                dist.barrier()
+            eb = timed_block(step, args.steps)
+            if dist:
+                tb = torch.tensor([eb], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+                eb = float(tb.item())
+            block_rates.append(world * args.steps / eb)
 
     if rank == 0:
         tr = pmc_traffic()
@@ -305,6 +436,24 @@ def main():
             dominant = kernels[-1]
         else:
             dominant = max(kernels, key=lambda k: k["ms"])
+        if layer_n.value > 0:
+            lf = layer_flops(w.channels, S.base_filter(args.network_mode), w.depth_num * w.height * w.width)
+            fused = layer_ms[LAYERS.index("3dconv1_0")] == 0.0 and layer_ms[LAYERS.index("3dconv0_1")] > 0.0
+            for li, name in enumerate(LAYERS):
+                ms = layer_ms[li]
+                if ms <= 0.0:
+                    continue
+                fl = lf[name] + (lf["3dconv1_0"] if (fused and name == "3dconv0_1") else 0.0)
+                row = {"kernel": "%s%s (in-pipeline, HIP events around the launch)" % (name, " + 3dconv1_0 fused" if (fused and name == "3dconv0_1") else ""),
+                       "ms": ms, "algorithmic_flops": fl, "launches_timed": layer_n.value}
+                if name == "3dconv6_2":                     # 8 -> 1 channels: reads two 8-channel volumes, writes one channel
+                    by = w.depth_num * w.height * w.width * (2 * 8 + 1) * 4
+                    row.update({"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": by})
+                else:
+                    row.update({"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS})
+                kernels.append(row)
         out = {
             "metric": "depth maps/sec (N=5, D=192, 160x128)" if args.workload == "M" else "depth maps/sec",
             "value": world * args.steps / elapsed,
@@ -323,7 +472,15 @@ def main():
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
             "roofline_kernels": kernels,
             "depth_checksum": float(np.float64(depth_np).sum()),
+            "per_rank_depth_maps_per_s": {"min": min(rank_rates), "max": max(rank_rates), "ranks": rank_rates},
         }
+        chain = ["3dconv2_0", "3dconv3_0", "3dconv3_1", "3dconv4_0", "3dconv5_0"]
+        if layer_n.value > 0:
+            out["low_resolution_chain_us"] = 1e3 * sum(layer_ms[LAYERS.index(n_)] for n_ in chain)
+        if block_rates:
+            out["repeat_blocks"] = {"blocks": len(block_rates), "steps_per_block": args.steps,
+                                    "median": float(np.median(block_rates)), "min": min(block_rates), "max": max(block_rates),
+                                    "values": block_rates}
         out["roofline"]["kernel"] = dominant["kernel"]
         out["roofline"]["traffic_source"] = tr.get("source")
         if args.with_images:
@@ -366,6 +523,10 @@ def main():
                 step2(i)
             torch.cuda.synchronize()
             out["depth_maps_per_s_two_streams"] = args.steps / (time.perf_counter() - t2)
+        if world == 1 and n_streams == 1 and not args.no_extra and args.workload == "M" and args.network_mode == "normal":
+            # BASELINE.json configs[1] and configs[2] on this GPU, each with its distance from the committed fixture
+            out["config_c2"] = extra_config_3dcnn("c2", dev)
+            out["config_c3_gru"] = extra_config_gru("c3", dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, rp, args.cpu_budget, depth_np)
         print(json.dumps(out), flush=True)

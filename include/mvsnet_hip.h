@@ -191,6 +191,15 @@ int mvs_deconv2d_gn_f32(const float* x, const double* stats, const float* gamma,
  * the number of samples, and clears them.  Do not enable during hipGraph capture. */
 int mvs_profile_dominant(int enable);
 int mvs_profile_dominant_ms(double* avg_ms, int* count);
+/* Per-layer timing inside a depth map (bench.py's `roofline_kernels` rows of the low-resolution layers): while
+ * enabled, every mvs_regnet_us0_*_f32 call brackets EACH of its layer launches with HIP events on the stream that
+ * launch goes to (the branch layers' side stream included), up to 32 calls.  mvs_profile_layers_ms waits for the
+ * events and returns, for the 11 layers in weight order (3dconv1_0 2_0 3_0 0_1 1_1 2_1 3_1 4_0 5_0 6_0 6_2), the
+ * average duration in milliseconds (the fused 3dconv0_1 + 3dconv1_0 pass reports its time under 3dconv0_1 and 0 under
+ * 3dconv1_0) and the number of calls sampled.  Every event costs a few microseconds of device idle time: use it
+ * outside timed regions; not during hipGraph capture. */
+int mvs_profile_layers(int enable);
+int mvs_profile_layers_ms(double* avg_ms11, int* count);
 int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int cin, int base,
                        const float* const* weights, const float* const* gammas,
                        const float* const* betas, float eps, void* workspace,

@@ -339,6 +339,7 @@ static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t
         if (Cin == 1) return mvs_conv3d_in1_launch(a, Cout, st);     // input gradient of the one-channel output layer
         if (Cin == 8) return mvs_conv3d_k8_launch(a, Cout, st);      // input gradient of 3dconv0_1 (8 -> 32)
         if (a.wprep_bf && mvs_conv3d_bf16x3_supported(Cin, Cout)) return mvs_conv3d_s1_bf16x3(a, Cin, Cout, st);
+        if (mvs_conv3d_os_covers(0, Cin, Cout)) return mvs_conv3d_os_launch(a, 0, Cin, Cout, st);     // low-resolution levels
         if (Cin == 32 && Cout == 8 && !a.x2 && !g_generic_c8) {
             int rc = mvs_conv3d_c8_launch(a, st);
             if (rc != MVS_E_SHAPE) return rc;            // >= 2 GB volumes stay on the generic kernel
@@ -355,6 +356,7 @@ static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t
     }
     auto pad_before = [](int n) { int o = (n + 1) / 2; int t = (o - 1) * 2 + 3 - n; return t < 0 ? 0 : t / 2; };
     a.pd = pad_before(a.D); a.ph = pad_before(a.H); a.pw = pad_before(a.W);
+    if (mvs_conv3d_os_covers(1, Cin, Cout)) return mvs_conv3d_os_launch(a, 1, Cin, Cout, st);
     return mvs_conv3d_s2_mfma(a, Cin, Cout, st);
 }
 
@@ -416,6 +418,7 @@ __global__ void weight_layout_kernel(const float* __restrict__ w, int kind, int 
 }  // namespace
 
 int mvs_conv_weight_layout(const float* w, int kind, int Cin, int Cout, float* out, hipStream_t st) {
+    if (mvs_conv3d_os_covers(kind, Cin, Cout)) return mvs_conv3d_os_weight_layout(w, kind, Cin, Cout, out, st);
     const int G = conv_coutg(kind, Cin, Cout);
     if (G == 0 || (Cin % 4)) return MVS_E_SHAPE;
     const int total = 27 * Cin * Cout;

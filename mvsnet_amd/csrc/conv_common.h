@@ -161,6 +161,10 @@ int mvs_conv3d_c8_launch(const ConvArgs& a, hipStream_t st);      // 32 -> 8 str
 // slots1 / slots2 > 1: the BatchNorm sums go to (slots, 2, C) partial rows (workgroup id modulo slots), see BnSrc::nslot
 int mvs_conv3d_c8_s2_launch(const ConvArgs& a, const float* w2, float* y2, double* stats2, hipStream_t st,
                             int slots1 = 1, int slots2 = 1);
+// output-stationary block kernels of the low-resolution levels (conv3d_os.hip); kind: 0 stride 1, 1 stride 2, 2 transposed
+bool mvs_conv3d_os_covers(int kind, int Cin, int Cout);
+int mvs_conv3d_os_weight_layout(const float* w, int kind, int Cin, int Cout, float* out, hipStream_t st);
+int mvs_conv3d_os_launch(const ConvArgs& a, int kind, int Cin, int Cout, hipStream_t st);
 // opt-in split-precision stride-1 path (conv3d_bf16x3.hip)
 bool mvs_conv3d_bf16x3_supported(int Cin, int Cout);
 int mvs_conv3d_s1_bf16x3(const ConvArgs& a, int Cin, int Cout, hipStream_t st);

