@@ -475,3 +475,44 @@ def test_device_matches_committed_golden_fixtures():
                                             weights=weights, features=t(w.features))
     d = n(depth)[0, :, :, 0]
     assert (np.abs(d - g["depth"]) <= 1e-6 * g["depth"]).mean() > 0.98
+
+
+def test_lds_staged_cost_volume_matches_the_register_cache_kernel():
+    """The opt-in LDS-staged sweep (MVS_CV_LDS=1, cost_volume_lds_kernel) against the default kernel in a child process
+    (the switch is read once per process): the metric workload, where every source footprint fits the LDS budget, and
+    the nearest 32 planes of c3 (400 x 300), where a sample point moves 1.4 pixels per plane and the footprints exceed the LDS
+    budget, so the rounds leave the staged path for the exact direct one."""
+    import os, subprocess, sys, tempfile
+    code = r'''
+import ctypes, sys, numpy as np, torch
+from mvsnet_amd import _lib, synthetic as S
+from mvsnet_amd.model import cost_volume
+from mvsnet_amd.homography_warping import homography_transforms
+out = {}
+for name in ("M", "c3"):
+    w = S.make_workload(name)
+    f = torch.as_tensor(w.features).cuda()
+    T8 = homography_transforms(torch.as_tensor(w.cams).cuda(), w.depth_num, w.depth_start, w.depth_interval)
+    r = ctypes.c_int(0)
+    _lib.load().mvs_cost_volume_fallback_rounds(ctypes.byref(r))
+    n = w.depth_num if name == "M" else 32
+    cv = cost_volume(f[0], f[1:], T8, 0, n, "mem")
+    torch.cuda.synchronize()
+    _lib.load().mvs_cost_volume_fallback_rounds(ctypes.byref(r))
+    out[name] = cv[:: max(1, n // 6)].cpu().numpy()
+    out[name + "_fallback"] = np.asarray(r.value)
+np.savez(sys.argv[1], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("reg", {}), ("lds", {"MVS_CV_LDS": "1"})):
+            path = os.path.join(td, tag + ".npz")
+            subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env={**os.environ, **env, "PYTHONPATH": root})
+            res[tag] = dict(np.load(path))
+    assert int(res["reg"]["M_fallback"]) == 0 and int(res["lds"]["M_fallback"]) == 0       # M stays on the staged path
+    assert int(res["lds"]["c3_fallback"]) > 0                                               # c3's near planes exercise the direct path
+    for name in ("M", "c3"):
+        a, b = res["reg"][name], res["lds"][name]
+        bad = np.abs(a - b) > 1e-5 + 1e-4 * np.abs(a)
+        assert bad.mean() < 1e-3, (name, float(bad.mean()))          # rcp vs division: a flipped floor() moves a whole tap
