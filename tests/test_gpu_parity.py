@@ -305,6 +305,28 @@ def test_regnet_matches_oracle(mode, shape, pad):
     np.testing.assert_allclose(got, exp, rtol=1e-3, atol=2e-4)
 
 
+def test_fat_mode_matches_oracle():
+    """network_mode 'fat' (network.py:82-83: base_divisor 0.5, base_filter 16, a 64-channel volume): wider than the shapes
+    the MFMA kernels tile, so RegNetUS0 runs on the shape-generic kernels; the regulariser alone and features -> depth."""
+    from mvsnet_amd.model import MVSNetWeights, RegNetWeights, regnet_us0, inference_mem
+    assert S.base_filter("fat") == 16
+    params = S.make_regnet_params("fat", seed=11, random_affine=True)
+    rs = np.random.RandomState(13)
+    cost = np.abs(rs.standard_normal((8, 8, 16, 64))).astype(np.float32)
+    wts = RegNetWeights(params, DEV)
+    assert wts.cin == 64 and wts.cin_native == 64
+    got = n(regnet_us0(t(cost), wts))
+    exp = O.regnet_us0(cost, params, np.float64)
+    assert rel_l1(got, exp) < 2e-5
+    w = S.make_workload("toy", network_mode="fat")
+    assert w.channels == 64
+    weights = MVSNetWeights.from_numpy("fat", regnet=params, device=DEV)
+    depth, _prob = inference_mem(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_interval, "fat",
+                                 weights=weights, features=t(w.features))
+    ed, _ep = O.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start, w.depth_interval, params, False, np.float64)
+    assert float(np.mean(np.abs(n(depth)[0, :, :, 0] - ed) / ed)) < 1e-4
+
+
 # ---- R6 / R7 -------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("inverse", [False, True])
 def test_softargmin_prob_matches_oracle(inverse):

@@ -159,3 +159,16 @@ def test_lite_mode_from_images_runs_padded_regulariser_and_torch_towers():
     ed, _ep = O.inference_mem_from_features(feats, cams, D, start, interval, rp, False, np.float64)
     d = depth.cpu().numpy()[0, :, :, 0]
     assert float(np.mean(np.abs(d - ed) / ed)) < 1e-3
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+@pytest.mark.parametrize("upsample", [False, True])
+@pytest.mark.parametrize("conf", [False, True])
+@pytest.mark.parametrize("network", ["original", "unet"])
+def test_depth_refine_on_the_device_matches_oracle(network, conf, upsample, stereo):
+    """SURVEY 8f f3 on the device: depth_refine (model.py:753-811) with both refinement towers (mvsnetworks.py:178-193,
+    261-324) on cuda -- TF1 resize_bilinear, SAME-padded biased convolutions, transposed convolutions cropped at the end,
+    residual re-scaling -- against the float64 numpy oracle, every flag combination of --upsample_before_refinement /
+    --refine_with_confidence / --refine_with_stereo."""
+    from tests.test_refine_and_fusion import _case
+    _case(network, conf, upsample, 11 + 2 * conf + upsample, stereo=stereo, device=DEV)

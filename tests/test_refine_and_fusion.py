@@ -35,7 +35,7 @@ def test_refine_tables_match_reference_topology():
     assert sorted(R.REFINE_UNET) == sorted(O.REFINE_UNET) and len(R.REFINE_UNET) == 28
 
 
-def _case(network_type, conf, upsample, seed, stereo=False):
+def _case(network_type, conf, upsample, seed, stereo=False, device="cpu"):
     from mvsnet_amd import refine as R
     rs = np.random.RandomState(seed)
     h, w, H, W = 16, 16, 32, 32                         # unet: 4 stride-2 levels need /16 at the tower's resolution
@@ -44,10 +44,12 @@ def _case(network_type, conf, upsample, seed, stereo=False):
     image = rs.standard_normal((1, H, W, 3)).astype(np.float32)
     partner = rs.standard_normal((1, H, W, 3)).astype(np.float32) if stereo else None
     params = R.make_refine_params(network_type, "normal", 3 + 1 + int(conf) + (3 if stereo else 0), seed)
-    net = R.RefineNet(params, network_type, "cpu")
-    got, got_res = R.depth_refine(torch.as_tensor(depth), torch.as_tensor(image), torch.as_tensor(prob), 192, 425.0, 2.65,
+    net = R.RefineNet(params, network_type, device)
+    dv = lambda a: torch.as_tensor(a).to(device)
+    got, got_res = R.depth_refine(dv(depth), dv(image), dv(prob), 192, 425.0, 2.65,
                                   net, upsample_depth=upsample, refine_with_confidence=conf,
-                                  stereo_image=torch.as_tensor(partner) if stereo else None)
+                                  stereo_image=dv(partner) if stereo else None)
+    got, got_res = got.cpu(), got_res.cpu()
     exp, exp_res = O.depth_refine(depth[0], image[0], prob[0], 192, 425.0, 2.65, params, network_type,
                                   upsample_depth=upsample, refine_with_confidence=conf, dtype=np.float64,
                                   stereo_image=partner[0] if stereo else None)
