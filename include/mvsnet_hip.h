@@ -204,6 +204,14 @@ int mvs_profile_dominant_ms(double* avg_ms, int* count);
  * outside timed regions; not during hipGraph capture. */
 int mvs_profile_layers(int enable);
 int mvs_profile_layers_ms(double* avg_ms11, int* count);
+/* RegNetUS0 on a batch (FLAGS.batch_size > 1, model.py:466-469): the reference's BatchNorm layers normalise with
+ * the statistics of the whole batch (B,D,H,W) (network.py:496-506), so samples are coupled through every layer's sums.
+ *   cost (B,D,H,W,cin) contiguous; reg (B,D,H,W); workspace >= B * mvs_regnet_workspace_bytes(D,H,W,cin,base);
+ *   prepared: the buffer of mvs_regnet_prepare_f32 or NULL. */
+int mvs_regnet_us0_batch_f32(const float* cost, int batch, int D, int H, int W, int cin, int base,
+                             const float* const* weights, const float* prepared,
+                             const float* const* gammas, const float* const* betas, float eps,
+                             void* workspace, size_t workspace_bytes, float* reg, void* stream);
 int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int cin, int base,
                        const float* const* weights, const float* const* gammas,
                        const float* const* betas, float eps, void* workspace,

@@ -8,6 +8,9 @@
 // element-wise stages, WTA update.  The sweep keeps all state resident in HBM/L2; only the
 // current cost slice (H*W*C) exists, never the (D,H,W,C) volume.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
 
 // cell-1 MFMA convolutions (gru_mfma.hip); MVS_E_SHAPE outside their tiling
 int mvs_gru1_split_weights(const float* w_gates, const float* w_out, int CA, int F, float* wx, float* wgh, float* woh,
@@ -493,15 +496,23 @@ struct GruStreams { hipStream_t s[3]; hipEvent_t fork, join[3], ready[2][2], rea
 // One set per caller stream (up to 4: sweeps of different reference views in flight on different streams
 // must not share side streams, or they would serialise behind each other); created on first use.
 GruStreams* gru_streams(hipStream_t caller) {
-    struct Slot { hipStream_t caller; GruStreams g; int state; };
-    static Slot slots[4];
+    struct Slot { int dev; hipStream_t caller; GruStreams g; int state; };
+    static Slot slots[8];
     static int used = 0;
+    static std::mutex mu;                                // slot creation is per (device, caller stream), thread-safe
     if (getenv("MVS_GRU_ONE_STREAM") != nullptr) return nullptr;     // A/B + test switch, read per sweep
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     for (int i = 0; i < used; ++i)
-        if (slots[i].caller == caller) return slots[i].state == 1 ? &slots[i].g : nullptr;
-    if (used == 4) return nullptr;                       // further caller streams run the one-stream sweep
+        if (slots[i].dev == dev && slots[i].caller == caller) return slots[i].state == 1 ? &slots[i].g : nullptr;
+    if (used == 8) {                                     // further caller streams run the (slower) one-stream sweep: say so once
+        static bool told = false;
+        if (!told) { told = true; fprintf(stderr, "mvsnet_hip: more than 8 caller streams use the recurrent sweep; the extra ones run it on one stream\n"); }
+        return nullptr;
+    }
     Slot& sl = slots[used++];
-    sl.caller = caller; sl.state = -1;
+    sl.dev = dev; sl.caller = caller; sl.state = -1;
     GruStreams& g = sl.g;
     bool ok = true;
     int lo = 0, hi = 0;

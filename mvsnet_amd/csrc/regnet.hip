@@ -3,6 +3,7 @@
 // No kernels here; every launch goes to the caller's stream and nothing allocates or syncs.
 #include "conv_common.h"
 #include <cstdlib>
+#include <mutex>
 
 // scalar path (conv3d_scalar.hip)
 int mvs_conv3d_scalar(const float*, const float*, const float*, const float*, const float*,
@@ -185,25 +186,34 @@ extern "C" size_t mvs_regnet_workspace_bytes(int D, int H, int W, int cin, int b
 }
 
 namespace {
-// Optional side stream for the branch layers (MVS_SIDE_STREAM=1; created on first use, one per process = one per
-// GPU; calls into the library are expected from one host thread per device, as everywhere else in this file).
+// Optional side stream for the branch layers (MVS_SIDE_STREAM=1).
 // Off by default since round 2: with the block kernels of conv3d_os.hip the low-resolution layers fill the CUs'
 // matrix pipes on their own, and a branch layer running beside them slows the chain by more than it hides
 // (rocprofv3, metric workload: 826 depth maps/s with the fork, 837 without).
 struct SideStream { hipStream_t stream; hipEvent_t fork[2]; hipEvent_t join; };
-SideStream* side_stream() {
-    static SideStream s;
-    static int state = 0;                          // 0 = not tried, 1 = ready, -1 = unavailable
-    if (state == 0) {
-        state = -1;
-        if (getenv("MVS_SIDE_STREAM") &&
-            hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&s.fork[0], hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&s.fork[1], hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess)
-            state = 1;
-    }
-    return state == 1 ? &s : nullptr;
+// One side stream + event set per (device, caller stream), up to 8; created on first use under a mutex (ADVICE r1:
+// a single process-wide set funnelled every plan's branch layers through one stream and was neither per-device nor
+// thread-safe).  Further caller streams run their branch layers on the caller's stream.
+SideStream* side_stream(hipStream_t caller) {
+    struct Slot { int dev; hipStream_t caller; SideStream s; int state; };
+    static Slot slots[8];
+    static int used = 0;
+    static std::mutex mu;
+    if (!getenv("MVS_SIDE_STREAM")) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used; ++i)
+        if (slots[i].dev == dev && slots[i].caller == caller) return slots[i].state == 1 ? &slots[i].s : nullptr;
+    if (used == 8) return nullptr;
+    Slot& sl = slots[used++];
+    sl.dev = dev; sl.caller = caller; sl.state = -1;
+    if (hipStreamCreateWithFlags(&sl.s.stream, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&sl.s.fork[0], hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&sl.s.fork[1], hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&sl.s.join, hipEventDisableTiming) == hipSuccess)
+        sl.state = 1;
+    return sl.state == 1 ? &sl.s : nullptr;
 }
 
 // layer table (order of the weights array) and offsets of the pre-laid-out weights
@@ -247,20 +257,26 @@ extern "C" int mvs_regnet_prepare_f32(const float* const* weights, int cin, int 
     return 0;
 }
 
-static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
+// `batch` samples share every BatchNorm layer's statistics (the reference normalises over (B,D,H,W), network.py:496-506):
+// each layer runs for all samples -- their float64 sums land in the same slab -- before any consumer reads them.
+// cost (B,D,H,W,cin), reg (B,D,H,W), workspace = B consecutive per-sample regions (the sums live in the first).
+static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin, int base,
                       const float* const* weights, const float* prepared, const float* const* gammas,
                       const float* const* betas, float eps, void* workspace, size_t workspace_bytes,
                       float* reg, void* stream) {
     const PrepLayout lay = prep_layout(cin, base);
     MVS_CHECK_ARG(cost && weights && gammas && betas && workspace && reg);
-    MVS_CHECK_ARG(D > 0 && H > 0 && W > 0 && cin > 0 && base > 0);
+    MVS_CHECK_ARG(batch > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && base > 0);
     if ((D % 8) || (H % 8) || (W % 8)) return MVS_E_SHAPE;
+    const size_t ws_bytes1 = carve(nullptr, D, H, W, cin, base).bytes;
+    if (workspace_bytes < ws_bytes1 * (size_t)batch) return MVS_E_WORKSPACE;
     RegnetWs ws = carve((char*)workspace, D, H, W, cin, base);
-    if (workspace_bytes < ws.bytes) return MVS_E_WORKSPACE;
+    const size_t ws_floats1 = ws_bytes1 / sizeof(float);        // regions are 256-byte aligned
+    const size_t cost1 = (size_t)D * H * W * cin, reg1 = (size_t)D * H * W;
     const int b = base, cmax = 8 * b;
     const int D1 = D / 2, H1 = H / 2, W1 = W / 2, D2 = D / 4, H2 = H / 4, W2 = W / 4,
               D3 = D / 8, H3 = H / 8, W3 = W / 8;
-    const double v0 = (double)D * H * W, v1 = v0 / 8, v2 = v1 / 8, v3 = v2 / 8;
+    const double v0 = (double)batch * D * H * W, v1 = v0 / 8, v2 = v1 / 8, v3 = v2 / 8;     // voxels behind each statistic
     int rc;
     if ((rc = mvs_zero_f64(ws.stats, (size_t)N_BN * 2 * cmax, stream))) return rc;
     hipStream_t hs = mvs_stream(stream);
@@ -301,11 +317,12 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
         return mvs_bn_finalize_f32(st(i), ch[i], cnt[i], gammas[i], betas[i], eps, ws.scale[i], ws.shift[i], stream);
     };
     // one layer: in = BN+ReLU(producer p1) [+ BN+ReLU(producer p2)], out = layer `out` (or reg)
-    auto layer_run = [&](bool deconv, int p1, int p2, int out, int d, int h, int w, int ci, int co,
+    auto layer_one = [&](int bi, bool deconv, int p1, int p2, int out, int d, int h, int w, int ci, int co,
                          int stride, hipStream_t hs) -> int {
-        const float* x = p1 >= 0 ? ws.y[p1] : cost;
-        const float* x2 = p2 >= 0 ? ws.y[p2] : nullptr;
-        float* y = out == L62 ? reg : ws.y[out];
+        const size_t wo = (size_t)bi * ws_floats1;                  // this sample's workspace region
+        const float* x = p1 >= 0 ? ws.y[p1] + wo : cost + (size_t)bi * cost1;
+        const float* x2 = p2 >= 0 ? ws.y[p2] + wo : nullptr;
+        float* y = out == L62 ? reg + (size_t)bi * reg1 : ws.y[out] + wo;
         double* so = out == L62 ? nullptr : st(out);
         if (g_conv_impl != MVS_CONV_IMPL_SCALAR) {
             const float* wp = (prepared && lay.ok[out]) ? prepared + lay.off[out] : nullptr;
@@ -323,6 +340,14 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
         return deconv ? mvs_deconv3d_scalar(x, s1, t1, x2, s2, t2, weights[out], d, h, w, ci, co, y, so, hs)
                       : mvs_conv3d_scalar(x, s1, t1, x2, s2, t2, weights[out], d, h, w, ci, co, stride, y, so, hs);
     };
+    auto layer_run = [&](bool deconv, int p1, int p2, int out, int d, int h, int w, int ci, int co,
+                         int stride, hipStream_t hs) -> int {
+        for (int bi = 0; bi < batch; ++bi) {
+            int r = layer_one(bi, deconv, p1, p2, out, d, h, w, ci, co, stride, hs);
+            if (r) return r;
+        }
+        return 0;
+    };
     auto layer = [&](bool deconv, int p1, int p2, int out, int d, int h, int w, int ci, int co,
                      int stride, hipStream_t hs_) -> int {
         int r = lp_mark(out, 0, hs_);
@@ -336,8 +361,11 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
     // volume: one fused pass when the shape is the one conv3d_c8.hip is built for.
     if ((g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA) && cin == 32 && b == 8 &&
         !getenv("MVS_NO_PAIR_FUSION")) {
-        ConvArgs a{cost, nullptr, nullptr, nullptr, nullptr, nullptr, weights[L01], ws.y[L01], st(L01), D, H, W, b,
-                   0, 0, 0, 0, {}, {}, prepared ? prepared + lay.off[L01] : nullptr, nullptr};
+        auto pair_args = [&](int bi) {
+            return ConvArgs{cost + (size_t)bi * cost1, nullptr, nullptr, nullptr, nullptr, nullptr, weights[L01],
+                            ws.y[L01] + (size_t)bi * ws_floats1, st(L01), D, H, W, b,
+                            0, 0, 0, 0, {}, {}, prepared ? prepared + lay.off[L01] : nullptr, nullptr};
+        };
         int slot = -1;
         if (g_prof.on && g_prof.used < 64) {
             slot = g_prof.used;
@@ -348,7 +376,10 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
         }
         if (slot >= 0) HIP_RUN(hipEventRecord(g_prof.ev[slot][0], hs));
         RUN(lp_mark(L01, 0, hs));
-        rc = mvs_conv3d_c8_s2_launch(a, weights[L10], ws.y[L10], st(L10), hs, slots01, slots10);
+        for (int bi = 0; bi < batch; ++bi) {
+            rc = mvs_conv3d_c8_s2_launch(pair_args(bi), weights[L10], ws.y[L10] + (size_t)bi * ws_floats1, st(L10), hs, slots01, slots10);
+            if (rc) break;
+        }
         if (rc == 0) RUN(lp_mark(L01, 1, hs));
         if (slot >= 0 && rc == 0) { HIP_RUN(hipEventRecord(g_prof.ev[slot][1], hs)); g_prof.used = slot + 1; }
         if (rc == 0) pair_done = true;
@@ -363,7 +394,7 @@ static int regnet_run(const float* cost, int D, int H, int W, int cin, int base,
     // stream next to the encoder's tail (fork / join with events: graph-capture safe, no host sync).
     // (only for the shape every layer of which has an MFMA kernel: the scalar fallback's BatchNorm
     // finalise bookkeeping is single-stream)
-    SideStream* side = (g_conv_impl != MVS_CONV_IMPL_SCALAR && cin == 32 && b == 8) ? side_stream() : nullptr;
+    SideStream* side = (g_conv_impl != MVS_CONV_IMPL_SCALAR && cin == 32 && b == 8) ? side_stream(hs) : nullptr;
     hipStream_t ss = side ? side->stream : hs;
     if (side) { HIP_RUN(hipEventRecord(side->fork[0], hs)); HIP_RUN(hipStreamWaitEvent(ss, side->fork[0], 0)); }
     RUN(layer(false, L10, -1, L11, D1, H1, W1, 2 * b, 2 * b, 1, ss));
@@ -389,7 +420,7 @@ extern "C" int mvs_regnet_us0_f32(const float* cost, int D, int H, int W, int ci
                                   const float* const* weights, const float* const* gammas,
                                   const float* const* betas, float eps, void* workspace,
                                   size_t workspace_bytes, float* reg, void* stream) {
-    return regnet_run(cost, D, H, W, cin, base, weights, nullptr, gammas, betas, eps, workspace,
+    return regnet_run(cost, 1, D, H, W, cin, base, weights, nullptr, gammas, betas, eps, workspace,
                       workspace_bytes, reg, stream);
 }
 
@@ -399,6 +430,15 @@ extern "C" int mvs_regnet_us0_prepared_f32(const float* cost, int D, int H, int 
                                            float eps, void* workspace, size_t workspace_bytes,
                                            float* reg, void* stream) {
     MVS_CHECK_ARG(prepared);
-    return regnet_run(cost, D, H, W, cin, base, weights, prepared, gammas, betas, eps, workspace,
+    return regnet_run(cost, 1, D, H, W, cin, base, weights, prepared, gammas, betas, eps, workspace,
+                      workspace_bytes, reg, stream);
+}
+
+extern "C" int mvs_regnet_us0_batch_f32(const float* cost, int batch, int D, int H, int W, int cin, int base,
+                                        const float* const* weights, const float* prepared,
+                                        const float* const* gammas, const float* const* betas,
+                                        float eps, void* workspace, size_t workspace_bytes,
+                                        float* reg, void* stream) {
+    return regnet_run(cost, batch, D, H, W, cin, base, weights, prepared, gammas, betas, eps, workspace,
                       workspace_bytes, reg, stream);
 }

@@ -18,6 +18,7 @@ import torch
 
 from . import _lib
 from .feature_net import UNetDS2GN
+from .homography_warping import homography_transforms
 
 REGNET_ORDER = ("3dconv1_0", "3dconv2_0", "3dconv3_0", "3dconv0_1", "3dconv1_1", "3dconv2_1",
                 "3dconv3_1", "3dconv4_0", "3dconv5_0", "3dconv6_0", "3dconv6_2")
@@ -212,8 +213,27 @@ def bn_finalize(stats, count, gamma, beta, eps=BN_EPSILON):
 
 
 def regnet_us0(cost_volume_, weights: RegNetWeights, workspace=None, out=None):
-    """RegNetUS0 (mvsnetworks.py:122-158): (D,H,W,Cin) -> filtered cost volume (D,H,W)."""
+    """RegNetUS0 (mvsnetworks.py:122-158): (D,H,W,Cin) -> filtered cost volume (D,H,W); a 5-D (B,D,H,W,Cin) input is a
+    batch whose BatchNorm layers share their statistics over (B,D,H,W) as in the reference (network.py:496-506)."""
     lib = _lib.load()
+    if cost_volume_.dim() == 5:
+        B, D, H, W, Cin = cost_volume_.shape
+        if Cin == weights.cin_native and Cin != weights.cin:
+            cost_volume_ = torch.nn.functional.pad(cost_volume_, (0, weights.cin - Cin)).contiguous()
+            Cin = weights.cin
+        if Cin != weights.cin:
+            raise _lib.MvsnetHipError("cost volume has %d channels, weights expect %d" % (Cin, weights.cin))
+        need = B * lib.mvs_regnet_workspace_bytes(D, H, W, Cin, weights.base)
+        if workspace is None:
+            workspace = torch.empty(need, device=cost_volume_.device, dtype=torch.uint8)
+        if out is None:
+            out = torch.empty((B, D, H, W), device=cost_volume_.device, dtype=torch.float32)
+        _lib.check(lib.mvs_regnet_us0_batch_f32(
+            _lib.ptr(_lib.f32(cost_volume_)), B, D, H, W, Cin, weights.base, weights.w_ptrs,
+            _lib.ptr(weights.prepared), weights.g_ptrs, weights.b_ptrs, BN_EPSILON,
+            C.c_void_p(workspace.data_ptr()), workspace.numel(), _lib.ptr(out), _lib.stream_ptr()),
+            "mvs_regnet_us0_batch_f32")
+        return out
     D, H, W, Cin = cost_volume_.shape
     if Cin == weights.cin_native and Cin != weights.cin:      # narrower mode running zero-padded (RegNetWeights)
         cost_volume_ = torch.nn.functional.pad(cost_volume_, (0, weights.cin - Cin)).contiguous()
@@ -366,6 +386,31 @@ def _scalar(x):
     return float(a[0])
 
 
+def _per_sample(x, batch):
+    """depth_start / depth_interval / depth_end: a scalar or one value per sample (predictlib.set_shapes:190-197)."""
+    if torch.is_tensor(x):
+        a = x.detach().reshape(-1).to(torch.float32).cpu().numpy()
+    else:
+        a = np.asarray(x, dtype=np.float32).reshape(-1)
+    if a.size == 1:
+        return [float(a[0])] * batch
+    if a.size != batch:
+        raise ValueError("expected 1 or %d values, got %d" % (batch, a.size))
+    return [float(v) for v in a]
+
+
+def _batch_of(images, features, cams):
+    t_ = features if features is not None else images
+    if t_.dim() == 5:
+        return int(t_.shape[0])
+    return 1
+
+
+def _sample(t_, b):
+    """Sample b of a batched (5-D) tensor as a batch of one; a 4-D tensor is its own single sample."""
+    return None if t_ is None else (t_[b:b + 1] if t_.dim() == 5 else t_)
+
+
 def _features(images, cams, weights, features, view_num):
     """Runs the UNetDS2GN towers (model.py:392-406) unless precomputed features are given."""
     if features is None:
@@ -401,8 +446,28 @@ def inference_mem(images, cams, depth_num, depth_start, depth_interval, network_
         raise _lib.MvsnetHipError("weights.regnet is required for the 3DCNN regulariser")
     if view_num is None:
         view_num = (features if features is not None else images).shape[-4]
-    start, interval = _scalar(depth_start), _scalar(depth_interval)
     D = int(depth_num)
+    B = _batch_of(images, features, cams)
+    if B > 1:
+        # FLAGS.batch_size > 1 (model.py:350,431,479): per-sample towers, homographies, cost volumes and soft-argmin;
+        # the regulariser's BatchNorm layers normalise over the whole batch (network.py:496-506).
+        starts, intervals = _per_sample(depth_start, B), _per_sample(depth_interval, B)
+        costs, Hh, Ww = [], None, None
+        for b in range(B):
+            f_b, c_b = _features(_sample(images, b), cams[b:b + 1], weights, _sample(features, b), view_num)
+            _, Hh, Ww, Cc = f_b.shape
+            end_b = float(np.float32(starts[b]) + (np.float32(D) - np.float32(1)) * np.float32(intervals[b]))   # model.py:378-379
+            t8 = homography_transforms(c_b, D, starts[b], intervals[b], end_b, inverse_depth)
+            costs.append(cost_volume(f_b[0], f_b[1:], t8, 0, D, variant))
+        reg = regnet_us0(torch.stack(costs), weights.regnet)
+        del costs
+        depth = torch.empty((B, Hh, Ww, 1), device=reg.device, dtype=torch.float32)
+        prob = torch.empty_like(depth)
+        for b in range(B):
+            d_b, p_b = softargmin_prob(reg[b], starts[b], intervals[b], inverse_depth)
+            depth[b, :, :, 0], prob[b, :, :, 0] = d_b, p_b
+        return depth, prob
+    start, interval = _scalar(depth_start), _scalar(depth_interval)
     feats, cams_ = _features(images, cams, weights, features, view_num)
     _, H, W, Cc = feats.shape
     end = np.float32(start) + (np.float32(D) - np.float32(1)) * np.float32(interval)   # model.py:378-379
@@ -448,8 +513,15 @@ def inference_winner_take_all(images, cams, depth_num, depth_start, depth_end, n
         raise _lib.MvsnetHipError("weights.gru is required for the GRU regulariser")
     if view_num is None:
         view_num = (features if features is not None else images).shape[-4]
-    start, end = _scalar(depth_start), _scalar(depth_end)
     D = int(depth_num)
+    B = _batch_of(images, features, cams)
+    if B > 1:        # every op of the recurrent path is per sample (layer_norm normalises over (H,W,C) of ONE sample, convgru.py:30-31)
+        starts, ends = _per_sample(depth_start, B), _per_sample(depth_end, B)
+        outs = [inference_winner_take_all(_sample(images, b), cams[b:b + 1], D, starts[b], ends[b], network_mode,
+                                          is_master_gpu, reg_type, inverse_depth, training, trainable, weights=weights,
+                                          view_num=view_num, features=_sample(features, b)) for b in range(B)]
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+    start, end = _scalar(depth_start), _scalar(depth_end)
     feats, cams_ = _features(images, cams, weights, features, view_num)
     _, H, W, Cc = feats.shape
     interval = float((np.float32(end) - np.float32(start)) / (np.float32(D) - np.float32(1)))  # :606-607

@@ -406,6 +406,28 @@ def regnet_us0(cost, params, dtype=np.float32, eps=1e-5):
     return out[..., 0]
 
 
+def regnet_us0_batch(costs, params, dtype=np.float32, eps=1e-5):
+    """RegNetUS0 on a batch (FLAGS.batch_size > 1, model.py:466-469): convolutions per sample, every BatchNorm layer's
+    mean / biased variance over (B,D,H,W) (tf.layers.batch_normalization reduces over all but the channel axis,
+    network.py:496-506).  costs (B,D,H,W,Cin) -> (B,D,H,W)."""
+    B = len(costs)
+
+    def bn(ys, name):
+        z = batch_norm_train(np.stack(ys), params[name]["gamma"], params[name]["beta"], eps, True, dtype)
+        return [z[b] for b in range(B)]
+    cb = lambda xs, name, stride: bn([conv3d_same(x, params[name]["w"], stride, dtype) for x in xs], name)
+    db = lambda xs, name: bn([conv3d_transpose_same(x, params[name]["w"], 2, dtype) for x in xs], name)
+    add = lambda a, b: [u + v for u, v in zip(a, b)]
+    x = [np.asarray(c, dtype=dtype) for c in costs]
+    c1_0 = cb(x, "3dconv1_0", 2); c2_0 = cb(c1_0, "3dconv2_0", 2); c3_0 = cb(c2_0, "3dconv3_0", 2)
+    c0_1 = cb(x, "3dconv0_1", 1); c1_1 = cb(c1_0, "3dconv1_1", 1); c2_1 = cb(c2_0, "3dconv2_1", 1)
+    c3_1 = cb(c3_0, "3dconv3_1", 1)
+    c4 = add(db(c3_1, "3dconv4_0"), c2_1)
+    c5 = add(db(c4, "3dconv5_0"), c1_1)
+    c6 = add(db(c5, "3dconv6_0"), c0_1)
+    return np.stack([conv3d_same(v, params["3dconv6_2"]["w"], 1, dtype)[..., 0] for v in c6])
+
+
 # --------------------------------------------------------------------------------------
 # R6 / R7  softmax over depth, soft-argmin, 4-bucket probability map
 # --------------------------------------------------------------------------------------

@@ -305,6 +305,43 @@ def test_regnet_matches_oracle(mode, shape, pad):
     np.testing.assert_allclose(got, exp, rtol=1e-3, atol=2e-4)
 
 
+def test_batch_of_two_shares_batchnorm_statistics():
+    """FLAGS.batch_size > 1 (model.py:28,350,431,479): towers / homographies / cost volumes / soft-argmin per sample,
+    RegNetUS0's BatchNorm over the whole batch (network.py:496-506) -- against the batched oracle, and NOT equal to
+    running the two samples one by one; the recurrent path is per sample throughout."""
+    from mvsnet_amd.model import MVSNetWeights, inference_mem, inference_winner_take_all
+    wa, wb = S.make_workload("small", seed=0), S.make_workload("small", seed=5)
+    rp = S.make_regnet_params("normal", seed=1, random_affine=True)
+    gp = S.make_gru_params("normal", seed=2, in_channels=wa.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", regnet=rp, gru=gp, device=DEV)
+    feats = t(np.stack([wa.features, wb.features]))
+    cams_b = np.stack([wa.cams, wb.cams]); cams_b[1, :, 1, 3, 0] += 10.0
+    starts = np.array([wa.depth_start, wa.depth_start + 10.0], np.float32)
+    intervals = np.array([wa.depth_interval, wa.depth_interval * 1.1], np.float32)
+    depth, prob = inference_mem(None, t(cams_b), wa.depth_num, starts, intervals, weights=weights, features=feats)
+    assert depth.shape == (2, wa.height, wa.width, 1) and prob.shape == depth.shape
+    costs = []
+    for b, w in enumerate((wa, wb)):
+        Hs = np.stack([O.get_homographies(w.cams[0], w.cams[v], w.depth_num, float(starts[b]), float(intervals[b]), np.float64)
+                       for v in range(1, w.view_num)])
+        costs.append(O.cost_volume(w.features[0], w.features[1:], Hs, w.view_num, "mem", np.float64))
+    reg = O.regnet_us0_batch(costs, rp, np.float64)
+    for b in range(2):
+        ed, ep = O.softargmin_and_prob(reg[b], wa.depth_num, float(starts[b]), float(intervals[b]), False, np.float64)
+        d = n(depth)[b, :, :, 0]
+        assert float(np.mean(np.abs(d - ed) / ed)) < 1e-4
+        assert (np.abs(n(prob)[b, :, :, 0] - ep) > 1e-3).mean() < 0.02
+    alone, _ = inference_mem(None, t(wa.cams)[None], wa.depth_num, float(starts[0]), float(intervals[0]), weights=weights,
+                             features=t(wa.features))
+    assert float((alone[0] - depth[0]).abs().mean()) > 1e-3                 # the batch statistics really couple the samples
+    # recurrent path: a batch is its samples one by one
+    ends = starts + (wa.depth_num - 1) * intervals
+    dg, pg = inference_winner_take_all(None, t(cams_b), wa.depth_num, starts, ends, weights=weights, features=feats)
+    d1, p1 = inference_winner_take_all(None, t(cams_b[1])[None], wa.depth_num, float(starts[1]), float(ends[1]), weights=weights,
+                                       features=t(wb.features))
+    assert dg.shape == (2, wa.height, wa.width, 1) and torch.equal(dg[1], d1[0]) and torch.allclose(pg[1], p1[0])
+
+
 def test_fat_mode_matches_oracle():
     """network_mode 'fat' (network.py:82-83: base_divisor 0.5, base_filter 16, a 64-channel volume): wider than the shapes
     the MFMA kernels tile, so RegNetUS0 runs on the shape-generic kernels; the regulariser alone and features -> depth."""
