@@ -38,6 +38,8 @@ def bind_device(local_rank=None):
     if local_rank is None:
         local_rank = rank_world()[1]
     n = torch.cuda.device_count()
+    if n > 0 and os.environ.get("MVS_ALLOW_SHARED_GPU"):      # rehearsing the multi-process path on a box with fewer GPUs
+        local_rank = local_rank % n
     if not (0 <= local_rank < n):
         raise RuntimeError("local rank %d needs cuda:%d but only %d GPU(s) are visible" % (local_rank, local_rank, n))
     torch.cuda.set_device(local_rank)
@@ -55,8 +57,8 @@ def init_process_group(backend=None):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:        # MVS_DIST_BACKEND=gloo: rehearsals with several ranks per GPU (RCCL wants one GPU per rank)
+        backend = os.environ.get("MVS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if not dist.is_initialized():
         if backend == "nccl":
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=bind_device(local_rank))
@@ -70,6 +72,8 @@ def gather_counts(dist, value: float, device="cpu") -> List[float]:
     if dist is None:
         return [float(value)]
     import torch
+    if dist.get_backend() != "nccl":
+        device = "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
