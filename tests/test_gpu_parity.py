@@ -569,9 +569,10 @@ np.savez(sys.argv[1], **out)
             path = os.path.join(td, tag + ".npz")
             subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env={**os.environ, **env, "PYTHONPATH": root})
             res[tag] = dict(np.load(path))
-    assert int(res["reg"]["M_fallback"]) == 0 and int(res["lds"]["M_fallback"]) == 0       # M stays on the staged path
-    assert int(res["lds"]["c3_fallback"]) > 0                                               # c3's near planes exercise the direct path
-    for name in ("M", "c3"):
-        a, b = res["reg"][name], res["lds"][name]
-        bad = np.abs(a - b) > 1e-5 + 1e-4 * np.abs(a)
-        assert bad.mean() < 1e-3, (name, float(bad.mean()))          # rcp vs division: a flipped floor() moves a whole tap
+    for form in ("lds",):
+        assert int(res["reg"]["M_fallback"]) == 0 and int(res[form]["M_fallback"]) == 0    # M stays on the staged path
+        assert int(res[form]["c3_fallback"]) > 0                                            # c3's near planes exercise the direct path
+        for name in ("M", "c3"):
+            a, b = res["reg"][name], res[form][name]
+            bad = np.abs(a - b) > 1e-5 + 1e-4 * np.abs(a)
+            assert bad.mean() < 1e-3, (form, name, float(bad.mean()))   # rcp vs division: a flipped floor() moves a whole tap
