@@ -208,7 +208,7 @@ def extra_config_gru(name, dev, steps=5, n_streams=1):
         p = plan.prob.cpu().numpy().astype(np.float64)
         same = np.abs(d - g["depth"]) <= 1e-6 * g["depth"]
         out["plane_agreement_vs_fixture"] = float(same.mean())
-        out["prob_rel_max_on_agreeing_pixels"] = float(np.max(np.abs(p[same] - g["prob"][same]) / g["prob"][same]))
+        out["prob_rel_max_on_agreeing_pixels"] = float(np.max(np.abs(p[same] - g["prob"][same]) / g["prob"][same])) if same.any() else None
         out["fixture"] = "tests/golden/full_%s.npz (float64 CPU oracle; float32 CPU restatement: agreement %.5f, prob rel max %.1e)" % (
             name, float(g["f32_cpu_plane_agreement"]), float(g["f32_cpu_prob_rel"]))
     del plan, plans

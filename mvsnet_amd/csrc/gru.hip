@@ -457,7 +457,7 @@ extern "C" int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, i
 
 namespace {
 struct GruWs {
-    float *x, *g[3], *g2[3], *c[3], *rh, *u, *h[3][2 * 4], *reg, *max_prob, *exp_sum;   // h: ring of 2*PG states; g2: the gate buffer of odd planes (cells whose blend is folded into the next plane's gate convolution)
+    float *x, *g[3], *g2[3], *c[3], *rh, *u, *h[3][8 * 4], *reg, *max_prob, *exp_sum;   // h: ring of RG*PG states (RG <= 8); g2: the gate buffer of odd planes (cells whose blend is folded into the next plane's gate convolution)
     float *px, *wx, *wgh, *woh;        // hoisted x-part of cell 1: (2, XB, H, W, 3*f1) and its prepared weights
     double* stats;     // per plane of a batch: 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
     size_t bytes;
@@ -466,8 +466,19 @@ struct GruWs {
 // come from ONE depth-sweep launch (register tap reuse along depth, cost_volume.hip) into a ring of
 // XB slices, instead of one single-plane launch per step (26 -> ~6 us per plane at 400 x 300).
 constexpr int XB = 16;
-// Planes per synchronisation group of the wavefront (see mvs_gru_wta_f32); the state ring holds 2*PG planes.
+// Planes per synchronisation group of the wavefront (see mvs_gru_wta_f32); the state ring holds RG groups of PG planes.
 constexpr int PG = 4;
+// Ring depth in groups.  A cell may run RG groups ahead of the cell that consumes its states.  Round 1 used 2: the kernel
+// trace (profiles/r02_gru_timeline.txt) showed every stream stalling ~100-200 us at EVERY group boundary -- cell k can start
+// group j only when cell k+1 has finished group j-2, i.e. one group time + two cross-stream signal latencies after cell k
+// finished it, and the signal latency (tens of microseconds) exceeds the slack.  With 4 groups the wait is already
+// satisfied when it is reached.  MVS_GRU_RING=2..8 for A/B runs.
+constexpr int RG_MAX = 8;
+static int ring_groups() {
+    static const int rg = [] { const char* e = getenv("MVS_GRU_RING"); int v = e ? atoi(e) : 4; return v < 2 ? 2 : v > RG_MAX ? RG_MAX : v; }();
+    return rg;
+}
+constexpr int SB = 4;          // LayerNorm-sum ring in batches of XB planes: cell 3 may lag cell 1 by 2 * RG_MAX groups = 4 batches at most
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     size_t hw = (size_t)H * W, off = 0;
@@ -480,19 +491,19 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     // consecutive planes run concurrently (see mvs_gru_wta_f32)
     for (int k = 0; k < 3; ++k) {
         w.g[k] = take(hw * 2 * F[k]); w.g2[k] = take(hw * 2 * F[k]); w.c[k] = take(hw * F[k]);
-        for (int r = 0; r < 2 * PG; ++r) w.h[k][r] = take(hw * F[k]);
+        for (int r = 0; r < RG_MAX * PG; ++r) w.h[k][r] = take(hw * F[k]);
     }
     w.rh = take(hw * fmax); w.u = take(hw * fmax);
     w.reg = take(hw); w.max_prob = take(hw); w.exp_sum = take(hw);
     w.px = take((size_t)2 * XB * hw * 3 * f1);
     w.wx = take((size_t)9 * C * 3 * f1); w.wgh = take((size_t)9 * f1 * 2 * f1); w.woh = take((size_t)9 * f1 * f1);
-    w.stats = (double*)(base ? base + off : nullptr); off += align256((size_t)2 * XB * 18 * 8);   // two batches deep
+    w.stats = (double*)(base ? base + off : nullptr); off += align256((size_t)(SB + 1) * XB * 18 * 8);   // SB + 1 batches deep
     w.bytes = off;
     return w;
 }
 
 // Side streams for cells 2 and 3 and for the per-batch producer (cost slices + hoisted x-part) (created on first use; one host thread per device as elsewhere).
-struct GruStreams { hipStream_t s[3]; hipEvent_t fork, join[3], ready[2][2], read[2][2], xready[2], xdone[2]; };
+struct GruStreams { hipStream_t s[3]; hipEvent_t fork, join[3], ready[2][RG_MAX], read[2][RG_MAX], xready[2], xdone[2]; };
 // One set per caller stream (up to 4: sweeps of different reference views in flight on different streams
 // must not share side streams, or they would serialise behind each other); created on first use.
 GruStreams* gru_streams(hipStream_t caller) {
@@ -521,7 +532,7 @@ GruStreams* gru_streams(hipStream_t caller) {
         ok = hipStreamCreateWithPriority(&g.s[i], hipStreamNonBlocking, i == 2 ? lo : hi) == hipSuccess;
     auto ev = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
     ev(&g.fork);
-    for (int i = 0; i < 2; ++i) { ev(&g.xready[i]); ev(&g.xdone[i]); for (int j = 0; j < 2; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
+    for (int i = 0; i < 2; ++i) { ev(&g.xready[i]); ev(&g.xdone[i]); for (int j = 0; j < RG_MAX; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
     for (int i = 0; i < 3; ++i) ev(&g.join[i]);
     if (ok) sl.state = 1;
     return ok ? &g : nullptr;
@@ -574,6 +585,7 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     // synchronise per GROUP of PG planes: states live in a ring of 2*PG planes (plane d reads h[k][d % 2PG], writes
     // h[k][(d+1) % 2PG]); per group j, ready[k][j&1] = cell k has written its states of group j, read[k][j&1] =
     // cell k+1 is done reading them (cell k may overwrite those ring slots in group j+2).
+    const int RG = ring_groups(), ring = RG * PG;
     GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2 * PG) ? gru_streams(st) : nullptr;
     hipStream_t sk[3] = {st, gs ? gs->s[0] : st, gs ? gs->s[1] : st};
     if (gs) {
@@ -585,9 +597,9 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     // start of a batch of XB planes (on cell 1's stream, before its first plane of the batch)
     auto batch_start = [&](int d) -> int {
         const int half = (d / XB) & 1;
-        // LayerNorm sums of this batch (the other half of the stats ring may still be in use by cells 2 / 3
-        // of the previous planes: they lag cell 1 by at most 4 groups = 16 planes)
-        if ((e = hipMemsetAsync(ws.stats + (size_t)half * XB * 18, 0, (size_t)XB * 18 * 8, st)) != hipSuccess) return (int)e;
+        // LayerNorm sums of this batch (other slots of the ring may still be in use by cells 2 / 3 of earlier planes: cell 3
+        // lags cell 1 by fewer than 2 * RG groups = at most SB batches)
+        if ((e = hipMemsetAsync(ws.stats + (size_t)((d / XB) % (SB + 1)) * XB * 18, 0, (size_t)XB * 18 * 8, st)) != hipSuccess) return (int)e;
         // Per batch: x = -variance cost slices (model.py:680-693,698) and, for the MFMA cell 1, the x halves of
         // its two convolutions for the whole batch (gru_mfma.hip: x-part hoisting).
         auto produce = [&](int d0, hipStream_t s) -> int {
@@ -620,11 +632,11 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     auto cell_plane = [&](int k, int d, hipStream_t s) -> int {
         const int slot = d % XB, half = (d / XB) & 1;
         const float* const* p = params + 10 * k;
-        double* sg = ws.stats + (size_t)(half * XB + slot) * 18 + 6 * k;
+        double* sg = ws.stats + (size_t)(((d / XB) % (SB + 1)) * XB + slot) * 18 + 6 * k;
         double* so = sg + 4;
-        float* hp_w = ws.h[k][d % (2 * PG)];
+        float* hp_w = ws.h[k][d % ring];
         const float* hp = hp_w;
-        float* hn = ws.h[k][(d + 1) % (2 * PG)];
+        float* hn = ws.h[k][(d + 1) % ring];
         // On the wavefront: the blend of a plane is folded into the NEXT plane's gate convolution (its
         // staging forms the state it convolves) except at the end of a synchronisation group, where the next cell
         // (and the WTA update) are about to read the state: 3 of 4 blend launches disappear.  The gate buffer
@@ -636,11 +648,11 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
         PrevPlane prev = {nullptr, nullptr, nullptr, nullptr};
         if (fused_in) {
             const int dp = d - 1;
-            double* sgp = ws.stats + (size_t)(((dp / XB) & 1) * XB + dp % XB) * 18 + 6 * k;
-            prev = {ws.h[k][dp % (2 * PG)], (dp & 1) ? ws.g2[k] : ws.g[k], sgp, sgp + 4};
+            double* sgp = ws.stats + (size_t)(((dp / XB) % (SB + 1)) * XB + dp % XB) * 18 + 6 * k;
+            prev = {ws.h[k][dp % ring], (dp & 1) ? ws.g2[k] : ws.g[k], sgp, sgp + 4};
         }
         const PrevPlane* pv = fused_in ? &prev : nullptr;
-        const float* xin = k == 0 ? ws.x + (size_t)slot * hw * C : ws.h[k - 1][(d + 1) % (2 * PG)];
+        const float* xin = k == 0 ? ws.x + (size_t)slot * hw * C : ws.h[k - 1][(d + 1) % ring];
         const float* px_d = ws.px + ((size_t)half * XB + slot) * hw * 3 * f1;
         const int cin = cins[k];
         int r;
@@ -701,13 +713,13 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
         }
     } else {
         for (int j = 0, d0 = 0; d0 < depth_num; ++j, d0 += PG) {
-            const int d1 = d0 + PG < depth_num ? d0 + PG : depth_num, jp = j & 1;
+            const int d1 = d0 + PG < depth_num ? d0 + PG : depth_num, jp = j % RG;
             for (int k = 0; k < 3; ++k) {
                 hipStream_t s = sk[k];
                 // the states cell k wrote in this group ...
                 if (k > 0 && (e = hipStreamWaitEvent(s, gs->ready[k - 1][jp], 0)) != hipSuccess) return (int)e;
-                // ... and the ring slots this cell is about to overwrite were read by cell k+1 two groups ago
-                if (k < 2 && j >= 2 && (e = hipStreamWaitEvent(s, gs->read[k][jp], 0)) != hipSuccess) return (int)e;
+                // ... and the ring slots this cell is about to overwrite were read by cell k+1 RG groups ago
+                if (k < 2 && j >= RG && (e = hipStreamWaitEvent(s, gs->read[k][jp], 0)) != hipSuccess) return (int)e;
                 for (int d = d0; d < d1; ++d) {
                     if (k == 0 && d % XB == 0 && (rc = batch_start(d))) return rc;
                     if ((rc = cell_plane(k, d, s))) return rc;
