@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one features->depth pass of the metric workload (BASELINE.json: N=5 views, D=192 planes,
+A step = one features->depth pass (one call of mvs_depth_from_features_f32) of the metric workload (BASELINE.json: N=5 views, D=192 planes,
 160x128 feature maps, C=32, 3D-CNN regulariser): homography transforms -> fused warp+variance
 cost volume -> RegNetUS0 -> soft-argmin + probability map, inputs (feature maps, cameras, weights)
 resident in HBM.  Reference views are independent, so ranks shard them with no
@@ -157,8 +157,7 @@ def extra_config_3dcnn(name, dev, steps=10):
     plan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", dev)
 
     def step(i, _r):
-        plan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
-        plan.run_3dcnn(feats, w.depth_start, w.depth_interval)
+        plan.run_depth(feats, cams, w.depth_start, w.depth_interval, w.depth_end, False)
     for i in range(3):
         step(i, False)
     el = timed_block(step, steps)
@@ -311,27 +310,34 @@ def main():
     def step(i, record):
         plan = plans[i % n_streams]
         with torch.cuda.stream(streams[i % n_streams]):
-            if record:
-                e = [ev() for _ in range(4)]
-                e[0].record()
+            if not record:
+                # the product's entry: homographies -> cost volume -> RegNetUS0 -> soft-argmin as ONE library call
+                plan.run_depth(feats, cams, w.depth_start, w.depth_interval, end, False)
+                return
+            # stage split for `roofline_kernels` (untimed pass): the same launches through the per-stage entries
+            e = [ev() for _ in range(4)]
+            e[0].record()
             plan.set_cameras(cams, w.depth_start, w.depth_interval, end, False)
             cost_volume(feats[0], feats[1:], plan.transforms, 0, plan.D, "mem", out=plan.cost)
-            if record:
-                e[1].record()
+            e[1].record()
             regnet_us0(plan.cost, weights.regnet, plan.workspace, plan.reg)
-            if record:
-                e[2].record()
+            e[2].record()
             softargmin_prob(plan.reg, w.depth_start, w.depth_interval, False, plan.depth, plan.prob)
-            if record:
-                e[3].record()
-                marks.append(e)
+            e[3].record()
+            marks.append(e)
 
     torch.cuda.synchronize()
     # untimed: the requested warm-up steps, topped up to 10 launches so that lazy one-off work (code-object
-    # load, LDS-size attributes, side-stream creation) and the clock ramp never land in the timed region
+    # load, LDS-size attributes) never lands in the timed region, then more of the same steps until 0.25 s have passed:
+    # the first block after an idle period measured 1-1.5 % below every later block of the same steps (clock ramp)
     for i in range(max(args.warmup, 10)):
         step(i, False)
     torch.cuda.synchronize()
+    t_prime = time.perf_counter()
+    while time.perf_counter() - t_prime < 0.25:
+        for i in range(10):
+            step(i, False)
+        torch.cuda.synchronize()
     # the library brackets the dominant kernel (fused 3dconv0_1 + 3dconv1_0 pass) of every step of
     # the timed region with HIP events on the stream it is launched on
     lib = _lib.load()
@@ -499,12 +505,8 @@ def main():
             s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
 
             def step2(i):
-                pl = p2[i % 2]
                 with torch.cuda.stream(s2[i % 2]):
-                    pl.set_cameras(cams, w.depth_start, w.depth_interval, end, False)
-                    cost_volume(feats[0], feats[1:], pl.transforms, 0, pl.D, "mem", out=pl.cost)
-                    regnet_us0(pl.cost, weights.regnet, pl.workspace, pl.reg)
-                    softargmin_prob(pl.reg, w.depth_start, w.depth_interval, False, pl.depth, pl.prob)
+                    p2[i % 2].run_depth(feats, cams, w.depth_start, w.depth_interval, end, False)
             for i in range(4):
                 step2(i)
             torch.cuda.synchronize()

@@ -204,6 +204,20 @@ int mvs_profile_dominant_ms(double* avg_ms, int* count);
  * outside timed regions; not during hipGraph capture. */
 int mvs_profile_layers(int enable);
 int mvs_profile_layers_ms(double* avg_ms11, int* count);
+/* The whole 3D-CNN path after the feature towers in ONE call (inference_mem, model.py:408-502): plane homographies ->
+ * fused warp + variance cost volume -> RegNetUS0 -> softmax / soft-argmin / probability map; 14 launches, none of them for
+ * bookkeeping (the BatchNorm sums are cleared by the homography launch).
+ *   features (view_num,H,W,C): the reference view first; cams (view_num,2,4,4); depth samples as in
+ *   mvs_homography_transforms_f32; variant as in mvs_cost_volume_f32;
+ *   caller-owned scratch: transforms (view_num-1,D,8), cost (D,H,W,C), workspace (mvs_regnet_workspace_bytes), reg (D,H,W);
+ *   outputs depth, prob (H,W).  prepared: mvs_regnet_prepare_f32's buffer or NULL. */
+int mvs_depth_from_features_f32(const float* features, const float* cams, int view_num, int depth_num,
+                                int H, int W, int C, int base, float depth_start, float depth_interval,
+                                float depth_end, int inverse_depth, int variant,
+                                const float* const* weights, const float* prepared,
+                                const float* const* gammas, const float* const* betas, float eps,
+                                float* transforms, float* cost, void* workspace, size_t workspace_bytes,
+                                float* reg, float* depth, float* prob, void* stream);
 /* RegNetUS0 on a batch (FLAGS.batch_size > 1, model.py:466-469): the reference's BatchNorm layers normalise with
  * the statistics of the whole batch (B,D,H,W) (network.py:496-506), so samples are coupled through every layer's sums.
  *   cost (B,D,H,W,cin) contiguous; reg (B,D,H,W); workspace >= B * mvs_regnet_workspace_bytes(D,H,W,cin,base);

@@ -49,6 +49,8 @@ SIGNATURES = {
     "mvs_regnet_us0_f32": (_i, [_p, _i, _i, _i, _i, _i, _pp, _pp, _pp, _f, _p, _sz, _p, _p]),
     "mvs_regnet_prepared_floats": (_sz, [_i, _i]),
     "mvs_regnet_prepare_f32": (_i, [_pp, _i, _i, _p, _p]),
+    "mvs_depth_from_features_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _pp, _p, _pp, _pp, _f,
+                                         _p, _p, _p, _sz, _p, _p, _p, _p]),
     "mvs_regnet_us0_batch_f32": (_i, [_p, _i, _i, _i, _i, _i, _i, _pp, _p, _pp, _pp, _f, _p, _sz, _p, _p]),
     "mvs_regnet_us0_prepared_f32": (_i, [_p, _i, _i, _i, _i, _i, _pp, _p, _pp, _pp, _f, _p, _sz, _p, _p]),
     "mvs_softargmin_prob_f32": (_i, [_p, _i, _i, _i, _f, _f, _i, _p, _p, _p]),

@@ -43,8 +43,10 @@ __device__ __forceinline__ M3 inverse(const M3& a) {
 __global__ void homography_kernel(const float* __restrict__ cams, int n_src, int D,
                                   float depth_start, float depth_interval, float depth_end,
                                   int inverse_depth, float* __restrict__ Hout,
-                                  float* __restrict__ Tout) {
+                                  float* __restrict__ Tout, double* __restrict__ zero, int zero_n) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // the fused features -> depth entry also clears the regulariser's BatchNorm sums here (one launch less per depth map)
+    for (int i = idx; i < zero_n; i += gridDim.x * blockDim.x) zero[i] = 0.0;
     if (idx >= n_src * D) return;
     int v = idx / D, d = idx - v * D;
     const float* L = cams;                    // reference ("left") camera
@@ -134,6 +136,16 @@ extern "C" int mvs_homography_transforms_f32(const float* cams, int view_num, in
     int n = (view_num - 1) * depth_num;
     homography_kernel<<<mvs_cdiv(n, 128), 128, 0, mvs_stream(stream)>>>(
         cams, view_num - 1, depth_num, depth_start, depth_interval, depth_end, inverse_depth,
-        homographies, transforms);
+        homographies, transforms, nullptr, 0);
     MVS_LAUNCH_RET();
+}
+
+// same + zero-fill of `zero_n` doubles (regnet.hip: the BatchNorm sums of the depth map about to be computed)
+int mvs_homography_transforms_zero(const float* cams, int view_num, int depth_num, float depth_start,
+                                   float depth_interval, float depth_end, int inverse_depth, float* transforms,
+                                   double* zero, int zero_n, hipStream_t st) {
+    int n = (view_num - 1) * depth_num;
+    homography_kernel<<<mvs_cdiv(n, 128), 128, 0, st>>>(cams, view_num - 1, depth_num, depth_start, depth_interval,
+                                                       depth_end, inverse_depth, nullptr, transforms, zero, zero_n);
+    return (int)hipGetLastError();
 }

@@ -263,7 +263,7 @@ extern "C" int mvs_regnet_prepare_f32(const float* const* weights, int cin, int 
 static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin, int base,
                       const float* const* weights, const float* prepared, const float* const* gammas,
                       const float* const* betas, float eps, void* workspace, size_t workspace_bytes,
-                      float* reg, void* stream) {
+                      float* reg, void* stream, bool stats_zeroed = false) {
     const PrepLayout lay = prep_layout(cin, base);
     MVS_CHECK_ARG(cost && weights && gammas && betas && workspace && reg);
     MVS_CHECK_ARG(batch > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && base > 0);
@@ -278,7 +278,7 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
               D3 = D / 8, H3 = H / 8, W3 = W / 8;
     const double v0 = (double)batch * D * H * W, v1 = v0 / 8, v2 = v1 / 8, v3 = v2 / 8;     // voxels behind each statistic
     int rc;
-    if ((rc = mvs_zero_f64(ws.stats, (size_t)N_BN * 2 * cmax, stream))) return rc;
+    if (!stats_zeroed && (rc = mvs_zero_f64(ws.stats, (size_t)N_BN * 2 * cmax, stream))) return rc;
     hipStream_t hs = mvs_stream(stream);
     int lp = -1;                                     // per-layer event slot of this call (mvs_profile_layers)
     if (g_lprof.on && g_lprof.used < 32) {
@@ -441,4 +441,32 @@ extern "C" int mvs_regnet_us0_batch_f32(const float* cost, int batch, int D, int
                                         float* reg, void* stream) {
     return regnet_run(cost, batch, D, H, W, cin, base, weights, prepared, gammas, betas, eps, workspace,
                       workspace_bytes, reg, stream);
+}
+
+// ---- features -> depth in one call (model.py:374-502 after the towers) ---------------------------------------------
+int mvs_homography_transforms_zero(const float* cams, int view_num, int depth_num, float depth_start,
+                                   float depth_interval, float depth_end, int inverse_depth, float* transforms,
+                                   double* zero, int zero_n, hipStream_t st);
+
+extern "C" int mvs_depth_from_features_f32(const float* features, const float* cams, int view_num, int depth_num,
+                                           int H, int W, int C, int base, float depth_start, float depth_interval,
+                                           float depth_end, int inverse_depth, int variant,
+                                           const float* const* weights, const float* prepared,
+                                           const float* const* gammas, const float* const* betas, float eps,
+                                           float* transforms, float* cost, void* workspace, size_t workspace_bytes,
+                                           float* reg, float* depth, float* prob, void* stream) {
+    MVS_CHECK_ARG(features && cams && weights && gammas && betas && transforms && cost && workspace && reg && depth && prob);
+    MVS_CHECK_ARG(view_num >= 2 && depth_num >= 1 && H > 0 && W > 0 && C > 0 && base > 0);
+    if ((depth_num % 8) || (H % 8) || (W % 8)) return MVS_E_SHAPE;
+    RegnetWs ws = carve((char*)workspace, depth_num, H, W, C, base);
+    if (workspace_bytes < ws.bytes) return MVS_E_WORKSPACE;
+    int rc;
+    // plane homographies -> 8-vectors, and the zero-fill of this depth map's BatchNorm sums, in one launch
+    if ((rc = mvs_homography_transforms_zero(cams, view_num, depth_num, depth_start, depth_interval, depth_end, inverse_depth,
+                                             transforms, ws.stats, N_BN * 2 * 8 * base, mvs_stream(stream)))) return rc;
+    if ((rc = mvs_cost_volume_f32(features, features + (size_t)H * W * C, transforms, view_num, depth_num, 0, depth_num,
+                                  H, W, C, variant, 0, 0, cost, stream))) return rc;
+    if ((rc = regnet_run(cost, 1, depth_num, H, W, C, base, weights, prepared, gammas, betas, eps, workspace,
+                         workspace_bytes, reg, stream, true))) return rc;
+    return mvs_softargmin_prob_f32(reg, depth_num, H, W, depth_start, depth_interval, inverse_depth, depth, prob, stream);
 }

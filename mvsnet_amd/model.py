@@ -348,6 +348,23 @@ class DepthPlan:
         softargmin_prob(self.reg, depth_start, depth_interval, inverse_depth, self.depth, self.prob)
         return self.depth, self.prob
 
+    def run_depth(self, features, cams, depth_start, depth_interval, depth_end, inverse_depth=False, variant="mem"):
+        """features (N,H,W,C), cams (N,2,4,4) -> (depth, prob): set_cameras + run_3dcnn as ONE library call
+        (mvs_depth_from_features_f32: the homography launch also clears the BatchNorm sums)."""
+        lib = _lib.load()
+        if features.shape[-1] != self.C:
+            self.fpad[..., :features.shape[-1]].copy_(features)       # padded channels stay zero
+            features = self.fpad
+        w = self.weights.regnet
+        _lib.check(lib.mvs_depth_from_features_f32(
+            _lib.ptr(_lib.f32(features)), _lib.ptr(_lib.f32(cams)), self.N, self.D, self.H, self.W, self.C, w.base,
+            float(depth_start), float(depth_interval), float(depth_end), int(bool(inverse_depth)),
+            0 if variant == "mem" else 1, w.w_ptrs, _lib.ptr(w.prepared), w.g_ptrs, w.b_ptrs, BN_EPSILON,
+            _lib.ptr(self.transforms), _lib.ptr(self.cost), C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(),
+            _lib.ptr(self.reg), _lib.ptr(self.depth), _lib.ptr(self.prob), _lib.stream_ptr()),
+            "mvs_depth_from_features_f32")
+        return self.depth, self.prob
+
     def run_gru(self, features, depth_values):
         lib = _lib.load()
         g = self.weights.gru
@@ -472,8 +489,7 @@ def inference_mem(images, cams, depth_num, depth_start, depth_interval, network_
     _, H, W, Cc = feats.shape
     end = np.float32(start) + (np.float32(D) - np.float32(1)) * np.float32(interval)   # model.py:378-379
     plan = _plan(view_num, D, H, W, Cc, weights, "3DCNN", feats.device)
-    plan.set_cameras(cams_, start, interval, float(end), inverse_depth)
-    depth, prob = plan.run_3dcnn(feats, start, interval, inverse_depth, variant)
+    depth, prob = plan.run_depth(feats, cams_, start, interval, float(end), inverse_depth, variant)
     return depth.reshape(1, H, W, 1).clone(), prob.reshape(1, H, W, 1).clone()
 
 
