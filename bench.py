@@ -220,8 +220,11 @@ def gru_config_in_child(name, steps=5):
     streams, paced by launch latency, and measured 44 ms per depth map when run at the tail of this process against 23 ms in
     a fresh one (round 2; cause not isolated -- tools/gru_after_3dcnn.py rules out earlier 3D-CNN work, streams and events)."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--regularization", "GRU", "--workload", name,
-                        "--steps", str(steps)], capture_output=True, text=True, timeout=300)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--regularization", "GRU", "--workload", name,
+                            "--steps", str(steps)], capture_output=True, text=True, timeout=300)
+    except Exception as e:                              # the record is informative: never fail the bench line over it
+        return {"error": repr(e)[:300]}
     for line in r.stdout.splitlines():
         if line.startswith("{"):
             d = json.loads(line)
