@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvsnet_hip.so")
+LIB_PATH = os.environ.get("MVS_LIB_PATH") or os.path.join(_HERE, "libmvsnet_hip.so")      # MVS_LIB_PATH: A/B builds of the library
 
 _f = C.c_float
 _i = C.c_int

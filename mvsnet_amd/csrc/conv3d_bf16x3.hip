@@ -243,7 +243,7 @@ conv3d_s1_bf16_kernel(ConvArgs a) {
         if (t + 2 < T) plane(std::integral_constant<int, 2>{}, t + 2);
     }
 
-    if (a.stats) stats_commit<COUT>(st_s, st_q, COUT == 8, reinterpret_cast<float*>(slab), a.stats, a.cout_total, co_base);
+    if (a.stats) stats_commit<COUT>(st_s, st_q, COUT == 8, reinterpret_cast<float*>(slab), conv_stats_row(a), a.cout_total, co_base);
 }
 
 // TensorFlow (3,3,3,Cin,Cout) fp32 -> per cout group [tap9][(kd,co) rows][Cin hi | Cin lo] bf16

@@ -301,7 +301,7 @@ conv3d_s1_kernel(ConvArgs a) {
     // ---- BatchNorm statistics ----------------------------------------------------------------------
     // channel quad of st_*: COUT=16: blocks start at row 0 of their tile -> quad kq.  COUT=8: blocks
     // 0,2 sit in lane groups 0,1 and block 1 in groups 2,3 -> quad kq&1, fold lanes l and l^32.
-    if (a.stats) stats_commit<COUT>(st_s, st_q, COUT == 8, slab, a.stats, a.cout_total, co_base);
+    if (a.stats) stats_commit<COUT>(st_s, st_q, COUT == 8, slab, conv_stats_row(a), a.cout_total, co_base);
 }
 
 template <int CIN, int COUT, int TH, int TWG = CONV_TW, int CR = 1>
@@ -377,15 +377,15 @@ int mvs_deconv3d_mfma(const float* x, const float* xs, const float* xb, const fl
 // Variants taking the producers' raw BatchNorm sums (regnet.hip): no bn_finalize launch in between.
 int mvs_conv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
                        const float* w, const float* wprep, const unsigned short* wprep_bf, int D, int H,
-                       int W, int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep, wprep_bf};
+                       int W, int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st, int stats_slots) {
+    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep, wprep_bf, stats_slots};
     return conv_dispatch(a, Cin, Cout, stride, st);
 }
 
 int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
                          const float* w, const float* wprep, int D, int H, int W, int Cin, int Cout,
-                         float* y, double* stats, hipStream_t st) {
-    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep, nullptr};
+                         float* y, double* stats, hipStream_t st, int stats_slots) {
+    ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep, nullptr, stats_slots};
     return mvs_deconv3d_mfma_launch(a, Cin, Cout, st);
 }
 

@@ -29,6 +29,7 @@ constexpr int OS_OOB = (int)0x80000000u;   // buffer byte offset with bit 31 set
 
 enum { OS_S1 = 0, OS_S2 = 1, OS_DECONV = 2 };
 
+
 template <int KIND, int CIN, int NCW, int VT, int BD, int BHT, int BWT>
 struct OsGeom {
     static constexpr int NVW = 4 / NCW;                    // waves along the voxel tiles
@@ -62,7 +63,7 @@ conv3d_os_kernel(ConvArgs a, int nbh, int nbw) {
     using Gm = OsGeom<KIND, CIN, NCW, VT, BD, BHT, BWT>;
     constexpr int S = Gm::S, PH = Gm::PH, PW = Gm::PW, CQ = Gm::CQ, NIT = Gm::NIT, G = Gm::G, NS = Gm::NS;
     constexpr int NACC = Gm::NACC;
-    constexpr int PF = VT == 1 ? 8 : 4;                     // weight loads in flight per wave (K steps ahead)
+    constexpr int PF = 8;                                   // weight loads in flight per wave (K steps ahead; 4 / 8 / 12 measured: 8)
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -93,6 +94,11 @@ conv3d_os_kernel(ConvArgs a, int nbh, int nbw) {
         const float* p = a.w + ((size_t)tap * CIN + ci) * a.cout_total + co;      // TensorFlow (3,3,3,Cin,Cout)
         return make_float4(p[0], p[a.cout_total], p[2 * a.cout_total], p[3 * a.cout_total]);
     };
+    // the producers' float64 BatchNorm sums first: they come from memory-side atomics (an L2 miss) and head the longest
+    // dependent chain of the prologue (sums -> float64 scale / shift -> staged values -> LDS -> barrier)
+    BnSums4 bs1 = {}, bs2 = {};
+    if (!a.xs && a.bn.stats) bs1 = bn_sums4(a.bn, 4 * (tid % CQ));
+    if (HAS_X2 && !a.x2s && a.bn2.stats) bs2 = bn_sums4(a.bn2, 4 * (tid % CQ));
     float4 areg[PF];
 #pragma unroll
     for (int s = 0; s < PF; ++s) areg[s] = load_a(s);       // in flight under the staging below
@@ -123,10 +129,10 @@ conv3d_os_kernel(ConvArgs a, int nbh, int nbw) {
         float4 sc2 = sc, sh2 = sh;
         const bool aff = a.xs != nullptr || a.bn.stats != nullptr;
         if (a.xs) { sc = *(const float4*)(a.xs + 4 * c4); sh = *(const float4*)(a.xb + 4 * c4); }
-        else if (a.bn.stats) bn_affine4(a.bn, 4 * c4, sc, sh);
+        else if (a.bn.stats) bn_affine4_from(a.bn, bs1, sc, sh);
         const bool aff2 = HAS_X2 && (a.x2s != nullptr || a.bn2.stats != nullptr);
         if (HAS_X2 && a.x2s) { sc2 = *(const float4*)(a.x2s + 4 * c4); sh2 = *(const float4*)(a.x2b + 4 * c4); }
-        else if (HAS_X2 && a.bn2.stats) bn_affine4(a.bn2, 4 * c4, sc2, sh2);
+        else if (HAS_X2 && a.bn2.stats) bn_affine4_from(a.bn2, bs2, sc2, sh2);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int f = tid + 256 * i;
@@ -256,6 +262,8 @@ conv3d_os_kernel(ConvArgs a, int nbh, int nbw) {
     }
     if (a.stats) {
         // fold the 16 voxel lanes, then the waves that share a cout tile, then one f64 atomic per channel and workgroup
+        // (one atomic instruction of 32 * NCW lanes: per-wave atomics without the barriers -- 8 instructions of 4 lanes per
+        // wave -- measured 15 us SLOWER on the 240-workgroup layers)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -272,7 +280,7 @@ conv3d_os_kernel(ConvArgs a, int nbh, int nbw) {
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < Gm::NVW; ++w) tot += (double)red[((w * NCW + t) * 2 + kk) * 16 + c];
-            atomicAdd(&a.stats[(size_t)kk * a.cout_total + (blockIdx.y * NCW + t) * 16 + c], tot);
+            atomicAdd(&conv_stats_row(a)[(size_t)kk * a.cout_total + (blockIdx.y * NCW + t) * 16 + c], tot);
         }
     }
 }

@@ -246,7 +246,7 @@ conv3d_s2_kernel(ConvArgs a) {
         if (t + 3 < T) plane(std::integral_constant<int, 3>{}, t + 3);
     }
 
-    if (a.stats) stats_commit<COUT>(st_s, st_q, false, slab, a.stats, a.cout_total, co_base);
+    if (a.stats) stats_commit<COUT>(st_s, st_q, false, slab, conv_stats_row(a), a.cout_total, co_base);
 }
 
 template <int CIN, int TOH>

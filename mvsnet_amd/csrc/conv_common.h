@@ -32,6 +32,34 @@ __device__ __forceinline__ void bn_affine4(const BnSrc& b, int c0, float4& sc, f
     sh = make_float4(t[0], t[1], t[2], t[3]);
 }
 
+// The same in two halves, for kernels that want the float64 sums in flight early: bn_sums4 only loads (and adds the partial
+// rows), bn_affine4_from turns the sums into (scale, shift).
+struct BnSums4 { double s1[4], s2[4]; float g[4], b[4]; };
+__device__ __forceinline__ BnSums4 bn_sums4(const BnSrc& b, int c0) {
+    BnSums4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double s1 = b.stats[c0 + k], s2 = b.stats[b.C + c0 + k];
+        for (int sl = 1; sl < b.nslot; ++sl) { s1 += b.stats[sl * 2 * b.C + c0 + k]; s2 += b.stats[sl * 2 * b.C + b.C + c0 + k]; }
+        r.s1[k] = s1; r.s2[k] = s2; r.g[k] = b.gamma[c0 + k]; r.b[k] = b.beta[c0 + k];
+    }
+    return r;
+}
+__device__ __forceinline__ void bn_affine4_from(const BnSrc& b, const BnSums4& r, float4& sc, float4& sh) {
+    float s[4], t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double mean = r.s1[k] / b.count;
+        double var = r.s2[k] / b.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        double inv = (double)r.g[k] / sqrt(var + (double)b.eps);
+        s[k] = (float)inv;
+        t[k] = (float)((double)r.b[k] - mean * inv);
+    }
+    sc = make_float4(s[0], s[1], s[2], s[3]);
+    sh = make_float4(t[0], t[1], t[2], t[3]);
+}
+
 struct ConvArgs {
     const float* x; const float* xs; const float* xb;      // input + producer BN affine (or null)
     const float* x2; const float* x2s; const float* x2b;   // optional additive skip input
@@ -43,7 +71,18 @@ struct ConvArgs {
     BnSrc bn, bn2;                                          // alternative to xs/xb, x2s/x2b (stats given)
     const float* wprep;                                     // weights already in the kernel's LDS order, or null
     const unsigned short* wprep_bf;                         // bf16 hi|lo split weights (opt-in bf16x3 path), or null
+    int stats_slots;                                        // > 1: stats is (slots, 2, CoutTotal) partial rows, see conv_stats_row
 };
+
+// BatchNorm sums go to memory-side float64 atomics.  With every workgroup of a layer adding into the same 2*C doubles the
+// atomics cost ~5 us at the end of each 240..960-workgroup layer (measured by leaving them out: the low-resolution chain
+// went 140 -> 120 us; they are native global_atomic_add_f64, one instruction of 32..128 lanes per workgroup).  A layer's sums
+// can be spread over `stats_slots` partial rows, workgroup w adds into row w % slots, and the consumer's bn_affine4 /
+// bn_sums4 add the rows up (BnSrc::nslot); regnet.hip uses 2 rows (more rows cost the consumers more than they save).
+__device__ __forceinline__ double* conv_stats_row(const ConvArgs& a) {
+    const int slots = a.stats_slots > 1 ? a.stats_slots : 1;
+    return a.stats + (size_t)((blockIdx.x + gridDim.x * blockIdx.z) % slots) * 2 * a.cout_total;
+}
 
 constexpr int CONV_TW = 16;      // voxels per MFMA column tile (along w)
 
@@ -147,6 +186,7 @@ __device__ __forceinline__ void load_prepared_weights(float* wl, const float* wp
 }
 
 // launchers implemented in the kernel files; MVS_E_SHAPE when the shape is outside their tiling
+constexpr int MVS_BN_SLOTS_MAX = 8;      // partial rows per BatchNorm layer in the regulariser's workspace
 int mvs_conv3d_s2_mfma(const ConvArgs& a, int Cin, int Cout, hipStream_t st);
 int mvs_deconv3d_mfma_launch(const ConvArgs& a, int Cin, int Cout, hipStream_t st);
 int mvs_conv3d_out_launch(const ConvArgs& a, int Cin, hipStream_t st);

@@ -279,7 +279,7 @@ deconv3d_c8_kernel(ConvArgs a) {
     }
 
     // every lane's st_* are the sums of channels 4*(kq&1) .. +3: fold lanes l and l^32
-    if (a.stats) stats_commit<COUT>(st_s, st_q, true, slab, a.stats, a.cout_total, co_base);
+    if (a.stats) stats_commit<COUT>(st_s, st_q, true, slab, conv_stats_row(a), a.cout_total, co_base);
 }
 
 template <int CIN>

@@ -219,7 +219,7 @@ deconv3d_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    if (a.stats) stats_commit<COUT>(st_s, st_q, false, slab, a.stats, a.cout_total, co_base);
+    if (a.stats) stats_commit<COUT>(st_s, st_q, false, slab, conv_stats_row(a), a.cout_total, co_base);
 }
 
 template <int CIN, int COUT, int TH>

@@ -22,10 +22,10 @@ int mvs_deconv3d_mfma(const float*, const float*, const float*, const float*, co
 // same, taking the producers' raw BatchNorm sums instead of a finalised (scale, shift)
 int mvs_conv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
                        const float* w, const float* wprep, const unsigned short* wprep_bf, int D, int H,
-                       int W, int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st);
+                       int W, int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st, int stats_slots);
 int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
                          const float* w, const float* wprep, int D, int H, int W, int Cin, int Cout,
-                         float* y, double* stats, hipStream_t st);
+                         float* y, double* stats, hipStream_t st, int stats_slots);
 int mvs_conv_weight_layout(const float* w, int kind, int Cin, int Cout, float* out, hipStream_t st);
 
 static int g_conv_impl = MVS_CONV_IMPL_AUTO;
@@ -150,7 +150,7 @@ struct RegnetWs {
     float* y[N_BN];        // raw (pre-BN) outputs
     float* scale[N_BN];
     float* shift[N_BN];
-    double* stats;         // N_BN x 2 x cmax
+    double* stats;         // N_BN x MVS_BN_SLOTS_MAX x 2 x cmax (partial rows per layer, conv_common.h: conv_stats_row)
     size_t bytes;
 };
 
@@ -173,7 +173,7 @@ RegnetWs carve(char* base, int D, int H, int W, int cin, int b) {
         w.shift[i] = (float*)(base ? base + off : nullptr); off += align256(cmax * sizeof(float));
     }
     w.stats = (double*)(base ? base + off : nullptr);
-    off += align256((size_t)N_BN * 2 * cmax * sizeof(double));
+    off += align256((size_t)N_BN * MVS_BN_SLOTS_MAX * 2 * cmax * sizeof(double));
     w.bytes = off;
     return w;
 }
@@ -278,7 +278,7 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
               D3 = D / 8, H3 = H / 8, W3 = W / 8;
     const double v0 = (double)batch * D * H * W, v1 = v0 / 8, v2 = v1 / 8, v3 = v2 / 8;     // voxels behind each statistic
     int rc;
-    if (!stats_zeroed && (rc = mvs_zero_f64(ws.stats, (size_t)N_BN * 2 * cmax, stream))) return rc;
+    if (!stats_zeroed && (rc = mvs_zero_f64(ws.stats, (size_t)N_BN * MVS_BN_SLOTS_MAX * 2 * cmax, stream))) return rc;
     hipStream_t hs = mvs_stream(stream);
     int lp = -1;                                     // per-layer event slot of this call (mvs_profile_layers)
     if (g_lprof.on && g_lprof.used < 32) {
@@ -299,16 +299,23 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
     };
     const int ch[N_BN] = {2 * b, 4 * b, 8 * b, b, 2 * b, 4 * b, 8 * b, 4 * b, 2 * b, b};
     const double cnt[N_BN] = {v1, v2, v3, v0, v1, v2, v3, v2, v1, v0};
-    auto st = [&](int i) { return ws.stats + (size_t)i * 2 * cmax; };
+    auto st = [&](int i) { return ws.stats + (size_t)i * MVS_BN_SLOTS_MAX * 2 * cmax; };
+    // partial rows per layer: only where EVERY layer has an MFMA kernel (the scalar fallback finalises one row)
+    // MVS_BN_SLOTS = 1 / 2 / 4 / 8 measured 858 / 864 / 860 / 848 depth maps/s at the metric workload: more rows shorten the
+    // producers' atomic tails but every consumer thread adds the rows up again
+    static const int slots_env = getenv("MVS_BN_SLOTS") ? atoi(getenv("MVS_BN_SLOTS")) : 2;
+    const bool all_mfma = (g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA) && cin == 32 && b == 8;
+    const int SL = all_mfma ? (slots_env < 1 ? 1 : slots_env > MVS_BN_SLOTS_MAX ? MVS_BN_SLOTS_MAX : slots_env) : 1;
     bool finalised[N_BN] = {false};
     bool pair_done = false;
     // the fused pass over the cost volume spreads its sums over partial rows (conv3d_c8.hip, FuseArgs): as many as
     // fit the layer's 2*cmax-double slab
-    const int slots01 = (2 * cmax) / (2 * b) < 8 ? (2 * cmax) / (2 * b) : 8, slots10 = (2 * cmax) / (4 * b) < 8 ? (2 * cmax) / (4 * b) : 8;
+    const int slots01 = all_mfma ? MVS_BN_SLOTS_MAX : ((2 * cmax) / (2 * b) < 8 ? (2 * cmax) / (2 * b) : 8);
+    const int slots10 = all_mfma ? MVS_BN_SLOTS_MAX : ((2 * cmax) / (4 * b) < 8 ? (2 * cmax) / (4 * b) : 8);
     auto bn_of = [&](int i) {      // producer i's raw BatchNorm sums (i < 0: raw input, no BN)
         BnSrc s{nullptr, nullptr, nullptr, 1.0, eps, 0, 1};
         if (i >= 0) s = BnSrc{st(i), gammas[i], betas[i], cnt[i], eps, ch[i],
-                              pair_done ? (i == L01 ? slots01 : i == L10 ? slots10 : 1) : 1};
+                              (pair_done && i == L01) ? slots01 : (pair_done && i == L10) ? slots10 : SL};
         return s;
     };
     auto ensure_final = [&](int i) -> int {
@@ -329,9 +336,9 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
             // opt-in split-precision path: bf16 hi|lo weights live behind the fp32 layouts
             const unsigned short* wbf = (prepared && g_conv_impl == MVS_CONV_IMPL_BF16X3 && lay.bf[out])
                 ? reinterpret_cast<const unsigned short*>(prepared + lay.total + lay.off[out]) : nullptr;
-            int r = deconv ? mvs_deconv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, d, h, w, ci, co, y, so, hs)
-                           : mvs_conv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, wbf, d, h, w, ci, co, stride, y, so, hs);
-            if (r != MVS_E_SHAPE || g_conv_impl == MVS_CONV_IMPL_MFMA || g_conv_impl == MVS_CONV_IMPL_BF16X3) return r;
+            int r = deconv ? mvs_deconv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, d, h, w, ci, co, y, so, hs, SL)
+                           : mvs_conv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, wbf, d, h, w, ci, co, stride, y, so, hs, SL);
+            if (r != MVS_E_SHAPE || g_conv_impl == MVS_CONV_IMPL_MFMA || g_conv_impl == MVS_CONV_IMPL_BF16X3 || SL > 1) return r;
         }
         int r;
         if ((r = ensure_final(p1)) || (r = ensure_final(p2))) return r;
@@ -463,7 +470,7 @@ extern "C" int mvs_depth_from_features_f32(const float* features, const float* c
     int rc;
     // plane homographies -> 8-vectors, and the zero-fill of this depth map's BatchNorm sums, in one launch
     if ((rc = mvs_homography_transforms_zero(cams, view_num, depth_num, depth_start, depth_interval, depth_end, inverse_depth,
-                                             transforms, ws.stats, N_BN * 2 * 8 * base, mvs_stream(stream)))) return rc;
+                                             transforms, ws.stats, N_BN * MVS_BN_SLOTS_MAX * 2 * 8 * base, mvs_stream(stream)))) return rc;
     if ((rc = mvs_cost_volume_f32(features, features + (size_t)H * W * C, transforms, view_num, depth_num, 0, depth_num,
                                   H, W, C, variant, 0, 0, cost, stream))) return rc;
     if ((rc = regnet_run(cost, 1, depth_num, H, W, C, base, weights, prepared, gammas, betas, eps, workspace,
