@@ -1,5 +1,7 @@
 """Phase split of the block kernels (conv3d_os.hip) inside a metric-size depth map, from s_memtime stamps of a DIAGNOSTIC build
-(the product source carries no stamps: see the round-2 notes in DESIGN 4.2b for the numbers this produced)."""
+(`git apply tools/os_prof.patch`, rebuild; the product source carries no stamps).  Ticks are s_memtime at its constant rate:
+round 2 read 3dconv3_1 as load-issue 3.1 k, sums + float64 affine 3.9 k, LDS write + barrier 2.0 k, K loop 33 k (= 864 MFMAs at the
+issue rate of the ~2.0 GHz the chip holds under MFMA load), stores 0.8 k, BatchNorm sums 8.7 k ticks."""
 import ctypes, sys, numpy as np, torch
 sys.path.insert(0, '.')
 from mvsnet_amd import _lib, synthetic as S
