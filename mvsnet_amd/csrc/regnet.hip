@@ -304,7 +304,9 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
     // MVS_BN_SLOTS = 1 / 2 / 4 / 8 measured 858 / 864 / 860 / 848 depth maps/s at the metric workload: more rows shorten the
     // producers' atomic tails but every consumer thread adds the rows up again
     static const int slots_env = getenv("MVS_BN_SLOTS") ? atoi(getenv("MVS_BN_SLOTS")) : 2;
-    const bool all_mfma = (g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA) && cin == 32 && b == 8;
+    // (volumes of 2 GB and more leave the 32-bit-offset MFMA kernels for the generic ones: one row there)
+    const bool all_mfma = (g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA) && cin == 32 && b == 8 &&
+                          (long long)D * H * W * cin * 4 < (1LL << 31);
     const int SL = all_mfma ? (slots_env < 1 ? 1 : slots_env > MVS_BN_SLOTS_MAX ? MVS_BN_SLOTS_MAX : slots_env) : 1;
     bool finalised[N_BN] = {false};
     bool pair_done = false;
