@@ -116,12 +116,14 @@ def test_plan_runs_under_hipgraph_capture(lib_built):
     feats, cams = t(w.features), t(w.cams)
     plan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", DEV)
 
-    def run():
-        plan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
-        plan.run_3dcnn(feats, w.depth_start, w.depth_interval)
+    def run():       # the one-call entry (mvs_depth_from_features_f32), as inference_mem uses it
+        plan.run_depth(feats, cams, w.depth_start, w.depth_interval, w.depth_end, False)
+    plan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
+    split = plan.run_3dcnn(feats, w.depth_start, w.depth_interval)[0].clone()       # per-stage entries: same launches
     run()
     torch.cuda.synchronize()
     eager = plan.depth.clone()
+    assert torch.allclose(eager, split, rtol=1e-6, atol=1e-4)
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
