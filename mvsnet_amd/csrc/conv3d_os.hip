@@ -13,7 +13,7 @@
 //     (+ additive skip) applied on the way in; the B operand is one ds_read_b128 per (tap, 16-channel group, tile)
 //     at lane base + immediate offset -- any patch shape and any stride is free;
 //   * the A operand (weights) never touches LDS: the pre-laid-out weights (mvs_regnet_prepare_f32) are read straight
-//     from L2 into registers, one coalesced 1 KB global_load_dwordx4 per wave and (tap, 16-channel group), four steps
+//     from L2 into registers, one coalesced 1 KB global_load_dwordx4 per wave and (tap, 16-channel group), eight steps
 //     ahead of use.  No weight upload, no prologue barrier for it, and the LDS footprint (20-61 KB) lets several
 //     workgroups -- of this kernel and of the branch layers on the side stream -- share a CU;
 //   * the four waves split the output channels (and the voxel tiles when Cout < 64), never K: no reduction.
