@@ -312,8 +312,12 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
     bool pair_done = false;
     // the fused pass over the cost volume spreads its sums over partial rows (conv3d_c8.hip, FuseArgs): as many as
     // fit the layer's 2*cmax-double slab
-    const int slots01 = all_mfma ? MVS_BN_SLOTS_MAX : ((2 * cmax) / (2 * b) < 8 ? (2 * cmax) / (2 * b) : 8);
-    const int slots10 = all_mfma ? MVS_BN_SLOTS_MAX : ((2 * cmax) / (4 * b) < 8 ? (2 * cmax) / (4 * b) : 8);
+    // rows of the fused pair's sums: MVS_PAIR_SLOTS = 8 (round 1) / 4 / 2 / 1 measured 864 / 869 / 869 / 870 depth maps/s -- the
+    // consumers (3dconv1_1, 2_0 and the 3 840-workgroup 3dconv6_2) pay for every row they add up
+    static const int pair_slots_env = getenv("MVS_PAIR_SLOTS") ? atoi(getenv("MVS_PAIR_SLOTS")) : 2;
+    const int pair_slots = pair_slots_env < 1 ? 1 : pair_slots_env > MVS_BN_SLOTS_MAX ? MVS_BN_SLOTS_MAX : pair_slots_env;
+    const int slots01 = all_mfma ? pair_slots : ((2 * cmax) / (2 * b) < 8 ? (2 * cmax) / (2 * b) : 8);
+    const int slots10 = all_mfma ? pair_slots : ((2 * cmax) / (4 * b) < 8 ? (2 * cmax) / (4 * b) : 8);
     auto bn_of = [&](int i) {      // producer i's raw BatchNorm sums (i < 0: raw input, no BN)
         BnSrc s{nullptr, nullptr, nullptr, 1.0, eps, 0, 1};
         if (i >= 0) s = BnSrc{st(i), gammas[i], betas[i], cnt[i], eps, ch[i],
