@@ -15,18 +15,28 @@ struct BnSrc {
     int nslot;                // stats is (nslot, 2, C): partial rows the consumer adds up (0 / 1: a single row)
 };
 
+// mean and variance in float64 (E[x^2] - E[x]^2 cancels), the reciprocal square root in float32 (v_rsq_f32, 1 ulp) as
+// TensorFlow's fused batch norm takes it: the float64 divisions and square root of a literal transcription are ~600
+// double-rate instructions per thread in EVERY workgroup's prologue (round 2: the consumers' prologues showed up as ~1.6 us
+// per 240-workgroup layer).
+__device__ __forceinline__ void bn_affine_finish(double s1, double s2, double inv_count, float gamma, float beta, float eps,
+                                                 float& scale, float& shift) {
+    const double mean = s1 * inv_count;
+    double var = s2 * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float inv = gamma * __builtin_amdgcn_rsqf((float)var + eps);
+    scale = inv;
+    shift = beta - (float)mean * inv;
+}
+
 __device__ __forceinline__ void bn_affine4(const BnSrc& b, int c0, float4& sc, float4& sh) {
     float s[4], t[4];
+    const double ic = 1.0 / b.count;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         double s1 = b.stats[c0 + k], s2 = b.stats[b.C + c0 + k];
         for (int sl = 1; sl < b.nslot; ++sl) { s1 += b.stats[sl * 2 * b.C + c0 + k]; s2 += b.stats[sl * 2 * b.C + b.C + c0 + k]; }
-        double mean = s1 / b.count;
-        double var = s2 / b.count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        double inv = (double)b.gamma[c0 + k] / sqrt(var + (double)b.eps);
-        s[k] = (float)inv;
-        t[k] = (float)((double)b.beta[c0 + k] - mean * inv);
+        bn_affine_finish(s1, s2, ic, b.gamma[c0 + k], b.beta[c0 + k], b.eps, s[k], t[k]);
     }
     sc = make_float4(s[0], s[1], s[2], s[3]);
     sh = make_float4(t[0], t[1], t[2], t[3]);
@@ -47,15 +57,9 @@ __device__ __forceinline__ BnSums4 bn_sums4(const BnSrc& b, int c0) {
 }
 __device__ __forceinline__ void bn_affine4_from(const BnSrc& b, const BnSums4& r, float4& sc, float4& sh) {
     float s[4], t[4];
+    const double ic = 1.0 / b.count;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        double mean = r.s1[k] / b.count;
-        double var = r.s2[k] / b.count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        double inv = (double)r.g[k] / sqrt(var + (double)b.eps);
-        s[k] = (float)inv;
-        t[k] = (float)((double)r.b[k] - mean * inv);
-    }
+    for (int k = 0; k < 4; ++k) bn_affine_finish(r.s1[k], r.s2[k], ic, r.g[k], r.b[k], b.eps, s[k], t[k]);
     sc = make_float4(s[0], s[1], s[2], s[3]);
     sh = make_float4(t[0], t[1], t[2], t[3]);
 }

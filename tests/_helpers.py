@@ -35,3 +35,34 @@ def add_depths(session, n_images=4, h=48, w=64, seed=0):
     for i in range(n_images):
         d = rs.randint(300, 1000, size=(h, w)).astype(np.uint16)           # some values fall outside (400, 900]
         Image.fromarray(d).save(os.path.join(session, "depths", "%d.png" % i))
+
+
+def run_ranks(code, env, world=2, timeout=300):
+    """Start `world` copies of `python -c code` (RANK / LOCAL_RANK set per copy) and wait for all of them.  Output goes
+    to temporary FILES, not pipes: a rank that fills a pipe while the parent is still draining its peer's would block
+    inside a collective the peer is waiting in.  Returns [(returncode, stdout, stderr)] by rank."""
+    import subprocess
+    import sys
+    import tempfile
+    import time
+    files, procs = [], []
+    for r in range(world):
+        fo, fe = tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")
+        files.append((fo, fe))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=fo, stderr=fe, text=True))
+    deadline = time.time() + timeout
+    try:
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    outs = []
+    for p, (fo, fe) in zip(procs, files):
+        fo.seek(0); fe.seek(0)
+        outs.append((p.returncode, fo.read(), fe.read()))
+        fo.close(); fe.close()
+    return outs

@@ -124,14 +124,10 @@ dist.destroy_process_group()
 
 def test_world_size_2_sharding_over_gloo(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
-    procs = []
-    for r in range(2):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER % {"root": ROOT}], env=e,
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=180) for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
-    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    from _helpers import run_ranks
+    outs = run_ranks(_WORKER % {"root": ROOT}, env, world=2, timeout=180)
+    assert all(rc == 0 for rc, _o, _e in outs), outs
+    res = json.loads(outs[0][1].strip().splitlines()[-1])
     assert res["world"] == 2 and res["counts"] == [6.0, 5.0]
     assert res["cover"] == [1] * 11
 

@@ -499,11 +499,9 @@ def test_sync_batchnorm_two_replicas_match_a_batch_of_two(tmp_path):
     np.savez(inp, feats=np.stack([f0, f1]), t8=t8, start=start, interval=interval, g=g)
     outp = str(tmp_path / "rank%d.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, "-c", _SYNC_WORKER % {"root": root, "inp": inp, "out": outp}],
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-             for r in range(2)]
-    outs = [p.communicate(timeout=300) for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    from _helpers import run_ranks
+    outs = run_ranks(_SYNC_WORKER % {"root": root, "inp": inp, "out": outp}, env, world=2, timeout=300)
+    assert all(rc == 0 for rc, _o, _e in outs), outs
     got = [np.load(outp % r) for r in range(2)]
     # checker: the batch of two through the restatement
     params = S.make_regnet_params("normal", seed=1, random_affine=True)
@@ -555,12 +553,10 @@ def test_data_parallel_training_keeps_two_replicas_identical(sync, reg):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563" if sync else ("29565" if reg == "3DCNN" else "29567"), WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, "-c", _DP_WORKER % {"root": root, "sync": sync, "reg": reg}],
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-             for r in range(2)]
-    outs = [p.communicate(timeout=400) for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
-    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    from _helpers import run_ranks
+    outs = run_ranks(_DP_WORKER % {"root": root, "sync": sync, "reg": reg}, env, world=2, timeout=400)
+    assert all(rc == 0 for rc, _o, _e in outs), outs
+    res = json.loads(outs[0][1].strip().splitlines()[-1])
     assert res["equal"] and res["steps"] == 3 and all(np.isfinite(res["losses"]))
 
 

@@ -110,14 +110,10 @@ dist.destroy_process_group()
 
 def test_gradient_averaging_world_size_2_over_gloo():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
-    procs = []
-    for r in range(2):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER % {"root": ROOT}], env=e,
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=240) for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
-    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    from _helpers import run_ranks
+    outs = run_ranks(_WORKER % {"root": ROOT}, env, world=2, timeout=240)
+    assert all(rc == 0 for rc, _o, _e in outs), outs
+    res = json.loads(outs[0][1].strip().splitlines()[-1])
     assert res["replicas_equal"]
     assert math.isclose(res["avg"], 1.5) and math.isclose(res["total"], 1.5 * res["n"])
 
