@@ -12,6 +12,10 @@
 #include <climits>
 #include <cstdlib>
 
+int mvs_cost_volume_mfma_launch(const float* ref, const float* src, const float* transforms, int n_src, int depth_total,
+                                int d_begin, int d_count, int H, int W, int variant, int negate, float* cost,
+                                hipStream_t st);      // cost_volume_mfma.hip
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -544,6 +548,12 @@ extern "C" int mvs_cost_volume_f32(const float* ref, const float* src, const flo
     // The LDS-staged sweep is OPT-IN (MVS_CV_LDS=1): exact, tested, and measured no faster than the register tap cache at
     // the metric workload (188 vs 186-190 us, round 2) -- see the note above cost_volume_lds2_kernel.
     static const int use_lds = getenv("MVS_CV_LDS") ? atoi(getenv("MVS_CV_LDS")) : 0;
+    // MFMA-blend sweeps (cost_volume_mfma.hip), OPT-IN: MVS_CV_MFMA=1 (LDS-staged) / 2 (direct).  Exact and tested; measured
+    // 262-293 us at the metric workload against 186-200 us of the register tap cache below.
+    static const int use_mfma = getenv("MVS_CV_MFMA") ? atoi(getenv("MVS_CV_MFMA")) : 0;
+    if (border == 0 && C == 32 && view_num >= 2 && off32 && H < 65535 && W < 65535 && use_mfma >= 1 && use_lds < 1)
+        return mvs_cost_volume_mfma_launch(ref, src, transforms, view_num - 1, depth_total, d_begin, d_count, H, W, variant,
+                                           negate, cost, mvs_stream(stream));
     if (border == 0 && C == 32 && view_num >= 2 && view_num <= 8 && off32 && use_lds >= 1) {  // LDS-staged sweep (opt-in)
         hipStream_t st = mvs_stream(stream);
         switch (view_num - 1) {

@@ -576,3 +576,49 @@ np.savez(sys.argv[1], **out)
             a, b = res["reg"][name], res[form][name]
             bad = np.abs(a - b) > 1e-5 + 1e-4 * np.abs(a)
             assert bad.mean() < 1e-3, (form, name, float(bad.mean()))   # rcp vs division: a flipped floor() moves a whole tap
+
+
+def test_mfma_blend_cost_volume_matches_the_register_cache_kernel():
+    """The opt-in MFMA-blend sweeps (cost_volume_mfma.hip: MVS_CV_MFMA=1 LDS-staged, =2 direct) against the default kernel in
+    child processes: the metric workload, the nearest 32 planes of c3 (boxes beyond the LDS budget, windows beyond the
+    unrolled shapes -> per-plane form), and ragged cases -- 1 to 6 source views, image sizes that are not multiples of the
+    4 x 16 tile, plane counts that are not multiples of 4 or 8, plane sub-ranges, both variance forms, negated output."""
+    import os, subprocess, sys, tempfile
+    code = r"""
+import sys, numpy as np, torch
+from mvsnet_amd import synthetic as S
+from mvsnet_amd.model import cost_volume
+from mvsnet_amd.homography_warping import homography_transforms
+out = {}
+for name in ("M", "c3"):
+    w = S.make_workload(name)
+    f = torch.as_tensor(w.features).cuda()
+    T8 = homography_transforms(torch.as_tensor(w.cams).cuda(), w.depth_num, w.depth_start, w.depth_interval)
+    n = w.depth_num if name == "M" else 32
+    cv = cost_volume(f[0], f[1:], T8, 0, n, "mem")
+    out[name] = cv[:: max(1, n // 6)].cpu().numpy()
+k = 0
+for (N, H, W, D, d0, dn, variant, neg, interval) in [(2, 9, 21, 5, 0, 5, "mem", False, 40.0), (3, 17, 33, 13, 2, 9, "eager", True, 25.0),
+                                                     (5, 30, 50, 19, 0, 19, "mem", False, 90.0), (7, 12, 70, 10, 3, 6, "eager", False, 15.0),
+                                                     (4, 8, 16, 8, 0, 8, "mem", False, 300.0), (6, 5, 130, 7, 1, 5, "mem", True, 60.0)]:
+    f = torch.as_tensor(S.make_features(N, H, W, 32, seed=11 + k)).cuda()
+    cams = S.make_cams(N, H, W, D, interval=interval)
+    T8 = homography_transforms(torch.as_tensor(cams).cuda(), D, float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1]))
+    out["r%d" % k] = cost_volume(f[0], f[1:], T8, d0, dn, variant, negate=neg).cpu().numpy()
+    k += 1
+np.savez(sys.argv[1], **out)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("reg", {}), ("lds", {"MVS_CV_MFMA": "1"}), ("direct", {"MVS_CV_MFMA": "2"})):
+            path = os.path.join(td, tag + ".npz")
+            subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env={**os.environ, **env, "PYTHONPATH": root})
+            res[tag] = dict(np.load(path))
+    for form in ("lds", "direct"):
+        assert set(res[form]) == set(res["reg"])
+        for name in sorted(res["reg"]):
+            a, b = res["reg"][name], res[form][name]
+            assert a.shape == b.shape and np.isfinite(b).all()
+            bad = np.abs(a - b) > 1e-5 + 1e-4 * np.abs(a)
+            assert bad.mean() < 1e-3, (form, name, float(bad.mean()))   # a flipped floor() moves a whole tap (rounding of the sample point)
