@@ -12,6 +12,7 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int OTH = 8, OTW = 32;
 constexpr int OPW = OTW + 2;
 
@@ -85,17 +86,28 @@ conv3d_out_kernel(ConvArgs a) {
             if (loff[i] < 0) continue;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (plane_ok && goff[i] >= 0) {             // SAME padding pads the NORMALISED input with 0
-                v = bn_relu4(pre[i], sc, sh, has_aff);
-                if (has_x2) {
-                    float4 v2 = bn_relu4(pre2[i], sc2, sh2, has_aff2);
-                    v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+                // BN + ReLU (+ skip) on channel pairs: v_pk_fma_f32 / v_pk_max_f32 / v_pk_add_f32
+                const f32x2 z2 = {0.f, 0.f};
+                f32x2 lo = {pre[i].x, pre[i].y}, hi = {pre[i].z, pre[i].w};
+                if (has_aff) {
+                    lo = __builtin_elementwise_max(lo * (f32x2){sc.x, sc.y} + (f32x2){sh.x, sh.y}, z2);
+                    hi = __builtin_elementwise_max(hi * (f32x2){sc.z, sc.w} + (f32x2){sh.z, sh.w}, z2);
                 }
+                if (has_x2) {
+                    f32x2 lo2 = {pre2[i].x, pre2[i].y}, hi2 = {pre2[i].z, pre2[i].w};
+                    if (has_aff2) {
+                        lo2 = __builtin_elementwise_max(lo2 * (f32x2){sc2.x, sc2.y} + (f32x2){sh2.x, sh2.y}, z2);
+                        hi2 = __builtin_elementwise_max(hi2 * (f32x2){sc2.z, sc2.w} + (f32x2){sh2.z, sh2.w}, z2);
+                    }
+                    lo += lo2; hi += hi2;
+                }
+                v = make_float4(lo[0], lo[1], hi[0], hi[1]);
             }
             *(float4*)(buf + loff[i]) = v;
         }
     };
 
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;      // kd = 0 (-> q+1), 1 (-> q), 2 (-> q-1)
+    f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};      // kd = 0 (-> q+1), 1 (-> q), 2 (-> q-1)
     const int base = (row * OPW + col) * S;
 
     issue_loads(d0 - 1);
@@ -118,15 +130,17 @@ conv3d_out_kernel(ConvArgs a) {
                         cfloat* w0p = wsh + ((0 * 9 + kh * 3 + kw) * CIN + 4 * cq);       // (3,3,3,Cin,1)
                         cfloat* w1p = wsh + ((1 * 9 + kh * 3 + kw) * CIN + 4 * cq);
                         cfloat* w2p = wsh + ((2 * 9 + kh * 3 + kw) * CIN + 4 * cq);
-                        acc0 += x.x * w0p[0] + x.y * w0p[1] + x.z * w0p[2] + x.w * w0p[3];
-                        acc1 += x.x * w1p[0] + x.y * w1p[1] + x.z * w1p[2] + x.w * w1p[3];
-                        acc2 += x.x * w2p[0] + x.y * w2p[1] + x.z * w2p[2] + x.w * w2p[3];
+                        // channel pairs: v_pk_fma_f32 with the weight pair straight from SGPRs (even / odd channel sums)
+                        const f32x2 xa = {x.x, x.y}, xb = {x.z, x.w};
+                        acc0 += xa * (f32x2){w0p[0], w0p[1]}; acc0 += xb * (f32x2){w0p[2], w0p[3]};
+                        acc1 += xa * (f32x2){w1p[0], w1p[1]}; acc1 += xb * (f32x2){w1p[2], w1p[3]};
+                        acc2 += xa * (f32x2){w2p[0], w2p[1]}; acc2 += xb * (f32x2){w2p[2], w2p[3]};
                     }
         }
         const int o = q - 1, h = h0 + row, w = w0 + col;
         if (o >= d0 && o < d1 && h < a.H && w < a.W)
-            a.y[(((size_t)o * a.H + h) * a.W) + w] = acc2;
-        acc2 = acc1; acc1 = acc0; acc0 = 0.f;
+            a.y[(((size_t)o * a.H + h) * a.W) + w] = acc2[0] + acc2[1];
+        acc2 = acc1; acc1 = acc0; acc0 = (f32x2){0.f, 0.f};
         if (more) write_slab(q + 1, slab[(t + 1) & 1]);
         __syncthreads();
     }

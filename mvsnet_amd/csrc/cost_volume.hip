@@ -183,6 +183,8 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
     float4* book = book_all + (size_t)(threadIdx.x >> 6) * (64 * NSRC * 2);      // [lg planes][ppw pixels][NSRC][2]
     const int pixl = (threadIdx.x & 63) / lg;
 
+    float* dstp = cost + ((size_t)dl0 * H * W + pix) * C + c;          // this lane's 16 bytes of plane dl0; walks plane by plane
+    const size_t plane_elems = (size_t)H * W * C;
     for (int dlb = dl0; dlb < dl1; dlb += lg) {
         {
             const int dmy = d_begin + min(dlb + sub, dl1 - 1);
@@ -199,9 +201,11 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
                 int ix0 = (int)x0, iy0 = (int)y0;                // v_cvt saturates, NaN -> 0
                 int jx0 = min(max(ix0, 0), W - 1), jx1 = min(max(ix0 + 1, 0), W - 1);
                 int jy0 = min(max(iy0, 0), H - 1), jy1 = min(max(iy0 + 1, 0), H - 1);
-                const int r0 = v * img_bytes + jy0 * row_bytes, r1 = v * img_bytes + jy1 * row_bytes;
-                const int o00 = r0 + jx0 * pix_bytes, o01 = r0 + jx1 * pix_bytes;
-                const int o10 = r1 + jx0 * pix_bytes, o11 = r1 + jx1 * pix_bytes;
+                // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): clamped indices and the strides are < 2^24 (host-checked)
+                const int r0 = v * img_bytes + (int)__umul24(jy0, row_bytes), r1 = v * img_bytes + (int)__umul24(jy1, row_bytes);
+                const int cx0 = (int)__umul24(jx0, pix_bytes), cx1 = (int)__umul24(jx1, pix_bytes);
+                const int o00 = r0 + cx0, o01 = r0 + cx1;
+                const int o10 = r1 + cx0, o11 = r1 + cx1;
                 // per-tap zero fill folded into the separable weights: a tap is dropped iff its row or
                 // its column is outside the image, exactly as reading 0 for it (w * finite = 0)
                 const float wx1 = (ix0 >= 0 && ix0 < W) ? (x0 + 1.0f) - sx : 0.0f;
@@ -215,7 +219,6 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
         const int np = min(lg, dl1 - dlb);
         // one plane: refill the register tap cache where the taps moved, blend, reduce, store
         auto plane = [&](int p, const float4 (&ofs)[NSRC], const float4 (&wts)[NSRC]) __attribute__((always_inline)) {
-            const int dl = dlb + p;
             // phase A: all views' loads are issued before the first one is consumed.
 #pragma unroll
             for (int v = 0; v < NSRC; ++v) {
@@ -250,7 +253,8 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
                     Qs[2 * k] += w0 * w0; Qs[2 * k + 1] += w1 * w1;
                 }
             }
-            float* dst = cost + ((size_t)dl * H * W + pix) * C + c;
+            float* dst = dstp;
+            dstp += plane_elems;
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
                 f32x2 o0, o1;
@@ -562,7 +566,8 @@ extern "C" int mvs_cost_volume_f32(const float* ref, const float* src, const flo
 #undef MVS_LSWEEP2
         }
     }
-    if (border == 0 && view_num <= 8 && cq_pow2 && off32) {      // depth sweep with register tap reuse
+    const bool u24 = H < (1 << 24) && W < (1 << 24) && (long long)W * C * 4 < (1 << 24);     // the sweep's 24-bit offset multiplies
+    if (border == 0 && view_num <= 8 && cq_pow2 && off32 && u24) {      // depth sweep with register tap reuse
         hipStream_t st = mvs_stream(stream);
 #define MVS_SWEEP(NS) case NS: launch_sweep<NS>(ref, src, transforms, depth_total, d_begin, d_count, H, W, C, variant, negate, cost, st); break;
         switch (view_num - 1) {
