@@ -19,6 +19,7 @@ int mvs_cost_volume_mfma_launch(const float* ref, const float* src, const float*
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -266,7 +267,9 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
                     o0 = Qs[2 * k] * inv_n - m0 * m0; o1 = Qs[2 * k + 1] * inv_n - m1 * m1;
                 }
                 if (negate) { o0 = -o0; o1 = -o1; }
-                *reinterpret_cast<float4*>(dst + 4 * k) = make_float4(o0[0], o0[1], o1[0], o1[1]);
+                // non-temporal: the 503 MB volume streams out and must not push the 13 MB of feature maps, which every plane
+                // re-reads, out of the L2 (199.7 -> 185.6 us inside a depth map, 246 -> 228 us alone)
+                __builtin_nontemporal_store((f32x4_nt){o0[0], o0[1], o1[0], o1[1]}, reinterpret_cast<f32x4_nt*>(dst + 4 * k));
             }
         };
         auto fetch = [&](int p, float4 (&ofs)[NSRC], float4 (&wts)[NSRC]) __attribute__((always_inline)) {
