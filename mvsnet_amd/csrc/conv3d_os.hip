@@ -348,6 +348,9 @@ static int os_variant_of(int kind, int Cin, int Cout) {
                      v30 = os_variant("MVS_OS_30", 0), v20 = os_variant("MVS_OS_20", -1),
                      v40 = os_variant("MVS_OS_40", 0), v50 = os_variant("MVS_OS_50", 0);
     if (off) return -1;
+    // network_mode 'fat' (base_filter 16, network.py:82-83): the four layers no plane-march kernel is built for
+    if ((kind == 0 && Cin == 128 && Cout == 128) || (kind == 1 && Cin == 64 && (Cout == 32 || Cout == 128)) ||
+        (kind == 2 && Cin == 128 && Cout == 64)) return 0;
     if (kind == 0) return (Cin == 64 && Cout == 64) ? v31 : (Cin == 32 && Cout == 32) ? v21 : (Cin == 16 && Cout == 16) ? v11 : -1;
     if (kind == 1) return (Cin == 32 && Cout == 64) ? v30 : (Cin == 16 && Cout == 32) ? v20 : -1;
     return (Cin == 64 && Cout == 32) ? v40 : (Cin == 32 && Cout == 16) ? v50 : -1;
@@ -373,5 +376,10 @@ int mvs_conv3d_os_launch(const ConvArgs& a, int kind, int Cin, int Cout, hipStre
     if (kind == 1 && Cin == 16 && Cout == 32) return launch_os<OS_S2, 16, 2, 2, 2, 1, 2>(a, Cout, st);      // 3dconv2_0 (off by default)
     if (kind == 2 && Cin == 64 && Cout == 32) return launch_os<OS_DECONV, 64, 2, 1, 2, 1, 1>(a, Cout, st);  // 3dconv4_0
     if (kind == 2 && Cin == 32 && Cout == 16) return launch_os<OS_DECONV, 32, 1, 2, 2, 2, 2>(a, Cout, st);  // 3dconv5_0
+    // 'fat' (64-channel volume, base_filter 16): 3dconv1_0, 3_0, 3_1, 4_0
+    if (kind == 1 && Cin == 64 && Cout == 32) return launch_os<OS_S2, 64, 2, 1, 2, 1, 1>(a, Cout, st);
+    if (kind == 1 && Cin == 64 && Cout == 128) return launch_os<OS_S2, 64, 4, 2, 2, 1, 1>(a, Cout, st);
+    if (kind == 0 && Cin == 128 && Cout == 128) return launch_os<OS_S1, 128, 4, 2, 2, 1, 1>(a, Cout, st);
+    if (kind == 2 && Cin == 128 && Cout == 64) return launch_os<OS_DECONV, 128, 2, 1, 2, 1, 1>(a, Cout, st);
     return MVS_E_SHAPE;
 }

@@ -148,6 +148,8 @@ CONV_CASES = [  # D,H,W,Cin,Cout,stride
     # widths 40 / 20 of the quarter / eighth resolution levels: 2x8 and 4x4 MFMA column tiles
     (6, 16, 24, 32, 32, 1), (5, 12, 40, 32, 16, 1), (4, 16, 20, 64, 64, 1), (5, 32, 12, 64, 16, 1),
     (7, 8, 16, 32, 8, 1), (6, 16, 32, 16, 16, 1),
+    # network_mode 'fat' (base_filter 16): 3dconv1_0, 3_0, 3_1 on the block kernels, ragged blocks
+    (6, 10, 14, 64, 32, 2), (5, 9, 12, 64, 128, 2), (3, 6, 10, 128, 128, 1),
 ]
 
 
@@ -233,7 +235,7 @@ def test_stride2_plane_ranges(cin, cout, depth, planes, monkeypatch):
     np.testing.assert_allclose(n(stats)[0], e.reshape(-1, cout).sum(0), rtol=1e-4, atol=1e-3)
 
 
-DECONV_CASES = [(2, 2, 4, 64, 32), (4, 4, 8, 32, 16), (4, 8, 8, 16, 8), (3, 5, 6, 8, 4)]
+DECONV_CASES = [(2, 2, 4, 64, 32), (4, 4, 8, 32, 16), (4, 8, 8, 16, 8), (3, 5, 6, 8, 4), (3, 5, 6, 128, 64)]     # last: 'fat' 3dconv4_0
 
 
 @pytest.mark.parametrize("impl", ["scalar", "auto"])
