@@ -451,9 +451,10 @@ def test_gru_wta_pipelined_sweep_with_ragged_depth_matches_oracle():
     assert np.array_equal(n(d2)[0, :, :, 0], depth) and np.array_equal(n(p2)[0, :, :, 0], prob)
 
 
-@pytest.mark.parametrize("inverse,mode", [(False, "normal"), (True, "normal"), (False, "lite")])
+@pytest.mark.parametrize("inverse,mode", [(False, "normal"), (True, "normal"), (False, "lite"), (False, "fat")])
 def test_gru_wta_matches_oracle(inverse, mode):
-    """'lite' (16-channel features, GRU filters 8 / 2 / 1) takes the shape-generic conv + gate kernels for cell 1."""
+    """'lite' (16-channel features, GRU filters 8 / 2 / 1) and 'fat' (64-channel features, filters 32 / 8 / 4) take the
+    shape-generic conv + gate kernels for cell 1."""
     from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
     w = S.make_workload("toy", network_mode=mode)
     gp = S.make_gru_params(mode, seed=2, in_channels=w.channels, random_affine=True)
