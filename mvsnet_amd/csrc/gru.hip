@@ -179,19 +179,30 @@ struct BlendIn {
     const double* stats_c; const double* stats_u;     // their LayerNorm moments [sum, sumsq]
     const float *og, *ob, *ug, *ub;                   // candidate / update LayerNorm gamma, beta
     float* h_out;                                     // receives the blended state (the tile's own pixels)
+    // cell 3 only (pw != null): prob_conv + exp + winner-take-all update of the PREVIOUS plane, whose final state is the
+    // state just formed in the tile (model.py:701-703, 721-731): one launch less per plane
+    const float* pw; const float* pbias; float depth_value;
+    float *max_prob, *depth_image, *exp_sum;
 };
 
 // MODE 2 folds the PREVIOUS plane's blend into the staging of xb: xb holds the state that entered the previous plane
 // and the state entering this one, u*h + (1-u)*tanh(LN c) (convgru.py:98,102,114-120), is formed on load (halo
 // positions are recomputed by the neighbouring tiles), written out for the tile's own pixels -- the candidate
 // convolution, the next cell and the WTA update read it -- and convolved: one launch less per plane and cell.
+struct SmallArgs {
+    const float* xa; const float* xb; const float* g; const double* g_stats; const float* r_gamma; const float* r_beta;
+    const float* w; const float* bias; int H, W; float* y; double* stats; int groups; BlendIn bl;
+};
+
 template <int CA, int CB, int CO, int MODE>
-__global__ void __launch_bounds__(256)
-conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
-                    const float* __restrict__ g, const double* __restrict__ g_stats,
-                    const float* __restrict__ r_gamma, const float* __restrict__ r_beta,
-                    const float* __restrict__ w, const float* __restrict__ bias, int H, int W,
-                    float* __restrict__ y, double* __restrict__ stats, int groups, BlendIn bl) {
+__device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int bid) {
+    const float* __restrict__ xa = sa.xa; const float* __restrict__ xb = sa.xb;
+    const float* __restrict__ g = sa.g; const double* __restrict__ g_stats = sa.g_stats;
+    const float* __restrict__ r_gamma = sa.r_gamma; const float* __restrict__ r_beta = sa.r_beta;
+    const float* __restrict__ w = sa.w; const float* __restrict__ bias = sa.bias;
+    const int H = sa.H, W = sa.W, groups = sa.groups;
+    float* __restrict__ y = sa.y; double* __restrict__ stats = sa.stats;
+    const BlendIn& bl = sa.bl;
     constexpr int CT = CA + CB;
     constexpr int TS = 16, PS = TS + 2;
     typedef const __attribute__((address_space(4))) float cfloat;      // wave-uniform -> s_load into SGPRs
@@ -220,7 +231,7 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
         }
     }
     const int tiles_x = (W + TS - 1) / TS;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
     for (int f = threadIdx.x; f < PS * PS; f += 256) {
         const int r = f / PS, c = f - r * PS;
@@ -265,6 +276,24 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
     const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
     const int py = y0 + ly, px = x0 + lx;
     const bool valid = py < H && px < W;
+    if (MODE == 2 && bl.pw != nullptr && valid) {     // as prob_wta_kernel: taps outside the image are staged zeros
+        float pacc = bl.pbias ? bl.pbias[0] : 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int gy = py + kh - 1, gx = px + kw - 1;
+                if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
+                const float* tp = tile + ((ly + kh) * PS + lx + kw) * CT + CA;
+#pragma unroll
+                for (int ci = 0; ci < CB; ++ci) pacc += tp[ci] * bl.pw[(kh * 3 + kw) * CB + ci];
+            }
+        const float pr = expf(pacc);
+        const int pix = py * W + px;
+        const float mp = bl.max_prob[pix];
+        if (mp < pr) { bl.max_prob[pix] = pr; bl.depth_image[pix] = bl.depth_value; }
+        bl.exp_sum[pix] += pr;
+    }
     float acc[CO];
 #pragma unroll
     for (int j = 0; j < CO; ++j) acc[j] = bias ? bias[j] : 0.f;
@@ -308,24 +337,31 @@ conv2d_small_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
     }
 }
 
+template <int CA, int CB, int CO, int MODE>
+__global__ void __launch_bounds__(256)
+conv2d_small_kernel(SmallArgs a) { conv2d_small_body<CA, CB, CO, MODE>(a, blockIdx.x); }
+
 // cells 2 / 3: gate conv then candidate conv (reset gate folded in); false if the shape has no instance
 // `prev`: the previous plane's blend has not been launched -- its inputs; h then RECEIVES the state entering this plane
 // (formed from h_before, the state that entered the previous plane) in the gate convolution's staging
 struct PrevPlane { const float* h_before; const float* g; const double* sg; const double* so; };
+// `wta` (cell 3, with `prev`): prob_conv + winner-take-all update of the previous plane inside the gate convolution
+struct WtaFold { const float* pw; const float* pbias; float depth_value; float *max_prob, *depth_image, *exp_sum; };
 template <int CA, int F>
 bool launch_small_cell(const float* xin, float* h, const float* const* p, int H, int W, float* g, float* c,
-                       double* sg, double* so, const PrevPlane* prev, hipStream_t st) {
+                       double* sg, double* so, const PrevPlane* prev, hipStream_t st, const WtaFold* wta = nullptr) {
     const int grid = ((H + 15) / 16) * ((W + 15) / 16);           // 16 x 16 pixel tiles
     BlendIn none = {};
     if (prev) {
-        BlendIn bl = {c, prev->g, prev->so, prev->sg + 2, p[8], p[9], p[4], p[5], h};
-        conv2d_small_kernel<CA, F, 2 * F, 2><<<grid, 256, 0, st>>>(xin, prev->h_before, nullptr, nullptr, nullptr, nullptr,
-                                                                   p[0], p[1], H, W, g, sg, 2, bl);
+        BlendIn bl = {c, prev->g, prev->so, prev->sg + 2, p[8], p[9], p[4], p[5], h, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr};
+        if (wta) { bl.pw = wta->pw; bl.pbias = wta->pbias; bl.depth_value = wta->depth_value; bl.max_prob = wta->max_prob; bl.depth_image = wta->depth_image; bl.exp_sum = wta->exp_sum; }
+        conv2d_small_kernel<CA, F, 2 * F, 2><<<grid, 256, 0, st>>>(SmallArgs{xin, prev->h_before, nullptr, nullptr, nullptr, nullptr,
+                                                                             p[0], p[1], H, W, g, sg, 2, bl});
     } else {
-        conv2d_small_kernel<CA, F, 2 * F, 0><<<grid, 256, 0, st>>>(xin, h, nullptr, nullptr, nullptr, nullptr,
-                                                                   p[0], p[1], H, W, g, sg, 2, none);
+        conv2d_small_kernel<CA, F, 2 * F, 0><<<grid, 256, 0, st>>>(SmallArgs{xin, h, nullptr, nullptr, nullptr, nullptr,
+                                                                             p[0], p[1], H, W, g, sg, 2, none});
     }
-    conv2d_small_kernel<CA, F, F, 1><<<grid, 256, 0, st>>>(xin, h, g, sg, p[2], p[3], p[6], p[7], H, W, c, so, 1, none);
+    conv2d_small_kernel<CA, F, F, 1><<<grid, 256, 0, st>>>(SmallArgs{xin, h, g, sg, p[2], p[3], p[6], p[7], H, W, c, so, 1, none});
     return true;
 }
 
@@ -656,6 +692,12 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
         const float* px_d = ws.px + ((size_t)half * XB + slot) * hw * 3 * f1;
         const int cin = cins[k];
         int r;
+        // cell 3: the previous plane's prob_conv + winner-take-all update rides in this plane's gate convolution, which forms
+        // that plane's final state in its tile anyway (MVS_GRU_NO_WTA_FOLD=1: the separate launch, A/B and parity switch)
+        static const bool no_wta_fold = getenv("MVS_GRU_NO_WTA_FOLD") != nullptr;
+        WtaFold wfold = {params[30], params[31], d >= 1 ? depth_values[d - 1] : 0.f, ws.max_prob, depth_out, ws.exp_sum};
+        const WtaFold* wf = (k == 2 && fused_in && !no_wta_fold) ? &wfold : nullptr;
+        bool wta_folded = false;
         if (route[k] == 1) {
             if (fused_in)
                 r = mvs_gru1_gates_h_blend_mfma(prev.h_before, ws.c[k], prev.g, prev.so, prev.sg + 2, p[8], p[9], p[4], p[5], hp_w,
@@ -665,10 +707,14 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
             if (r) return r;
             if ((r = mvs_gru1_out_h_mfma(hp, gcur, sg, p[2], p[3], ws.woh, px_d, H, W, ws.c[k], so, s))) return r;
             if (gs && (slot == XB - 1 || d == depth_num - 1) && (e = hipEventRecord(gs->xdone[half], s)) != hipSuccess) return (int)e;
-        } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s)) {
-        } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s)) {
-        } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s)) {
-        } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s)) {
+        } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s, wf)) {
+            wta_folded = wf != nullptr;
+        } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s, wf)) {
+            wta_folded = wf != nullptr;
+        } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s, wf)) {
+            wta_folded = wf != nullptr;
+        } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s, wf)) {
+            wta_folded = wf != nullptr;
         } else {
             if ((r = launch_conv2d(xin, cin, hp, F[k], p[0], p[1], H, W, 2 * F[k], ws.g[k], sg, 2, s))) return r;
             if ((r = mvs_gru_gates_f32(ws.g[k], sg, p[2], p[3], p[4], p[5], hp, H, W, F[k], ws.rh, ws.u, s))) return r;
@@ -688,7 +734,7 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
             }
             return (int)hipGetLastError();
         };
-        if (k == 2 && fused_in && (r = prob_wta(hp, d - 1))) return r;     // plane d-1's state exists since this plane's gate convolution
+        if (k == 2 && fused_in && !wta_folded && (r = prob_wta(hp, d - 1))) return r;     // plane d-1's state exists since this plane's gate convolution
         if (blend_now) {
             if (F[k] % 4 == 0)
                 gru_blend_fused_kernel<4><<<mvs_cdiv(hw_ll * F[k] / 4, 256), 256, 0, s>>>(
