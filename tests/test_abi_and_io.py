@@ -146,3 +146,21 @@ def test_bind_device_refuses_a_rank_without_a_gpu(monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
     with pytest.raises(RuntimeError, match="only 2 GPU"):
         shard.bind_device(3)
+
+
+def test_package_import_switches_off_the_miopen_solver_that_over_reads_its_filter():
+    """mvsnet_amd/__init__.py: MIOpen's NHWC implicit-GEMM assembly kernel for the data gradient reads past the end of its
+    filter tensor when the output-channel count is below its K tile (a GPU memory fault in narrow-tower training when the
+    filter is the last block of an allocator segment, round 2); the package default disables that solver unless the user
+    set the variable, and it must be in place before the first convolution."""
+    import importlib
+    import os
+    import mvsnet_amd
+    importlib.reload(mvsnet_amd)
+    assert os.environ.get("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC") in ("0", "1")
+    saved = os.environ.pop("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC")
+    try:
+        importlib.reload(mvsnet_amd)
+        assert os.environ["MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC"] == "0"
+    finally:
+        os.environ["MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC"] = saved
