@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- depth maps/sec of the plane-sweep hot path on N MI355X (one process per GPU).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps 20 --warmup 5          (N > 1: starts the N one-GPU ranks itself, parent GPU-less)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -254,24 +254,29 @@ def main():
                     help="also time images->depth (adds the PyTorch UNetDS2GN towers)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`, as the driver starts --gpus 1): this process stays GPU-less and
+        # starts the N one-GPU ranks itself; rank 0's JSON line goes to the inherited stdout, exit code = the ranks'
+        from mvsnet_amd.shard import launch_ranks
+        raise SystemExit(launch_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    # one rank per GPU; MVS_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the
-    # multi-process path on a 1-GPU box (ranks then share device 0)
+    # one rank per GPU; MVS_DIST_BACKEND=gloo + MVS_ALLOW_SHARED_GPU=1 rehearse the multi-process path on a box with
+    # fewer GPUs than ranks (ranks then share devices)
     ndev = torch.cuda.device_count()
-    if world > 1 and os.environ.get("MVS_DIST_BACKEND", "nccl") == "nccl" and ndev < world:
-        raise SystemExit("bench.py --gpus %d over RCCL needs %d GPUs on this node, found %d (one rank per GPU; "
-                         "MVS_DIST_BACKEND=gloo rehearses the multi-process path on fewer)" % (args.gpus, world, ndev))
+    backend = os.environ.get("MVS_DIST_BACKEND", "nccl")
+    if world > 1 and ndev < world and (backend == "nccl" or not os.environ.get("MVS_ALLOW_SHARED_GPU")):
+        raise SystemExit("bench.py --gpus %d needs %d GPUs on this node, found %d (one rank per GPU; MVS_DIST_BACKEND=gloo "
+                         "MVS_ALLOW_SHARED_GPU=1 rehearses the multi-process path on fewer)" % (args.gpus, world, ndev))
     if args.gpus != world:
-        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch N ranks with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     dev_index = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    backend = os.environ.get("MVS_DIST_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
@@ -364,6 +369,11 @@ def main():
         rank_rates = [args.steps / float(e.item()) for e in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    rank_devices = [{"rank": rank, "device_index": dev_index, "device": torch.cuda.get_device_name(dev_index)}]
+    if dist:
+        every_dev = [None] * world
+        dist.all_gather_object(every_dev, rank_devices[0])
+        rank_devices = every_dev
 
     import ctypes
     pair_ms, pair_n = ctypes.c_double(0.0), ctypes.c_int(0)
@@ -472,6 +482,8 @@ def main():
             "roofline_kernels": kernels,
             "depth_checksum": float(np.float64(depth_np).sum()),
             "per_rank_depth_maps_per_s": {"min": min(rank_rates), "max": max(rank_rates), "ranks": rank_rates},
+            "ranks": {"world_size": dist.get_world_size() if dist else 1, "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if dist else None,
+                      "devices": rank_devices},
         }
         chain = ["3dconv2_0", "3dconv3_0", "3dconv3_1", "3dconv4_0", "3dconv5_0"]
         if layer_n.value > 0:

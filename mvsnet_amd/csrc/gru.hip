@@ -538,16 +538,25 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     return w;
 }
 
-// Side streams for cells 2 and 3 and for the per-batch producer (cost slices + hoisted x-part) (created on first use; one host thread per device as elsewhere).
-struct GruStreams { hipStream_t s[3]; hipEvent_t fork, join[3], ready[2][RG_MAX], read[2][RG_MAX], xready[2], xdone[2]; };
-// One set per caller stream (up to 4: sweeps of different reference views in flight on different streams
-// must not share side streams, or they would serialise behind each other); created on first use.
+// The sweep's four streams: cell 1 (the recurrent chain), cell 2, cell 3 (+ WTA), and the per-batch producer (cost slices +
+// hoisted x-part).  ALL FOUR are the library's own, of ONE priority class, and their hardware queues are created back to
+// back.  Round 2 ran cell 1 on the CALLER's stream and the producer at low priority, and the same sweep took 44 ms instead
+// of 23 ms in any process whose caller stream's hardware queue was not the one created right before the side streams'
+// (profiles/r03_gru_bisect*.log): the runtime binds a stream to a hardware queue on first use, hardware queues are dealt
+// round-robin over the compute pipes of the command processor in creation order (4 pipes: queue ids k and k + 4 share
+// one), and two queues of ONE pipe neither dispatch concurrently nor see each other's completion signals promptly.  With
+// the caller's queue created first, one unrelated queue (any torch.cuda.Stream that ran a kernel) in between put the
+// producer -- or cell 3 -- on the chain's pipe.  Four queues of one priority pool created consecutively have ids
+// k .. k+3: four different pipes whatever else the process has created.
+struct GruStreams { hipStream_t s[4]; hipEvent_t fork, join[4], ready[2][RG_MAX], read[2][RG_MAX], xready[2], xdone[2]; };
+// One set per caller stream (sweeps of different reference views in flight on different caller streams must not share
+// them, or they would serialise behind each other); created on first use.
 GruStreams* gru_streams(hipStream_t caller) {
     struct Slot { int dev; hipStream_t caller; GruStreams g; int state; };
     static Slot slots[8];
     static int used = 0;
     static std::mutex mu;                                // slot creation is per (device, caller stream), thread-safe
-    if (getenv("MVS_GRU_ONE_STREAM") != nullptr) return nullptr;     // A/B + test switch, read per sweep
+    if (getenv("MVS_GRU_ONE_STREAM") != nullptr) return nullptr;     // test hook (one-stream sweep parity), read per sweep
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
@@ -563,13 +572,14 @@ GruStreams* gru_streams(hipStream_t caller) {
     GruStreams& g = sl.g;
     bool ok = true;
     int lo = 0, hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;   // lo = least urgent: the batch producer yields to the cells
-    for (int i = 0; ok && i < 3; ++i)
-        ok = hipStreamCreateWithPriority(&g.s[i], hipStreamNonBlocking, i == 2 ? lo : hi) == hipSuccess;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;   // hi = most urgent class (its queue pool is normally empty)
+    for (int i = 0; ok && i < 4; ++i) ok = hipStreamCreateWithPriority(&g.s[i], hipStreamNonBlocking, hi) == hipSuccess;
     auto ev = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
     ev(&g.fork);
     for (int i = 0; i < 2; ++i) { ev(&g.xready[i]); ev(&g.xdone[i]); for (int j = 0; j < RG_MAX; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
-    for (int i = 0; i < 3; ++i) ev(&g.join[i]);
+    for (int i = 0; i < 4; ++i) ev(&g.join[i]);
+    // first use = hardware queue creation: touch the four streams now, in order, with nothing in between
+    for (int i = 0; ok && i < 4; ++i) ok = hipEventRecord(g.join[i], g.s[i]) == hipSuccess;
     if (ok) sl.state = 1;
     return ok ? &g : nullptr;
 }
@@ -588,23 +598,13 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     MVS_CHECK_ARG(view_num >= 2 && depth_num >= 1 && H > 0 && W > 0 && C > 0 && f1 > 0 && f2 > 0 && f3 > 0);
     GruWs ws = carve((char*)workspace, H, W, C, f1, f2, f3);
     if (workspace_bytes < ws.bytes) return MVS_E_WORKSPACE;
-    hipStream_t st = mvs_stream(stream);
+    const hipStream_t caller = mvs_stream(stream);
     const size_t hw = (size_t)H * W;
     hipError_t e;
     const int F[3] = {f1, f2, f3};
-    // zero initial states and WTA accumulators (model.py:649-654, 737-739)
-    for (int k = 0; k < 3; ++k)
-        if ((e = hipMemsetAsync(ws.h[k][0], 0, hw * F[k] * 4, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(ws.max_prob, 0, hw * 4, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(ws.exp_sum, 0, hw * 4, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(depth_out, 0, hw * 4, st)) != hipSuccess) return (int)e;
-
     int rc;
     // cell 1 (90 % of the MACs) runs on the fp32-MFMA kernels when its shape fits their tiling
     bool mfma1 = (mvs_get_conv_impl() != MVS_CONV_IMPL_SCALAR) && C == 32 && f1 == 16;
-    if (mfma1) {
-        if ((rc = mvs_gru1_split_weights(params[0], params[6], C, f1, ws.wx, ws.wgh, ws.woh, st))) return rc;
-    }
     // which kernels each cell gets; the generic conv + gates route shares rh / u and stays on one stream
     const int cins[3] = {C, f1, f2};
     int route[3];                                    // 0 generic, 1 MFMA (cell 1), 2 small-cell kernels
@@ -622,13 +622,21 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     // h[k][(d+1) % 2PG]); per group j, ready[k][j&1] = cell k has written its states of group j, read[k][j&1] =
     // cell k+1 is done reading them (cell k may overwrite those ring slots in group j+2).
     const int RG = ring_groups(), ring = RG * PG;
-    GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2 * PG) ? gru_streams(st) : nullptr;
-    hipStream_t sk[3] = {st, gs ? gs->s[0] : st, gs ? gs->s[1] : st};
+    GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2 * PG) ? gru_streams(caller) : nullptr;
+    hipStream_t sk[3] = {gs ? gs->s[0] : caller, gs ? gs->s[1] : caller, gs ? gs->s[2] : caller};
+    const hipStream_t st = sk[0];                    // cell 1's stream: everything "on the chain" below goes here
     if (gs) {
-        if ((e = hipEventRecord(gs->fork, st)) != hipSuccess) return (int)e;
-        for (int i = 0; i < 3; ++i) if ((e = hipStreamWaitEvent(gs->s[i], gs->fork, 0)) != hipSuccess) return (int)e;
+        if ((e = hipEventRecord(gs->fork, caller)) != hipSuccess) return (int)e;
+        for (int i = 0; i < 4; ++i) if ((e = hipStreamWaitEvent(gs->s[i], gs->fork, 0)) != hipSuccess) return (int)e;
     }
     const long long hw_ll = (long long)H * W;
+    // zero initial states and WTA accumulators (model.py:649-654, 737-739)
+    for (int k = 0; k < 3; ++k)
+        if ((e = hipMemsetAsync(ws.h[k][0], 0, hw * F[k] * 4, st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(ws.max_prob, 0, hw * 4, st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(ws.exp_sum, 0, hw * 4, st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(depth_out, 0, hw * 4, st)) != hipSuccess) return (int)e;
+    if (mfma1 && (rc = mvs_gru1_split_weights(params[0], params[6], C, f1, ws.wx, ws.wgh, ws.woh, st))) return rc;
 
     // start of a batch of XB planes (on cell 1's stream, before its first plane of the batch)
     auto batch_start = [&](int d) -> int {
@@ -649,7 +657,7 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
         if (!(gs && mfma1)) return produce(d, st);
         // the producer runs one batch ahead on its own (low-priority) stream: 2/3 of cell 1's MACs leave the
         // recurrent chain
-        hipStream_t sx = gs->s[2];
+        hipStream_t sx = gs->s[3];
         int r;
         if (d == 0) {
             if ((r = produce(0, sx))) return r;
@@ -776,9 +784,9 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
         }
     }
     if (gs)
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 4; ++i) {
             if ((e = hipEventRecord(gs->join[i], gs->s[i])) != hipSuccess) return (int)e;
-            if ((e = hipStreamWaitEvent(st, gs->join[i], 0)) != hipSuccess) return (int)e;
+            if ((e = hipStreamWaitEvent(caller, gs->join[i], 0)) != hipSuccess) return (int)e;
         }
     return mvs_wta_finish_f32(ws.max_prob, ws.exp_sum, H, W, prob_out, stream);
 }

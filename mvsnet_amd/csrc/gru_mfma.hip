@@ -172,8 +172,11 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
             }
         }
     };
-    auto sig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); };
-    auto tanh_ = [](float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); };
+    // tf.sigmoid / tf.tanh (convgru.py:101-102,117) in the forms cells 2 / 3 use (gru.hip): libm expf with an IEEE divide, and
+    // tanh without the cancellation of 1 - 2/(e^{2x}+1) near 0: t = e^{-2|x|}, (1-t)/(1+t) with the sign of x (round 2 used
+    // v_rcp + __expf here and landed 2x further from the float64 fixture than float32 needs to)
+    auto sig = [](float x) { return 1.0f / (1.0f + expf(-x)); };
+    auto tanh_ = [](float x) { const float t = expf(-2.0f * fabsf(x)); return copysignf((1.0f - t) / (1.0f + t), x); };
     auto stage_piece = [&](int i, float* buf, int tile_of) __attribute__((always_inline)) {
         float4 v = pre[i];                           // zeros outside the image (SAME padding)
         if (MODE == 1 && i >= NA) {                  // xb = sigmoid(LN(g_r)) * h (convgru.py:97,101,107)

@@ -69,8 +69,10 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
     if device is None:
         device = sh.bind_device(local_rank)           # one process drives one GPU
     else:
-        device = torch.device(device)
-        torch.cuda.set_device(device)                 # library launches go to the current device
+        device = torch.device(device)                 # 'cuda' without an index = the current device
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        torch.cuda.set_device(idx)                    # library launches go to the current device
+        device = torch.device("cuda", idx)
     output_dir = pl.setup_output_dir(input_dir, config.output_dir)
     gen = make_generator(input_dir, config.view_num, config.width, config.height, config.max_d,
                            config.interval_scale, config.base_image_size, mode="inference",
@@ -163,8 +165,14 @@ def main(argv=None):
     ap.add_argument("--ckpt_step", type=int, default=400000)
     ap.add_argument("--extractor", choices=("hip", "torch"), default="hip",
                     help="2D feature towers: HIP library kernels (default) or the PyTorch/MIOpen module")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="N > 1 without a torch.distributed.run environment: start N one-GPU ranks of this command "
+                         "(reference views sharded round-robin, no data-path collective)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=os.environ.get("LOG_LEVEL", "INFO"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # before anything touches the GPU: the parent stays GPU-less
+        import sys
+        raise SystemExit(sh.launch_ranks(list(sys.argv[1:] if argv is None else argv), args.gpus, module="mvsnet_amd.inference"))
     weights_path = args.weights
     for name in vars(cfg):
         setattr(cfg, name, getattr(args, name))

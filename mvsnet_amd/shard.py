@@ -46,6 +46,26 @@ def bind_device(local_rank=None):
     return torch.device("cuda", local_rank)
 
 
+def launch_ranks(script_args, n_ranks, module=None):
+    """Starts `n_ranks` one-GPU worker processes of `script_args` (or of `-m module`) under torch.distributed.run on this
+    node and returns its exit code (non-zero when any rank failed).  For entry points started plainly as
+    `python bench.py --gpus N` / `python -m mvsnet_amd.inference --gpus N`: the caller must not have touched the GPU
+    (the parent stays GPU-less, every rank binds its own device), the ranks inherit stdout / stderr, rank 0 prints."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:      # a free rendezvous port on the loopback address
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_ranks)),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += (["-m", module] if module else []) + list(script_args)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // int(n_ranks))))
+    return subprocess.call(cmd, env=env)
+
+
 def init_process_group(backend=None):
     """Initialises torch.distributed when WORLD_SIZE > 1 (rendezvous on 127.0.0.1 by default).
     Returns the module or None for single-process runs.  With the RCCL backend the process is bound

@@ -199,15 +199,20 @@ def conv_gru_cell(x, h, p):
 
 @torch.no_grad()
 def inference_winner_take_all_from_features(features, cams, depth_num, depth_start, depth_end, gru_params,
-                                            dtype=torch.float32, progress=None):
-    """Same contract as mvsnet_oracle.inference_winner_take_all_from_features (non-inverse depth).
+                                            dtype=torch.float32, progress=None, inverse_depth=False):
+    """Same contract as mvsnet_oracle.inference_winner_take_all_from_features (inverse_depth: planes uniform in
+    1/depth, homography_warping.py:60-106, model.py:706-713).
     Returns numpy depth (H,W), prob (H,W) and the winning plane index (H,W) int32."""
     npdt = _NP[dtype]
     N, Hh, W, _ = features.shape
     D = int(depth_num)
-    interval = (npdt(depth_end) - npdt(depth_start)) / (npdt(D) - npdt(1))          # model.py:605-607
-    T = _transforms(cams, D, depth_start, interval, npdt)
-    depths = O.wta_depths(D, depth_start, depth_end, False, npdt)
+    if inverse_depth:
+        Hs = np.stack([O.get_homographies_inv_depth(cams[0], cams[v], D, depth_start, depth_end, npdt) for v in range(1, N)])
+        T = O.homography_to_transform8(Hs, npdt)
+    else:
+        interval = (npdt(depth_end) - npdt(depth_start)) / (npdt(D) - npdt(1))      # model.py:605-607
+        T = _transforms(cams, D, depth_start, interval, npdt)
+    depths = O.wta_depths(D, depth_start, depth_end, bool(inverse_depth), npdt)
     cells = [_cell_params(gru_params[k], dtype) for k in ("gru1", "gru2", "gru3")]
     pw = _t(gru_params["prob_w"], dtype).permute(3, 2, 0, 1).contiguous()
     pb = _t(gru_params["prob_b"], dtype)

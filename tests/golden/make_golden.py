@@ -36,10 +36,11 @@ def full(names):
     import torch
     from oracle import torch_restatement as TR
     for name in names:
-        w = S.make_workload(name)
+        inverse = name == "c3inv"                # configs[2] with --inverse_depth (R1' / model.py:706-713): same inputs as c3
+        w = S.make_workload("c3" if inverse else name)
         sha = hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest()
         t0 = time.time()
-        if name != "c3":
+        if not name.startswith("c3"):
             rp = S.make_regnet_params("normal", seed=1, random_affine=True)
             d, p = TR.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start, w.depth_interval,
                                                   rp, torch.float64)
@@ -50,9 +51,9 @@ def full(names):
             gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
             say = lambda a, b: print("  c3 plane %d/%d  %.0f s" % (a, b, time.time() - t0), flush=True)
             d, p, idx = TR.inference_winner_take_all_from_features(w.features, w.cams, w.depth_num, w.depth_start,
-                                                                   w.depth_end, gp, torch.float64, say)
+                                                                   w.depth_end, gp, torch.float64, say, inverse)
             d32, p32, i32 = TR.inference_winner_take_all_from_features(w.features, w.cams, w.depth_num, w.depth_start,
-                                                                       w.depth_end, gp, torch.float32)
+                                                                       w.depth_end, gp, torch.float32, None, inverse)
             same = i32 == idx
             extra = dict(index=idx.astype(np.uint8), f32_cpu_plane_agreement=float(same.mean()),
                          f32_cpu_prob_rel=float(np.max(np.abs(p32[same] - p[same]) / p[same])))
@@ -64,7 +65,7 @@ def full(names):
 
 def main():
     if "--full" in sys.argv:
-        names = [a for a in sys.argv[1:] if a in S.WORKLOADS]
+        names = [a for a in sys.argv[1:] if a in S.WORKLOADS or a == "c3inv"]
         return full(names or ["c1", "M", "c2", "c3"])
     w = S.make_workload("toy")
     sha = hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest()

@@ -5,11 +5,12 @@ and c3 (N=5, D=256, 400x300) on the ConvGRU sweep (SURVEY 8d sizes, seeded input
 The expected outputs are the committed fixtures tests/golden/full_<workload>.npz, written in the build container
 by tests/golden/make_golden.py --full from oracle/torch_restatement.py in float64 (held to the strict numpy oracle
 at ~1e-15 by tests/test_cpu_restatement.py); each records the SHA-256 of its inputs and how far the float32 CPU
-restatement lands from it (the rounding-noise floor).  Tolerances: depth abs-rel < 1e-4 (north_star: 1e-3), probability
-map within 1e-3 on > 98 % of the pixels (the four-bucket sum jumps where the depth index crosses an integer); recurrent
-path: winning plane equal on > 98 % of the pixels; on the agreeing ones the probability max(exp)/sum(exp) within 3e-3
-at worst and 1e-4 on average (the float32 CPU restatement itself lands 6.5e-4 from the float64 one at worst: 256 planes
-of recurrent float32 state).
+restatement lands from it (the rounding-noise floor).  Tolerances (round 3: the noise floor, not north_star's 1e-3): depth abs-rel <= 3 x what the
+float32 CPU restatement lands at (~5e-7 .. 8e-7), probability map within 1e-3 except on <= max(3 x the CPU's fraction, 5e-4)
+of the pixels (the four-bucket sum jumps where the depth index crosses an integer), no pixel off by more than 1e-4; recurrent
+path: winning plane equal on >= 99.95 % of the pixels, on the agreeing ones the probability max(exp)/sum(exp) within
+2 x the float32 CPU restatement's own worst distance (6.5e-4: 256 planes of recurrent float32 state) and 5e-5 on average;
+the same with inverse depth (full_c3inv.npz).
 """
 import hashlib
 import os
@@ -51,9 +52,28 @@ def test_3dcnn_depth_and_probability_match_the_fixture(lib_built, name):
     mismatch = float((np.abs(p - g["prob"]) > 1e-3).mean())
     print("%s: abs-rel %.3e (float32 CPU restatement: %.3e), prob mismatch %.4f (CPU %.4f)"
           % (name, abs_rel, float(g["f32_cpu_abs_rel"]), mismatch, float(g["f32_cpu_prob_mismatch"])))
-    assert abs_rel < 1e-4, abs_rel
-    assert mismatch < 0.02, mismatch
-    assert float(np.max(np.abs(d - g["depth"]) / g["depth"])) < 1e-2        # no stray pixel (a wrong tile would be O(1))
+    # held to the float32 rounding-noise floor the fixture records (what the float32 CPU restatement lands at), not to
+    # north_star's 1e-3: a dropped halo row at one tile edge or a wrong tap on 1 % of the pixels must fail here
+    assert abs_rel <= 3.0 * float(g["f32_cpu_abs_rel"]), (abs_rel, float(g["f32_cpu_abs_rel"]))
+    assert mismatch <= max(3.0 * float(g["f32_cpu_prob_mismatch"]), 5e-4), mismatch
+    worst = float(np.max(np.abs(d - g["depth"]) / g["depth"]))
+    print("%s: worst pixel %.3e" % (name, worst))
+    assert worst < 1e-3, worst                                             # no stray pixel (a wrong tile would be O(1))
+
+
+def check_sweep(tag, w, g, depth, prob):
+    """Winner-take-all outputs against a c3 fixture: winning plane on >= 99.95 % of the pixels, probability within twice the
+    float32 CPU restatement's own worst distance from the float64 fixture on the agreeing pixels."""
+    d = depth.cpu().numpy().reshape(w.height, w.width)
+    p = prob.cpu().numpy().reshape(w.height, w.width).astype(np.float64)
+    same = np.abs(d - g["depth"]) <= 1e-6 * g["depth"]
+    agree = float(same.mean())
+    rel = np.abs(p[same] - g["prob"][same]) / g["prob"][same]
+    print("%s: plane agreement %.5f (float32 CPU restatement: %.5f), prob rel max %.3e mean %.3e (CPU max %.3e)"
+          % (tag, agree, float(g["f32_cpu_plane_agreement"]), float(rel.max()), float(rel.mean()), float(g["f32_cpu_prob_rel"])))
+    assert agree >= 0.9995, agree
+    assert float(rel.max()) <= 2.0 * float(g["f32_cpu_prob_rel"]) and float(rel.mean()) < 5e-5, (float(rel.max()), float(rel.mean()))
+    return d, p
 
 
 @pytest.mark.parametrize("one_stream", [False, True])
@@ -67,15 +87,21 @@ def test_gru_sweep_matches_the_fixture(lib_built, one_stream, monkeypatch):
         monkeypatch.setenv("MVS_GRU_ONE_STREAM", "1")
     depth, prob = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end,
                                             weights=weights, features=t(w.features))
-    d = depth.cpu().numpy()[0, :, :, 0]
-    p = prob.cpu().numpy()[0, :, :, 0].astype(np.float64)
-    same = np.abs(d - g["depth"]) <= 1e-6 * g["depth"]
-    agree = float(same.mean())
-    rel = np.abs(p[same] - g["prob"][same]) / g["prob"][same]
-    print("c3 (one_stream=%s): plane agreement %.5f (float32 CPU restatement: %.5f), prob rel max %.3e mean %.3e (CPU max %.3e)"
-          % (one_stream, agree, float(g["f32_cpu_plane_agreement"]), float(rel.max()), float(rel.mean()), float(g["f32_cpu_prob_rel"])))
-    assert agree > 0.98, agree
-    assert float(rel.max()) < 3e-3 and float(rel.mean()) < 1e-4, (float(rel.max()), float(rel.mean()))
+    d, _ = check_sweep("c3 (one_stream=%s)" % one_stream, w, g, depth, prob)
     interval = (w.depth_end - w.depth_start) / (w.depth_num - 1)
     idx = np.rint((d - w.depth_start) / interval).astype(np.int64)
     assert idx.min() >= 0 and idx.max() < w.depth_num
+
+
+def test_gru_sweep_inverse_depth_matches_the_fixture(lib_built):
+    """c3 with --inverse_depth (R1' homography_warping.py:60-106, WTA depths model.py:706-713): planes uniform in 1/depth."""
+    from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
+    g = np.load(os.path.join(GOLDEN, "full_c3inv.npz"))
+    w = S.make_workload("c3")
+    assert hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest() == str(g["input_sha256"])
+    gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
+    depth, prob = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end,
+                                            inverse_depth=True, weights=weights, features=t(w.features))
+    d, _ = check_sweep("c3 inverse depth", w, g, depth, prob)
+    assert d.min() >= w.depth_start * (1 - 1e-6) and d.max() <= w.depth_end * (1 + 1e-6)
