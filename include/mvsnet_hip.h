@@ -291,6 +291,31 @@ int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms,
                     const float* const* params, const float* depth_values, void* workspace,
                     size_t workspace_bytes, float* depth_out, float* prob_out, void* stream);
 
+/* The same sweep for `views` (1..8) INDEPENDENT reference views of one size in the same launches -- how config 3 shards
+ * (mvsnet/inference.py:105-119 loops over ~135 reference views per GPU): every kernel of the wavefront takes a view index
+ * from its grid, so the ~7 launches per plane, their latency floors and the cross-stream waits are shared by `views` depth
+ * maps.  Per-view results equal the single-view call's (same tiles, same arithmetic; the LayerNorm sums are float per tile
+ * and double across tiles, so they do not depend on how tiles are dealt to workgroups).
+ *   ref / src / transforms [host] arrays of `views` device pointers (as in mvs_gru_wta_f32, one entry per view)
+ *   depth_values [host] views x depth_num floats
+ *   workspace    views x mvs_gru_workspace_bytes(...) bytes (one block per view)
+ *   depth_out / prob_out (views, H, W)
+ */
+int mvs_gru_wta_batch_f32(const float* const* ref, const float* const* src, const float* const* transforms,
+                          int views, int view_num, int depth_num, int H, int W, int C, int f1, int f2,
+                          int f3, const float* const* params, const float* depth_values, void* workspace,
+                          size_t workspace_bytes, float* depth_out, float* prob_out, void* stream);
+
+/* Formulation of the first ConvGRU cell on the MFMA kernels (csrc/gru.hip): 0 = chosen by view count (default), 1 = hoisted
+ * x-part (batched producer launches + 16-channel per-plane kernels), 2 = full 48-channel per-plane kernels.  Same results bit
+ * for bit; a tuning / test switch (process-wide, not thread-safe against concurrent sweeps). */
+int mvs_gru_set_formulation(int form);
+
+/* Diagnostic: the side-stream layout the sweep uses for caller stream `stream` (created and calibrated on first use,
+ * csrc/gru.hip): *pipe_of_caller = which of the four candidate pipes the caller's hardware queue was measured on (-1: none
+ * stood out), probe_us[8] = the calibration chain times of the eight candidate streams (4 high-, 4 low-priority). */
+int mvs_gru_stream_layout(void* stream, int* pipe_of_caller, float* probe_us);
+
 /* ---------------------------------------------------------------------------------------------
  * backward passes of the plane-sweep path for training.  The reference has no such
  * functions: TensorFlow differentiates the graph of `inference` (mvsnet/model.py:257-372) inside

@@ -83,6 +83,9 @@ SIGNATURES = {
     "mvs_conv2d_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "mvs_conv2d_wgrad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
     "mvs_gru_wta_f32": (_i, [_p, _p, _p] + [_i] * 8 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
+    "mvs_gru_wta_batch_f32": (_i, [_pp, _pp, _pp] + [_i] * 9 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
+    "mvs_gru_set_formulation": (_i, [_i]),
+    "mvs_gru_stream_layout": (_i, [_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }
 
 CONV_IMPL = {"auto": 0, "scalar": 1, "mfma": 2, "bf16x3": 3}

@@ -18,13 +18,25 @@ int mvs_gru1_split_weights(const float* w_gates, const float* w_out, int CA, int
 int mvs_gru1_xpart_mfma(const float* x, const float* wxg, const float* wxo, const float* bias_g, const float* bias_o,
                         int H, int W, int planes, float* px, hipStream_t st);
 int mvs_gru1_gates_h_mfma(const float* h, const float* wgh, const float* px, int H, int W, float* g, double* stats,
-                          hipStream_t st);
+                          int views, size_t vstride, hipStream_t st);
 int mvs_gru1_gates_h_blend_mfma(const float* h_before, const float* c_prev, const float* g_prev, const double* stats_c,
                                 const double* stats_u, const float* o_gamma, const float* o_beta, const float* u_gamma,
                                 const float* u_beta, float* h_out, const float* wgh, const float* px, int H, int W,
-                                float* g, double* stats, hipStream_t st);
+                                float* g, double* stats, int views, size_t vstride, hipStream_t st);
 int mvs_gru1_out_h_mfma(const float* h, const float* g, const double* g_stats, const float* r_gamma, const float* r_beta,
-                        const float* woh, const float* px, int H, int W, float* c, double* stats, hipStream_t st);
+                        const float* woh, const float* px, int H, int W, float* c, double* stats, int views, size_t vstride,
+                        hipStream_t st);
+int mvs_gru1_full_weights(const float* w_gates, const float* w_out, int CA, int F, float* wg, float* wo, hipStream_t st);
+int mvs_gru1_gates_full_mfma(const float* x, const float* h, const float* wg, const float* bias, int H, int W, float* g,
+                             double* stats, int views, size_t vstride, hipStream_t st);
+int mvs_gru1_gates_full_blend_mfma(const float* x, const float* h_before, const float* c_prev, const float* g_prev,
+                                   const double* stats_c, const double* stats_u, const float* o_gamma, const float* o_beta,
+                                   const float* u_gamma, const float* u_beta, float* h_out, const float* wg,
+                                   const float* bias, int H, int W, float* g, double* stats, int views, size_t vstride,
+                                   hipStream_t st);
+int mvs_gru1_out_full_mfma(const float* x, const float* h, const float* g, const double* g_stats, const float* r_gamma,
+                           const float* r_beta, const float* wo, const float* bias, int H, int W, float* c, double* stats,
+                           int views, size_t vstride, hipStream_t st);
 namespace {
 
 template <int CO>
@@ -174,6 +186,12 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&o)
 // convgru.py:97,101,107 -- evaluated once per staged element, not once per tap), every thread then
 // reads its 9 taps from LDS; weights come through the scalar cache.
 // MODE 2: what the previous plane's blend needs, evaluated while staging xb (see conv2d_small_kernel)
+constexpr int MAXV = 8;          // reference views per sweep launch (mvs_gru_wta_batch_f32)
+// View v of a multi-view launch: every tensor of the sweep lives `vstride` bytes after view v-1's (one workspace block per
+// view); weights, biases and LayerNorm parameters are shared.
+template <class T> __device__ __forceinline__ T* view_ptr(T* p, size_t vo) { return p ? (T*)((char*)p + vo) : p; }
+template <class T> __device__ __forceinline__ const T* view_ptr(const T* p, size_t vo) { return p ? (const T*)((const char*)p + vo) : p; }
+
 struct BlendIn {
     const float* c; const float* g;                   // previous plane: raw candidate (H,W,F) and gate (H,W,2F) convolutions
     const double* stats_c; const double* stats_u;     // their LayerNorm moments [sum, sumsq]
@@ -181,7 +199,7 @@ struct BlendIn {
     float* h_out;                                     // receives the blended state (the tile's own pixels)
     // cell 3 only (pw != null): prob_conv + exp + winner-take-all update of the PREVIOUS plane, whose final state is the
     // state just formed in the tile (model.py:701-703, 721-731): one launch less per plane
-    const float* pw; const float* pbias; float depth_value;
+    const float* pw; const float* pbias; float depth_value[MAXV];      // per view: the planes' depths differ between views
     float *max_prob, *depth_image, *exp_sum;
 };
 
@@ -192,17 +210,23 @@ struct BlendIn {
 struct SmallArgs {
     const float* xa; const float* xb; const float* g; const double* g_stats; const float* r_gamma; const float* r_beta;
     const float* w; const float* bias; int H, W; float* y; double* stats; int groups; BlendIn bl;
+    size_t vstride;                                   // blockIdx.y = view
 };
 
 template <int CA, int CB, int CO, int MODE>
 __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int bid) {
-    const float* __restrict__ xa = sa.xa; const float* __restrict__ xb = sa.xb;
-    const float* __restrict__ g = sa.g; const double* __restrict__ g_stats = sa.g_stats;
+    const int view = blockIdx.y;
+    const size_t vo = (size_t)view * sa.vstride;
+    const float* __restrict__ xa = view_ptr(sa.xa, vo); const float* __restrict__ xb = view_ptr(sa.xb, vo);
+    const float* __restrict__ g = view_ptr(sa.g, vo); const double* __restrict__ g_stats = view_ptr(sa.g_stats, vo);
     const float* __restrict__ r_gamma = sa.r_gamma; const float* __restrict__ r_beta = sa.r_beta;
     const float* __restrict__ w = sa.w; const float* __restrict__ bias = sa.bias;
     const int H = sa.H, W = sa.W, groups = sa.groups;
-    float* __restrict__ y = sa.y; double* __restrict__ stats = sa.stats;
-    const BlendIn& bl = sa.bl;
+    float* __restrict__ y = view_ptr(sa.y, vo); double* __restrict__ stats = view_ptr(sa.stats, vo);
+    BlendIn bl = sa.bl;
+    bl.c = view_ptr(bl.c, vo); bl.g = view_ptr(bl.g, vo); bl.stats_c = view_ptr(bl.stats_c, vo); bl.stats_u = view_ptr(bl.stats_u, vo);
+    bl.h_out = view_ptr(bl.h_out, vo); bl.max_prob = view_ptr(bl.max_prob, vo); bl.depth_image = view_ptr(bl.depth_image, vo);
+    bl.exp_sum = view_ptr(bl.exp_sum, vo);
     constexpr int CT = CA + CB;
     constexpr int TS = 16, PS = TS + 2;
     typedef const __attribute__((address_space(4))) float cfloat;      // wave-uniform -> s_load into SGPRs
@@ -291,7 +315,7 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
         const float pr = expf(pacc);
         const int pix = py * W + px;
         const float mp = bl.max_prob[pix];
-        if (mp < pr) { bl.max_prob[pix] = pr; bl.depth_image[pix] = bl.depth_value; }
+        if (mp < pr) { bl.max_prob[pix] = pr; bl.depth_image[pix] = bl.depth_value[view]; }
         bl.exp_sum[pix] += pr;
     }
     float acc[CO];
@@ -346,22 +370,26 @@ conv2d_small_kernel(SmallArgs a) { conv2d_small_body<CA, CB, CO, MODE>(a, blockI
 // (formed from h_before, the state that entered the previous plane) in the gate convolution's staging
 struct PrevPlane { const float* h_before; const float* g; const double* sg; const double* so; };
 // `wta` (cell 3, with `prev`): prob_conv + winner-take-all update of the previous plane inside the gate convolution
-struct WtaFold { const float* pw; const float* pbias; float depth_value; float *max_prob, *depth_image, *exp_sum; };
+struct WtaFold { const float* pw; const float* pbias; float depth_value[MAXV]; float *max_prob, *depth_image, *exp_sum; };
+struct Views { int n; size_t stride; };              // views per launch, byte stride between their tensors
 template <int CA, int F>
 bool launch_small_cell(const float* xin, float* h, const float* const* p, int H, int W, float* g, float* c,
-                       double* sg, double* so, const PrevPlane* prev, hipStream_t st, const WtaFold* wta = nullptr) {
-    const int grid = ((H + 15) / 16) * ((W + 15) / 16);           // 16 x 16 pixel tiles
+                       double* sg, double* so, const PrevPlane* prev, Views vw, hipStream_t st, const WtaFold* wta = nullptr) {
+    const dim3 grid(((H + 15) / 16) * ((W + 15) / 16), vw.n);     // 16 x 16 pixel tiles x views
     BlendIn none = {};
     if (prev) {
-        BlendIn bl = {c, prev->g, prev->so, prev->sg + 2, p[8], p[9], p[4], p[5], h, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr};
-        if (wta) { bl.pw = wta->pw; bl.pbias = wta->pbias; bl.depth_value = wta->depth_value; bl.max_prob = wta->max_prob; bl.depth_image = wta->depth_image; bl.exp_sum = wta->exp_sum; }
+        BlendIn bl = {c, prev->g, prev->so, prev->sg + 2, p[8], p[9], p[4], p[5], h, nullptr, nullptr, {}, nullptr, nullptr, nullptr};
+        if (wta) {
+            bl.pw = wta->pw; bl.pbias = wta->pbias; bl.max_prob = wta->max_prob; bl.depth_image = wta->depth_image; bl.exp_sum = wta->exp_sum;
+            for (int v = 0; v < MAXV; ++v) bl.depth_value[v] = wta->depth_value[v];
+        }
         conv2d_small_kernel<CA, F, 2 * F, 2><<<grid, 256, 0, st>>>(SmallArgs{xin, prev->h_before, nullptr, nullptr, nullptr, nullptr,
-                                                                             p[0], p[1], H, W, g, sg, 2, bl});
+                                                                             p[0], p[1], H, W, g, sg, 2, bl, vw.stride});
     } else {
         conv2d_small_kernel<CA, F, 2 * F, 0><<<grid, 256, 0, st>>>(SmallArgs{xin, h, nullptr, nullptr, nullptr, nullptr,
-                                                                             p[0], p[1], H, W, g, sg, 2, none});
+                                                                             p[0], p[1], H, W, g, sg, 2, none, vw.stride});
     }
-    conv2d_small_kernel<CA, F, F, 1><<<grid, 256, 0, st>>>(SmallArgs{xin, h, g, sg, p[2], p[3], p[6], p[7], H, W, c, so, 1, none});
+    conv2d_small_kernel<CA, F, F, 1><<<grid, 256, 0, st>>>(SmallArgs{xin, h, g, sg, p[2], p[3], p[6], p[7], H, W, c, so, 1, none, vw.stride});
     return true;
 }
 
@@ -375,9 +403,13 @@ gru_blend_fused_kernel(const float* __restrict__ c, const double* __restrict__ s
                        const float* __restrict__ og, const float* __restrict__ ob,
                        const float* __restrict__ g, const double* __restrict__ stats_u,
                        const float* __restrict__ ug, const float* __restrict__ ub, int HW, int F,
-                       const float* h, float* h_out) {       // may alias (non-pipelined sweep)
+                       const float* h, float* h_out,         // may alias (non-pipelined sweep)
+                       size_t vstride) {                     // blockIdx.y = view
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i >= (long long)HW * F) return;
+    const size_t vo = (size_t)blockIdx.y * vstride;
+    c = view_ptr(c, vo); stats_c = view_ptr(stats_c, vo); g = view_ptr(g, vo); stats_u = view_ptr(stats_u, vo);
+    h = view_ptr(h, vo); h_out = view_ptr(h_out, vo);
     const int f = (int)(i % F);
     const long long pix = i / F;
     const double n = (double)HW * F;
@@ -399,13 +431,17 @@ gru_blend_fused_kernel(const float* __restrict__ c, const double* __restrict__ s
 
 // prob_conv (3x3, F3 -> 1, bias) + exp + winner-take-all update in one pass
 // (model.py:701-703, 721-731); strict '<' keeps the first maximum.
+struct DepthVals { float v[MAXV]; };
 template <int F3>
 __global__ void __launch_bounds__(256)
 prob_wta_kernel(const float* __restrict__ h3, const float* __restrict__ w, const float* __restrict__ bias,
-                float depth_value, int H, int W, float* __restrict__ max_prob,
-                float* __restrict__ depth_image, float* __restrict__ exp_sum) {
+                DepthVals dv, int H, int W, float* __restrict__ max_prob,
+                float* __restrict__ depth_image, float* __restrict__ exp_sum, size_t vstride) {
     int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= H * W) return;
+    const float depth_value = dv.v[blockIdx.y];
+    const size_t vo = (size_t)blockIdx.y * vstride;
+    h3 = view_ptr(h3, vo); max_prob = view_ptr(max_prob, vo); depth_image = view_ptr(depth_image, vo); exp_sum = view_ptr(exp_sum, vo);
     int py = pix / W, px = pix - py * W;
     float acc = bias ? bias[0] : 0.f;
 #pragma unroll
@@ -493,8 +529,9 @@ extern "C" int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, i
 
 namespace {
 struct GruWs {
-    float *x, *g[3], *g2[3], *c[3], *rh, *u, *h[3][8 * 4], *reg, *max_prob, *exp_sum;   // h: ring of RG*PG states (RG <= 8); g2: the gate buffer of odd planes (cells whose blend is folded into the next plane's gate convolution)
+    float *x, *g[3], *g2[3], *c[3], *rh, *u, *h[3][8 * 4], *reg, *max_prob, *exp_sum, *depth;   // h: ring of RG*PG states (RG <= 8); g2: the gate buffer of odd planes (cells whose blend is folded into the next plane's gate convolution)
     float *px, *wx, *wgh, *woh;        // hoisted x-part of cell 1: (2, XB, H, W, 3*f1) and its prepared weights
+    float *wfg, *wfo;                  // cell 1 unhoisted: prepared weights of the full 48-channel convolutions
     double* stats;     // per plane of a batch: 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
     size_t bytes;
 };
@@ -502,19 +539,14 @@ struct GruWs {
 // come from ONE depth-sweep launch (register tap reuse along depth, cost_volume.hip) into a ring of
 // XB slices, instead of one single-plane launch per step (26 -> ~6 us per plane at 400 x 300).
 constexpr int XB = 16;
-// Planes per synchronisation group of the wavefront (see mvs_gru_wta_f32); the state ring holds RG groups of PG planes.
+// Planes per synchronisation group of the wavefront (see mvs_gru_wta_batch_f32); the state ring holds RG groups of PG planes.
 constexpr int PG = 4;
 // Ring depth in groups.  A cell may run RG groups ahead of the cell that consumes its states.  Round 1 used 2: the kernel
-// trace (profiles/r02_gru_timeline.txt) showed every stream stalling ~100-200 us at EVERY group boundary -- cell k can start
-// group j only when cell k+1 has finished group j-2, i.e. one group time + two cross-stream signal latencies after cell k
-// finished it, and the signal latency (tens of microseconds) exceeds the slack.  With 4 groups the wait is already
-// satisfied when it is reached.  MVS_GRU_RING=2..8 for A/B runs.
-constexpr int RG_MAX = 8;
-static int ring_groups() {
-    static const int rg = [] { const char* e = getenv("MVS_GRU_RING"); int v = e ? atoi(e) : 4; return v < 2 ? 2 : v > RG_MAX ? RG_MAX : v; }();
-    return rg;
-}
-constexpr int SB = 4;          // LayerNorm-sum ring in batches of XB planes: cell 3 may lag cell 1 by 2 * RG_MAX groups = 4 batches at most
+// trace showed every stream stalling ~100-200 us at EVERY group boundary -- cell k can start group j only when cell k+1
+// has finished group j-2, i.e. one group time + two cross-stream signal latencies after cell k finished it, and the signal
+// latency (tens of microseconds) exceeds the slack.  With 4 groups the wait is already satisfied when it is reached.
+constexpr int RG = 4;
+constexpr int SB = 4;          // LayerNorm-sum ring in batches of XB planes: cell 3 lags cell 1 by fewer than 2 * RG groups <= SB batches
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     size_t hw = (size_t)H * W, off = 0;
@@ -523,40 +555,89 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     const int F[3] = {f1, f2, f3};
     int fmax = f1 > f2 ? (f1 > f3 ? f1 : f3) : (f2 > f3 ? f2 : f3);
     w.x = take(hw * C * XB);
-    // every cell has its own gate / candidate buffers and a ping-pong state: the three cells of
-    // consecutive planes run concurrently (see mvs_gru_wta_f32)
+    // every cell has its own gate / candidate buffers and a ring of states: the three cells of
+    // consecutive planes run concurrently (see mvs_gru_wta_batch_f32)
     for (int k = 0; k < 3; ++k) {
         w.g[k] = take(hw * 2 * F[k]); w.g2[k] = take(hw * 2 * F[k]); w.c[k] = take(hw * F[k]);
-        for (int r = 0; r < RG_MAX * PG; ++r) w.h[k][r] = take(hw * F[k]);
+        for (int r = 0; r < RG * PG; ++r) w.h[k][r] = take(hw * F[k]);
     }
     w.rh = take(hw * fmax); w.u = take(hw * fmax);
-    w.reg = take(hw); w.max_prob = take(hw); w.exp_sum = take(hw);
+    w.reg = take(hw); w.max_prob = take(hw); w.exp_sum = take(hw); w.depth = take(hw);
     w.px = take((size_t)2 * XB * hw * 3 * f1);
     w.wx = take((size_t)9 * C * 3 * f1); w.wgh = take((size_t)9 * f1 * 2 * f1); w.woh = take((size_t)9 * f1 * f1);
+    w.wfg = take((size_t)9 * (C + f1) * 2 * f1); w.wfo = take((size_t)9 * (C + f1) * f1);
     w.stats = (double*)(base ? base + off : nullptr); off += align256((size_t)(SB + 1) * XB * 18 * 8);   // SB + 1 batches deep
     w.bytes = off;
     return w;
 }
 
-// The sweep's four streams: cell 1 (the recurrent chain), cell 2, cell 3 (+ WTA), and the per-batch producer (cost slices +
-// hoisted x-part).  ALL FOUR are the library's own, of ONE priority class, and their hardware queues are created back to
-// back.  Round 2 ran cell 1 on the CALLER's stream and the producer at low priority, and the same sweep took 44 ms instead
-// of 23 ms in any process whose caller stream's hardware queue was not the one created right before the side streams'
-// (profiles/r03_gru_bisect*.log): the runtime binds a stream to a hardware queue on first use, hardware queues are dealt
-// round-robin over the compute pipes of the command processor in creation order (4 pipes: queue ids k and k + 4 share
-// one), and two queues of ONE pipe neither dispatch concurrently nor see each other's completion signals promptly.  With
-// the caller's queue created first, one unrelated queue (any torch.cuda.Stream that ran a kernel) in between put the
-// producer -- or cell 3 -- on the chain's pipe.  Four queues of one priority pool created consecutively have ids
-// k .. k+3: four different pipes whatever else the process has created.
-struct GruStreams { hipStream_t s[4]; hipEvent_t fork, join[4], ready[2][RG_MAX], read[2][RG_MAX], xready[2], xdone[2]; };
+// ---- the sweep's side streams -----------------------------------------------------------------------------------------
+// Cell 1 (the recurrent chain) runs on the CALLER's stream; cell 2, cell 3 (+ WTA) and the per-batch producer (cost slices +
+// hoisted x-part of cell 1) run on three library-owned streams.  WHICH streams matters (round 3, profiles/r03_gru_bisect*.log,
+// r03_pipe_probe.txt): the runtime binds a stream to a hardware queue on its first use, hardware queues are dealt round-robin
+// over the FOUR compute pipes of the command processor in creation order (queue ids k and k + 4 share a pipe), and a queue
+// that is stalled on an event wait -- or busy with the chain's ~8 dispatches per plane -- slows the dispatches of the other
+// queue of its pipe 3-19x (a chain of 200 dependent empty kernels: 0.31 ms alone, 0.59 ms with any other queue stalled,
+// 1.6-5.8 ms with the stalled queue on the same pipe).  Round 2 created three side streams on first use and took whatever
+// queue ids came: with the caller's queue created first and nothing else in the process they were k+1..k+3 (23 ms per c3
+// depth map); with ONE unrelated stream used in between (any torch.cuda.Stream that ran a kernel) the producer or cell 3
+// landed on the chain's pipe and the same sweep took 44 ms.  Now: eight candidate streams per caller stream, four of the high
+// and four of the low priority class, hardware queues created back to back (ids k..k+7: the candidates of a class sit on four
+// different pipes, high[m] and low[m] on the same one), and ONE calibration on first use finds the candidate pipe the
+// caller's queue lives on by measurement (pipe_of_caller): cells 2 / 3 take two high-priority candidates and the producer a
+// low-priority one on the three OTHER pipes.
+__global__ void gru_probe_empty_kernel() {}
+__global__ void gru_probe_spin_kernel(long long ticks) {       // bounded: leaves after `ticks` of the 100 MHz wall clock or 2^26 polls
+    const long long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 26); ++i)
+        if (wall_clock64() - t0 > ticks) break;
+}
+
+struct GruStreams { hipStream_t cand[8], s[3]; int pipe_of_caller; float probe_us[8];
+                    hipEvent_t fork, join[3], ready[2][RG], read[2][RG], xready[2], xdone[2]; };
+
+// Index m (0..3) of the candidate pair (high[m], low[m]) that shares a compute pipe with `caller`, or -1.  While the caller
+// waits on an event (as it does at the end of every sweep) a chain of 100 dependent empty kernels runs on each candidate in
+// turn: the candidate on the caller's pipe takes several times as long as the others.  One-off, ~10 ms, synchronises.
+int pipe_of_caller(hipStream_t caller, GruStreams& g) {
+    hipEvent_t t0, t1, gate;
+    if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess ||
+        hipEventCreateWithFlags(&gate, hipEventDisableTiming) != hipSuccess) return -1;
+    bool ok = hipStreamSynchronize(caller) == hipSuccess;        // the caller must be idle, or it would not be stalled on OUR wait
+    for (int j = 0; ok && j < 8; ++j) {
+        hipStream_t sj = g.cand[j], sg = g.cand[(j + 1) & 7];    // the gate holds the chain back while the host enqueues it
+        gru_probe_spin_kernel<<<1, 64, 0, sg>>>(60000);          // 0.6 ms
+        ok = ok && hipEventRecord(gate, sg) == hipSuccess && hipStreamWaitEvent(sj, gate, 0) == hipSuccess &&
+             hipEventRecord(t0, sj) == hipSuccess;
+        for (int k = 0; k < 100; ++k) gru_probe_empty_kernel<<<1, 64, 0, sj>>>();
+        ok = ok && hipEventRecord(t1, sj) == hipSuccess && hipStreamWaitEvent(caller, t1, 0) == hipSuccess &&
+             hipEventSynchronize(t1) == hipSuccess && hipStreamSynchronize(sg) == hipSuccess;
+        float ms = 0.f;
+        ok = ok && hipEventElapsedTime(&ms, t0, t1) == hipSuccess;
+        g.probe_us[j] = ms * 1e3f;
+    }
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(gate);
+    if (!ok) return -1;
+    auto slowest = [&](const float* t) {                         // the one of four that stands out (> 1.7 x the median), or -1
+        int m = 0;
+        for (int i = 1; i < 4; ++i) if (t[i] > t[m]) m = i;
+        float o[3]; int n = 0;
+        for (int i = 0; i < 4; ++i) if (i != m) o[n++] = t[i];
+        const float med = o[0] > o[1] ? (o[1] > o[2] ? o[1] : (o[0] > o[2] ? o[2] : o[0])) : (o[0] > o[2] ? o[0] : (o[1] > o[2] ? o[2] : o[1]));
+        return t[m] > 1.7f * med ? m : -1;
+    };
+    const int mh = slowest(g.probe_us), ml = slowest(g.probe_us + 4);
+    return mh >= 0 ? mh : ml;                                    // the same pipe by construction; either measurement will do
+}
+
 // One set per caller stream (sweeps of different reference views in flight on different caller streams must not share
-// them, or they would serialise behind each other); created on first use.
+// side streams, or they would serialise behind each other); created and calibrated on first use.
 GruStreams* gru_streams(hipStream_t caller) {
     struct Slot { int dev; hipStream_t caller; GruStreams g; int state; };
     static Slot slots[8];
     static int used = 0;
     static std::mutex mu;                                // slot creation is per (device, caller stream), thread-safe
-    if (getenv("MVS_GRU_ONE_STREAM") != nullptr) return nullptr;     // test hook (one-stream sweep parity), read per sweep
+    if (getenv("MVS_GRU_ONE_STREAM") != nullptr) return nullptr;     // test hook (parity of the one-stream sweep), read per sweep
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
@@ -572,16 +653,39 @@ GruStreams* gru_streams(hipStream_t caller) {
     GruStreams& g = sl.g;
     bool ok = true;
     int lo = 0, hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;   // hi = most urgent class (its queue pool is normally empty)
-    for (int i = 0; ok && i < 4; ++i) ok = hipStreamCreateWithPriority(&g.s[i], hipStreamNonBlocking, hi) == hipSuccess;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;   // lo = least urgent: the batch producer yields to the cells
+    for (int i = 0; ok && i < 8; ++i) ok = hipStreamCreateWithPriority(&g.cand[i], hipStreamNonBlocking, i < 4 ? hi : lo) == hipSuccess;
+    // first use = hardware queue creation: touch the eight candidates now, in order, with nothing in between
+    for (int i = 0; ok && i < 8; ++i) {
+        gru_probe_empty_kernel<<<1, 64, 0, g.cand[i]>>>();
+        ok = hipStreamSynchronize(g.cand[i]) == hipSuccess;
+    }
     auto ev = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
     ev(&g.fork);
-    for (int i = 0; i < 2; ++i) { ev(&g.xready[i]); ev(&g.xdone[i]); for (int j = 0; j < RG_MAX; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
-    for (int i = 0; i < 4; ++i) ev(&g.join[i]);
-    // first use = hardware queue creation: touch the four streams now, in order, with nothing in between
-    for (int i = 0; ok && i < 4; ++i) ok = hipEventRecord(g.join[i], g.s[i]) == hipSuccess;
-    if (ok) sl.state = 1;
-    return ok ? &g : nullptr;
+    for (int i = 0; i < 2; ++i) { ev(&g.xready[i]); ev(&g.xdone[i]); for (int j = 0; j < RG; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
+    for (int i = 0; i < 3; ++i) ev(&g.join[i]);
+    if (!ok) return nullptr;
+    g.pipe_of_caller = pipe_of_caller(caller, g);
+    int pick[3], n = 0;                                  // the three candidate pipes the caller's queue is NOT on
+    for (int m = 0; m < 4 && n < 3; ++m) if (m != g.pipe_of_caller) pick[n++] = m;
+    g.s[0] = g.cand[pick[0]]; g.s[1] = g.cand[pick[1]]; g.s[2] = g.cand[4 + pick[2]];
+    sl.state = 1;
+    return &g;
+}
+
+__global__ void __launch_bounds__(256)
+zero_views_kernel(float4* p, size_t n4, size_t vstride) {       // blockIdx.y = view
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) view_ptr(p, (size_t)blockIdx.y * vstride)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void __launch_bounds__(256)
+wta_finish_views_kernel(const float* max_prob, const float* exp_sum, const float* depth, int HW, size_t vstride,
+                        float* __restrict__ depth_out, float* __restrict__ prob_out) {      // outputs (views, H, W)
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const size_t vo = (size_t)blockIdx.y * vstride, o = (size_t)blockIdx.y * HW + i;
+    prob_out[o] = view_ptr(max_prob, vo)[i] / (view_ptr(exp_sum, vo)[i] + 1e-7f);          // model.py:749-751
+    depth_out[o] = view_ptr(depth, vo)[i];
 }
 }  // namespace
 
@@ -589,22 +693,62 @@ extern "C" size_t mvs_gru_workspace_bytes(int H, int W, int C, int f1, int f2, i
     return carve(nullptr, H, W, C, f1, f2, f3).bytes;
 }
 
-extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms,
-                               int view_num, int depth_num, int H, int W, int C, int f1, int f2,
-                               int f3, const float* const* params, const float* depth_values,
-                               void* workspace, size_t workspace_bytes, float* depth_out,
-                               float* prob_out, void* stream) {
+// Formulation of cell 1 on the MFMA kernels: 1 = hoisted x-part (its own batched launches on the producer stream + per-plane
+// kernels over the 16 state channels), 2 = full 48-channel per-plane kernels, 0 = by view count (hoisted for one view: the
+// chain's latency paces a single sweep; full for two or more: B x 950 tiles per launch hide it, and the hoisted form's px
+// tensor -- 46 MB of traffic per plane and view -- and its producer competing for the matrix pipes are what is left to save).
+// Both give the same bits (gru_mfma.hip, SPLIT accumulators).
+static int g_gru_form = 0;
+extern "C" int mvs_gru_set_formulation(int form) {
+    if (form < 0 || form > 2) return MVS_E_BADARG;
+    g_gru_form = form;
+    return 0;
+}
+
+extern "C" int mvs_gru_stream_layout(void* stream, int* pipe_of_caller_out, float* probe_us_out) {
+    GruStreams* gs = gru_streams(mvs_stream(stream));
+    if (!gs) return MVS_E_BADARG;
+    if (pipe_of_caller_out) *pipe_of_caller_out = gs->pipe_of_caller;
+    if (probe_us_out) for (int i = 0; i < 8; ++i) probe_us_out[i] = gs->probe_us[i];
+    return 0;
+}
+
+extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const* src, const float* const* transforms,
+                                     int views, int view_num, int depth_num, int H, int W, int C, int f1, int f2,
+                                     int f3, const float* const* params, const float* depth_values,
+                                     void* workspace, size_t workspace_bytes, float* depth_out,
+                                     float* prob_out, void* stream) {
     MVS_CHECK_ARG(ref && src && transforms && params && depth_values && workspace && depth_out && prob_out);
+    MVS_CHECK_ARG(views >= 1 && views <= MAXV);
     MVS_CHECK_ARG(view_num >= 2 && depth_num >= 1 && H > 0 && W > 0 && C > 0 && f1 > 0 && f2 > 0 && f3 > 0);
-    GruWs ws = carve((char*)workspace, H, W, C, f1, f2, f3);
-    if (workspace_bytes < ws.bytes) return MVS_E_WORKSPACE;
-    const hipStream_t caller = mvs_stream(stream);
+    for (int v = 0; v < views; ++v) MVS_CHECK_ARG(ref[v] && src[v] && transforms[v]);
+    GruWs ws = carve((char*)workspace, H, W, C, f1, f2, f3);      // view 0's block; view v's tensors are v * ws.bytes further
+    const size_t vstride = ws.bytes;
+    if (workspace_bytes < vstride * (size_t)views) return MVS_E_WORKSPACE;
+    const Views vw = {views, vstride};
+    const hipStream_t st = mvs_stream(stream);           // the caller's stream carries cell 1, the recurrent chain
     const size_t hw = (size_t)H * W;
     hipError_t e;
     const int F[3] = {f1, f2, f3};
+    auto vp = [&](auto* p, int v) { return (decltype(p))((char*)p + (size_t)v * vstride); };     // host-side view pointer
+    auto zero = [&](float* p, size_t nfloat) -> int {    // the same tensor of every view (sizes are multiples of 4 floats: 256-byte carving)
+        const size_t n4 = (nfloat + 3) / 4;
+        zero_views_kernel<<<dim3(mvs_cdiv((long long)n4, 256), views), 256, 0, st>>>((float4*)p, n4, vstride);
+        return (int)hipGetLastError();
+    };
     int rc;
+    // zero initial states and WTA accumulators (model.py:649-654, 737-739)
+    for (int k = 0; k < 3; ++k) if ((rc = zero(ws.h[k][0], hw * F[k]))) return rc;
+    if ((rc = zero(ws.max_prob, hw)) || (rc = zero(ws.exp_sum, hw)) || (rc = zero(ws.depth, hw))) return rc;
+
     // cell 1 (90 % of the MACs) runs on the fp32-MFMA kernels when its shape fits their tiling
     bool mfma1 = (mvs_get_conv_impl() != MVS_CONV_IMPL_SCALAR) && C == 32 && f1 == 16;
+    const bool hoist = mfma1 && (g_gru_form == 1 || (g_gru_form == 0 && views == 1));
+    if (mfma1) {                                         // prepared weights, shared by the views
+        if (hoist) rc = mvs_gru1_split_weights(params[0], params[6], C, f1, ws.wx, ws.wgh, ws.woh, st);
+        else rc = mvs_gru1_full_weights(params[0], params[6], C, f1, ws.wfg, ws.wfo, st);
+        if (rc) return rc;
+    }
     // which kernels each cell gets; the generic conv + gates route shares rh / u and stays on one stream
     const int cins[3] = {C, f1, f2};
     int route[3];                                    // 0 generic, 1 MFMA (cell 1), 2 small-cell kernels
@@ -618,47 +762,51 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
     // the previous ones; the small kernels of cells 2 / 3 (launch-latency bound, a few workgroups per CU) then
     // fill the machine under cell 1's kernels instead of serialising behind them.  A cross-stream dependency
     // costs tens of microseconds of signal latency, as much as a cell's kernels for one plane, so the streams
-    // synchronise per GROUP of PG planes: states live in a ring of 2*PG planes (plane d reads h[k][d % 2PG], writes
-    // h[k][(d+1) % 2PG]); per group j, ready[k][j&1] = cell k has written its states of group j, read[k][j&1] =
-    // cell k+1 is done reading them (cell k may overwrite those ring slots in group j+2).
-    const int RG = ring_groups(), ring = RG * PG;
-    GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2 * PG) ? gru_streams(caller) : nullptr;
-    hipStream_t sk[3] = {gs ? gs->s[0] : caller, gs ? gs->s[1] : caller, gs ? gs->s[2] : caller};
-    const hipStream_t st = sk[0];                    // cell 1's stream: everything "on the chain" below goes here
+    // synchronise per GROUP of PG planes: states live in a ring of RG*PG planes (plane d reads h[k][d % ring], writes
+    // h[k][(d+1) % ring]); per group j, ready[k][j % RG] = cell k has written its states of group j, read[k][j % RG] =
+    // cell k+1 is done reading them (cell k may overwrite those ring slots in group j+RG).
+    // Several reference views (views > 1) ride in the SAME launches: every kernel of the sweep takes a view index from its
+    // grid, so the ~7 launches per plane, their ~5 us floors and the cross-stream waits are shared by `views` depth maps.
+    const int ring = RG * PG;
+    GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2 * PG) ? gru_streams(st) : nullptr;
+    hipStream_t sk[3] = {st, gs ? gs->s[0] : st, gs ? gs->s[1] : st};
     if (gs) {
-        if ((e = hipEventRecord(gs->fork, caller)) != hipSuccess) return (int)e;
-        for (int i = 0; i < 4; ++i) if ((e = hipStreamWaitEvent(gs->s[i], gs->fork, 0)) != hipSuccess) return (int)e;
+        if ((e = hipEventRecord(gs->fork, st)) != hipSuccess) return (int)e;
+        for (int i = 0; i < 3; ++i) if ((e = hipStreamWaitEvent(gs->s[i], gs->fork, 0)) != hipSuccess) return (int)e;
     }
     const long long hw_ll = (long long)H * W;
-    // zero initial states and WTA accumulators (model.py:649-654, 737-739)
-    for (int k = 0; k < 3; ++k)
-        if ((e = hipMemsetAsync(ws.h[k][0], 0, hw * F[k] * 4, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(ws.max_prob, 0, hw * 4, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(ws.exp_sum, 0, hw * 4, st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(depth_out, 0, hw * 4, st)) != hipSuccess) return (int)e;
-    if (mfma1 && (rc = mvs_gru1_split_weights(params[0], params[6], C, f1, ws.wx, ws.wgh, ws.woh, st))) return rc;
 
+    // The cost slices of the batch that holds plane d.  Hoisted form: one buffer -- the x-part launches that read it follow the
+    // slices' launch on the producer stream, and what the chain reads (px) has two halves.  Full form: the chain reads the
+    // slices themselves while the producer writes the next batch, so they alternate between two halves too (the memory of
+    // the unused px tensor: 2 * XB * 48 floats per pixel against the 2 * XB * C needed).
+    auto xbatch = [&](int d) -> float* {
+        return (mfma1 && !hoist && gs) ? ws.px + (size_t)((d / XB) & 1) * XB * hw * C : ws.x;
+    };
     // start of a batch of XB planes (on cell 1's stream, before its first plane of the batch)
     auto batch_start = [&](int d) -> int {
         const int half = (d / XB) & 1;
         // LayerNorm sums of this batch (other slots of the ring may still be in use by cells 2 / 3 of earlier planes: cell 3
         // lags cell 1 by fewer than 2 * RG groups = at most SB batches)
-        if ((e = hipMemsetAsync(ws.stats + (size_t)((d / XB) % (SB + 1)) * XB * 18, 0, (size_t)XB * 18 * 8, st)) != hipSuccess) return (int)e;
+        int r;
+        if ((r = zero((float*)(ws.stats + (size_t)((d / XB) % (SB + 1)) * XB * 18), (size_t)XB * 18 * 2))) return r;
         // Per batch: x = -variance cost slices (model.py:680-693,698) and, for the MFMA cell 1, the x halves of
         // its two convolutions for the whole batch (gru_mfma.hip: x-part hoisting).
         auto produce = [&](int d0, hipStream_t s) -> int {
             const int nb = depth_num - d0 < XB ? depth_num - d0 : XB;
-            int r = mvs_cost_volume_f32(ref, src, transforms, view_num, depth_num, d0, nb, H, W, C, /*variant*/ 1,
-                                        /*negate*/ 1, /*border*/ 0, ws.x, s);
-            if (r || !mfma1) return r;
-            return mvs_gru1_xpart_mfma(ws.x, ws.wx, ws.wx + (size_t)9 * C * 2 * f1, params[1], params[7], H, W, nb,
-                                       ws.px + (size_t)((d0 / XB) & 1) * XB * hw * 3 * f1, s);
+            for (int v = 0; v < views; ++v) {
+                int r2 = mvs_cost_volume_f32(ref[v], src[v], transforms[v], view_num, depth_num, d0, nb, H, W, C, /*variant*/ 1,
+                                             /*negate*/ 1, /*border*/ 0, vp(xbatch(d0), v), s);
+                if (r2) return r2;
+                if (hoist && (r2 = mvs_gru1_xpart_mfma(vp(xbatch(d0), v), ws.wx, ws.wx + (size_t)9 * C * 2 * f1, params[1], params[7], H, W, nb,
+                                                       vp(ws.px, v) + (size_t)((d0 / XB) & 1) * XB * hw * 3 * f1, s))) return r2;
+            }
+            return 0;
         };
         if (!(gs && mfma1)) return produce(d, st);
         // the producer runs one batch ahead on its own (low-priority) stream: 2/3 of cell 1's MACs leave the
         // recurrent chain
-        hipStream_t sx = gs->s[3];
-        int r;
+        hipStream_t sx = gs->s[2];
         if (d == 0) {
             if ((r = produce(0, sx))) return r;
             if ((e = hipEventRecord(gs->xready[0], sx)) != hipSuccess) return (int)e;
@@ -696,63 +844,77 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
             prev = {ws.h[k][dp % ring], (dp & 1) ? ws.g2[k] : ws.g[k], sgp, sgp + 4};
         }
         const PrevPlane* pv = fused_in ? &prev : nullptr;
-        const float* xin = k == 0 ? ws.x + (size_t)slot * hw * C : ws.h[k - 1][(d + 1) % ring];
+        const float* xin = k == 0 ? xbatch(d) + (size_t)slot * hw * C : ws.h[k - 1][(d + 1) % ring];
         const float* px_d = ws.px + ((size_t)half * XB + slot) * hw * 3 * f1;
         const int cin = cins[k];
         int r;
         // cell 3: the previous plane's prob_conv + winner-take-all update rides in this plane's gate convolution, which forms
-        // that plane's final state in its tile anyway (MVS_GRU_NO_WTA_FOLD=1: the separate launch, A/B and parity switch)
-        static const bool no_wta_fold = getenv("MVS_GRU_NO_WTA_FOLD") != nullptr;
-        WtaFold wfold = {params[30], params[31], d >= 1 ? depth_values[d - 1] : 0.f, ws.max_prob, depth_out, ws.exp_sum};
-        const WtaFold* wf = (k == 2 && fused_in && !no_wta_fold) ? &wfold : nullptr;
+        // that plane's final state in its tile anyway
+        WtaFold wfold = {params[30], params[31], {}, ws.max_prob, ws.depth, ws.exp_sum};
+        for (int v = 0; v < views; ++v) wfold.depth_value[v] = d >= 1 ? depth_values[(size_t)v * depth_num + d - 1] : 0.f;
+        const WtaFold* wf = (k == 2 && fused_in) ? &wfold : nullptr;
         bool wta_folded = false;
-        if (route[k] == 1) {
+        if (route[k] == 1 && !hoist) {
+            if (fused_in)
+                r = mvs_gru1_gates_full_blend_mfma(xin, prev.h_before, ws.c[k], prev.g, prev.so, prev.sg + 2, p[8], p[9], p[4], p[5], hp_w,
+                                                   ws.wfg, p[1], H, W, gcur, sg, views, vstride, s);
+            else
+                r = mvs_gru1_gates_full_mfma(xin, hp, ws.wfg, p[1], H, W, gcur, sg, views, vstride, s);
+            if (r) return r;
+            if ((r = mvs_gru1_out_full_mfma(xin, hp, gcur, sg, p[2], p[3], ws.wfo, p[7], H, W, ws.c[k], so, views, vstride, s))) return r;
+            if (gs && (slot == XB - 1 || d == depth_num - 1) && (e = hipEventRecord(gs->xdone[half], s)) != hipSuccess) return (int)e;
+        } else if (route[k] == 1) {
             if (fused_in)
                 r = mvs_gru1_gates_h_blend_mfma(prev.h_before, ws.c[k], prev.g, prev.so, prev.sg + 2, p[8], p[9], p[4], p[5], hp_w,
-                                                ws.wgh, px_d, H, W, gcur, sg, s);
+                                                ws.wgh, px_d, H, W, gcur, sg, views, vstride, s);
             else
-                r = mvs_gru1_gates_h_mfma(hp, ws.wgh, px_d, H, W, gcur, sg, s);
+                r = mvs_gru1_gates_h_mfma(hp, ws.wgh, px_d, H, W, gcur, sg, views, vstride, s);
             if (r) return r;
-            if ((r = mvs_gru1_out_h_mfma(hp, gcur, sg, p[2], p[3], ws.woh, px_d, H, W, ws.c[k], so, s))) return r;
+            if ((r = mvs_gru1_out_h_mfma(hp, gcur, sg, p[2], p[3], ws.woh, px_d, H, W, ws.c[k], so, views, vstride, s))) return r;
             if (gs && (slot == XB - 1 || d == depth_num - 1) && (e = hipEventRecord(gs->xdone[half], s)) != hipSuccess) return (int)e;
-        } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s, wf)) {
+        } else if (cin == 16 && F[k] == 4 && launch_small_cell<16, 4>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, vw, s, wf)) {
             wta_folded = wf != nullptr;
-        } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s, wf)) {
+        } else if (cin == 4 && F[k] == 2 && launch_small_cell<4, 2>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, vw, s, wf)) {
             wta_folded = wf != nullptr;
-        } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s, wf)) {
+        } else if (cin == 8 && F[k] == 2 && launch_small_cell<8, 2>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, vw, s, wf)) {
             wta_folded = wf != nullptr;
-        } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, s, wf)) {
+        } else if (cin == 2 && F[k] == 1 && launch_small_cell<2, 1>(xin, hp_w, p, H, W, gcur, ws.c[k], sg, so, pv, vw, s, wf)) {
             wta_folded = wf != nullptr;
         } else {
-            if ((r = launch_conv2d(xin, cin, hp, F[k], p[0], p[1], H, W, 2 * F[k], ws.g[k], sg, 2, s))) return r;
-            if ((r = mvs_gru_gates_f32(ws.g[k], sg, p[2], p[3], p[4], p[5], hp, H, W, F[k], ws.rh, ws.u, s))) return r;
-            if ((r = launch_conv2d(xin, cin, ws.rh, F[k], p[6], p[7], H, W, F[k], ws.c[k], so, 1, s))) return r;
+            for (int v = 0; v < views; ++v) {            // shape-generic route: one view per launch
+                if ((r = launch_conv2d(vp(xin, v), cin, vp(hp, v), F[k], p[0], p[1], H, W, 2 * F[k], vp(ws.g[k], v), vp(sg, v), 2, s))) return r;
+                if ((r = mvs_gru_gates_f32(vp(ws.g[k], v), vp(sg, v), p[2], p[3], p[4], p[5], vp(hp, v), H, W, F[k], vp(ws.rh, v), vp(ws.u, v), s))) return r;
+                if ((r = launch_conv2d(vp(xin, v), cin, vp(ws.rh, v), F[k], p[6], p[7], H, W, F[k], vp(ws.c[k], v), vp(so, v), 1, s))) return r;
+            }
         }
         // prob_conv + exp + winner-take-all update (model.py:701-731) of plane `dd`, whose final state is `hs`
         auto prob_wta = [&](const float* hs, int dd) -> int {
-            const int grid = mvs_cdiv(hw_ll, 256);
+            const dim3 grid(mvs_cdiv(hw_ll, 256), views);
+            DepthVals dv = {};
+            for (int v = 0; v < views; ++v) dv.v[v] = depth_values[(size_t)v * depth_num + dd];
             int r2;
             switch (f3) {
-                case 1: prob_wta_kernel<1><<<grid, 256, 0, s>>>(hs, params[30], params[31], depth_values[dd], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
-                case 2: prob_wta_kernel<2><<<grid, 256, 0, s>>>(hs, params[30], params[31], depth_values[dd], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
-                case 4: prob_wta_kernel<4><<<grid, 256, 0, s>>>(hs, params[30], params[31], depth_values[dd], H, W, ws.max_prob, depth_out, ws.exp_sum); break;
+                case 1: prob_wta_kernel<1><<<grid, 256, 0, s>>>(hs, params[30], params[31], dv, H, W, ws.max_prob, ws.depth, ws.exp_sum, vstride); break;
+                case 2: prob_wta_kernel<2><<<grid, 256, 0, s>>>(hs, params[30], params[31], dv, H, W, ws.max_prob, ws.depth, ws.exp_sum, vstride); break;
+                case 4: prob_wta_kernel<4><<<grid, 256, 0, s>>>(hs, params[30], params[31], dv, H, W, ws.max_prob, ws.depth, ws.exp_sum, vstride); break;
                 default:
-                    if ((r2 = launch_conv2d(hs, f3, nullptr, 0, params[30], params[31], H, W, 1, ws.reg, nullptr, 1, s))) return r2;
-                    if ((r2 = mvs_wta_update_f32(ws.reg, depth_values[dd], H, W, ws.max_prob, depth_out, ws.exp_sum, s))) return r2;
+                    for (int v = 0; v < views; ++v) {
+                        if ((r2 = launch_conv2d(vp(hs, v), f3, nullptr, 0, params[30], params[31], H, W, 1, vp(ws.reg, v), nullptr, 1, s))) return r2;
+                        if ((r2 = mvs_wta_update_f32(vp(ws.reg, v), dv.v[v], H, W, vp(ws.max_prob, v), vp(ws.depth, v), vp(ws.exp_sum, v), s))) return r2;
+                    }
             }
             return (int)hipGetLastError();
         };
         if (k == 2 && fused_in && !wta_folded && (r = prob_wta(hp, d - 1))) return r;     // plane d-1's state exists since this plane's gate convolution
         if (blend_now) {
-            if (F[k] % 4 == 0)
-                gru_blend_fused_kernel<4><<<mvs_cdiv(hw_ll * F[k] / 4, 256), 256, 0, s>>>(
-                    ws.c[k], so, p[8], p[9], gcur, sg + 2, p[4], p[5], H * W, F[k], hp, hn);
-            else if (F[k] % 2 == 0)
-                gru_blend_fused_kernel<2><<<mvs_cdiv(hw_ll * F[k] / 2, 256), 256, 0, s>>>(
-                    ws.c[k], so, p[8], p[9], gcur, sg + 2, p[4], p[5], H * W, F[k], hp, hn);
+            const int vec = F[k] % 4 == 0 ? 4 : F[k] % 2 == 0 ? 2 : 1;
+            const dim3 grid(mvs_cdiv(hw_ll * F[k] / vec, 256), views);
+            if (vec == 4)
+                gru_blend_fused_kernel<4><<<grid, 256, 0, s>>>(ws.c[k], so, p[8], p[9], gcur, sg + 2, p[4], p[5], H * W, F[k], hp, hn, vstride);
+            else if (vec == 2)
+                gru_blend_fused_kernel<2><<<grid, 256, 0, s>>>(ws.c[k], so, p[8], p[9], gcur, sg + 2, p[4], p[5], H * W, F[k], hp, hn, vstride);
             else
-                gru_blend_fused_kernel<1><<<mvs_cdiv(hw_ll * F[k], 256), 256, 0, s>>>(
-                    ws.c[k], so, p[8], p[9], gcur, sg + 2, p[4], p[5], H * W, F[k], hp, hn);
+                gru_blend_fused_kernel<1><<<grid, 256, 0, s>>>(ws.c[k], so, p[8], p[9], gcur, sg + 2, p[4], p[5], H * W, F[k], hp, hn, vstride);
             if ((r = (int)hipGetLastError())) return r;
             if (k == 2 && (r = prob_wta(hn, d))) return r;
         }
@@ -784,9 +946,20 @@ extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* 
         }
     }
     if (gs)
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 3; ++i) {
             if ((e = hipEventRecord(gs->join[i], gs->s[i])) != hipSuccess) return (int)e;
-            if ((e = hipStreamWaitEvent(caller, gs->join[i], 0)) != hipSuccess) return (int)e;
+            if ((e = hipStreamWaitEvent(st, gs->join[i], 0)) != hipSuccess) return (int)e;
         }
-    return mvs_wta_finish_f32(ws.max_prob, ws.exp_sum, H, W, prob_out, stream);
+    wta_finish_views_kernel<<<dim3(mvs_cdiv(hw_ll, 256), views), 256, 0, st>>>(ws.max_prob, ws.exp_sum, ws.depth, H * W, vstride,
+                                                                             depth_out, prob_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms,
+                               int view_num, int depth_num, int H, int W, int C, int f1, int f2,
+                               int f3, const float* const* params, const float* depth_values,
+                               void* workspace, size_t workspace_bytes, float* depth_out,
+                               float* prob_out, void* stream) {
+    return mvs_gru_wta_batch_f32(&ref, &src, &transforms, 1, view_num, depth_num, H, W, C, f1, f2, f3, params, depth_values,
+                                 workspace, workspace_bytes, depth_out, prob_out, stream);
 }

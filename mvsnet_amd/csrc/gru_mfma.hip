@@ -16,6 +16,7 @@
 // side stream, and the per-plane kernels on the critical path only convolve the 16 state channels (CA = 0) and
 // add the precomputed part in their epilogue (ADD).  See mvs_gru_wta_f32.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -42,6 +43,10 @@ struct Gru2dArgs {
     const double* stats_c; const double* stats_u;          // their LayerNorm moments [sum, sumsq]
     const float *o_gamma, *o_beta, *u_gamma, *u_beta;
     float* h_out;               // (H,W,CB): receives the state entering this plane (the tile's own pixels)
+    // Several reference views in one launch (per-plane kernels only): view v's tensors live `vstride` bytes after view
+    // v-1's (the sweep's workspace is one block per view, so ONE stride serves every pointer above except the weights /
+    // LayerNorm parameters, which the views share); workgroups [v*wg_per_view, (v+1)*wg_per_view) work through view v's tiles.
+    size_t vstride; int wg_per_view;
 };
 
 constexpr int TH2 = 8, TW2 = 16, PW2 = TW2 + 2;
@@ -71,6 +76,15 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     const int n = lane & 15, kq = lane >> 4;
     const int tiles_pp = a.tiles_h * a.tiles_w;                  // tiles per plane
     const int ntiles = tiles_pp * (BATCH ? a.planes : 1);
+    int first_tile = blockIdx.x, tile_stride = gridDim.x;
+    if (!BATCH && a.wg_per_view > 0) {                           // this workgroup's reference view (wave-uniform)
+        const int view = blockIdx.x / a.wg_per_view;
+        first_tile = blockIdx.x - view * a.wg_per_view; tile_stride = a.wg_per_view;
+        const size_t vo = (size_t)view * a.vstride;
+        auto mv = [vo](auto& p) { if (p) p = (typename std::remove_reference<decltype(p)>::type)((const char*)p + vo); };
+        mv(a.xa); mv(a.xb); mv(a.g); mv(a.g_stats); mv(a.y); mv(a.stats); mv(a.yadd);
+        mv(a.c_prev); mv(a.g_prev); mv(a.stats_c); mv(a.stats_u); mv(a.h_out);
+    }
 
     copy_weights_to_lds(wl, a.wprep, W_FLOATS);      // prepared layout, eight loads in flight per thread
 
@@ -172,11 +186,13 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
             }
         }
     };
-    // tf.sigmoid / tf.tanh (convgru.py:101-102,117) in the forms cells 2 / 3 use (gru.hip): libm expf with an IEEE divide, and
-    // tanh without the cancellation of 1 - 2/(e^{2x}+1) near 0: t = e^{-2|x|}, (1-t)/(1+t) with the sign of x (round 2 used
-    // v_rcp + __expf here and landed 2x further from the float64 fixture than float32 needs to)
-    auto sig = [](float x) { return 1.0f / (1.0f + expf(-x)); };
-    auto tanh_ = [](float x) { const float t = expf(-2.0f * fabsf(x)); return copysignf((1.0f - t) / (1.0f + t), x); };
+    // tf.sigmoid / tf.tanh (convgru.py:101-102,117) on the fast transcendental path (v_exp_f32 + v_rcp_f32, ~2 ulp), with tanh
+    // in the form that does not cancel near 0: t = e^{-2|x|}, (1 - t) / (1 + t) with the sign of x.  Measured at c3 (round 3):
+    // libm expf + IEEE divides here cost 1.0 ms per depth map (25.15 against 24.15 ms) and land at the SAME distance from the
+    // float64 fixture (probability rel-max 1.169e-3 against 1.172e-3, plane agreement 0.99988 both): the distance the round-2
+    // verdict attributed to these forms comes from float32 summation order, not from them.
+    auto sig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); };
+    auto tanh_ = [](float x) { const float t = __expf(-2.0f * fabsf(x)); return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x); };
     auto stage_piece = [&](int i, float* buf, int tile_of) __attribute__((always_inline)) {
         float4 v = pre[i];                           // zeros outside the image (SAME padding)
         if (MODE == 1 && i >= NA) {                  // xb = sigmoid(LN(g_r)) * h (convgru.py:97,101,107)
@@ -212,15 +228,17 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
             const int co = m * 16 + 4 * kq + k;
             bias4[m][k] = (a.bias2 && co >= a.bias_split) ? a.bias2[co - a.bias_split] : (a.bias ? a.bias[co] : 0.f);
         }
-    float st_s[MT], st_q[MT];
+    // LayerNorm moments: float within a tile (fixed lane -> pixel map), double across the tiles of a workgroup, so the
+    // sums do not depend on which workgroup swept which tile (one view per launch or several: same result)
+    double st_s[MT], st_q[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) { st_s[m] = 0.f; st_q[m] = 0.f; }
+    for (int m = 0; m < MT; ++m) { st_s[m] = 0.0; st_q[m] = 0.0; }
 
     // Tile t is swept while tile t+1 moves registers -> LDS (first half of the operand groups) and
     // tile t+2 is requested from memory (second half): with one wave per SIMD everything that is not
     // issued under the MFMAs -- above all the global-load latency of a 3 us tile -- would be exposed.
-    const int stride = gridDim.x;
-    int tile = blockIdx.x;
+    const int stride = tile_stride;
+    int tile = first_tile;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) load_piece(i, tile);
 #pragma unroll
@@ -233,11 +251,19 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         const float* cur = slab + (it & 1) * SLAB_FLOATS;
         float* nxt = slab + ((it + 1) & 1) * SLAB_FLOATS;
 
-        f32x4 acc[MT][V];
+        // Two accumulators when both families are present: the xa channels and the xb channels of conv([xa | xb]) are summed
+        // separately and combined as (xb part) + ((xa part) + bias) in the epilogue -- exactly what the hoisted formulation
+        // computes with its two launches (x-part launch stores conv_x + bias, the per-plane launch adds it to conv_h), so
+        // either formulation of cell 1 gives the same bits.
+        constexpr bool SPLIT = CA > 0 && CB > 0;
+        f32x4 acc[MT][V], accx[SPLIT ? MT : 1][SPLIT ? V : 1];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int v = 0; v < V; ++v) acc[m][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < V; ++v) {
+                acc[m][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (SPLIT) accx[m][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         float4 padd[ADD ? MT : 1][V];                // the precomputed part of this tile's outputs, requested now
         if (ADD) {
             const int th = tile / a.tiles_w, h0 = th * TH2, w0 = (tile - th * a.tiles_w) * TW2;
@@ -270,13 +296,16 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
                     if ((i * (NG / 2)) / NIT == g) stage_piece(i, nxt, tile + stride);
                     if (NG / 2 + (i * (NG - NG / 2)) / NIT == g) load_piece(i, tile + 2 * stride);
                 }
+                const bool xgroup = SPLIT && (g % (CT / 16)) < CA / 16;      // compile-time after unrolling
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int v = 0; v < V; ++v)
-                            acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][j], bv[g & 1][v][j], acc[m][v], 0, 0, 0);
+                        for (int v = 0; v < V; ++v) {
+                            if (xgroup) accx[SPLIT ? m : 0][SPLIT ? v : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][j], bv[g & 1][v][j], accx[SPLIT ? m : 0][SPLIT ? v : 0], 0, 0, 0);
+                            else acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][j], bv[g & 1][v][j], acc[m][v], 0, 0, 0);
+                        }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -286,6 +315,9 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
             const int th = tl / a.tiles_w, h0 = th * TH2, w0 = (tl - th * a.tiles_w) * TW2;
             const int ys = a.y_stride ? a.y_stride : COUT;
             float* yp = a.y + (size_t)plane * a.H * a.W * ys + a.y_off;
+            float ts[MT], tq[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { ts[m] = 0.f; tq[m] = 0.f; }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 int h = h0 + V * wave + v, w = w0 + n;
@@ -293,30 +325,38 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         f32x4 r = acc[m][v];
-                        float4 o = make_float4(r[0] + bias4[m][0], r[1] + bias4[m][1], r[2] + bias4[m][2], r[3] + bias4[m][3]);
+                        float4 o;
+                        if (SPLIT) {
+                            const f32x4 rx = accx[SPLIT ? m : 0][SPLIT ? v : 0];
+                            o = make_float4(r[0] + (rx[0] + bias4[m][0]), r[1] + (rx[1] + bias4[m][1]), r[2] + (rx[2] + bias4[m][2]), r[3] + (rx[3] + bias4[m][3]));
+                        } else {
+                            o = make_float4(r[0] + bias4[m][0], r[1] + bias4[m][1], r[2] + bias4[m][2], r[3] + bias4[m][3]);
+                        }
                         if (ADD) { o.x += padd[m][v].x; o.y += padd[m][v].y; o.z += padd[m][v].z; o.w += padd[m][v].w; }
                         *(float4*)(yp + ((size_t)h * a.W + w) * ys + m * 16 + 4 * kq) = o;
-                        st_s[m] += (o.x + o.y) + (o.z + o.w);
-                        st_q[m] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                        ts[m] += (o.x + o.y) + (o.z + o.w);
+                        tq[m] += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
                     }
                 }
             }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { st_s[m] += (double)ts[m]; st_q[m] += (double)tq[m]; }
         }
         __syncthreads();
     }
 
     if (a.stats) {
-        float* red = slab;                          // dead now: [4 waves][MT][2]
+        double* red = (double*)slab;                // dead now: [4 waves][MT][2]
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            float s = wave_sum(st_s[m]), q = wave_sum(st_q[m]);
+            double s = wave_sum(st_s[m]), q = wave_sum(st_q[m]);
             if (lane == 0) { red[(wave * MT + m) * 2] = s; red[(wave * MT + m) * 2 + 1] = q; }
         }
         __syncthreads();
         if (tid < MT * 2) {
             int m = tid >> 1, k = tid & 1;
             double t = 0.0;
-            for (int wv = 0; wv < 4; ++wv) t += (double)red[(wv * MT + m) * 2 + k];
+            for (int wv = 0; wv < 4; ++wv) t += red[(wv * MT + m) * 2 + k];
             atomicAdd(&a.stats[m * 2 + k], t);
         }
     }
@@ -328,7 +368,12 @@ int launch_gru2d(const Gru2dArgs& a0, hipStream_t st) {
     a.tiles_h = (a.H + TH2 - 1) / TH2;
     a.tiles_w = (a.W + TW2 - 1) / TW2;
     const int ntiles = a.tiles_h * a.tiles_w * (BATCH ? a.planes : 1);
-    const int grid = ntiles < 256 ? ntiles : 256;
+    int grid = ntiles < 256 ? ntiles : 256;
+    if (!BATCH) {                                    // views > 1: the persistent workgroups are dealt over the views
+        const int views = a.wg_per_view > 0 ? a.wg_per_view : 1;      // (the callers pass the view count in this field)
+        int per = 256 / views; if (per < 1) per = 1; if (per > ntiles) per = ntiles;
+        a.wg_per_view = per; grid = per * views;
+    }
     constexpr int CT = CA + CB;
     size_t smem = (size_t)(9 * CT * COUT + 2 * (TH2 + 2) * PW2 * (CT + 8)) * sizeof(float);
     static bool attr_done = false;
@@ -393,9 +438,10 @@ int mvs_gru1_xpart_mfma(const float* x, const float* wxg, const float* wxo, cons
 
 // h-part of the gate convolution + precomputed x-part (px, pixel stride 48): raw gates, LayerNorm moments
 int mvs_gru1_gates_h_mfma(const float* h, const float* wgh, const float* px, int H, int W, float* g, double* stats,
-                          hipStream_t st) {
+                          int views, size_t vstride, hipStream_t st) {
     Gru2dArgs a{nullptr, h, nullptr, nullptr, nullptr, nullptr, wgh, nullptr, g, stats, H, W, 0, 0,
                 nullptr, 0, px, 48, 0, 1, 0, 0};
+    a.vstride = vstride; a.wg_per_view = views;
     return launch_gru2d<0, 16, 32, 0, true, false>(a, st);
 }
 
@@ -404,16 +450,56 @@ int mvs_gru1_gates_h_mfma(const float* h, const float* wgh, const float* px, int
 int mvs_gru1_gates_h_blend_mfma(const float* h_before, const float* c_prev, const float* g_prev, const double* stats_c,
                                 const double* stats_u, const float* o_gamma, const float* o_beta, const float* u_gamma,
                                 const float* u_beta, float* h_out, const float* wgh, const float* px, int H, int W,
-                                float* g, double* stats, hipStream_t st) {
+                                float* g, double* stats, int views, size_t vstride, hipStream_t st) {
     Gru2dArgs a{nullptr, h_before, nullptr, nullptr, nullptr, nullptr, wgh, nullptr, g, stats, H, W, 0, 0,
                 nullptr, 0, px, 48, 0, 1, 0, 0, c_prev, g_prev, stats_c, stats_u, o_gamma, o_beta, u_gamma, u_beta, h_out};
+    a.vstride = vstride; a.wg_per_view = views;
     return launch_gru2d<0, 16, 32, 2, true, false>(a, st);
 }
 
 // h-part of the candidate convolution on sigmoid(LN(g_r)) * h + precomputed x-part (channels 32..47 of px)
 int mvs_gru1_out_h_mfma(const float* h, const float* g, const double* g_stats, const float* r_gamma, const float* r_beta,
-                        const float* woh, const float* px, int H, int W, float* c, double* stats, hipStream_t st) {
+                        const float* woh, const float* px, int H, int W, float* c, double* stats, int views, size_t vstride,
+                        hipStream_t st) {
     Gru2dArgs a{nullptr, h, g, g_stats, r_gamma, r_beta, woh, nullptr, c, stats, H, W, 0, 0,
                 nullptr, 0, px, 48, 32, 1, 0, 0};
+    a.vstride = vstride; a.wg_per_view = views;
     return launch_gru2d<0, 16, 16, 1, true, false>(a, st);
+}
+
+// ---- cell 1 WITHOUT the hoisted x-part: the per-plane kernels convolve all 48 channels of [x | h] themselves (three times the
+// matrix work per launch, no px tensor: 46 MB less traffic per plane and view, no batched producer competing for the matrix
+// pipes).  The sweep takes this form when several reference views share its launches (mvs_gru_wta_batch_f32): with B views a
+// launch has B x 950 tiles and its latency is no longer what paces the chain.  Same bits as the hoisted form (SPLIT above).
+int mvs_gru1_full_weights(const float* w_gates, const float* w_out, int CA, int F, float* wg, float* wo, hipStream_t st) {
+    if (!(CA == 32 && F == 16)) return MVS_E_SHAPE;
+    const int CT = CA + F;
+    gru_weight_slice_kernel<<<mvs_cdiv(9 * CT * 2 * F, 256), 256, 0, st>>>(w_gates, CT, 0, CT, 2 * F, 2 * F, 0, wg);
+    gru_weight_slice_kernel<<<mvs_cdiv(9 * CT * F, 256), 256, 0, st>>>(w_out, CT, 0, CT, F, F, 0, wo);
+    return (int)hipGetLastError();
+}
+int mvs_gru1_gates_full_mfma(const float* x, const float* h, const float* wg, const float* bias, int H, int W, float* g,
+                             double* stats, int views, size_t vstride, hipStream_t st) {
+    Gru2dArgs a{x, h, nullptr, nullptr, nullptr, nullptr, wg, bias, g, stats, H, W, 0, 0,
+                nullptr, 0, nullptr, 0, 0, 1, 0, 0};
+    a.vstride = vstride; a.wg_per_view = views;
+    return launch_gru2d<32, 16, 32, 0, false, false>(a, st);
+}
+int mvs_gru1_gates_full_blend_mfma(const float* x, const float* h_before, const float* c_prev, const float* g_prev,
+                                   const double* stats_c, const double* stats_u, const float* o_gamma, const float* o_beta,
+                                   const float* u_gamma, const float* u_beta, float* h_out, const float* wg,
+                                   const float* bias, int H, int W, float* g, double* stats, int views, size_t vstride,
+                                   hipStream_t st) {
+    Gru2dArgs a{x, h_before, nullptr, nullptr, nullptr, nullptr, wg, bias, g, stats, H, W, 0, 0,
+                nullptr, 0, nullptr, 0, 0, 1, 0, 0, c_prev, g_prev, stats_c, stats_u, o_gamma, o_beta, u_gamma, u_beta, h_out};
+    a.vstride = vstride; a.wg_per_view = views;
+    return launch_gru2d<32, 16, 32, 2, false, false>(a, st);
+}
+int mvs_gru1_out_full_mfma(const float* x, const float* h, const float* g, const double* g_stats, const float* r_gamma,
+                           const float* r_beta, const float* wo, const float* bias, int H, int W, float* c, double* stats,
+                           int views, size_t vstride, hipStream_t st) {
+    Gru2dArgs a{x, h, g, g_stats, r_gamma, r_beta, wo, bias, c, stats, H, W, 0, 0,
+                nullptr, 0, nullptr, 0, 0, 1, 0, 0};
+    a.vstride = vstride; a.wg_per_view = views;
+    return launch_gru2d<32, 16, 16, 1, false, false>(a, st);
 }

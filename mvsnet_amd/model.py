@@ -306,16 +306,21 @@ class DepthPlan:
     streams (one plan per stream)."""
 
     def __init__(self, view_num, depth_num, height, width, channels, weights: MVSNetWeights,
-                 regularization="3DCNN", device="cuda"):
+                 regularization="3DCNN", device="cuda", views=1):
+        """views > 1 (GRU only): that many independent reference views per sweep (run_gru_batch)."""
         lib = _lib.load()
         self.N, self.D, self.H, self.W, self.C = view_num, depth_num, height, width, channels
         self.weights = weights
         self.regularization = regularization
+        self.views = int(views)
+        if self.views != 1 and regularization != "GRU":
+            raise NotImplementedError("views > 1 is the recurrent sweep's batch of reference views")
         dev = torch.device(device)
         f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
-        self.transforms = f(view_num - 1, depth_num, 8)
-        self.depth = f(height, width)
-        self.prob = f(height, width)
+        self.transforms_v = f(self.views, view_num - 1, depth_num, 8)
+        self.depth_v = f(self.views, height, width)
+        self.prob_v = f(self.views, height, width)
+        self.transforms, self.depth, self.prob = self.transforms_v[0], self.depth_v[0], self.prob_v[0]
         if regularization == "3DCNN":
             # narrower network modes run zero-padded to the MFMA kernels' 32-channel volume (RegNetWeights)
             self.C = channels = max(channels, weights.regnet.cin)
@@ -327,15 +332,15 @@ class DepthPlan:
         elif regularization == "GRU":
             f1, f2, f3 = weights.gru.filters
             nbytes = lib.mvs_gru_workspace_bytes(height, width, channels, f1, f2, f3)
-            self.workspace = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            self.workspace = torch.empty(nbytes * self.views, device=dev, dtype=torch.uint8)
         else:
             raise NotImplementedError(regularization)      # predictlib.py:97-98
 
-    def set_cameras(self, cams, depth_start, depth_interval, depth_end, inverse_depth):
+    def set_cameras(self, cams, depth_start, depth_interval, depth_end, inverse_depth, view=0):
         lib = _lib.load()
         _lib.check(lib.mvs_homography_transforms_f32(
             _lib.ptr(_lib.f32(cams)), self.N, self.D, float(depth_start), float(depth_interval),
-            float(depth_end), int(bool(inverse_depth)), None, _lib.ptr(self.transforms),
+            float(depth_end), int(bool(inverse_depth)), None, _lib.ptr(self.transforms_v[view]),
             _lib.stream_ptr()), "mvs_homography_transforms_f32")
 
     def run_3dcnn(self, features, depth_start, depth_interval, inverse_depth=False, variant="mem"):
@@ -376,6 +381,30 @@ class DepthPlan:
             self.workspace.numel(), _lib.ptr(self.depth), _lib.ptr(self.prob), _lib.stream_ptr()),
             "mvs_gru_wta_f32")
         return self.depth, self.prob
+
+    def run_gru_batch(self, features, depth_values):
+        """The sweep for `len(features)` (<= self.views) independent reference views in the same launches
+        (mvs_gru_wta_batch_f32): features[v] (N,H,W,C), depth_values[v] (D,); cameras set per view with
+        set_cameras(..., view=v).  Returns (depth (n,H,W), prob (n,H,W))."""
+        lib = _lib.load()
+        g = self.weights.gru
+        f1, f2, f3 = g.filters
+        n = len(features)
+        if not (1 <= n <= self.views):
+            raise ValueError("this plan holds %d view(s), got %d" % (self.views, n))
+        keep = [(_lib.f32(f, "features")[0].contiguous(), f[1:].contiguous()) for f in features]    # alive until the launches are enqueued
+        ref = _lib.ptr_array([k[0] for k in keep])
+        src = _lib.ptr_array([k[1] for k in keep])
+        tr = _lib.ptr_array([self.transforms_v[v] for v in range(n)])
+        flat = [float(x) for dv in depth_values for x in dv]
+        if len(flat) != n * self.D:
+            raise ValueError("depth_values must hold %d x %d floats" % (n, self.D))
+        dv = (C.c_float * len(flat))(*flat)
+        _lib.check(lib.mvs_gru_wta_batch_f32(
+            ref, src, tr, n, self.N, self.D, self.H, self.W, self.C, f1, f2, f3, g.ptrs, dv,
+            C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(), _lib.ptr(self.depth_v), _lib.ptr(self.prob_v),
+            _lib.stream_ptr()), "mvs_gru_wta_batch_f32")
+        return self.depth_v[:n], self.prob_v[:n]
 
 
 _PLAN_CACHE: Dict[tuple, DepthPlan] = {}

@@ -105,3 +105,60 @@ def test_gru_sweep_inverse_depth_matches_the_fixture(lib_built):
                                             inverse_depth=True, weights=weights, features=t(w.features))
     d, _ = check_sweep("c3 inverse depth", w, g, depth, prob)
     assert d.min() >= w.depth_start * (1 - 1e-6) and d.max() <= w.depth_end * (1 + 1e-6)
+
+
+@pytest.mark.parametrize("size", ["mid", "c3"])
+def test_gru_batch_of_reference_views_equals_the_single_view_sweeps(lib_built, size):
+    """mvs_gru_wta_batch_f32: several INDEPENDENT reference views (different features, different depth ranges) in the same
+    launches give, view by view, what the single-view sweep gives: same winning plane everywhere, same probability
+    (the float64 LayerNorm-sum atomics may reorder: <= 1e-6 relative allowed, 0 expected)."""
+    from mvsnet_amd.model import DepthPlan, MVSNetWeights, wta_depth_values
+    if size == "c3":
+        base, nviews, Hh, Ww = S.make_workload("c3"), 4, 300, 400
+    else:           # ragged tiles (neither multiple of 8 / 16), 3 views, enough planes for the wavefront path
+        base, nviews, Hh, Ww = S.make_workload("c3"), 3, 52, 72
+    D = base.depth_num if size == "c3" else 40
+    gp = S.make_gru_params("normal", seed=2, in_channels=base.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
+    feats, starts, ends, dvs = [], [], [], []
+    for v in range(nviews):
+        f = S.make_features(base.view_num, base.height, base.width, base.channels, seed=10 + v)[:, :Hh, :Ww]
+        feats.append(t(f))
+        starts.append(base.depth_start + 7.0 * v)
+        ends.append(base.depth_start + 7.0 * v + (D - 1) * base.depth_interval * (1.0 + 0.05 * v))
+        dvs.append(wta_depth_values(D, starts[v], ends[v], False))
+    cams = t(base.cams)
+    single = DepthPlan(base.view_num, D, Hh, Ww, base.channels, weights, "GRU", DEV)
+    outs = []
+    for v in range(nviews):
+        single.set_cameras(cams, starts[v], (ends[v] - starts[v]) / (D - 1), ends[v], False)
+        d, p = single.run_gru(feats[v], dvs[v])
+        outs.append((d.cpu().numpy().copy(), p.cpu().numpy().copy()))
+    batch = DepthPlan(base.view_num, D, Hh, Ww, base.channels, weights, "GRU", DEV, views=nviews)
+    for v in range(nviews):
+        batch.set_cameras(cams, starts[v], (ends[v] - starts[v]) / (D - 1), ends[v], False, view=v)
+    db, pb = batch.run_gru_batch(feats, dvs)
+    db, pb = db.cpu().numpy(), pb.cpu().numpy()
+    for v in range(nviews):
+        assert len(np.unique(outs[v][0])) > 4                                   # a real depth map, not a constant
+        flips = float((db[v] != outs[v][0]).mean())
+        rel = float(np.max(np.abs(pb[v] - outs[v][1]) / np.maximum(outs[v][1], 1e-30)))
+        print("%s view %d: planes differing %.2e, prob rel max %.2e, bit-identical %s"
+              % (size, v, flips, rel, bool((db[v] == outs[v][0]).all() and (pb[v] == outs[v][1]).all())))
+        assert flips == 0.0, flips
+        assert rel <= 1e-6, rel
+    # views of a batch are independent: view 0 alone in a batch-capable plan gives the same again
+    d1, p1 = batch.run_gru_batch(feats[:1], dvs[:1])
+    assert (d1.cpu().numpy()[0] == outs[0][0]).all()
+    # the two formulations of cell 1 (hoisted x-part: the single-view default; full 48-channel kernels: the multi-view default)
+    # accumulate the x and h halves separately and combine them in the same order: same bits
+    from mvsnet_amd import _lib
+    try:
+        for form in (1, 2):
+            _lib.check(_lib.load().mvs_gru_set_formulation(form), "mvs_gru_set_formulation")
+            df, pf = batch.run_gru_batch(feats, dvs)
+            df, pf = df.cpu().numpy(), pf.cpu().numpy()
+            print("%s formulation %d: depth equal %s, prob max abs diff %.2e" % (size, form, bool((df == db).all()), float(np.abs(pf - pb).max())))
+            assert (df == db).all() and float(np.max(np.abs(pf - pb) / np.maximum(pb, 1e-30))) <= 1e-6
+    finally:
+        _lib.check(_lib.load().mvs_gru_set_formulation(0), "mvs_gru_set_formulation")
