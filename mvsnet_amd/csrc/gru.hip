@@ -223,10 +223,12 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
     const float* __restrict__ w = sa.w; const float* __restrict__ bias = sa.bias;
     const int H = sa.H, W = sa.W, groups = sa.groups;
     float* __restrict__ y = view_ptr(sa.y, vo); double* __restrict__ stats = view_ptr(sa.stats, vo);
-    BlendIn bl = sa.bl;
-    bl.c = view_ptr(bl.c, vo); bl.g = view_ptr(bl.g, vo); bl.stats_c = view_ptr(bl.stats_c, vo); bl.stats_u = view_ptr(bl.stats_u, vo);
-    bl.h_out = view_ptr(bl.h_out, vo); bl.max_prob = view_ptr(bl.max_prob, vo); bl.depth_image = view_ptr(bl.depth_image, vo);
-    bl.exp_sum = view_ptr(bl.exp_sum, vo);
+    // (no local copy of sa.bl: its per-view depth array would be indexed dynamically in registers, i.e. put into scratch memory)
+    const BlendIn& bl = sa.bl;
+    const float* __restrict__ bl_c = view_ptr(bl.c, vo); const float* __restrict__ bl_g = view_ptr(bl.g, vo);
+    const double* __restrict__ bl_stats_c = view_ptr(bl.stats_c, vo); const double* __restrict__ bl_stats_u = view_ptr(bl.stats_u, vo);
+    float* __restrict__ bl_h_out = view_ptr(bl.h_out, vo); float* __restrict__ bl_max_prob = view_ptr(bl.max_prob, vo);
+    float* __restrict__ bl_depth_image = view_ptr(bl.depth_image, vo); float* __restrict__ bl_exp_sum = view_ptr(bl.exp_sum, vo);
     constexpr int CT = CA + CB;
     constexpr int TS = 16, PS = TS + 2;
     typedef const __attribute__((address_space(4))) float cfloat;      // wave-uniform -> s_load into SGPRs
@@ -250,8 +252,8 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
         const double cnt = (double)H * W * CB;
 #pragma unroll
         for (int f = 0; f < CB; ++f) {
-            ln_affine(bl.stats_u, cnt, bl.ug[f], bl.ub[f], ua[f], ub_[f]);
-            ln_affine(bl.stats_c, cnt, bl.og[f], bl.ob[f], ca[f], cb_[f]);
+            ln_affine(bl_stats_u, cnt, bl.ug[f], bl.ub[f], ua[f], ub_[f]);
+            ln_affine(bl_stats_c, cnt, bl.og[f], bl.ob[f], ca[f], cb_[f]);
         }
     }
     const int tiles_x = (W + TS - 1) / TS;
@@ -277,8 +279,8 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
             }
             if (MODE == 2) {
                 float cv[CB], gu[CB];
-                load_vec<CB>(bl.c + p * CB, cv);
-                load_vec<CB>(bl.g + p * 2 * CB + CB, gu);
+                load_vec<CB>(bl_c + p * CB, cv);
+                load_vec<CB>(bl_g + p * 2 * CB + CB, gu);
 #pragma unroll
                 for (int i = 0; i < CB; ++i) {
                     const float uu = sigmoidf(gu[i] * ua[i] + ub_[i]);
@@ -286,7 +288,7 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
                 }
                 if (r >= 1 && r <= TS && c >= 1 && c <= TS) {
 #pragma unroll
-                    for (int i = 0; i < CB; ++i) bl.h_out[p * CB + i] = vb[i];
+                    for (int i = 0; i < CB; ++i) bl_h_out[p * CB + i] = vb[i];
                 }
             }
         }
@@ -314,9 +316,9 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
             }
         const float pr = expf(pacc);
         const int pix = py * W + px;
-        const float mp = bl.max_prob[pix];
-        if (mp < pr) { bl.max_prob[pix] = pr; bl.depth_image[pix] = bl.depth_value[view]; }
-        bl.exp_sum[pix] += pr;
+        const float mp = bl_max_prob[pix];
+        if (mp < pr) { bl_max_prob[pix] = pr; bl_depth_image[pix] = bl.depth_value[view]; }     // kernarg array, uniform index: s_load
+        bl_exp_sum[pix] += pr;
     }
     float acc[CO];
 #pragma unroll
@@ -669,6 +671,8 @@ GruStreams* gru_streams(hipStream_t caller) {
     int pick[3], n = 0;                                  // the three candidate pipes the caller's queue is NOT on
     for (int m = 0; m < 4 && n < 3; ++m) if (m != g.pipe_of_caller) pick[n++] = m;
     g.s[0] = g.cand[pick[0]]; g.s[1] = g.cand[pick[1]]; g.s[2] = g.cand[4 + pick[2]];
+    for (int i = 0; i < 8; ++i)                          // the five candidates that lost go back (their hardware queues with them)
+        if (g.cand[i] != g.s[0] && g.cand[i] != g.s[1] && g.cand[i] != g.s[2]) { (void)hipStreamDestroy(g.cand[i]); g.cand[i] = nullptr; }
     sl.state = 1;
     return &g;
 }
