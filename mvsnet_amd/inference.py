@@ -53,8 +53,27 @@ def build_weights(config, device, weights_path=None, model_dir=None, ckpt_step=N
                                     refine=refine, refine_type=config.refinement_network, extractor=extractor)
 
 
-def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwargs):
-    """mvsnet/inference.py:83-119.  Returns the number of depth maps this rank wrote."""
+def center_images_device(u8):
+    """mvs_data_generation/utils.py:33-38 (per-image, per-channel standardisation) on the device: (n,H,W,3) uint8 ->
+    float32 (x - mean) / (sqrt(var) + 1e-8) with the moments accumulated in float64 (the reference's numpy float32
+    reductions agree with them to ~1e-7 relative)."""
+    import torch
+    x = u8.to(torch.float32)
+    x64 = x.double()
+    mean = x64.mean(dim=(1, 2), keepdim=True)
+    var = ((x64 - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+    return ((x - mean.float()) / (var.sqrt().float() + 0.00000001)).contiguous()
+
+
+def compute_depth_maps(input_dir, config=None, weights=None, device=None, timings=None, gru_views=4, **kwargs):
+    """mvsnet/inference.py:83-119.  Returns the number of depth maps this rank wrote.
+
+    `timings` (a dict) receives the stage breakdown of the run in seconds: wall, load (decode + resize + crop + centre on the
+    loader threads, summed over threads), wait_load (this thread blocked on the loaders), towers / hot_path / d2h (GPU time from
+    stream events, host -> device copies of the images included in towers), host_gpu_submit (this thread enqueueing), write (file
+    writers, summed over threads).  `gru_views`: reference views per recurrent sweep (mvs_gru_wta_batch_f32) with the GRU
+    regulariser."""
+    import threading
     import torch
     from . import predictlib as pl
     from . import shard as sh
@@ -82,6 +101,18 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
     mine = sh.shard(clusters, rank, world)
     if weights is None:
         weights = build_weights(config, device)
+    t_wall = time.perf_counter()
+    tm = {"load": 0.0, "wait_load": 0.0, "host_gpu_submit": 0.0, "write": 0.0}
+    tm_lock = threading.Lock()
+
+    def timed(name, fn, *a):
+        t0 = time.perf_counter()
+        try:
+            return fn(*a)
+        finally:
+            with tm_lock:
+                tm[name] += time.perf_counter() - t0
+
     # Per-image feature cache: the reference re-runs the UNetDS2GN tower on
     # every source image of every cluster (model.py:392-406); an image's features only depend on
     # the image and on the (rescale, crop) it received, so they are computed once per session and
@@ -90,63 +121,220 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, **kwar
     done = 0
     # Host pipeline: like the reference, whose generator runs in a tf.data thread with a prefetch buffer
     # (predictlib.py:48-51), image loading / resizing of the next clusters and the file writes of the previous ones run
-    # on worker threads (numpy / PIL / file IO release the GIL); this thread only drives the GPU.
+    # on worker threads (numpy / PIL / file IO release the GIL); this thread only drives the GPU and never waits for it:
+    # results go device -> PINNED host buffers with an asynchronous copy, and the writer thread that owns a buffer waits for
+    # the copy's event (round 2 called .cpu() here, which held this thread -- and with it the next reference view's launches
+    # -- until the GPU had finished the current one).
     from concurrent.futures import ThreadPoolExecutor
-    loader, writer = ThreadPoolExecutor(max_workers=2), ThreadPoolExecutor(max_workers=2)
+    n_loaders = max(2, min(6, (os.cpu_count() or 4) // 2))
+    n_writers = 4
+    loader, writer = ThreadPoolExecutor(max_workers=n_loaders), ThreadPoolExecutor(max_workers=n_writers)
     pending, writes = [], []
-    ahead = 3
+    ahead = 16
+    slots = threading.BoundedSemaphore(8)             # pinned result buffers in flight
+    ev_marks = []                                     # per reference view: events at the stage boundaries
+
+    from .mvs_data_generation import Cluster
+    device_center = lambda c_: type(c_) is Cluster        # session format: uint8 up, standardised on the device
 
     def submit_next(it):
         for c_ in it:
-            pending.append((c_, loader.submit(gen.prepare, c_)))
+            if device_center(c_):
+                pending.append((c_, loader.submit(timed, "load", gen.prepare, c_, False)))
+            else:
+                pending.append((c_, loader.submit(timed, "load", gen.prepare, c_)))
             return
 
+    def keys_of(c, in_images):
+        ids = getattr(c, "indices", None) or [p_ for p_ in getattr(c, "paths", [])[0::2]]
+        return [(c.session_dir, ids[v], round(float(c.rescale), 9), in_images[v].shape) if v < len(ids) else ("view", id(c), v)
+                for v in range(config.view_num)]
+
+    staging = {}                                      # (shape, dtype) -> [pinned buffers, their last copy's event, next index]
+
+    def to_device(imgs):
+        """list / array of images -> device float32, standardised there when they come as uint8.  The upload goes through two
+        alternating pinned staging buffers (asynchronous copy; a buffer is re-filled only after its previous copy's event)."""
+        imgs = list(imgs)
+        n, shp, dt = len(imgs), imgs[0].shape, imgs[0].dtype
+        st_ = staging.setdefault((shp, dt), [[None, None], [None, None], 0])
+        i_ = st_[2]; st_[2] ^= 1
+        cap = 0 if st_[0][i_] is None else st_[0][i_].shape[0]
+        if cap < n:
+            st_[0][i_] = torch.empty((max(n, 16),) + shp, dtype=torch.from_numpy(np.empty(0, dt)).dtype).pin_memory()
+        elif st_[1][i_] is not None:
+            st_[1][i_].synchronize()
+        buf = st_[0][i_]
+        view = buf.numpy()
+        for j, im in enumerate(imgs):
+            view[j] = im
+        t_ = buf[:n].to(device, non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(); st_[1][i_] = ev
+        return center_images_device(t_) if t_.dtype == torch.uint8 else t_.to(torch.float32)
+
+    def prefetch_features(group):
+        """The images of these reference views that the cache misses go through the towers as ONE batch (a tower pass is ~31
+        launches on a ~25 us floor each: one image costs nearly as much as sixteen)."""
+        need = {}
+        for c_, res_ in group:
+            for v, k_ in enumerate(keys_of(c_, res_[1])):
+                if k_ not in feature_cache and k_ not in need:
+                    need[k_] = res_[1][v]
+        if need:
+            fb = weights.unet(to_device(need.values()))
+            for j, k_ in enumerate(need):
+                while len(feature_cache) >= 256:
+                    feature_cache.pop(next(iter(feature_cache)))
+                feature_cache[k_] = fb[j]
+
+    def features_of(c, in_images):
+        """(N,H/4,W/4,C) of one reference view from the per-image cache (filled by prefetch_features)."""
+        return torch.stack([feature_cache[k_] for k_ in keys_of(c, in_images)]).contiguous()
+
+    pinned = {}                                       # shape -> free pinned (depth, prob) buffer pairs, re-used across reference views
+
+    def finish(d, p, out_images, in_images, out_cams, full_cams, index, marks):
+        """device results -> pinned host buffers (asynchronous copy on the compute stream, no host wait) -> writer thread"""
+        slots.acquire()
+        with tm_lock:
+            free = pinned.setdefault(tuple(d.shape), [])
+            pair = free.pop() if free else None
+        if pair is None:
+            pair = (torch.empty(d.shape, dtype=torch.float32).pin_memory(), torch.empty(p.shape, dtype=torch.float32).pin_memory())
+        dh, ph = pair
+        dh.copy_(d, non_blocking=True); ph.copy_(p, non_blocking=True)
+        copied = torch.cuda.Event(enable_timing=timings is not None)
+        copied.record()
+        if marks is not None:
+            marks.append(copied)
+
+        def write():
+            try:
+                copied.synchronize()
+                if config.refinement and config.upsample_before_refinement:      # full-size outputs (predictlib.py:107-115)
+                    from .mvs_data_generation import center_image       # the reference writes the STANDARDISED input image here
+                    img0 = center_image(in_images[0]) if in_images.dtype == np.uint8 else in_images[0]
+                    return timed("write", pl.write_output_slice, output_dir, dh.numpy(), ph.numpy(), img0, full_cams[0],
+                                 index, config.visualize, 1.0 / config.sample_scale)
+                return timed("write", pl.write_output_slice, output_dir, dh.numpy(), ph.numpy(), out_images[0], out_cams[0],
+                             index, config.visualize)
+            finally:
+                with tm_lock:
+                    pinned[tuple(dh.shape)].append(pair)
+                slots.release()
+        writes.append(writer.submit(write))
+
+    def mark():
+        if timings is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    gru_batch = []                                    # GRU: reference views waiting to share one sweep
+
+    def flush_gru():
+        if not gru_batch:
+            return
+        from .model import DepthPlan, wta_depth_values
+        t0 = time.perf_counter()
+        feats0 = gru_batch[0][0]
+        _, Hf, Wf, Cf = feats0.shape
+        D = gru_batch[0][2]
+        key = ("gru", config.view_num, D, Hf, Wf, Cf, id(weights), max(1, gru_views))
+        plan = plan_cache.get(key)
+        if plan is None:
+            plan = plan_cache[key] = DepthPlan(config.view_num, D, Hf, Wf, Cf, weights, "GRU", device, views=max(1, gru_views))
+        dvs = []
+        for v, (f_, cams_, D_, start_, end_, _rest) in enumerate(gru_batch):
+            interval_ = float((np.float32(end_) - np.float32(start_)) / (np.float32(D_) - np.float32(1)))      # model.py:606-607
+            plan.set_cameras(cams_, start_, interval_, end_, config.inverse_depth, view=v)
+            dvs.append(wta_depth_values(D_, start_, end_, config.inverse_depth))
+        m0 = mark()
+        dd, pp_ = plan.run_gru_batch([g_[0] for g_ in gru_batch], dvs)
+        m1 = mark()
+        for v, g_ in enumerate(gru_batch):
+            marks = [None, None, m0, m1] if (timings is not None and v == 0) else None
+            finish(dd[v], pp_[v], *g_[5], marks)        # copied out in stream order, before the next sweep overwrites the plan's buffers
+            if marks is not None:
+                ev_marks.append(marks)
+        gru_batch.clear()
+
+    plan_cache = {}
     it = iter(mine)
     for _ in range(ahead):
         submit_next(it)
+    chunk = 8                                         # reference views per tower pass (their new images form one batch)
     while pending:
-        c, fut = pending.pop(0)
-        submit_next(it)
-        start = time.time()
-        try:
-            out_images, in_images, out_cams, full_cams, index = fut.result()
-        except Exception as e:                        # skip-and-log per reference view
-            logger.warning("skipping cluster %s/%d: %s", c.session_dir, c.ref_index, e)
+        group = []
+        t0 = time.perf_counter()
+        while pending and len(group) < chunk:
+            c, fut = pending.pop(0)
+            submit_next(it)
+            try:
+                group.append((c, fut.result()))
+            except Exception as e:                    # skip-and-log per reference view (SURVEY 5)
+                logger.warning("skipping cluster %s/%d: %s", c.session_dir, c.ref_index, e)
+        t1 = time.perf_counter()
+        tm["wait_load"] += t1 - t0
+        if not group:
             continue
-        ids = getattr(c, "indices", None) or [p for p in getattr(c, "paths", [])[0::2]]
-        feats = []
-        for v in range(config.view_num):
-            key = (ids[v], round(float(c.rescale), 9), in_images[v].shape) if v < len(ids) else None
-            f = feature_cache.get(key) if key is not None else None
-            if f is None:
-                f = weights.unet(torch.as_tensor(in_images[v:v + 1], dtype=torch.float32, device=device))[0]
-                if key is not None:
-                    if len(feature_cache) >= 256:
-                        feature_cache.pop(next(iter(feature_cache)))
-                    feature_cache[key] = f
-            feats.append(f)
-        features = torch.stack(feats).contiguous()
-        cams = torch.as_tensor(out_cams, dtype=torch.float32, device=device)[None]
-        depth_start = float(out_cams[0, 1, 3, 0])     # predictlib.set_shapes :190-197
-        depth_interval = float(out_cams[0, 1, 3, 1])
-        depth_num = int(out_cams[0, 1, 3, 2])
-        depth_end = float(out_cams[0, 1, 3, 3])
-        ref_image = torch.as_tensor(in_images[0:1], dtype=torch.float32, device=device) if config.refinement else None
-        d, p, _ = pl.get_depth_and_prob_map(None, cams, depth_start, depth_interval, config, weights,
-                                            depth_num=depth_num, depth_end=depth_end, features=features,
-                                            ref_image=ref_image)
-        d_np, p_np = d.cpu().numpy(), p.cpu().numpy()
-        if config.refinement and config.upsample_before_refinement:      # full-size outputs (predictlib.py:107-115)
-            writes.append(writer.submit(pl.write_output_slice, output_dir, d_np, p_np, in_images[0], full_cams[0],
-                                        index, config.visualize, 1.0 / config.sample_scale))
-        else:
-            writes.append(writer.submit(pl.write_output_slice, output_dir, d_np, p_np, out_images[0], out_cams[0],
-                                        index, config.visualize))
-        done += 1
-        logger.info("Depth inference %d/%d finished. (%.3f sec/step)", done, len(mine), time.time() - start)
+        m_start = mark()
+        prefetch_features(group)
+        m_towers = mark()
+        first = True
+        for c, (out_images, in_images, out_cams, full_cams, index) in group:
+            start = time.time()
+            features = features_of(c, in_images)
+            cams = torch.as_tensor(out_cams, dtype=torch.float32).to(device, non_blocking=True)
+            depth_start = float(out_cams[0, 1, 3, 0])     # predictlib.set_shapes :190-197
+            depth_interval = float(out_cams[0, 1, 3, 1])
+            depth_num = int(out_cams[0, 1, 3, 2])
+            depth_end = float(out_cams[0, 1, 3, 3])
+            rest = (out_images, in_images, out_cams, full_cams, index)
+            batched_gru = (config.regularization == "GRU" and gru_views > 1 and not config.refinement and
+                           (not gru_batch or (gru_batch[0][0].shape == features.shape and gru_batch[0][2] == depth_num)))
+            if config.regularization == "GRU" and gru_views > 1 and not config.refinement and not batched_gru:
+                flush_gru()                               # a view of another size starts a new batch
+                batched_gru = True
+            if batched_gru:
+                gru_batch.append((features, cams, depth_num, depth_start, depth_end, rest))
+                if len(gru_batch) >= gru_views:
+                    flush_gru()
+            else:
+                ref_image = to_device(in_images[0:1]) if config.refinement else None
+                m_a = mark()
+                d, p, _ = pl.get_depth_and_prob_map(None, cams[None], depth_start, depth_interval, config, weights,
+                                                    depth_num=depth_num, depth_end=depth_end, features=features,
+                                                    ref_image=ref_image)
+                m_depth = mark()
+                marks = [m_start if first else None, m_towers if first else None, m_a, m_depth] if timings is not None else None
+                finish(d, p, *rest, marks)
+                if marks is not None:
+                    ev_marks.append(marks)
+            first = False
+            done += 1
+            logger.info("Depth inference %d/%d finished. (%.3f sec/step)", done, len(mine), time.time() - start)
+        with tm_lock:
+            tm["host_gpu_submit"] += time.perf_counter() - t1
+    flush_gru()
     for w_ in writes:
         w_.result()                                   # surfaces write errors; all files are on disk on return
     loader.shutdown(); writer.shutdown()
+    if timings is not None:
+        torch.cuda.synchronize()
+        timings.update(tm)
+        timings["wall"] = time.perf_counter() - t_wall
+        timings["depth_maps"] = done
+        timings["loader_threads"], timings["writer_threads"] = n_loaders, n_writers
+        tw = th = td = 0.0
+        for m in ev_marks:
+            if m[0] is not None and m[1] is not None:
+                tw += m[0].elapsed_time(m[1]) * 1e-3
+            th += m[2].elapsed_time(m[3]) * 1e-3
+            if len(m) > 4:
+                td += m[3].elapsed_time(m[4]) * 1e-3
+        timings["towers"], timings["hot_path"], timings["d2h"] = tw, th, td
     return done
 
 
@@ -165,6 +353,7 @@ def main(argv=None):
     ap.add_argument("--ckpt_step", type=int, default=400000)
     ap.add_argument("--extractor", choices=("hip", "torch"), default="hip",
                     help="2D feature towers: HIP library kernels (default) or the PyTorch/MIOpen module")
+    ap.add_argument("--gru_views", type=int, default=4, help="reference views per recurrent sweep (GRU regulariser)")
     ap.add_argument("--gpus", type=int, default=1,
                     help="N > 1 without a torch.distributed.run environment: start N one-GPU ranks of this command "
                          "(reference views sharded round-robin, no data-path collective)")
@@ -192,7 +381,7 @@ def main(argv=None):
     weights = build_weights(cfg, device, weights_path, args.model_dir, args.ckpt_step, args.extractor)
     total = 0
     for d in dirs:
-        total += compute_depth_maps(d, cfg, weights, device)
+        total += compute_depth_maps(d, cfg, weights, device, gru_views=args.gru_views)
     counts = sh.gather_counts(dist, total, device=device if dist is not None else "cpu")
     if rank == 0:
         logger.info("all dense finished: %d depth maps (%s per rank)", int(sum(counts)), counts)

@@ -43,6 +43,8 @@ def scale_image(image, scale=1, interpolation="linear"):
     img = np.asarray(image)
     h, w = img.shape[:2]
     nh, nw = int(round(h * scale)), int(round(w * scale))
+    if scale == 1:                    # every sample position is a pixel centre: the identity for both interpolations
+        return img
     if interpolation == "nearest":
         ys = np.minimum((np.arange(nh) / scale).astype(np.int64), h - 1)
         xs = np.minimum((np.arange(nw) / scale).astype(np.int64), w - 1)
@@ -59,11 +61,11 @@ def scale_image(image, scale=1, interpolation="linear"):
 
     y0, y1, fy = taps(nh, h)
     x0, x1, fx = taps(nw, w)
-    src = img.astype(np.float64)
-    if src.ndim == 2:
-        src = src[..., None]
-    top = src[y0][:, x0] * (1 - fx)[None, :, None] + src[y0][:, x1] * fx[None, :, None]
-    bot = src[y1][:, x0] * (1 - fx)[None, :, None] + src[y1][:, x1] * fx[None, :, None]
+    src = img if img.ndim == 3 else img[..., None]
+    # only the rows / columns that are sampled are converted to float64 (same arithmetic as on the whole image)
+    r0, r1 = src[y0], src[y1]
+    top = r0[:, x0].astype(np.float64) * (1 - fx)[None, :, None] + r0[:, x1].astype(np.float64) * fx[None, :, None]
+    bot = r1[:, x0].astype(np.float64) * (1 - fx)[None, :, None] + r1[:, x1].astype(np.float64) * fx[None, :, None]
     out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
     if img.ndim == 2:
         out = out[..., 0]
@@ -267,7 +269,64 @@ class ClusterGenerator:
                                         self.image_height, self.depth_num, self.interval_scale))
                 added += 1
 
-    def prepare(self, c: Cluster):
+    def _prepare_cached(self, c, center=True):
+        """Inference mode: what prepare() does per image -- decode, rescale, crop, centre, output-scale -- depends only on the
+        image file and on (rescale, crop window), so it is kept per image across the reference views of a session that list
+        the image as a source (the reference decodes and resizes every image once per cluster, cluster_generator.py:234-286).
+        Same values as the uncached path; an LRU of 64 images per generator, shared by the loader threads.
+        center=False: the input images come back as cropped uint8 BGR (N,H,W,3) and the caller standardises them (on the
+        device, inference.center_images_device): a quarter of the bytes to upload and no 1.3 M-element float32 reductions per image
+        on the loader threads."""
+        import threading
+        if not hasattr(self, "_img_cache"):
+            self._img_cache, self._img_lock = {}, threading.Lock()
+        raw = {}
+
+        def raw_image(i):
+            if i not in raw:
+                raw[i] = c.load_image(i)
+            return raw[i]
+        # the cluster-level rescale needs every image's size (mvs_cluster.py:178-192): sizes are cached with the images
+        sizes = []
+        for i in c.indices:
+            with self._img_lock:
+                hit = self._img_cache.get(("size", c.session_dir, i))
+            if hit is None:
+                hit = raw_image(i).shape
+                with self._img_lock:
+                    self._img_cache[("size", c.session_dir, i)] = hit
+            sizes.append(hit)
+        c.original_image_shape = sizes[0]
+        c.rescale = max(max(float(self.image_height) / s_[0] for s_ in sizes), max(float(self.image_width) / s_[1] for s_ in sizes))
+        cams = c.cameras()
+        ins, outs, full_cams, out_cams = [], [], [], []
+        for v, i in enumerate(c.indices):
+            key = (c.session_dir, i, round(float(c.rescale), 12), bool(center))
+            with self._img_lock:
+                hit = self._img_cache.get(key)
+            if hit is None:
+                im, _ = scale_mvs_input([raw_image(i)], [cams[v]], scale=c.rescale)
+                cr, _ = crop_mvs_input(im, [cams[v]], self.image_width, self.image_height, self.base_image_size)
+                hit = (center_image(cr[0]) if center else np.ascontiguousarray(cr[0]), scale_image(cr[0], self.output_scale))
+                with self._img_lock:
+                    if len(self._img_cache) >= 192:
+                        for k_ in [k_ for k_ in self._img_cache if k_[0] != "size"][:32]:
+                            self._img_cache.pop(k_, None)
+                    self._img_cache[key] = hit
+            _, cm = scale_mvs_input([], [cams[v]], scale=c.rescale)
+            # crop_mvs_input only shifts the principal point by the crop offset: recompute it for the camera from the size
+            h0, w0 = int(round(sizes[v][0] * c.rescale)), int(round(sizes[v][1] * c.rescale))
+            dummy = [np.empty((h0, w0, 0), np.uint8)]
+            _, cc = crop_mvs_input(dummy, cm, self.image_width, self.image_height, self.base_image_size)
+            _, oc = scale_mvs_input([], cc, scale=self.output_scale)
+            ins.append(hit[0]); outs.append(hit[1]); full_cams.append(cc[0]); out_cams.append(oc[0])
+        return (np.stack(outs, axis=0), np.stack(ins, axis=0), np.stack(out_cams, axis=0), np.stack(full_cams, axis=0), c.ref_index)
+
+    def prepare(self, c: Cluster, center=True):
+        if self.mode == "inference" and type(c) is Cluster:
+            return self._prepare_cached(c, center)
+        if not center:
+            raise NotImplementedError("center=False is the cached session-format inference path")
         images = c.images()
         cams = c.cameras()
         depth = None

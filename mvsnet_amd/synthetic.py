@@ -197,3 +197,41 @@ def make_workload(name="M", network_mode="normal", seed=0) -> Workload:
     cams = make_cams(w["view_num"], w["height"], w["width"], w["depth_num"], DEPTH_START, w["interval"])
     return Workload(name, w["view_num"], w["depth_num"], w["height"], w["width"], C,
                     DEPTH_START, float(np.float32(w["interval"])), feats, cams)
+
+
+def write_session(path, n_images=8, height=512, width=640, view_num=5, depth_num=192, interval=2.5 * 1.06, seed=0):
+    """A synthetic on-disk session in the reference's format (mvsnet/mvs_data_generation/mvs_cluster.py:72-127,
+    cluster_generator.py:126-156): images/<i>.jpg, cameras/<i>.json (pose in metres, intrinsics in pixels),
+    covisibility.json listing the view_num - 1 nearest images of every reference view with the depth range that makes
+    `depth_num` planes of `interval` mm.  Cameras sit on an arc around the point (0, 0, 650 mm), as make_cams places
+    them; the images are smooth random textures (JPEG-friendly, unlike white noise).  For end-to-end throughput runs
+    (bench.py `session_depth_maps_per_s`) and tests; no dataset exists offline."""
+    import json
+    import os
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    os.makedirs(os.path.join(path, "images"), exist_ok=True)
+    os.makedirs(os.path.join(path, "cameras"), exist_ok=True)
+    focal = FOCAL_AT_160 * (width / 160.0)
+    covis = {}
+    for i in range(n_images):
+        low = rs.randint(0, 256, size=(height // 16 + 1, width // 16 + 1, 3)).astype(np.uint8)
+        img = np.asarray(Image.fromarray(low).resize((width, height), Image.BICUBIC)).astype(np.int16)
+        img = np.clip(img + rs.randint(-6, 7, size=img.shape), 0, 255).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(path, "images", "%d.jpg" % i), quality=90)
+        theta = math.radians(-12.0 + 24.0 * i / max(1, n_images - 1))
+        c, s_ = math.cos(theta), math.sin(theta)
+        R = np.array([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]])
+        pivot = np.array([0.0, 0.0, PIVOT_DEPTH / 1000.0])              # metres
+        t = pivot - R @ pivot                                           # x_cam = R (x - pivot) + pivot
+        pose = np.eye(4)
+        pose[:3, :3], pose[:3, 3] = R, t
+        cam = {"pose": {"matrix": {"%d,%d" % (r, c_): float(pose[r, c_]) for r in range(4) for c_ in range(4)}},
+               "intrinsics": {"fx": focal, "fy": focal, "px": width / 2.0, "py": height / 2.0}}
+        with open(os.path.join(path, "cameras", "%d.json" % i), "w") as f:
+            json.dump(cam, f)
+        near = sorted((j for j in range(n_images) if j != i), key=lambda j: (abs(j - i), j))[:view_num - 1]
+        covis[str(i)] = {"views": near, "min_depth": DEPTH_START, "max_depth": DEPTH_START + (depth_num - 1) * interval}
+    with open(os.path.join(path, "covisibility.json"), "w") as f:
+        json.dump(covis, f)
+    return path
