@@ -863,3 +863,50 @@ def test_new_training_entry_points_report_errors_instead_of_launching():
     assert lib.mvs_conv2d_wgrad_f32(P(x), P(gg), 30, 0, D, H, W, 16, 16, wp, need, P(dw), st) == -2      # stride not a multiple of 4
     assert lib.mvs_conv2d_wgrad_f32(None, P(gg), 32, 0, D, H, W, 16, 32, wp, need, P(dw), st) == -1
     torch.cuda.synchronize()
+
+
+def test_config5_training_step_at_its_own_size():
+    """BASELINE.json configs[4]'s per-GPU workload (mvsnet/train.py:412-445 with N = 3 views, D = 128 planes, 640 x 480
+    images -> 160 x 120 feature maps): (1) the hot path's gradient at that size is the directional derivative of its forward
+    -- <grad_features, v> and <grad_W(3dconv0_1), vw> against central differences of <depth(features), g>, float64
+    accumulation over the fp32 forward (the identity the full-size kernel tests use); (2) whole training steps run on
+    that batch and reduce the loss."""
+    from mvsnet_amd import backward as B, train as T
+    from mvsnet_amd.homography_warping import homography_transforms
+    N, D, H, W = 3, 128, 120, 160
+    cams = S.make_cams(N, H, W, D)
+    start, interval = float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1])
+    t8 = homography_transforms(t(cams), D, start, interval)
+    rp = S.make_regnet_params("normal", seed=1, random_affine=True)
+    f0 = t(S.make_features(N, H, W, 32, seed=5))
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    g = torch.randn(H, W, generator=gen).to(DEV)
+    v = torch.randn(N, H, W, 32, generator=gen).to(DEV)
+    vw = torch.randn(3, 3, 3, 32, 8, generator=gen).to(DEV) * float(np.sqrt(2.0 / (27 * 32)))
+    ft = f0.clone().requires_grad_(True)
+    pt = {k: {kk: t(vv).requires_grad_(True) for kk, vv in p.items()} for k, p in rp.items()}
+    depth, _ = B.plane_sweep_depth(ft, t8, start, interval, pt)
+    assert depth.shape == (H, W) and torch.isfinite(depth).all()
+    (depth.double() * g.double()).sum().backward()
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    ana_f, ana_w = dot(ft.grad, v), dot(pt["3dconv0_1"]["w"].grad, vw)
+    scale_f = sum(abs(dot(ft.grad[i], v[i])) for i in range(N))       # the views' contributions cancel: compare at THEIR scale
+    with torch.no_grad():
+        def fwd(feats, w01):
+            p2 = {k: dict(p) for k, p in pt.items()}
+            p2["3dconv0_1"]["w"] = w01
+            return dot(B.plane_sweep_depth(feats, t8, start, interval, p2)[0], g)
+        w01 = pt["3dconv0_1"]["w"].detach()
+        num_f = (fwd(f0 + 5e-4 * v, w01) - fwd(f0 - 5e-4 * v, w01)) / (2 * 5e-4)
+        num_w = (fwd(f0, w01 + 2e-3 * vw) - fwd(f0, w01 - 2e-3 * vw)) / (2 * 2e-3)
+    print("config 5 size: <grad_f, v> %.6g vs central difference %.6g (scale %.4g); <grad_W, vw> %.6g vs %.6g" % (
+        ana_f, num_f, scale_f, ana_w, num_w))
+    # 15 M ReLU inputs and a soft-argmin over 128 planes sit between the features and the depth: the finite difference of the
+    # whole path wanders by a few per cent with the step (tools/dd_probe.py); the strict checks are the float64-autograd
+    # comparisons at small sizes and the per-kernel identities at full size above
+    assert abs(num_f - ana_f) < 4e-2 * scale_f, (num_f, ana_f, scale_f)
+    assert abs(num_w - ana_w) < 2e-2 * max(abs(ana_w), 1.0), (num_w, ana_w)
+    images, cams_img, gt, _ = _train_batch(N=3, H=480, W=640, D=D)
+    tr = T.Trainer("normal", DEV, seed=0)
+    losses = [float(tr.train_step(images, cams_img, gt, D)[0]) for _ in range(4)]
+    assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0], losses

@@ -174,3 +174,71 @@ def test_depth_refine_on_the_device_matches_oracle(network, conf, upsample, ster
     --refine_with_confidence / --refine_with_stereo."""
     from tests.test_refine_and_fusion import _case
     _case(network, conf, upsample, 11 + 2 * conf + upsample, stereo=stereo, device=DEV)
+
+
+@pytest.mark.parametrize("regularization", ["3DCNN", "GRU"])
+def test_session_pipeline_equals_the_per_reference_view_calls(tmp_path, lib_built, regularization):
+    """compute_depth_maps (loader threads, per-image decode cache, uint8 upload + standardisation on the device, one tower
+    pass per group of reference views, several views per recurrent sweep, asynchronous D2H) writes, reference view by
+    reference view, what the plain sequence of the reference's loop gives (mvsnet/inference.py:105-119: generator ->
+    inference -> write): towers on the host-standardised images, one hot-path call per view."""
+    from mvsnet_amd.inference import build_weights, compute_depth_maps
+    from mvsnet_amd.mvs_data_generation import make_generator
+    from mvsnet_amd import predictlib as pl, preprocess as pp
+    sess = S.write_session(str(tmp_path / "sess"), n_images=7, height=100, width=132, view_num=3, depth_num=24, interval=10.0)
+    cfg = pl.InferenceConfig(input_dir=sess, view_num=3, max_d=24, width=128, height=96, base_image_size=8,
+                             regularization=regularization, output_dir=str(tmp_path / "out"))
+    weights = build_weights(cfg, torch.device("cuda", 0))
+    tm = {}
+    n = compute_depth_maps(sess, cfg, weights, torch.device("cuda", 0), timings=tm, gru_views=3)
+    assert n == 7 and tm["depth_maps"] == 7 and tm["wall"] > 0 and tm["hot_path"] > 0
+    gen = make_generator(sess, 3, 128, 96, 24, 1.0, 8, mode="inference", output_scale=0.25)
+    for c in sorted(gen.clusters, key=lambda c_: c_.ref_index):
+        out_images, in_images, out_cams, full_cams, index = gen.prepare(c)          # float32, standardised on the host
+        assert in_images.dtype == np.float32
+        d, p, _ = pl.get_depth_and_prob_map(t(in_images)[None], t(out_cams)[None], float(out_cams[0, 1, 3, 0]),
+                                            float(out_cams[0, 1, 3, 1]), cfg, weights, depth_num=int(out_cams[0, 1, 3, 2]),
+                                            depth_end=float(out_cams[0, 1, 3, 3]))
+        want_d, want_p = d.cpu().numpy()[0, :, :, 0], p.cpu().numpy()[0, :, :, 0]
+        got_d = pp.load_pfm(os.path.join(cfg.output_dir, "%d_init.pfm" % index))
+        got_p = pp.load_pfm(os.path.join(cfg.output_dir, "%d_prob.pfm" % index))
+        assert got_d.shape == want_d.shape == (24, 32)
+        if regularization == "3DCNN":
+            # device standardisation (float64 moments) against numpy's float32 reductions: ~1e-7 on the inputs
+            assert float(np.mean(np.abs(got_d - want_d) / want_d)) < 1e-5
+            assert float((np.abs(got_p - want_p) > 1e-3).mean()) < 0.02
+        else:
+            assert float((got_d == want_d).mean()) > 0.97          # winner-take-all: a near-tie may flip on a few pixels
+
+
+def test_bench_and_inference_start_their_own_ranks(tmp_path, lib_built):
+    """`python bench.py --gpus 2` and `python -m mvsnet_amd.inference --gpus 2` WITHOUT a launcher: the parent stays GPU-less and
+    starts one worker per rank (torch.distributed.run); rehearsed on this one-GPU box over gloo with both ranks on cuda:0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVS_DIST_BACKEND="gloo", MVS_ALLOW_SHARED_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["ranks"]["world_size"] == 2 and len(rec["ranks"]["devices"]) == 2
+    assert len(rec["per_rank_depth_maps_per_s"]["ranks"]) == 2 and rec["value"] > 0
+    assert rec["scaling"] == "weak" and "roofline" in rec
+    # a rank count the node cannot serve over RCCL is refused with a message, not a hang
+    env2 = {k: v for k, v in env.items() if k not in ("MVS_DIST_BACKEND", "MVS_ALLOW_SHARED_GPU")}
+    if torch.cuda.device_count() < 2:
+        r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--no-extra",
+                             "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env2, cwd=root)
+        assert r2.returncode != 0 and "needs 2 GPUs" in (r2.stdout + r2.stderr)
+    sess = S.write_session(str(tmp_path / "sess"), n_images=5, height=96, width=128, view_num=3, depth_num=8, interval=60.0)
+    out = str(tmp_path / "out")
+    r3 = subprocess.run([sys.executable, "-m", "mvsnet_amd.inference", "--gpus", "2", "--input_dir", sess, "--output_dir", out,
+                         "--view_num", "3", "--max_d", "8", "--width", "128", "--height", "96"],
+                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r3.returncode == 0, (r3.stdout[-2000:], r3.stderr[-2000:])
+    assert sorted(f for f in os.listdir(out) if f.endswith("_init.pfm")) == ["%d_init.pfm" % i for i in range(5)]
