@@ -81,10 +81,6 @@ int mvs_cost_volume_f32(const float* ref, const float* src, const float* transfo
                         int view_num, int depth_total, int d_begin, int d_count,
                         int H, int W, int C, int variant, int negate, int border,
                         float* cost, void* stream);
-/* Test / tuning aid for the LDS-staged form of mvs_cost_volume_f32 (C = 32): the number of (wave, 8-plane round)
- * pairs that left the staged path for the direct one since the previous call, because a source footprint exceeded
- * the LDS budget or a tap fell outside the staged box (results are exact either way).  Waits for the device. */
-int mvs_cost_volume_fallback_rounds(int* rounds);
 
 /* Stand-alone warp of one feature map by one transform (tf_transform_homography,
  * mvsnet/homography_warping.py:211-253); used by the parity tests.  image/out (H,W,C). */

@@ -11,4 +11,18 @@ import os as _os
 # memory fault when the filter happens to be the last block of one.  That solver is switched off unless the user has
 # chosen otherwise; MIOpen falls back to its other data-gradient solvers.  MIOpen latches the variable on its first
 # convolution, so this has to happen before any: import this package before running torch convolutions.
-_os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
+MIOPEN_WORKAROUND = "MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC"
+_os.environ.setdefault(MIOPEN_WORKAROUND, "0")
+
+
+def ensure_miopen_workaround(where="mvsnet_amd"):
+    """Called by every entry point that may run ATen convolutions (train, inference, test, the Trainer) BEFORE its first GPU
+    work: makes the switch above explicit instead of an import side effect.  Returns True when the faulty solver is off.
+    A user who set the variable to something else keeps the choice and is told what it risks; a process that ran a torch
+    convolution before importing this package has already latched MIOpen's setting -- nothing in-process can change that."""
+    import warnings
+    val = _os.environ.setdefault(MIOPEN_WORKAROUND, "0")
+    if val != "0":
+        warnings.warn("%s: %s=%s keeps MIOpen's igemm_bwd_gtcx35_nhwc data-gradient solver, which over-reads small "
+                      "filters (GPU memory fault in narrow-tower training, DESIGN.md section 9)" % (where, MIOPEN_WORKAROUND, val))
+    return val == "0"

@@ -27,7 +27,6 @@ SIGNATURES = {
     "mvs_get_conv_impl": (_i, []),
     "mvs_homography_transforms_f32": (_i, [_p, _i, _i, _f, _f, _f, _i, _p, _p, _p]),
     "mvs_cost_volume_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
-    "mvs_cost_volume_fallback_rounds": (_i, [C.POINTER(C.c_int)]),
     "mvs_warp_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "mvs_conv3d_f32": (_i, [_p] * 7 + [_i] * 6 + [_p, _p, _p]),
     "mvs_deconv3d_f32": (_i, [_p] * 7 + [_i] * 5 + [_p, _p, _p]),

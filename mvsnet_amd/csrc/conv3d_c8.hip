@@ -404,8 +404,6 @@ int launch_c8(const ConvArgs& a0, const FuseArgs& fa, hipStream_t st) {
             if (cost < best_cost) { best_cost = cost; best = dr; }
         }
         a.planes_per_wg = best;
-        static const int dr_env = getenv("MVS_C8_DR") ? atoi(getenv("MVS_C8_DR")) : 0;   // developer A/B switch
-        if (dr_env >= 2) a.planes_per_wg = dr_env & ~1;
     } else {
         a.planes_per_wg = conv_pick_planes(a.D, tiles, 2);
     }

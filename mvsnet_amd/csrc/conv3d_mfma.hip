@@ -330,8 +330,6 @@ int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
 }  // namespace
 
 // test hook: MVS_GENERIC_C8=1 keeps the 32 -> 8 layer on the generic kernel (A/B timing, parity)
-static const bool g_generic_c8 = getenv("MVS_GENERIC_C8") != nullptr;
-static const bool g_wide_tiles = getenv("MVS_WIDE_TILES") != nullptr;        // test hook: 16-wide column tiles only
 
 static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t st) {
     if (stride == 1) {
@@ -340,16 +338,16 @@ static int conv_dispatch(ConvArgs& a, int Cin, int Cout, int stride, hipStream_t
         if (Cin == 8) return mvs_conv3d_k8_launch(a, Cout, st);      // input gradient of 3dconv0_1 (8 -> 32)
         if (a.wprep_bf && mvs_conv3d_bf16x3_supported(Cin, Cout)) return mvs_conv3d_s1_bf16x3(a, Cin, Cout, st);
         if (mvs_conv3d_os_covers(0, Cin, Cout)) return mvs_conv3d_os_launch(a, 0, Cin, Cout, st);     // low-resolution levels
-        if (Cin == 32 && Cout == 8 && !a.x2 && !g_generic_c8) {
+        if (Cin == 32 && Cout == 8 && !a.x2) {
             int rc = mvs_conv3d_c8_launch(a, st);
             if (rc != MVS_E_SHAPE) return rc;            // >= 2 GB volumes stay on the generic kernel
         }
         if (Cin == 32 && Cout == 8) return launch_s1<32, 8, 8>(a, Cout, st);
         if (Cin == 16 && Cout % 16 == 0) return launch_s1<16, 16, 8>(a, Cout, st);
         // widths that are not multiples of 16 (the /4 and /8 levels of a 160-wide volume): 2x8 / 4x4 column tiles
-        if (Cin == 32 && Cout % 16 == 0 && a.W % 16 != 0 && a.W % 8 == 0 && !g_wide_tiles) return launch_s1<32, 16, 8, 8, 2>(a, Cout, st);
+        if (Cin == 32 && Cout % 16 == 0 && a.W % 16 != 0 && a.W % 8 == 0) return launch_s1<32, 16, 8, 8, 2>(a, Cout, st);
         if (Cin == 32 && Cout % 16 == 0) return launch_s1<32, 16, 8>(a, Cout, st);
-        if (Cin == 64 && Cout % 8 == 0 && a.W % 16 != 0 && a.W % 4 == 0 && a.H % 16 == 0 && !g_wide_tiles) return launch_s1<64, 8, 16, 4, 4>(a, Cout, st);
+        if (Cin == 64 && Cout % 8 == 0 && a.W % 16 != 0 && a.W % 4 == 0 && a.H % 16 == 0) return launch_s1<64, 8, 16, 4, 4>(a, Cout, st);
         if (Cin == 64 && Cout % 8 == 0) return launch_s1<64, 8, 4>(a, Cout, st);
         if (Cin == 16 && Cout == 8) return launch_s1<16, 8, 8>(a, Cout, st);
         return MVS_E_SHAPE;

@@ -332,22 +332,13 @@ __global__ void os_weight_layout_kernel(const float* __restrict__ w, int transpo
 
 }  // namespace
 
-// Per-layer A/B switches MVS_OS_<layer>=-1 (the plane-march kernel of conv3d_mfma.hip / conv3d_s2_mfma.hip /
-// deconv3d_*.hip) or 0 (this family), read once.  Defaults = the faster one at the metric workload (tools/os_sweep.sh,
-// round 2, in-pipeline microseconds plane-march -> block kernel): 3dconv3_1 38.9 -> 27.5, 2_1 46.3 -> 42.4,
+// Which layers take this family: the faster one of the two at the metric workload (round 2, in-pipeline microseconds
+// plane-march kernel of conv3d_mfma.hip / conv3d_s2_mfma.hip / deconv3d_*.hip -> block kernel): 3dconv3_1 38.9 -> 27.5, 2_1 46.3 -> 42.4,
 // 3_0 28.1 -> 21.3, 4_0 35.4 -> 21.5, 5_0 43.9 -> 34.0; 3dconv2_0 (16 -> 32, K = 432) 37.0 -> 41.3 and 3dconv1_1
 // (16 -> 16) 75 -> 108 stay on the plane march: with 16 input channels the work per staged byte is too small for a
 // stage-then-compute block.  One voxel tile per wave (smaller, more numerous workgroups) measured slower everywhere.
-static int os_variant(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
 static int os_variant_of(int kind, int Cin, int Cout) {
-    static const bool off = getenv("MVS_NO_OS") != nullptr;         // A/B switch: the plane-march kernels everywhere
-    static const int v31 = os_variant("MVS_OS_31", 0), v21 = os_variant("MVS_OS_21", 0), v11 = os_variant("MVS_OS_11", -1),
-                     v30 = os_variant("MVS_OS_30", 0), v20 = os_variant("MVS_OS_20", -1),
-                     v40 = os_variant("MVS_OS_40", 0), v50 = os_variant("MVS_OS_50", 0);
-    if (off) return -1;
+    constexpr int v31 = 0, v21 = 0, v11 = -1, v30 = 0, v20 = -1, v40 = 0, v50 = 0;      // 0 = this family, -1 = plane march
     // network_mode 'fat' (base_filter 16, network.py:82-83): the four layers no plane-march kernel is built for
     if ((kind == 0 && Cin == 128 && Cout == 128) || (kind == 1 && Cin == 64 && (Cout == 32 || Cout == 128)) ||
         (kind == 2 && Cin == 128 && Cout == 64)) return 0;
@@ -371,9 +362,7 @@ int mvs_conv3d_os_launch(const ConvArgs& a, int kind, int Cin, int Cout, hipStre
     //                                                          KIND    CIN NCW VT BD BHT BWT
     if (kind == 0 && Cin == 64 && Cout == 64) return launch_os<OS_S1, 64, 4, 2, 2, 1, 1>(a, Cout, st);      // 3dconv3_1
     if (kind == 0 && Cin == 32 && Cout == 32) return launch_os<OS_S1, 32, 2, 2, 2, 1, 2>(a, Cout, st);      // 3dconv2_1
-    if (kind == 0 && Cin == 16 && Cout == 16) return launch_os<OS_S1, 16, 1, 2, 2, 2, 2>(a, Cout, st);      // 3dconv1_1 (off by default)
     if (kind == 1 && Cin == 32 && Cout == 64) return launch_os<OS_S2, 32, 4, 2, 2, 1, 1>(a, Cout, st);      // 3dconv3_0
-    if (kind == 1 && Cin == 16 && Cout == 32) return launch_os<OS_S2, 16, 2, 2, 2, 1, 2>(a, Cout, st);      // 3dconv2_0 (off by default)
     if (kind == 2 && Cin == 64 && Cout == 32) return launch_os<OS_DECONV, 64, 2, 1, 2, 1, 1>(a, Cout, st);  // 3dconv4_0
     if (kind == 2 && Cin == 32 && Cout == 16) return launch_os<OS_DECONV, 32, 1, 2, 2, 2, 2>(a, Cout, st);  // 3dconv5_0
     // 'fat' (64-channel volume, base_filter 16): 3dconv1_0, 3_0, 3_1, 4_0

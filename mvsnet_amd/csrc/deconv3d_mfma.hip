@@ -247,9 +247,10 @@ int launch_deconv(const ConvArgs& a0, int Cout, hipStream_t st) {
 }  // namespace
 
 int mvs_deconv3d_mfma_launch(const ConvArgs& a, int Cin, int Cout, hipStream_t st) {
-    static const bool generic_only = getenv("MVS_GENERIC_DECONV") != nullptr;     // test hook (A/B timing, parity)
-    if (!generic_only && mvs_conv3d_os_covers(2, Cin, Cout)) return mvs_conv3d_os_launch(a, 2, Cin, Cout, st);
-    if (!generic_only && Cout % 8 == 0 && ((Cin == 16 && Cout == 8) || Cin == 64)) {
+    // (weights prepared for the block kernels carry THEIR layout, mvs_conv_weight_layout: a layer this test sends there must
+    //  not fall through to the kernels below with that array -- a.wprep is only ever built for the kernel chosen here)
+    if (mvs_conv3d_os_covers(2, Cin, Cout)) return mvs_conv3d_os_launch(a, 2, Cin, Cout, st);
+    if (Cout % 8 == 0 && ((Cin == 16 && Cout == 8) || Cin == 64)) {
         int rc = mvs_deconv3d_c8_launch(a, Cin, Cout, st);       // packed 8-channel kernel (deconv3d_c8.hip)
         if (rc != MVS_E_SHAPE) return rc;
     }

@@ -36,7 +36,7 @@
 //    runs of 4 planes and otherwise takes the direct path entirely.
 //  * cost_volume_mfma_kernel (any n_src): the direct path alone -- range-checked buffer loads, weight masks.
 // Roofline: HBM write of the volume.
-#include "common.h"
+#include "../common.h"
 #include <climits>
 #include <cstdlib>
 
@@ -458,13 +458,17 @@ int launch_mfma_lds(const float* ref, const float* src, const float* transforms,
 
 }  // namespace
 
-// Internal (cost_volume.hip dispatches here): C = 32, zero fill, all source maps together below 2 GiB, H, W < 65535.
-// MVS_CV_MFMA=2 forces the direct kernel (no LDS staging).
-int mvs_cost_volume_mfma_launch(const float* ref, const float* src, const float* transforms, int n_src, int depth_total,
-                                int d_begin, int d_count, int H, int W, int variant, int negate, float* cost,
-                                hipStream_t st) {
-    static const int mode = getenv("MVS_CV_MFMA") ? atoi(getenv("MVS_CV_MFMA")) : 1;
-    if (mode != 2) {
+// LAB VARIANT entry point (not in libmvsnet_hip.so; `python -m mvsnet_amd.build --lab`, tests/test_gpu_lab.py).  C = 32, zero
+// fill, all source maps together below 2 GiB, H, W < 65535.  direct != 0 forces the direct kernel (no LDS staging).
+extern "C" int mvs_lab_cost_volume_mfma_f32(const float* ref, const float* src, const float* transforms, int view_num,
+                                            int depth_total, int d_begin, int d_count, int H, int W, int C, int variant,
+                                            int negate, int direct, float* cost, void* stream) {
+    MVS_CHECK_ARG(ref && src && transforms && cost);
+    MVS_CHECK_ARG(view_num >= 2 && depth_total >= 1 && d_begin >= 0 && d_count >= 1 && d_begin + d_count <= depth_total && H > 0 && W > 0);
+    if (C != 32 || H >= 65535 || W >= 65535 || (long long)(view_num - 1) * H * W * C * 4 >= (1LL << 31)) return MVS_E_SHAPE;
+    const int n_src = view_num - 1;
+    hipStream_t st = mvs_stream(stream);
+    if (!direct) {
         switch (n_src) {
             case 1: return launch_mfma_lds<1>(ref, src, transforms, depth_total, d_begin, d_count, H, W, variant, negate, cost, st);
             case 2: return launch_mfma_lds<2>(ref, src, transforms, depth_total, d_begin, d_count, H, W, variant, negate, cost, st);
@@ -473,8 +477,7 @@ int mvs_cost_volume_mfma_launch(const float* ref, const float* src, const float*
             default: break;
         }
     }
-    static const int ppb_env = getenv("MVS_CV_PPB") ? atoi(getenv("MVS_CV_PPB")) : 0;
-    int ppb = ppb_env > 0 ? (ppb_env + 3) / 4 * 4 : 16;
+    int ppb = 16;
     if (ppb > (d_count + 3) / 4 * 4) ppb = (d_count + 3) / 4 * 4;
     const long long hw = (long long)H * W;
     dim3 grid((unsigned)mvs_cdiv(hw, 64), (unsigned)mvs_cdiv(d_count, ppb));

@@ -89,6 +89,17 @@ extern "C" int mvs_conv3d_pair_f32(const float* x, const float* w1, const float*
 // When enabled, every RegNetUS0 run brackets its first launch -- the fused 3dconv0_1 + 3dconv1_0 pass,
 // ~45 % of a depth map -- with a pair of HIP events on the caller's stream.  Not for graph capture.
 namespace {
+// (nslot, n) partial rows of BatchNorm sums -> row 0 holds the total, the other rows zero
+__global__ void bn_fold_rows_kernel(double* stats, int nslot, int n) {
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        double t = stats[j];
+        for (int r = 1; r < nslot; ++r) { t += stats[(size_t)r * n + j]; stats[(size_t)r * n + j] = 0.0; }
+        stats[j] = t;
+    }
+}
+}  // namespace
+
+namespace {
 struct DominantProfile { bool on = false; hipEvent_t ev[64][2]; int used = 0; int created = 0; } g_prof;
 }
 extern "C" int mvs_profile_dominant(int enable) {
@@ -186,36 +197,6 @@ extern "C" size_t mvs_regnet_workspace_bytes(int D, int H, int W, int cin, int b
 }
 
 namespace {
-// Optional side stream for the branch layers (MVS_SIDE_STREAM=1).
-// Off by default since round 2: with the block kernels of conv3d_os.hip the low-resolution layers fill the CUs'
-// matrix pipes on their own, and a branch layer running beside them slows the chain by more than it hides
-// (rocprofv3, metric workload: 826 depth maps/s with the fork, 837 without).
-struct SideStream { hipStream_t stream; hipEvent_t fork[2]; hipEvent_t join; };
-// One side stream + event set per (device, caller stream), up to 8; created on first use under a mutex (ADVICE r1:
-// a single process-wide set funnelled every plan's branch layers through one stream and was neither per-device nor
-// thread-safe).  Further caller streams run their branch layers on the caller's stream.
-SideStream* side_stream(hipStream_t caller) {
-    struct Slot { int dev; hipStream_t caller; SideStream s; int state; };
-    static Slot slots[8];
-    static int used = 0;
-    static std::mutex mu;
-    if (!getenv("MVS_SIDE_STREAM")) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < used; ++i)
-        if (slots[i].dev == dev && slots[i].caller == caller) return slots[i].state == 1 ? &slots[i].s : nullptr;
-    if (used == 8) return nullptr;
-    Slot& sl = slots[used++];
-    sl.dev = dev; sl.caller = caller; sl.state = -1;
-    if (hipStreamCreateWithFlags(&sl.s.stream, hipStreamNonBlocking) == hipSuccess &&
-        hipEventCreateWithFlags(&sl.s.fork[0], hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&sl.s.fork[1], hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&sl.s.join, hipEventDisableTiming) == hipSuccess)
-        sl.state = 1;
-    return sl.state == 1 ? &sl.s : nullptr;
-}
-
 // layer table (order of the weights array) and offsets of the pre-laid-out weights
 struct PrepLayout { int kind[11]; int ci[11]; int co[11]; size_t off[11]; bool ok[11]; bool bf[11]; size_t total; };
 PrepLayout prep_layout(int cin, int b) {
@@ -303,7 +284,7 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
     // partial rows per layer: only where EVERY layer has an MFMA kernel (the scalar fallback finalises one row)
     // MVS_BN_SLOTS = 1 / 2 / 4 / 8 measured 858 / 864 / 860 / 848 depth maps/s at the metric workload: more rows shorten the
     // producers' atomic tails but every consumer thread adds the rows up again
-    static const int slots_env = getenv("MVS_BN_SLOTS") ? atoi(getenv("MVS_BN_SLOTS")) : 2;
+    constexpr int slots_env = 2;
     // (volumes of 2 GB and more leave the 32-bit-offset MFMA kernels for the generic ones: one row there)
     const bool all_mfma = (g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA) && cin == 32 && b == 8 &&
                           (long long)D * H * W * cin * 4 < (1LL << 31);
@@ -314,19 +295,26 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
     // fit the layer's 2*cmax-double slab
     // rows of the fused pair's sums: MVS_PAIR_SLOTS = 8 (round 1) / 4 / 2 / 1 measured 864 / 869 / 869 / 870 depth maps/s -- the
     // consumers (3dconv1_1, 2_0 and the 3 840-workgroup 3dconv6_2) pay for every row they add up
-    static const int pair_slots_env = getenv("MVS_PAIR_SLOTS") ? atoi(getenv("MVS_PAIR_SLOTS")) : 2;
-    const int pair_slots = pair_slots_env < 1 ? 1 : pair_slots_env > MVS_BN_SLOTS_MAX ? MVS_BN_SLOTS_MAX : pair_slots_env;
+    constexpr int pair_slots = 2;
     const int slots01 = all_mfma ? pair_slots : ((2 * cmax) / (2 * b) < 8 ? (2 * cmax) / (2 * b) : 8);
     const int slots10 = all_mfma ? pair_slots : ((2 * cmax) / (4 * b) < 8 ? (2 * cmax) / (4 * b) : 8);
     auto bn_of = [&](int i) {      // producer i's raw BatchNorm sums (i < 0: raw input, no BN)
         BnSrc s{nullptr, nullptr, nullptr, 1.0, eps, 0, 1};
         if (i >= 0) s = BnSrc{st(i), gammas[i], betas[i], cnt[i], eps, ch[i],
-                              (pair_done && i == L01) ? slots01 : (pair_done && i == L10) ? slots10 : SL};
+                              (pair_done && i == L01) ? slots01 : (pair_done && i == L10) ? slots10 : SL};      // = nslot_of(i)
         return s;
     };
-    auto ensure_final = [&](int i) -> int {
+    auto nslot_of = [&](int i) { return (pair_done && i == L01) ? slots01 : (pair_done && i == L10) ? slots10 : SL; };
+    auto ensure_final = [&](int i) -> int {        // (scale, shift) of producer i for the scalar kernels
         if (i < 0 || finalised[i]) return 0;
         finalised[i] = true;
+        // the producer may have spread its sums over partial rows: fold them into row 0 (the other rows become zero, so an MFMA
+        // consumer that adds the rows up again still gets the total)
+        if (nslot_of(i) > 1) {
+            bn_fold_rows_kernel<<<1, 256, 0, mvs_stream(stream)>>>(st(i), nslot_of(i), 2 * ch[i]);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return (int)e;
+        }
         return mvs_bn_finalize_f32(st(i), ch[i], cnt[i], gammas[i], betas[i], eps, ws.scale[i], ws.shift[i], stream);
     };
     // one layer: in = BN+ReLU(producer p1) [+ BN+ReLU(producer p2)], out = layer `out` (or reg)
@@ -344,7 +332,8 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
                 ? reinterpret_cast<const unsigned short*>(prepared + lay.total + lay.off[out]) : nullptr;
             int r = deconv ? mvs_deconv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, d, h, w, ci, co, y, so, hs, SL)
                            : mvs_conv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, wbf, d, h, w, ci, co, stride, y, so, hs, SL);
-            if (r != MVS_E_SHAPE || g_conv_impl == MVS_CONV_IMPL_MFMA || g_conv_impl == MVS_CONV_IMPL_BF16X3 || SL > 1) return r;
+            // a (D, H, W) outside a layer's MFMA tiling falls back to the shape-generic kernel for THAT layer (AUTO only)
+            if (r != MVS_E_SHAPE || g_conv_impl == MVS_CONV_IMPL_MFMA || g_conv_impl == MVS_CONV_IMPL_BF16X3) return r;
         }
         int r;
         if ((r = ensure_final(p1)) || (r = ensure_final(p2))) return r;
@@ -372,8 +361,7 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
 #define HIP_RUN(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return (int)e__; } while (0)
     // encoder on the raw cost volume (mvsnetworks.py:130-136).  3dconv1_0 and 3dconv0_1 read the same
     // volume: one fused pass when the shape is the one conv3d_c8.hip is built for.
-    if ((g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA) && cin == 32 && b == 8 &&
-        !getenv("MVS_NO_PAIR_FUSION")) {
+    if ((g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA) && cin == 32 && b == 8) {
         auto pair_args = [&](int bi) {
             return ConvArgs{cost + (size_t)bi * cost1, nullptr, nullptr, nullptr, nullptr, nullptr, weights[L01],
                             ws.y[L01] + (size_t)bi * ws_floats1, st(L01), D, H, W, b,
@@ -402,24 +390,16 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
         RUN(layer(false, -1, -1, L10, D, H, W, cin, 2 * b, 2, hs));
         RUN(layer(false, -1, -1, L01, D, H, W, cin, b, 1, hs));
     }
-    // The same-resolution branches 3dconv1_1 / 3dconv2_1 (mvsnetworks.py:138-141) are only needed by
-    // the decoder; the layers below them are too small to fill 256 CUs, so the branches run on a side
-    // stream next to the encoder's tail (fork / join with events: graph-capture safe, no host sync).
-    // (only for the shape every layer of which has an MFMA kernel: the scalar fallback's BatchNorm
-    // finalise bookkeeping is single-stream)
-    SideStream* side = (g_conv_impl != MVS_CONV_IMPL_SCALAR && cin == 32 && b == 8) ? side_stream(hs) : nullptr;
-    hipStream_t ss = side ? side->stream : hs;
-    if (side) { HIP_RUN(hipEventRecord(side->fork[0], hs)); HIP_RUN(hipStreamWaitEvent(ss, side->fork[0], 0)); }
-    RUN(layer(false, L10, -1, L11, D1, H1, W1, 2 * b, 2 * b, 1, ss));
+    // The same-resolution branches 3dconv1_1 / 3dconv2_1 (mvsnetworks.py:138-141) are only needed by the decoder.  (Round 1 ran
+    // them on a side stream beside the encoder's tail; with the block kernels of conv3d_os.hip a layer running beside the
+    // chain slows it by more than it hides -- 826 depth maps/s with the fork, 837 without -- so everything is one stream.)
+    RUN(layer(false, L10, -1, L11, D1, H1, W1, 2 * b, 2 * b, 1, hs));
     RUN(layer(false, L10, -1, L20, D1, H1, W1, 2 * b, 4 * b, 2, hs));
-    if (side) { HIP_RUN(hipEventRecord(side->fork[1], hs)); HIP_RUN(hipStreamWaitEvent(ss, side->fork[1], 0)); }
-    RUN(layer(false, L20, -1, L21, D2, H2, W2, 4 * b, 4 * b, 1, ss));
-    if (side) HIP_RUN(hipEventRecord(side->join, ss));
+    RUN(layer(false, L20, -1, L21, D2, H2, W2, 4 * b, 4 * b, 1, hs));
     RUN(layer(false, L20, -1, L30, D2, H2, W2, 4 * b, 8 * b, 2, hs));
     RUN(layer(false, L30, -1, L31, D3, H3, W3, 8 * b, 8 * b, 1, hs));
     // decoder with additive skips (mvsnetworks.py:146-157)
     RUN(layer(true, L31, -1, L40, D3, H3, W3, 8 * b, 4 * b, 2, hs));
-    if (side) HIP_RUN(hipStreamWaitEvent(hs, side->join, 0));
     RUN(layer(true, L40, L21, L50, D2, H2, W2, 4 * b, 2 * b, 2, hs));
     RUN(layer(true, L50, L11, L60, D1, H1, W1, 2 * b, b, 2, hs));
     // output conv, no BN / ReLU / bias (mvsnetworks.py:158)

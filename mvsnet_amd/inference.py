@@ -339,6 +339,8 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
 
 
 def main(argv=None):
+    from . import ensure_miopen_workaround
+    ensure_miopen_workaround("mvsnet_amd.inference")      # the torch extractor / refinement towers run ATen convolutions
     from . import predictlib as pl
     from . import shard as sh
     ap = argparse.ArgumentParser(description=__doc__)

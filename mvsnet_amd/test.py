@@ -71,6 +71,8 @@ def benchmark_depth_maps(input_dir, config, weights, device, losses, less_ones, 
 
 
 def main(argv=None):
+    from . import ensure_miopen_workaround
+    ensure_miopen_workaround("mvsnet_amd.test")
     import torch
     from . import predictlib as pl, shard as sh
     from .inference import build_weights

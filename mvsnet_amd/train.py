@@ -127,6 +127,8 @@ class Trainer:
                  sync_bn=False, refinement=False, refinement_network="unet", upsample_before_refinement=True,
                  refine_with_confidence=True, refinement_train_mode="all", refine_with_stereo=False,
                  regularization="3DCNN"):
+        from . import ensure_miopen_workaround
+        ensure_miopen_workaround("mvsnet_amd.train")      # before the first ATen convolution of this process (narrow towers, 2D backward)
         if regularization not in ("3DCNN", "GRU"):
             raise NotImplementedError("regularization %r" % regularization)
         if regularization == "GRU" and refinement:

@@ -162,5 +162,10 @@ def test_package_import_switches_off_the_miopen_solver_that_over_reads_its_filte
     try:
         importlib.reload(mvsnet_amd)
         assert os.environ["MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC"] == "0"
+        assert mvsnet_amd.ensure_miopen_workaround("test") is True
+        os.environ[mvsnet_amd.MIOPEN_WORKAROUND] = "1"          # the user's explicit choice is kept, with a warning
+        import pytest
+        with pytest.warns(UserWarning, match="igemm_bwd_gtcx35_nhwc"):
+            assert mvsnet_amd.ensure_miopen_workaround("test") is False
     finally:
         os.environ["MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC"] = saved

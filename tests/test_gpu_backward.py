@@ -910,3 +910,30 @@ def test_config5_training_step_at_its_own_size():
     tr = T.Trainer("normal", DEV, seed=0)
     losses = [float(tr.train_step(images, cams_img, gt, D)[0]) for _ in range(4)]
     assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0], losses
+
+
+def test_narrow_tower_data_gradient_shape_that_made_miopen_over_read():
+    """Round-2 GPU memory fault, kept as a regression case: the DATA gradient of a 3x3 convolution with 16 input and 8 output
+    channels on a 32 x 48 channels_last map -- the shape for which MIOpen's igemm_bwd_gtcx35_nhwc_fp32 solver read 4 608 bytes
+    past its (8,16,3,3) filter (a fault when the filter is the last block of an allocator segment).  With the package's
+    switch (mvsnet_amd.ensure_miopen_workaround) the solver is off: the gradient is right and nothing faults, whatever
+    the allocator does around the filter."""
+    import mvsnet_amd
+    assert mvsnet_amd.ensure_miopen_workaround("test")
+    rs = np.random.RandomState(3)
+    x = rs.randn(1, 16, 32, 48).astype(np.float32)
+    g = rs.randn(1, 8, 32, 48).astype(np.float32)
+    for rep in range(6):
+        torch.cuda.empty_cache()                              # fresh segments: the filter lands at different places
+        pad = [torch.empty(257 * (rep + 1), device=DEV) for _ in range(rep)]
+        w = torch.as_tensor(rs.randn(8, 16, 3, 3).astype(np.float32)).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        xt = torch.as_tensor(x).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = F.conv2d(xt, w, padding=1)
+        y.backward(torch.as_tensor(g).to(DEV).contiguous(memory_format=torch.channels_last))
+        torch.cuda.synchronize()
+        w64 = w.detach().double().cpu().requires_grad_(True)
+        x64 = torch.as_tensor(x).double().requires_grad_(True)
+        F.conv2d(x64, w64, padding=1).backward(torch.as_tensor(g).double())
+        assert rel_l1(n(xt.grad), x64.grad.numpy()) < 1e-5
+        assert rel_l1(n(w.grad), w64.grad.numpy()) < 1e-5
+        del pad

@@ -1,6 +1,6 @@
 """Warp + variance cost volume alone at a BASELINE workload, timed with HIP events (and runnable under rocprofv3):
     python tools/cv_time.py [M|c1|c2] [--iters 20] [--planes D]
-Library switches: MVS_CV_MFMA=0 (register-tap-cache sweep), MVS_CV_LDS=1 (LDS-staged), MVS_CV_PPB=<planes per block>,
+(the LDS-staged and MFMA-blend variants are lab kernels now: tests/test_gpu_lab.py, python -m mvsnet_amd.build --lab)
 MVS_LIB_PATH=<another build>."""
 import argparse
 import os
