@@ -51,15 +51,23 @@ struct Gru2dArgs {
 
 constexpr int TH2 = 8, TW2 = 16, PW2 = TW2 + 2;
 
+// Waves per workgroup.  The per-plane kernels of the recurrent chain run EIGHT (two per SIMD, one tile row each): with the four of
+// the batched x-part kernel (one per SIMD, two rows each) every LDS / global latency a wave meets between two tiles -- the
+// barrier, the first operand reads of the next tile, a late staging load -- idles that SIMD's matrix pipe, and a chain kernel
+// sweeps only 4-15 tiles per workgroup.  Same LDS, same MFMA count; the A operands are read by twice as many waves (free
+// under MFMA load).
+template <bool BATCH> struct GruNT { static constexpr int value = BATCH ? 256 : 512; };
+
 template <int CA, int CB, int COUT, int MODE, bool ADD, bool BATCH>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(GruNT<BATCH>::value, 1)
 conv2d_cat_mfma_kernel(Gru2dArgs a) {
+    constexpr int NT = GruNT<BATCH>::value, NWV = NT / 64;
     constexpr int CT = CA + CB;
     constexpr int S = CT + 8;
     constexpr int NPOS = (TH2 + 2) * PW2;
     constexpr int CQ = CT / 4, CQA = CA / 4;
     constexpr int MT = COUT / 16;
-    constexpr int V = 2;
+    constexpr int V = TH2 / NWV;                    // tile rows per wave
     constexpr int WROW = COUT * 4;
     constexpr int W_FLOATS = 9 * CQ * WROW;
     constexpr int SLAB_FLOATS = NPOS * S;
@@ -86,7 +94,18 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         mv(a.c_prev); mv(a.g_prev); mv(a.stats_c); mv(a.stats_u); mv(a.h_out);
     }
 
-    copy_weights_to_lds(wl, a.wprep, W_FLOATS);      // prepared layout, eight loads in flight per thread
+    {   // prepared weights -> LDS, eight 16-byte loads in flight per thread
+        const float4* s4 = reinterpret_cast<const float4*>(a.wprep);
+        float4* d4 = reinterpret_cast<float4*>(wl);
+        constexpr int n4 = W_FLOATS / 4;
+        for (int i0 = tid; i0 < n4; i0 += 8 * NT) {
+            float4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = i0 + NT * k; t[k] = i < n4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = i0 + NT * k; if (i < n4) d4[i] = t[k]; }
+        }
+    }
 
     // ---- staging, in pieces that are issued between the MFMAs of the sweep (branch-free) -------------
     // Piece i of a tile: global -> registers (load_piece), registers -> LDS (stage_piece).  The xa
@@ -96,8 +115,8 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     // the horizontal wrap needs a test.
     constexpr int CQB = CB / 4;
     constexpr int NFA = NPOS * CQA, NFB = NPOS * CQB;
-    constexpr int NA = (NFA + 255) / 256, NB = (NFB + 255) / 256, NIT = NA + NB;      // either family may be empty
-    static_assert((CA == 0 || (256 % CQA == 0 && NFA >= 256)) && (CB == 0 || (256 % CQB == 0 && NFB >= 256)), "staging map");
+    constexpr int NA = (NFA + NT - 1) / NT, NB = (NFB + NT - 1) / NT, NIT = NA + NB;      // either family may be empty
+    static_assert((CA == 0 || (NT % CQA == 0 && NFA >= NT)) && (CB == 0 || (NT % CQB == 0 && NFB >= NT)), "staging map");
     static_assert(MODE == 0 || CB > 0, "the reset gate applies to the xb family");
     static_assert(!BATCH || (CB == 0 && MODE == 0 && !ADD), "only the x-part launch is batched over planes");
     const int qb = tid % (CQB ? CQB : 1);            // this thread's channel quad in the xb pieces
@@ -145,8 +164,8 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     for (int i = 0; i < NIT; ++i) {
         const bool isb = i >= NA;
         const int cq = isb ? (CQB ? CQB : 1) : (CQA ? CQA : 1), nf = isb ? NFB : NFA;
-        int f = tid + 256 * (isb ? i - NA : i);
-        if (f >= nf) f -= 256;                       // spare threads of a family's last piece redo their previous one
+        int f = tid + NT * (isb ? i - NA : i);
+        if (f >= nf) f -= NT;                       // spare threads of a family's last piece redo their previous one
         const int pos = f / cq, q = f % cq;
         const int r = pos / PW2, c = pos - r * PW2;
         pcol[i] = c;
@@ -208,7 +227,7 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
             if (!((inside >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             // the tile's own pixels keep the state: the candidate convolution, the next cell and later planes read it
             const int r = prow[i], c = pcol[i];
-            if (tile_of < ntiles && r >= 1 && r <= TH2 && c >= 1 && c <= TW2 && ((inside >> i) & 1u) && tid + 256 * (i - NA) < NFB) {
+            if (tile_of < ntiles && r >= 1 && r <= TH2 && c >= 1 && c <= TW2 && ((inside >> i) & 1u) && tid + NT * (i - NA) < NFB) {
                 const int th = tile_of / a.tiles_w, h0 = th * TH2, w0 = (tile_of - th * a.tiles_w) * TW2;
                 *(float4*)(a.h_out + ((size_t)(h0 - 1 + r) * a.W + (w0 - 1 + c)) * CB + 4 * qb) = v;
             }
@@ -346,7 +365,7 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     }
 
     if (a.stats) {
-        double* red = (double*)slab;                // dead now: [4 waves][MT][2]
+        double* red = (double*)slab;                // dead now: [NWV waves][MT][2]
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             double s = wave_sum(st_s[m]), q = wave_sum(st_q[m]);
@@ -356,7 +375,7 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
         if (tid < MT * 2) {
             int m = tid >> 1, k = tid & 1;
             double t = 0.0;
-            for (int wv = 0; wv < 4; ++wv) t += red[(wv * MT + m) * 2 + k];
+            for (int wv = 0; wv < NWV; ++wv) t += red[(wv * MT + m) * 2 + k];
             atomicAdd(&a.stats[m * 2 + k], t);
         }
     }
@@ -383,7 +402,7 @@ int launch_gru2d(const Gru2dArgs& a0, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv2d_cat_mfma_kernel<CA, CB, COUT, MODE, ADD, BATCH><<<grid, 256, smem, st>>>(a);
+    conv2d_cat_mfma_kernel<CA, CB, COUT, MODE, ADD, BATCH><<<grid, GruNT<BATCH>::value, smem, st>>>(a);
     return (int)hipGetLastError();
 }
 
