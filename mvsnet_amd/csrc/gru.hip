@@ -235,25 +235,37 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
     cfloat* wsh = (cfloat*)w;
     __shared__ __attribute__((aligned(16))) float tile[PS * PS * CT];
     __shared__ float red[4][2][2];
+    // LayerNorm moments -> (mean, 1 / sqrt(var + eps)) ONCE per workgroup (two lanes, then LDS): every thread used to run the
+    // float64 divisions and square roots itself, per channel -- ~1000 instruction slots per wave at the head of a kernel whose
+    // own work is a few hundred (round 3: the four small-cell kernels 43 / 30 / 27 / 15 us per 4-view plane before)
+    __shared__ double lnp[2][2];
+    if (MODE != 0) {
+        if (threadIdx.x < (MODE == 2 ? 2 : 1)) {
+            const double cnt = (double)H * W * CB;
+            const double* st = MODE == 1 ? g_stats : (threadIdx.x == 0 ? bl_stats_u : bl_stats_c);
+            const double mean = st[0] / cnt;
+            double var = st[1] / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            lnp[threadIdx.x][0] = mean;
+            lnp[threadIdx.x][1] = 1.0 / sqrt(var + 1e-12);          // tf.contrib.layers.layer_norm, eps 1e-12
+        }
+        __syncthreads();
+    }
+    auto affine = [&](int k, float gamma, float beta, float& sc, float& sh) {
+        const double inv = (double)gamma * lnp[k][1];
+        sc = (float)inv; sh = (float)((double)beta - lnp[k][0] * inv);
+    };
     float ra[CB], rb[CB];
     if (MODE == 1) {
-        const double cnt = (double)H * W * CB;
-        double mean = g_stats[0] / cnt;
-        double var = g_stats[1] / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
 #pragma unroll
-        for (int f = 0; f < CB; ++f) {
-            double inv = (double)r_gamma[f] / sqrt(var + 1e-12);
-            ra[f] = (float)inv; rb[f] = (float)((double)r_beta[f] - mean * inv);
-        }
+        for (int f = 0; f < CB; ++f) affine(0, r_gamma[f], r_beta[f], ra[f], rb[f]);
     }
     float ua[CB], ub_[CB], ca[CB], cb_[CB];
     if (MODE == 2) {
-        const double cnt = (double)H * W * CB;
 #pragma unroll
         for (int f = 0; f < CB; ++f) {
-            ln_affine(bl_stats_u, cnt, bl.ug[f], bl.ub[f], ua[f], ub_[f]);
-            ln_affine(bl_stats_c, cnt, bl.og[f], bl.ob[f], ca[f], cb_[f]);
+            affine(0, bl.ug[f], bl.ub[f], ua[f], ub_[f]);
+            affine(1, bl.og[f], bl.ob[f], ca[f], cb_[f]);
         }
     }
     const int tiles_x = (W + TS - 1) / TS;
