@@ -181,3 +181,49 @@ def test_semilite_has_the_reference_runtime_channel_counts():
     a = S.make_regnet_params("semilite", seed=1)
     b = S.make_regnet_params("normal", seed=1)
     assert all(a[k]["w"].shape == b[k]["w"].shape for k in b)
+
+
+def test_session_writer_and_per_image_cache_equal_the_per_cluster_path(tmp_path):
+    """synthetic.write_session produces a session the generator reads (N = 5, D = 192 from the depth range), and the cached
+    inference path of ClusterGenerator (decode / rescale / crop once per IMAGE, round 3) returns exactly what the reference's
+    per-cluster sequence returns (cluster_generator.py:234-286: load all views, scale, crop, centre, output-scale) -- also
+    when the images need rescaling and cropping, and with the standardisation left to the caller (uint8 out)."""
+    from mvsnet_amd import synthetic as S
+    from mvsnet_amd import mvs_data_generation as G
+    sess = S.write_session(str(tmp_path / "s"), n_images=6, height=100, width=132, view_num=5, depth_num=192)
+    gen = G.make_generator(sess, 5, 128, 96, 192, 1.0, 8, mode="inference", output_scale=0.25)
+    assert len(gen.clusters) == 6
+    for ci in (0, 3, 5):
+        c = gen.clusters[ci]
+        got = gen.prepare(c)
+        c2 = G.make_generator(sess, 5, 128, 96, 192, 1.0, 8, mode="inference", output_scale=0.25).clusters[ci]
+        images, cams = c2.images(), c2.cameras()
+        images, cams = G.scale_mvs_input(images, cams, scale=c2.rescale)
+        ci_, cc_ = G.crop_mvs_input(images, cams, 128, 96, 8)
+        oi, oc = G.scale_mvs_input(ci_, cc_, scale=0.25)
+        want = (np.stack(oi), np.stack([G.center_image(i) for i in ci_]), np.stack(oc), np.stack(cc_), c2.ref_index)
+        assert c.rescale == c2.rescale and len(c.indices) == 5
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        raw = gen.prepare(c, center=False)
+        assert raw[1].dtype == np.uint8 and np.array_equal(raw[1], np.stack(ci_))
+        assert got[2][0, 1, 3, 2] == 192 and abs(got[2][0, 1, 3, 1] - 2.65) < 1e-6
+    # second request of a cluster: served from the cache, same arrays
+    again = gen.prepare(gen.clusters[0])
+    assert np.array_equal(again[1], gen.prepare(gen.clusters[0])[1])
+
+
+def test_launch_ranks_starts_the_ranks_and_returns_their_exit_code(tmp_path):
+    """shard.launch_ranks (what `bench.py --gpus N` / `inference --gpus N` call when started without a launcher): N ranks
+    under torch.distributed.run on 127.0.0.1 and a free port; exit code 0 when all ranks succeed, non-zero when one fails."""
+    from mvsnet_amd.shard import launch_ranks
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os, sys\nsys.path.insert(0, %r)\nfrom mvsnet_amd import shard as sh\ndist = sh.init_process_group('gloo')\n"
+                  "r, l, w = sh.rank_world()\nassert w == 2\nopen(os.path.join(%r, 'rank%%d' %% r), 'w').write(str(sh.gather_counts(dist, r + 1)))\n"
+                  "dist.destroy_process_group()\n" % (ROOT, str(tmp_path)))
+    assert launch_ranks([str(ok)], 2) == 0
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("rank")) == ["rank0", "rank1"]
+    assert open(tmp_path / "rank0").read() == "[1.0, 2.0]"
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
+    assert launch_ranks([str(bad)], 2) != 0
