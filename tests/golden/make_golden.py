@@ -36,6 +36,23 @@ def full(names):
     import torch
     from oracle import torch_restatement as TR
     for name in names:
+        if name == "c1img":                      # configs[0] from IMAGES: UNetDS2GN towers (numpy oracle) -> hot path (torch restatement)
+            w = S.make_workload("c1")
+            images = S.make_images(w.view_num, 4 * w.height, 4 * w.width, seed=0)
+            up = S.make_unet_params("normal", seed=3)
+            rp = S.make_regnet_params("normal", seed=1, random_affine=True)
+            sha = hashlib.sha256(images.tobytes() + w.cams.tobytes()).hexdigest()
+            t0 = time.time()
+            out = {}
+            for tag, npdt, tdt in (("f64", np.float64, torch.float64), ("f32", np.float32, torch.float32)):
+                feats = np.stack([O.unet_ds2gn(images[v], up, npdt) for v in range(w.view_num)])
+                out[tag] = TR.inference_mem_from_features(feats, w.cams, w.depth_num, w.depth_start, w.depth_interval, rp, tdt)
+            d, p = out["f64"]
+            extra = dict(f32_cpu_abs_rel=abs_rel(out["f32"][0], d), f32_cpu_prob_mismatch=float((np.abs(out["f32"][1] - p) > 1e-3).mean()))
+            np.savez_compressed(os.path.join(HERE, "full_c1img.npz"), depth=d.astype(np.float32), prob=p.astype(np.float32),
+                                input_sha256=sha, **extra)
+            print("wrote full_c1img.npz in %.0f s: %s" % (time.time() - t0, extra), flush=True)
+            continue
         inverse = name == "c3inv"                # configs[2] with --inverse_depth (R1' / model.py:706-713): same inputs as c3
         w = S.make_workload("c3" if inverse else name)
         sha = hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest()
@@ -65,7 +82,7 @@ def full(names):
 
 def main():
     if "--full" in sys.argv:
-        names = [a for a in sys.argv[1:] if a in S.WORKLOADS or a == "c3inv"]
+        names = [a for a in sys.argv[1:] if a in S.WORKLOADS or a in ("c3inv", "c1img")]
         return full(names or ["c1", "M", "c2", "c3"])
     w = S.make_workload("toy")
     sha = hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest()

@@ -162,3 +162,26 @@ def test_gru_batch_of_reference_views_equals_the_single_view_sweeps(lib_built, s
             assert (df == db).all() and float(np.max(np.abs(pf - pb) / np.maximum(pb, 1e-30))) <= 1e-6
     finally:
         _lib.check(_lib.load().mvs_gru_set_formulation(0), "mvs_gru_set_formulation")
+
+
+@pytest.mark.parametrize("extractor", ["hip", "torch"])
+def test_images_to_depth_at_c1_size_matches_the_fixture(lib_built, extractor):
+    """configs[0] from IMAGES at full size: 3 views of 640x512 -> UNetDS2GN towers (HIP library / PyTorch module) -> warp +
+    variance -> RegNetUS0 -> soft-argmin, against tests/golden/full_c1img.npz (float64: numpy towers + torch-CPU hot path;
+    the float32 CPU composition lands 8.8e-7 from it)."""
+    from mvsnet_amd.model import MVSNetWeights, inference_mem
+    g = np.load(os.path.join(GOLDEN, "full_c1img.npz"))
+    w = S.make_workload("c1")
+    images = S.make_images(w.view_num, 4 * w.height, 4 * w.width, seed=0)
+    assert hashlib.sha256(images.tobytes() + w.cams.tobytes()).hexdigest() == str(g["input_sha256"])
+    weights = MVSNetWeights.from_numpy("normal", unet=S.make_unet_params("normal", seed=3),
+                                       regnet=S.make_regnet_params("normal", seed=1, random_affine=True), device=DEV, extractor=extractor)
+    depth, prob = inference_mem(t(images)[None], t(w.cams)[None], w.depth_num, w.depth_start, w.depth_interval, weights=weights)
+    d = depth.cpu().numpy()[0, :, :, 0].astype(np.float64)
+    p = prob.cpu().numpy()[0, :, :, 0].astype(np.float64)
+    abs_rel = float(np.mean(np.abs(d - g["depth"]) / g["depth"]))
+    mismatch = float((np.abs(p - g["prob"]) > 1e-3).mean())
+    print("c1 from images (%s towers): abs-rel %.3e (float32 CPU: %.3e), prob mismatch %.5f, worst pixel %.3e"
+          % (extractor, abs_rel, float(g["f32_cpu_abs_rel"]), mismatch, float(np.max(np.abs(d - g["depth"]) / g["depth"]))))
+    assert abs_rel <= 3.0 * float(g["f32_cpu_abs_rel"]), abs_rel
+    assert mismatch <= 5e-4, mismatch
