@@ -220,7 +220,7 @@ def extra_config_gru(name, dev, steps=5, views=1):
     return out
 
 
-def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN"):
+def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN", procs_per_gpu=3):
     """End-to-end throughput of the reference's own loop (mvsnet/inference.py:105-119: load a cluster -> run the graph -> write
     the outputs, 'Depth inference ... sec/step') on a synthetic on-disk session of the metric's shape: `n_images` JPEGs of
     640x512 with cameras and a covisibility file (mvsnet_amd.synthetic.write_session), view_num 5, max_d 192 -> 160x128 feature
@@ -257,6 +257,20 @@ def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN"):
                        "d2h (GPU, to pinned buffers)": 1e3 * tm["d2h"] / max(n, 1),
                        "file_writes (writer threads, summed)": 1e3 * tm["write"] / max(n, 1)},
                    "loader_threads": tm["loader_threads"], "writer_threads": tm["writer_threads"]}
+        # the same session with several worker PROCESSES sharing this GPU (python -m mvsnet_amd.inference --procs_per_gpu P): the
+        # one-process loop above is bound by its Python main thread, not by the GPU
+        if procs_per_gpu > 1:
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+            try:
+                r = subprocess.run([sys.executable, "-m", "mvsnet_amd.inference", "--input_dir", root, "--output_dir", os.path.join(root, "outp"),
+                                    "--view_num", "5", "--max_d", "192", "--width", "640", "--height", "512", "--regularization", regularization,
+                                    "--procs_per_gpu", str(procs_per_gpu), "--passes", "6"], capture_output=True, text=True, timeout=240,
+                                   env=env, cwd=ROOT)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                out["processes_sharing_the_gpu"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:
+                out["processes_sharing_the_gpu"] = {"error": repr(e)[:300]}
         return out
     except Exception as e:                                  # informative record: never fail the bench line over it
         return {"error": repr(e)[:400]}

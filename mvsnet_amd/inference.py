@@ -372,11 +372,22 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1,
                     help="N > 1 without a torch.distributed.run environment: start N one-GPU ranks of this command "
                          "(reference views sharded round-robin, no data-path collective)")
+    ap.add_argument("--procs_per_gpu", type=int, default=1,
+                    help="worker processes sharing each GPU (ranks = gpus x procs_per_gpu, collectives over gloo): the loop "
+                         "load -> towers -> hot path -> write is bound by ONE Python thread per process (DESIGN section 5, "
+                         "`session`), several processes per GPU fill it")
+    ap.add_argument("--passes", type=int, default=1,
+                    help="run the whole input this many times and report all passes after the first together (throughput "
+                         "measurements: the first pass pays plans, code objects and pinned buffers)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=os.environ.get("LOG_LEVEL", "INFO"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # before anything touches the GPU: the parent stays GPU-less
+    n_ranks = max(1, args.gpus) * max(1, args.procs_per_gpu)
+    if n_ranks > 1 and "WORLD_SIZE" not in os.environ:         # before anything touches the GPU: the parent stays GPU-less
         import sys
-        raise SystemExit(sh.launch_ranks(list(sys.argv[1:] if argv is None else argv), args.gpus, module="mvsnet_amd.inference"))
+        if args.procs_per_gpu > 1:                             # ranks share GPUs: RCCL wants one GPU per rank
+            os.environ["MVS_ALLOW_SHARED_GPU"] = "1"
+            os.environ["MVS_DIST_BACKEND"] = "gloo"
+        raise SystemExit(sh.launch_ranks(list(sys.argv[1:] if argv is None else argv), n_ranks, module="mvsnet_amd.inference"))
     weights_path = args.weights
     for name in vars(cfg):
         setattr(cfg, name, getattr(args, name))
@@ -394,12 +405,23 @@ def main(argv=None):
     rank, local_rank, world = sh.rank_world()
     device = sh.bind_device(local_rank)
     weights = build_weights(cfg, device, weights_path, args.model_dir, args.ckpt_step, args.extractor)
-    total = 0
-    for d in dirs:
-        total += compute_depth_maps(d, cfg, weights, device, gru_views=args.gru_views)
+    total, wall, t0 = 0, 0.0, time.perf_counter()
+    for p_ in range(max(1, args.passes)):
+        if p_ <= 1:                                   # the timed region = every pass after the first (or the only one)
+            if dist is not None:
+                dist.barrier()                        # the ranks start together: the rate is all maps / the slowest rank
+            t0, total = time.perf_counter(), 0
+        for d in dirs:
+            total += compute_depth_maps(d, cfg, weights, device, gru_views=args.gru_views)
+        wall = time.perf_counter() - t0
     counts = sh.gather_counts(dist, total, device=device if dist is not None else "cpu")
+    walls = sh.gather_counts(dist, wall, device=device if dist is not None else "cpu")
     if rank == 0:
+        import json
         logger.info("all dense finished: %d depth maps (%s per rank)", int(sum(counts)), counts)
+        print(json.dumps({"depth_maps": int(sum(counts)), "ranks": len(counts), "procs_per_gpu": args.procs_per_gpu,
+                          "seconds_slowest_rank": max(walls), "depth_maps_per_s": sum(counts) / max(max(walls), 1e-9),
+                          "sec_per_step": max(walls) / max(sum(counts), 1), "passes": max(1, args.passes)}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
