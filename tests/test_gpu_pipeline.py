@@ -242,3 +242,16 @@ def test_bench_and_inference_start_their_own_ranks(tmp_path, lib_built):
                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r3.returncode == 0, (r3.stdout[-2000:], r3.stderr[-2000:])
     assert sorted(f for f in os.listdir(out) if f.endswith("_init.pfm")) == ["%d_init.pfm" % i for i in range(5)]
+    # several worker processes per GPU (the session loop is bound by one Python thread per process): no environment needed,
+    # the flag itself selects gloo + shared GPUs for its ranks; the summary line reports all passes after the first
+    env3 = {k: v for k, v in env.items() if k not in ("MVS_DIST_BACKEND", "MVS_ALLOW_SHARED_GPU")}
+    out2 = str(tmp_path / "out2")
+    r4 = subprocess.run([sys.executable, "-m", "mvsnet_amd.inference", "--procs_per_gpu", "2", "--passes", "2", "--input_dir", sess,
+                         "--output_dir", out2, "--view_num", "3", "--max_d", "8", "--width", "128", "--height", "96"],
+                        capture_output=True, text=True, timeout=600, env=env3, cwd=root)
+    assert r4.returncode == 0, (r4.stdout[-2000:], r4.stderr[-2000:])
+    rec4 = json.loads([l for l in r4.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec4["ranks"] == 2 and rec4["depth_maps"] == 5 and rec4["depth_maps_per_s"] > 0
+    for i in range(5):                                     # same files as the two-rank run above
+        a = open(os.path.join(out, "%d_init.pfm" % i), "rb").read()
+        assert a == open(os.path.join(out2, "%d_init.pfm" % i), "rb").read()
