@@ -553,3 +553,46 @@ def test_device_matches_committed_golden_fixtures():
                                             weights=weights, features=t(w.features))
     d = n(depth)[0, :, :, 0]
     assert (np.abs(d - g["depth"]) <= 1e-6 * g["depth"]).mean() > 0.98
+
+
+def test_gru_batch_entry_point_argument_checks_and_ragged_batches():
+    """mvs_gru_wta_batch_f32: 1..8 views, a workspace block per view, per-view depth values; errors are return codes (no fault).
+    A ragged volume (tiles cut on both axes, planes not a multiple of the group / batch sizes) with 8 views against the oracle."""
+    import ctypes as C
+    from mvsnet_amd import _lib
+    from mvsnet_amd.model import DepthPlan, MVSNetWeights, wta_depth_values
+    w = S.make_workload("small")
+    D, Hh, Ww = 19, 21, 37
+    gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
+    nv = 8
+    plan = DepthPlan(w.view_num, D, Hh, Ww, w.channels, weights, "GRU", DEV, views=nv)
+    feats, dvs, ends = [], [], []
+    for v in range(nv):
+        f = S.make_features(w.view_num, Hh, Ww, w.channels, seed=30 + v)
+        feats.append(f)
+        ends.append(w.depth_start + (D - 1) * w.depth_interval * (1.0 + 0.1 * v))
+        plan.set_cameras(t(w.cams), w.depth_start, (ends[v] - w.depth_start) / (D - 1), ends[v], False, view=v)
+        dvs.append(wta_depth_values(D, w.depth_start, ends[v], False))
+    d, p = plan.run_gru_batch([t(f) for f in feats], dvs)
+    d, p = n(d), n(p)
+    for v in (0, 3, 7):
+        ed, ep = O.inference_winner_take_all_from_features(feats[v], w.cams, D, w.depth_start, ends[v], gp, False, np.float64)
+        same = d[v] == ed.astype(np.float32)
+        assert same.mean() > 0.97, (v, float(same.mean()))
+        assert np.abs(p[v][same] - ep[same]).max() < 2e-4
+    # argument checks
+    lib = _lib.load()
+    g = weights.gru
+    f1, f2, f3 = g.filters
+    keep = [(t(f)[0].contiguous(), t(f)[1:].contiguous()) for f in feats]
+    ref = _lib.ptr_array([k[0] for k in keep]); src = _lib.ptr_array([k[1] for k in keep])
+    tr = _lib.ptr_array([plan.transforms_v[v] for v in range(nv)])
+    flat = (C.c_float * (nv * D))(*[float(x) for dv in dvs for x in dv])
+    call = lambda views, ws_bytes: lib.mvs_gru_wta_batch_f32(ref, src, tr, views, w.view_num, D, Hh, Ww, w.channels, f1, f2, f3, g.ptrs, flat,
+                                                             C.c_void_p(plan.workspace.data_ptr()), ws_bytes, _lib.ptr(plan.depth_v),
+                                                             _lib.ptr(plan.prob_v), _lib.stream_ptr())
+    assert call(9, plan.workspace.numel()) == -1 and call(0, plan.workspace.numel()) == -1        # MVS_E_BADARG
+    assert call(nv, plan.workspace.numel() // nv * (nv - 1)) == -3                                   # MVS_E_WORKSPACE
+    assert lib.mvs_gru_set_formulation(3) == -1
+    torch.cuda.synchronize()
