@@ -278,6 +278,35 @@ def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN", procs_
         shutil.rmtree(root, ignore_errors=True)
 
 
+def training_record(dev, iters=5, configs=(("3dcnn_d128_config5", "3DCNN", 128),)):
+    """SURVEY 8f f4 / BASELINE configs[4]'s per-GPU work: one training step (images -> towers -> hot path forward + backward ->
+    optimiser, mvsnet/train.py:412-445) at train.py's default size (3 views x 640x480, D = 192, batch 1) for both regularisers
+    and at configuration 5's depth count (D = 128); milliseconds per step after two warm-up steps."""
+    from mvsnet_amd import synthetic as S, train as T
+    out = {}
+    try:
+        for tag, reg, D in configs:
+            N, H, W = 3, 480, 640
+            images = S.make_images(N, H, W)
+            cams = S.make_cams(N, H // 4, W // 4, D)
+            start, interval = float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1])
+            gt = np.full((H // 4, W // 4, 1), start + interval * D * 0.5, np.float32)
+            tr = T.Trainer("normal", dev, regularization=reg)
+            for _ in range(2):
+                tr.train_step(images, cams, gt, D)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                tr.train_step(images, cams, gt, D)
+            torch.cuda.synchronize()
+            out[tag] = {"ms_per_step": (time.perf_counter() - t0) / iters * 1e3, "views": N, "image": "%dx%d" % (W, H), "depth_planes": D}
+            del tr
+            torch.cuda.empty_cache()
+    except Exception as e:                                  # informative record: never fail the bench line over it
+        out["error"] = repr(e)[:300]
+    return out
+
+
 def gru_config_in_child(name, steps=5):
     """The same recurrent configuration in a fresh process (the GPU is idle here), for comparison with the in-process record:
     round 2 measured 44 ms in this process against 23 ms in a fresh one (hardware-queue / compute-pipe interference, fixed in
@@ -314,6 +343,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the informative records (repeated blocks, two-stream pass, c2 / c3 configurations)")
     ap.add_argument("--blocks", type=int, default=5, help="repeated blocks of --steps steps after the timed region")
+    ap.add_argument("--training-all", action="store_true", help="training record for D = 192 and the recurrent model too")
     ap.add_argument("--with-images", action="store_true",
                     help="also time images->depth (adds the PyTorch UNetDS2GN towers)")
     args = ap.parse_args()
@@ -597,11 +627,18 @@ def main():
             out["depth_maps_per_s_two_streams"] = n2 / (time.perf_counter() - t2)
         if world == 1 and n_streams == 1 and not args.no_extra and args.workload == "M" and args.network_mode == "normal":
             # BASELINE.json configs[1] and configs[2] on this GPU, each with its distance from the committed fixture
-            out["config_c2"] = extra_config_3dcnn("c2", dev)
-            out["config_c3_gru"] = extra_config_gru("c3", dev, 5, 1)
-            out["config_c3_gru"]["fresh_process"] = gru_config_in_child("c3")
-            out["config_c3_gru_4_views"] = extra_config_gru("c3", dev, 3, 4)
-            out["session"] = session_record(dev, out["value"])
+            t_x = [time.perf_counter()]
+
+            def lap(tag):
+                t_x.append(time.perf_counter())
+                print("bench extra %-28s %6.1f s" % (tag, t_x[-1] - t_x[-2]), file=sys.stderr, flush=True)
+            out["config_c2"] = extra_config_3dcnn("c2", dev); lap("config_c2")
+            out["config_c3_gru"] = extra_config_gru("c3", dev, 5, 1); lap("config_c3_gru")
+            out["config_c3_gru"]["fresh_process"] = gru_config_in_child("c3"); lap("c3 fresh process")
+            out["config_c3_gru_4_views"] = extra_config_gru("c3", dev, 3, 4); lap("config_c3_gru_4_views")
+            out["session"] = session_record(dev, out["value"]); lap("session")
+            out["training"] = training_record(dev, configs=(("3dcnn_d192", "3DCNN", 192), ("3dcnn_d128_config5", "3DCNN", 128), ("gru_d192", "GRU", 192))
+                                              if args.training_all else (("3dcnn_d128_config5", "3DCNN", 128),)); lap("training")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, rp, args.cpu_budget, depth_np)
         print(json.dumps(out), flush=True)
