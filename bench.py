@@ -307,6 +307,42 @@ def training_record(dev, iters=5, configs=(("3dcnn_d128_config5", "3DCNN", 128),
     return out
 
 
+def gru_production_order(dev, n_views=8, views_per_sweep=4):
+    """configs[2] in the production order inside ONE process: for each of `n_views` reference views the
+    UNetDS2GN towers on the HIP library (5 images of 1600x1200 -> 400x300x32 feature maps), then the recurrent sweep, several
+    views per sweep -- towers and sweeps alternate on the same stream, as mvsnet_amd.inference runs them."""
+    from mvsnet_amd import synthetic as S
+    from mvsnet_amd.feature_net_hip import HipUNetDS2GN
+    from mvsnet_amd.model import DepthPlan, MVSNetWeights, wta_depth_values
+    try:
+        w = S.make_workload("c3")
+        weights = MVSNetWeights.from_numpy("normal", gru=S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True), device=dev)
+        net = HipUNetDS2GN(S.make_unet_params("normal", seed=3), dev)
+        cams = torch.as_tensor(w.cams).to(dev)
+        imgs = [torch.as_tensor(S.make_images(w.view_num, 4 * w.height, 4 * w.width, seed=v)).to(dev) for v in range(2)]
+        dv = wta_depth_values(w.depth_num, w.depth_start, w.depth_end, False)
+        plan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "GRU", dev, views=views_per_sweep)
+
+        def run():
+            for v0 in range(0, n_views, views_per_sweep):
+                feats = []
+                for v in range(views_per_sweep):
+                    feats.append(net(imgs[(v0 + v) % 2]))
+                    plan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False, view=v)
+                plan.run_gru_batch(feats, [dv] * views_per_sweep)
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {"workload": "c3 from IMAGES: %d reference views, each 5 images of %dx%d -> towers (HIP library) -> ConvGRU sweep, %d views per sweep, one process"
+                            % (n_views, 4 * w.width, 4 * w.height, views_per_sweep),
+                "depth_maps_per_s": n_views / el, "ms_per_depth_map": el / n_views * 1e3}
+    except Exception as e:                                  # informative record: never fail the bench line over it
+        return {"error": repr(e)[:300]}
+
+
 def gru_config_in_child(name, steps=5):
     """The same recurrent configuration in a fresh process (the GPU is idle here), for comparison with the in-process record:
     round 2 measured 44 ms in this process against 23 ms in a fresh one (hardware-queue / compute-pipe interference, fixed in
@@ -636,6 +672,7 @@ def main():
             out["config_c3_gru"] = extra_config_gru("c3", dev, 5, 1); lap("config_c3_gru")
             out["config_c3_gru"]["fresh_process"] = gru_config_in_child("c3"); lap("c3 fresh process")
             out["config_c3_gru_4_views"] = extra_config_gru("c3", dev, 3, 4); lap("config_c3_gru_4_views")
+            out["config_c3_gru_from_images"] = gru_production_order(dev); lap("config_c3_gru_from_images")
             out["session"] = session_record(dev, out["value"]); lap("session")
             out["training"] = training_record(dev, configs=(("3dcnn_d192", "3DCNN", 192), ("3dcnn_d128_config5", "3DCNN", 128), ("gru_d192", "GRU", 192))
                                               if args.training_all else (("3dcnn_d128_config5", "3DCNN", 128),)); lap("training")
