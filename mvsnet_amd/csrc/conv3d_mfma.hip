@@ -30,8 +30,6 @@
 
 namespace {
 
-constexpr int TW = CONV_TW;
-
 // ------------------------------------------------------------------------------------------------
 // stride-1 convolution, input-stationary.  COUT = output channels handled by this workgroup (8|16).
 // ------------------------------------------------------------------------------------------------
