@@ -255,3 +255,22 @@ def test_bench_and_inference_start_their_own_ranks(tmp_path, lib_built):
     for i in range(5):                                     # same files as the two-rank run above
         a = open(os.path.join(out, "%d_init.pfm" % i), "rb").read()
         assert a == open(os.path.join(out2, "%d_init.pfm" % i), "rb").read()
+
+
+def test_compute_depth_maps_on_an_upstream_pair_txt_project(tmp_path, lib_built):
+    """The upstream MVSNet project format (pair.txt, cams/%08d_cam.txt, images/%08d.jpg; README.md:165-215) through the same
+    pipeline: its clusters take the host-standardised float32 path (no per-image decode cache), same outputs on disk."""
+    from tests.test_data_and_sharding import make_pair_project
+    from mvsnet_amd.inference import compute_depth_maps
+    from mvsnet_amd import predictlib as pl, preprocess as pp
+    proj = make_pair_project(str(tmp_path / "proj"), n_images=4, h=96, w=128)
+    cfg = pl.InferenceConfig(view_num=3, max_d=8, width=128, height=96, base_image_size=8, interval_scale=20.0)
+    tm = {}
+    n = compute_depth_maps(proj, cfg, timings=tm)
+    assert n == 4 and tm["depth_maps"] == 4
+    out = os.path.join(proj, "depths_mvsnet")
+    for idx in range(4):
+        d = pp.load_pfm(os.path.join(out, "%d_init.pfm" % idx))
+        assert d.shape == (24, 32) and np.isfinite(d).all() and d.min() >= 425.0 - 1e-3
+        for suffix in ("_prob.pfm", "_depth.png", "_prob.png", ".jpg", ".txt"):
+            assert os.path.exists(os.path.join(out, "%d%s" % (idx, suffix)))
