@@ -40,6 +40,11 @@ conv3d_out_kernel(ConvArgs a) {
     const int d0 = blockIdx.z * a.planes_per_wg;
     const int d1 = min(d0 + a.planes_per_wg, a.D);
     const int T = d1 - d0 + 2;
+    // Even depth chunks march forwards, odd ones BACKWARDS: the chunks z and z + 1 of a tile (all of a tile's chunks run at the
+    // same time and, the tile count being a multiple of 8, on the same XCD) then reach their two shared halo planes at the
+    // same moment -- at the end of both marches, or at the start of both -- and the second reader finds them in that XCD's L2
+    // instead of fetching them from HBM again (the depth halo was 23 of the layer's 304 MB of reads at the metric workload).
+    const bool fwd = (blockIdx.z & 1) == 0;
 
     const int c4 = tid % CQ;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -107,18 +112,22 @@ conv3d_out_kernel(ConvArgs a) {
         }
     };
 
-    f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};      // kd = 0 (-> q+1), 1 (-> q), 2 (-> q-1)
+    // accN: the output plane one step AHEAD of the input plane q in march direction, accM: plane q, accO: one step behind
+    // (complete after this input plane).  Forwards that is kd = 0 / 1 / 2, backwards kd = 2 / 1 / 0.
+    f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
     const int base = (row * OPW + col) * S;
+    const int step = fwd ? 1 : -1, q0 = fwd ? d0 - 1 : d1;
+    const int kdN = fwd ? 0 : 2, kdO = fwd ? 2 : 0;
 
-    issue_loads(d0 - 1);
-    write_slab(d0 - 1, slab[0]);
+    issue_loads(q0);
+    write_slab(q0, slab[0]);
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
-        const int q = d0 - 1 + t;
+        const int q = q0 + step * t;
         const float* cur = slab[t & 1];
         const bool more = (t + 1 < T);
-        if (more) issue_loads(q + 1);
+        if (more) issue_loads(q + step);
         if (q >= 0 && q < a.D) {
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
@@ -127,9 +136,9 @@ conv3d_out_kernel(ConvArgs a) {
 #pragma unroll
                     for (int cq = 0; cq < CQ; ++cq) {
                         float4 x = *(const float4*)(cur + base + (kh * OPW + kw) * S + 4 * cq);
-                        cfloat* w0p = wsh + ((0 * 9 + kh * 3 + kw) * CIN + 4 * cq);       // (3,3,3,Cin,1)
+                        cfloat* w0p = wsh + ((kdN * 9 + kh * 3 + kw) * CIN + 4 * cq);     // (3,3,3,Cin,1)
                         cfloat* w1p = wsh + ((1 * 9 + kh * 3 + kw) * CIN + 4 * cq);
-                        cfloat* w2p = wsh + ((2 * 9 + kh * 3 + kw) * CIN + 4 * cq);
+                        cfloat* w2p = wsh + ((kdO * 9 + kh * 3 + kw) * CIN + 4 * cq);
                         // channel pairs: v_pk_fma_f32 with the weight pair straight from SGPRs (even / odd channel sums)
                         const f32x2 xa = {x.x, x.y}, xb = {x.z, x.w};
                         acc0 += xa * (f32x2){w0p[0], w0p[1]}; acc0 += xb * (f32x2){w0p[2], w0p[3]};
@@ -137,11 +146,11 @@ conv3d_out_kernel(ConvArgs a) {
                         acc2 += xa * (f32x2){w2p[0], w2p[1]}; acc2 += xb * (f32x2){w2p[2], w2p[3]};
                     }
         }
-        const int o = q - 1, h = h0 + row, w = w0 + col;
+        const int o = q - step, h = h0 + row, w = w0 + col;
         if (o >= d0 && o < d1 && h < a.H && w < a.W)
             a.y[(((size_t)o * a.H + h) * a.W) + w] = acc2[0] + acc2[1];
         acc2 = acc1; acc1 = acc0; acc0 = (f32x2){0.f, 0.f};
-        if (more) write_slab(q + 1, slab[(t + 1) & 1]);
+        if (more) write_slab(q + step, slab[(t + 1) & 1]);
         __syncthreads();
     }
 }
