@@ -65,13 +65,56 @@ def center_images_device(u8):
     return ((x - mean.float()) / (var.sqrt().float() + 0.00000001)).contiguous()
 
 
+class FeatureCache:
+    """Per-image feature maps of a session, least-recently-used first out.
+
+    `fill(group, tower)` makes every key of one group of reference views available and PINS them in `self.group` until the next
+    `fill`: eviction only ever removes entries that the current group does not use, and `get` reads the pinned dict, so a key
+    that was a hit when the group was formed cannot disappear before the group's last reference view has read it (round 3's FIFO
+    of 256 entries evicted while it inserted: a session whose covisibility lists reach back more than `limit` images -- loop
+    closures, score-ranked pair.txt -- raised KeyError outside the per-view try / except and ended the whole run)."""
+
+    def __init__(self, limit=256):
+        from collections import OrderedDict
+        self.limit = max(1, int(limit))
+        self.entries = OrderedDict()
+        self.group = {}
+        self.hits = self.misses = 0
+
+    def fill(self, keyed_images, tower):
+        """keyed_images: iterable of (key, image) over all views of the group (repeats allowed); tower(list of images) ->
+        indexable batch of feature maps, called once for the images the cache misses."""
+        self.group = {}
+        need = {}
+        for k_, img in keyed_images:
+            if k_ in self.group or k_ in need:
+                continue
+            if k_ in self.entries:
+                self.entries.move_to_end(k_)
+                self.group[k_] = self.entries[k_]
+                self.hits += 1
+            else:
+                need[k_] = img
+                self.misses += 1
+        if need:
+            fb = tower(list(need.values()))
+            for j, k_ in enumerate(need):
+                self.group[k_] = self.entries[k_] = fb[j]
+        while len(self.entries) > self.limit:                    # oldest first; the group's own keys are the newest
+            self.entries.popitem(last=False)
+
+    def get(self, keys):
+        return [self.group[k_] for k_ in keys]
+
+
 # Pinned host buffers are expensive to create (~1.5 ms each) and cheap to keep: the staging buffers of the uploads and the result
 # buffers of the downloads live for the process, not for one compute_depth_maps call (a session is one call).
 _PINNED_STAGING = {}
 _PINNED_RESULTS = {}
 
 
-def compute_depth_maps(input_dir, config=None, weights=None, device=None, timings=None, gru_views=4, **kwargs):
+def compute_depth_maps(input_dir, config=None, weights=None, device=None, timings=None, gru_views=4,
+                       feature_cache_limit=256, **kwargs):
     """mvsnet/inference.py:83-119.  Returns the number of depth maps this rank wrote.
 
     `timings` (a dict) receives the stage breakdown of the run in seconds: wall, load (decode + resize + crop + centre on the
@@ -123,7 +166,7 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     # every source image of every cluster (model.py:392-406); an image's features only depend on
     # the image and on the (rescale, crop) it received, so they are computed once per session and
     # re-used by all the reference views that list the image as a source.
-    feature_cache = {}
+    feature_cache = FeatureCache(feature_cache_limit)
     done = 0
     # Host pipeline: like the reference, whose generator runs in a tf.data thread with a prefetch buffer
     # (predictlib.py:48-51), image loading / resizing of the next clusters and the file writes of the previous ones run
@@ -185,21 +228,12 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     def prefetch_features(group):
         """The images of these reference views that the cache misses go through the towers as ONE batch (a tower pass is ~31
         launches on a ~25 us floor each: one image costs nearly as much as sixteen)."""
-        need = {}
-        for c_, res_ in group:
-            for v, k_ in enumerate(keys_of(c_, res_[1])):
-                if k_ not in feature_cache and k_ not in need:
-                    need[k_] = res_[1][v]
-        if need:
-            fb = weights.unet(images_to_device(need.values()))
-            for j, k_ in enumerate(need):
-                while len(feature_cache) >= 256:
-                    feature_cache.pop(next(iter(feature_cache)))
-                feature_cache[k_] = fb[j]
+        feature_cache.fill(((k_, res_[1][v]) for c_, res_ in group for v, k_ in enumerate(keys_of(c_, res_[1]))),
+                           lambda imgs: weights.unet(images_to_device(imgs)))
 
     def features_of(c, in_images):
-        """(N,H/4,W/4,C) of one reference view from the per-image cache (filled by prefetch_features)."""
-        return torch.stack([feature_cache[k_] for k_ in keys_of(c, in_images)]).contiguous()
+        """(N,H/4,W/4,C) of one reference view from the per-image cache (pinned for the group by prefetch_features)."""
+        return torch.stack(feature_cache.get(keys_of(c, in_images))).contiguous()
 
     pinned = _PINNED_RESULTS                          # shape -> free pinned (depth, prob) buffer pairs, re-used across reference views
 
@@ -380,6 +414,8 @@ def main(argv=None):
                     help="run the whole input this many times and report all passes after the first together (throughput "
                          "measurements: the first pass pays plans, code objects and pinned buffers)")
     args = ap.parse_args(argv)
+    if not (1 <= args.gru_views <= 8):                         # MVS_GRU_MAX_VIEWS of the library (mvs_gru_wta_batch_f32)
+        ap.error("--gru_views must be 1..8 (reference views per recurrent sweep)")
     logging.basicConfig(level=os.environ.get("LOG_LEVEL", "INFO"))
     if args.procs_per_gpu > 1 and args.regularization == "GRU":
         # measured (round 3, 160x128, D = 192): 165 depth maps/s with one process, 53 with three -- the recurrent sweep is a
@@ -391,9 +427,9 @@ def main(argv=None):
     if n_ranks > 1 and "WORLD_SIZE" not in os.environ:         # before anything touches the GPU: the parent stays GPU-less
         import sys
         if args.procs_per_gpu > 1:                             # ranks share GPUs: RCCL wants one GPU per rank
-            os.environ["MVS_ALLOW_SHARED_GPU"] = "1"
             os.environ["MVS_DIST_BACKEND"] = "gloo"
-        raise SystemExit(sh.launch_ranks(list(sys.argv[1:] if argv is None else argv), n_ranks, module="mvsnet_amd.inference"))
+        raise SystemExit(sh.launch_ranks(list(sys.argv[1:] if argv is None else argv), n_ranks, module="mvsnet_amd.inference",
+                                         gpus=max(1, args.gpus)))
     weights_path = args.weights
     for name in vars(cfg):
         setattr(cfg, name, getattr(args, name))
@@ -422,10 +458,12 @@ def main(argv=None):
         wall = time.perf_counter() - t0
     counts = sh.gather_counts(dist, total, device=device if dist is not None else "cpu")
     walls = sh.gather_counts(dist, wall, device=device if dist is not None else "cpu")
+    devs = sh.gather_counts(dist, device.index, device=device if dist is not None else "cpu")      # the GPU each rank was bound to
     if rank == 0:
         import json
         logger.info("all dense finished: %d depth maps (%s per rank)", int(sum(counts)), counts)
         print(json.dumps({"depth_maps": int(sum(counts)), "ranks": len(counts), "procs_per_gpu": args.procs_per_gpu,
+                          "devices": [int(x) for x in devs],
                           "seconds_slowest_rank": max(walls), "depth_maps_per_s": sum(counts) / max(max(walls), 1e-9),
                           "sec_per_step": max(walls) / max(sum(counts), 1), "passes": max(1, args.passes)}), flush=True)
     if dist is not None:

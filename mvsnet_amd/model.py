@@ -313,6 +313,8 @@ class DepthPlan:
         self.weights = weights
         self.regularization = regularization
         self.views = int(views)
+        if not (1 <= self.views <= 8):
+            raise ValueError("views must be 1..8 (mvs_gru_wta_batch_f32 takes at most 8 reference views per sweep)")
         if self.views != 1 and regularization != "GRU":
             raise NotImplementedError("views > 1 is the recurrent sweep's batch of reference views")
         dev = torch.device(device)

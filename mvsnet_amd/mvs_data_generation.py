@@ -226,6 +226,13 @@ class ClusterGenerator:
         self.max_clusters_per_session = max_clusters_per_session
         self.flip_cams = flip_cams
         self.clusters = []
+        # per-image cache of the inference path (_prepare_cached), shared by the loader threads: created HERE, not lazily
+        # from the threads (a thread could see the cache before the lock existed); image sizes (never evicted, a tuple per
+        # image) live apart from the decoded images (LRU of `image_cache_limit` entries)
+        import collections
+        import threading
+        self._img_cache, self._img_sizes, self._img_lock = collections.OrderedDict(), {}, threading.Lock()
+        self.image_cache_limit = 192
         if mode in ("train", "val"):
             sessions_dir = os.path.join(data_dir, mode)
             sessions = sorted(f for f in os.listdir(sessions_dir)
@@ -273,13 +280,10 @@ class ClusterGenerator:
         """Inference mode: what prepare() does per image -- decode, rescale, crop, centre, output-scale -- depends only on the
         image file and on (rescale, crop window), so it is kept per image across the reference views of a session that list
         the image as a source (the reference decodes and resizes every image once per cluster, cluster_generator.py:234-286).
-        Same values as the uncached path; an LRU of 64 images per generator, shared by the loader threads.
+        Same values as the uncached path; an LRU of `image_cache_limit` (192) images per generator, shared by the loader threads.
         center=False: the input images come back as cropped uint8 BGR (N,H,W,3) and the caller standardises them (on the
         device, inference.center_images_device): a quarter of the bytes to upload and no 1.3 M-element float32 reductions per image
         on the loader threads."""
-        import threading
-        if not hasattr(self, "_img_cache"):
-            self._img_cache, self._img_lock = {}, threading.Lock()
         raw = {}
 
         def raw_image(i):
@@ -290,11 +294,11 @@ class ClusterGenerator:
         sizes = []
         for i in c.indices:
             with self._img_lock:
-                hit = self._img_cache.get(("size", c.session_dir, i))
+                hit = self._img_sizes.get((c.session_dir, i))
             if hit is None:
                 hit = raw_image(i).shape
                 with self._img_lock:
-                    self._img_cache[("size", c.session_dir, i)] = hit
+                    self._img_sizes[(c.session_dir, i)] = hit
             sizes.append(hit)
         c.original_image_shape = sizes[0]
         c.rescale = max(max(float(self.image_height) / s_[0] for s_ in sizes), max(float(self.image_width) / s_[1] for s_ in sizes))
@@ -304,15 +308,16 @@ class ClusterGenerator:
             key = (c.session_dir, i, round(float(c.rescale), 12), bool(center))
             with self._img_lock:
                 hit = self._img_cache.get(key)
+                if hit is not None:
+                    self._img_cache.move_to_end(key)
             if hit is None:
                 im, _ = scale_mvs_input([raw_image(i)], [cams[v]], scale=c.rescale)
                 cr, _ = crop_mvs_input(im, [cams[v]], self.image_width, self.image_height, self.base_image_size)
                 hit = (center_image(cr[0]) if center else np.ascontiguousarray(cr[0]), scale_image(cr[0], self.output_scale))
                 with self._img_lock:
-                    if len(self._img_cache) >= 192:
-                        for k_ in [k_ for k_ in self._img_cache if k_[0] != "size"][:32]:
-                            self._img_cache.pop(k_, None)
                     self._img_cache[key] = hit
+                    while len(self._img_cache) > self.image_cache_limit:
+                        self._img_cache.popitem(last=False)
             _, cm = scale_mvs_input([], [cams[v]], scale=c.rescale)
             # crop_mvs_input only shifts the principal point by the crop offset: recompute it for the camera from the size
             h0, w0 = int(round(sizes[v][0] * c.rescale)), int(round(sizes[v][1] * c.rescale))

@@ -38,19 +38,32 @@ def bind_device(local_rank=None):
     if local_rank is None:
         local_rank = rank_world()[1]
     n = torch.cuda.device_count()
-    if n > 0 and os.environ.get("MVS_ALLOW_SHARED_GPU"):      # rehearsing the multi-process path on a box with fewer GPUs
-        local_rank = local_rank % n
+    local_rank = device_index_of(local_rank, n)
     if not (0 <= local_rank < n):
         raise RuntimeError("local rank %d needs cuda:%d but only %d GPU(s) are visible" % (local_rank, local_rank, n))
     torch.cuda.set_device(local_rank)
     return torch.device("cuda", local_rank)
 
 
-def launch_ranks(script_args, n_ranks, module=None):
+def device_index_of(local_rank, n_visible):
+    """The GPU index local rank `local_rank` drives.  MVS_GPUS=G (set by launch_ranks for --procs_per_gpu P > 1: G x P ranks)
+    folds the ranks onto the FIRST G devices, ranks r, r+G, r+2G, ... sharing GPU r -- not onto however many devices the node
+    happens to show (round 3 took `% device_count`, so `--gpus 1 --procs_per_gpu 3` on an 8-GPU node used GPUs 0, 1 and 2).
+    MVS_ALLOW_SHARED_GPU additionally folds onto the visible devices (rehearsing N ranks on a box with fewer GPUs)."""
+    g = int(os.environ.get("MVS_GPUS", "0") or 0)
+    if g > 0:
+        local_rank = local_rank % g
+    if n_visible > 0 and os.environ.get("MVS_ALLOW_SHARED_GPU"):
+        local_rank = local_rank % n_visible
+    return local_rank
+
+
+def launch_ranks(script_args, n_ranks, module=None, gpus=None):
     """Starts `n_ranks` one-GPU worker processes of `script_args` (or of `-m module`) under torch.distributed.run on this
     node and returns its exit code (non-zero when any rank failed).  For entry points started plainly as
     `python bench.py --gpus N` / `python -m mvsnet_amd.inference --gpus N`: the caller must not have touched the GPU
-    (the parent stays GPU-less, every rank binds its own device), the ranks inherit stdout / stderr, rank 0 prints."""
+    (the parent stays GPU-less, every rank binds its own device), the ranks inherit stdout / stderr, rank 0 prints.
+    `gpus` < n_ranks: several ranks per GPU on the first `gpus` devices (MVS_GPUS, see device_index_of)."""
     import socket
     import subprocess
     import sys
@@ -62,6 +75,8 @@ def launch_ranks(script_args, n_ranks, module=None):
     cmd += (["-m", module] if module else []) + list(script_args)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    if gpus is not None and 0 < int(gpus) < int(n_ranks):
+        env["MVS_GPUS"] = str(int(gpus))
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // int(n_ranks))))
     return subprocess.call(cmd, env=env)
 

@@ -141,23 +141,32 @@ def softargmin_prob(reg, depth_start, depth_interval):
     return depth, g(l0) + g(r0) + g(l1) + g(r1)
 
 
-def _transforms(cams, depth_num, depth_start, depth_interval, npdt):
-    """fp32: the reference's fp32 homography algebra; fp64: the strict oracle's."""
+def _transforms(cams, depth_num, depth_start, depth_interval, npdt, inverse_depth=False):
+    """fp32: the reference's fp32 homography algebra; fp64: the strict oracle's.  inverse_depth: R1'
+    (homography_warping.py:60-106) with end = start + (D-1)*interval as model.py:378-379,439-441 pass it."""
     N = cams.shape[0]
-    Hs = np.stack([O.get_homographies(cams[0], cams[v], depth_num, depth_start, depth_interval, npdt)
-                   for v in range(1, N)])
+    if inverse_depth:
+        end = npdt(depth_start) + (npdt(depth_num) - npdt(1)) * npdt(depth_interval)
+        Hs = np.stack([O.get_homographies_inv_depth(cams[0], cams[v], depth_num, depth_start, end, npdt)
+                       for v in range(1, N)])
+    else:
+        Hs = np.stack([O.get_homographies(cams[0], cams[v], depth_num, depth_start, depth_interval, npdt)
+                       for v in range(1, N)])
     return O.homography_to_transform8(Hs, npdt)
 
 
 @torch.no_grad()
 def inference_mem_from_features(features, cams, depth_num, depth_start, depth_interval, regnet_params,
-                                dtype=torch.float32):
-    """Same contract as mvsnet_oracle.inference_mem_from_features (non-inverse depth), all host cores.
+                                dtype=torch.float32, inverse_depth=False):
+    """Same contract as mvsnet_oracle.inference_mem_from_features, all host cores.  With inverse_depth the
+    soft-argmin / four-bucket tail (model.py:480-485,83-107) is the strict numpy oracle's own (vectorised, seconds).
     Returns numpy depth (H,W), prob (H,W) in `dtype`."""
     N = features.shape[0]
-    T = _transforms(cams, depth_num, depth_start, depth_interval, _NP[dtype])
+    T = _transforms(cams, depth_num, depth_start, depth_interval, _NP[dtype], inverse_depth)
     cost = cost_volume(features, T, N, dtype)
     reg = regnet_us0(cost, regnet_params)
+    if inverse_depth:
+        return O.softargmin_and_prob(reg.numpy(), int(depth_num), depth_start, depth_interval, True, _NP[dtype])
     depth, prob = softargmin_prob(reg, depth_start, depth_interval)
     return depth.numpy(), prob.numpy()
 

@@ -53,16 +53,16 @@ def full(names):
                                 input_sha256=sha, **extra)
             print("wrote full_c1img.npz in %.0f s: %s" % (time.time() - t0, extra), flush=True)
             continue
-        inverse = name == "c3inv"                # configs[2] with --inverse_depth (R1' / model.py:706-713): same inputs as c3
-        w = S.make_workload("c3" if inverse else name)
+        inverse = name in ("c3inv", "Minv")      # --inverse_depth (R1'; model.py:706-713 for the sweep, :480-485,83-107 for the 3D-CNN tail): inputs of c3 / M
+        w = S.make_workload({"c3inv": "c3", "Minv": "M"}.get(name, name))
         sha = hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest()
         t0 = time.time()
         if not name.startswith("c3"):
             rp = S.make_regnet_params("normal", seed=1, random_affine=True)
             d, p = TR.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start, w.depth_interval,
-                                                  rp, torch.float64)
+                                                  rp, torch.float64, inverse)
             d32, p32 = TR.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start,
-                                                      w.depth_interval, rp, torch.float32)
+                                                      w.depth_interval, rp, torch.float32, inverse)
             extra = dict(f32_cpu_abs_rel=abs_rel(d32, d), f32_cpu_prob_mismatch=float((np.abs(p32 - p) > 1e-3).mean()))
         else:
             gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
@@ -82,7 +82,7 @@ def full(names):
 
 def main():
     if "--full" in sys.argv:
-        names = [a for a in sys.argv[1:] if a in S.WORKLOADS or a in ("c3inv", "c1img")]
+        names = [a for a in sys.argv[1:] if a in S.WORKLOADS or a in ("c3inv", "c1img", "Minv")]
         return full(names or ["c1", "M", "c2", "c3"])
     w = S.make_workload("toy")
     sha = hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest()

@@ -227,3 +227,78 @@ def test_launch_ranks_starts_the_ranks_and_returns_their_exit_code(tmp_path):
     bad = tmp_path / "bad.py"
     bad.write_text("import os, sys\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
     assert launch_ranks([str(bad)], 2) != 0
+
+
+def test_eight_ranks_plumbing_over_gloo(tmp_path):
+    """SURVEY 8e at the node's size: 8 ranks started by shard.launch_ranks (free port, 127.0.0.1), gloo group, round-robin shard
+    of config 4's 1078 reference views (22 scans x 49 views), the per-rank gathers and object gather bench.py's record uses,
+    8 ranks x 3 processes per GPU folded onto the first 8 devices (MVS_GPUS), and the exit code of ONE failing rank among 8.
+    (The GPU box admits at most 6 processes on its card, so the 8-rank case is rehearsed here on the CPU; the GPU suite runs
+    bench.py with 5 ranks on one card, tests/test_gpu_pipeline.py.)"""
+    from mvsnet_amd.shard import launch_ranks
+    ok = tmp_path / "ok8.py"
+    ok.write_text(
+        "import os, sys, json\nsys.path.insert(0, %r)\nfrom mvsnet_amd import shard as sh\nimport torch\n"
+        "dist = sh.init_process_group('gloo')\nr, l, w = sh.rank_world()\nassert w == 8 and l == r\n"
+        "mine = sh.shard(list(range(1078)), r, w)\ncounts = sh.gather_counts(dist, len(mine))\n"
+        "t = torch.tensor([0.5 + 0.01 * r], dtype=torch.float64)\ndist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "devs = [None] * w\ndist.all_gather_object(devs, {'rank': r, 'device_index': sh.device_index_of(l, 8)})\ndist.barrier()\n"
+        "if r == 0:\n    open(os.path.join(%r, 'rec.json'), 'w').write(json.dumps({'counts': counts, 'max': float(t), 'devs': devs}))\n"
+        "dist.destroy_process_group()\n" % (ROOT, str(tmp_path)))
+    assert launch_ranks([str(ok)], 8) == 0
+    rec = json.loads(open(tmp_path / "rec.json").read())
+    assert rec["counts"] == [135.0] * 6 + [134.0] * 2 and sum(rec["counts"]) == 1078        # ~135 reference views per GPU
+    assert abs(rec["max"] - 0.57) < 1e-12
+    assert [d["device_index"] for d in rec["devs"]] == list(range(8)) and [d["rank"] for d in rec["devs"]] == list(range(8))
+    bad = tmp_path / "bad8.py"
+    bad.write_text("import os, sys, time\ntime.sleep(0.2)\nsys.exit(3 if os.environ['RANK'] == '5' else 0)\n")
+    assert launch_ranks([str(bad)], 8) != 0
+
+
+def test_processes_per_gpu_fold_onto_the_requested_gpus_not_onto_all_visible(monkeypatch):
+    """`--gpus G --procs_per_gpu P` starts G x P ranks; rank r drives GPU r mod G whatever the node shows (round 3
+    took r mod device_count: `--gpus 1 --procs_per_gpu 3` on an 8-GPU node spread over GPUs 0, 1, 2)."""
+    from mvsnet_amd import shard as sh
+    monkeypatch.delenv("MVS_ALLOW_SHARED_GPU", raising=False)
+    monkeypatch.setenv("MVS_GPUS", "1")
+    assert [sh.device_index_of(r, 8) for r in range(3)] == [0, 0, 0]
+    monkeypatch.setenv("MVS_GPUS", "2")
+    assert [sh.device_index_of(r, 8) for r in range(6)] == [0, 1, 0, 1, 0, 1]
+    monkeypatch.delenv("MVS_GPUS")
+    assert [sh.device_index_of(r, 8) for r in range(8)] == list(range(8))
+    assert sh.device_index_of(3, 1) == 3                                 # no folding without the rehearsal switch: bind_device refuses
+    monkeypatch.setenv("MVS_ALLOW_SHARED_GPU", "1")
+    assert [sh.device_index_of(r, 1) for r in range(8)] == [0] * 8
+    # launch_ranks hands MVS_GPUS to its ranks only when ranks share GPUs
+    import subprocess
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(env=env, cmd=cmd) or 0)
+    monkeypatch.delenv("MVS_GPUS", raising=False)
+    assert sh.launch_ranks(["x.py"], 6, gpus=2) == 0 and seen["env"]["MVS_GPUS"] == "2" and "6" in seen["cmd"]
+    assert sh.launch_ranks(["x.py"], 8, gpus=8) == 0 and "MVS_GPUS" not in seen["env"]
+    assert sh.launch_ranks(["x.py"], 8) == 0 and "MVS_GPUS" not in seen["env"]
+
+
+def test_feature_cache_never_evicts_a_key_of_the_group_in_hand():
+    """the per-image feature cache is a true LRU whose limit may be SMALLER than one group's key set; keys that were
+    hits when the group was formed stay readable until the next group (round 3: FIFO eviction during insertion -> KeyError)."""
+    from mvsnet_amd.inference import FeatureCache
+    calls = []
+
+    def tower(imgs):
+        calls.append(list(imgs))
+        return ["F(%s)" % i for i in imgs]
+    c = FeatureCache(limit=4)
+    c.fill([(k, "img%d" % k) for k in (0, 1, 2, 3)], tower)
+    assert calls == [["img0", "img1", "img2", "img3"]] and c.get([3, 0]) == ["F(img3)", "F(img0)"]
+    # group 2: hits 0 and 1 (old entries, first in line for eviction), misses 4..8 -- more keys than the limit
+    c.fill([(k, "img%d" % k) for k in (0, 1, 4, 5, 6, 7, 8, 0, 4)], tower)
+    assert calls[1] == ["img4", "img5", "img6", "img7", "img8"]                       # one tower pass, misses only, no repeats
+    assert c.get([0, 1, 4, 5, 6, 7, 8]) == ["F(img%d)" % k for k in (0, 1, 4, 5, 6, 7, 8)]
+    assert len(c.entries) == 4 and list(c.entries) == [5, 6, 7, 8]                    # newest kept
+    # LRU, not FIFO: a hit refreshes the entry
+    c.fill([(5, "img5")], tower)
+    c.fill([(9, "img9")], tower)
+    assert list(c.entries) == [7, 8, 5, 9] and c.hits == 3 and c.misses == 10
+    with pytest.raises(KeyError):
+        c.get([6])                                                                     # not part of the group in hand

@@ -7,10 +7,18 @@ by tests/golden/make_golden.py --full from oracle/torch_restatement.py in float6
 at ~1e-15 by tests/test_cpu_restatement.py); each records the SHA-256 of its inputs and how far the float32 CPU
 restatement lands from it (the rounding-noise floor).  Tolerances (round 3: the noise floor, not north_star's 1e-3): depth abs-rel <= 3 x what the
 float32 CPU restatement lands at (~5e-7 .. 8e-7), probability map within 1e-3 except on <= max(3 x the CPU's fraction, 5e-4)
-of the pixels (the four-bucket sum jumps where the depth index crosses an integer), no pixel off by more than 1e-4; recurrent
-path: winning plane equal on >= 99.95 % of the pixels, on the agreeing ones the probability max(exp)/sum(exp) within
-2 x the float32 CPU restatement's own worst distance (6.5e-4: 256 planes of recurrent float32 state) and 5e-5 on average;
-the same with inverse depth (full_c3inv.npz).
+of the pixels (the four-bucket sum jumps where the depth index crosses an integer), no pixel off by more than 1e-4 (measured
+5e-6 .. 1.1e-5); the 3D-CNN path with inverse depth (full_Minv.npz: R1' + the inverse soft-argmin / bucket tail,
+model.py:480-485,83-107) under the same rule.  Recurrent path: winning plane equal on >= 99.95 % of the pixels, on the agreeing
+ones the probability max(exp)/sum(exp) within 2 x the float32 CPU restatement's own worst distance (6.5e-4: 256 planes of
+recurrent float32 state) and 5e-5 on average; the same with inverse depth (full_c3inv.npz).
+
+Why 2 x for the sweep: the worst-pixel distance after 256 recurrent planes is a tail statistic of float32 SUMMATION ORDER, not
+of the arithmetic's quality: the CPU restatement (one 48-channel im2col GEMM per convolution) lands at 6.5e-4, the device (x part
+and h part in separate accumulators, MFMA k-groups of 4) at 1.17e-3 with the libm-exact activations and with the fast ones alike
+(DESIGN 2), while the MEAN distance is 1.9e-5 for both.  2 x the CPU's own worst distance is therefore "the same noise
+distribution, another draw" (a wrong tap, a dropped halo or a wrong LayerNorm moment moves the mean by orders of magnitude and
+fails the 5e-5 mean bound and the plane agreement first); the test prints the margin so a drift towards the bound is visible.
 """
 import hashlib
 import os
@@ -37,14 +45,22 @@ def fixture(name):
     return w, g
 
 
-@pytest.mark.parametrize("name", ["c1", "M", "c2"])
+@pytest.mark.parametrize("name", ["c1", "M", "c2", "Minv"])
 def test_3dcnn_depth_and_probability_match_the_fixture(lib_built, name):
+    """Minv = the metric workload through inference_mem(inverse_depth=True): planes uniform in 1/depth (R1'), soft-argmin over
+    1/linspace(1/start, 1/end, D) and the inverse four-bucket index arithmetic (model.py:480-485,83-107)."""
     from mvsnet_amd.model import MVSNetWeights, inference_mem
-    w, g = fixture(name)
+    inverse = name == "Minv"
+    if inverse:
+        g = np.load(os.path.join(GOLDEN, "full_Minv.npz"))
+        w = S.make_workload("M")
+        assert hashlib.sha256(w.features.tobytes() + w.cams.tobytes()).hexdigest() == str(g["input_sha256"])
+    else:
+        w, g = fixture(name)
     rp = S.make_regnet_params("normal", seed=1, random_affine=True)
     weights = MVSNetWeights.from_numpy("normal", regnet=rp, device=DEV)
     depth, prob = inference_mem(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_interval,
-                                weights=weights, features=t(w.features))
+                                inverse_depth=inverse, weights=weights, features=t(w.features))
     d = depth.cpu().numpy()[0, :, :, 0].astype(np.float64)
     p = prob.cpu().numpy()[0, :, :, 0].astype(np.float64)
     assert d.shape == (w.height, w.width)
@@ -58,7 +74,7 @@ def test_3dcnn_depth_and_probability_match_the_fixture(lib_built, name):
     assert mismatch <= max(3.0 * float(g["f32_cpu_prob_mismatch"]), 5e-4), mismatch
     worst = float(np.max(np.abs(d - g["depth"]) / g["depth"]))
     print("%s: worst pixel %.3e" % (name, worst))
-    assert worst < 1e-3, worst                                             # no stray pixel (a wrong tile would be O(1))
+    assert worst < 1e-4, worst                                             # no stray pixel (a wrong tile would be O(1)); measured 5e-6 .. 1.1e-5
 
 
 def check_sweep(tag, w, g, depth, prob):
@@ -71,6 +87,8 @@ def check_sweep(tag, w, g, depth, prob):
     rel = np.abs(p[same] - g["prob"][same]) / g["prob"][same]
     print("%s: plane agreement %.5f (float32 CPU restatement: %.5f), prob rel max %.3e mean %.3e (CPU max %.3e)"
           % (tag, agree, float(g["f32_cpu_plane_agreement"]), float(rel.max()), float(rel.mean()), float(g["f32_cpu_prob_rel"])))
+    bound = 2.0 * float(g["f32_cpu_prob_rel"])
+    print("%s: worst-pixel margin: %.3e of the %.3e allowed (%.0f %% used)" % (tag, float(rel.max()), bound, 100.0 * float(rel.max()) / bound))
     assert agree >= 0.9995, agree
     assert float(rel.max()) <= 2.0 * float(g["f32_cpu_prob_rel"]) and float(rel.mean()) < 5e-5, (float(rel.max()), float(rel.mean()))
     return d, p
