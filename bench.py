@@ -403,6 +403,8 @@ def main():
                          "MVS_ALLOW_SHARED_GPU=1 rehearses the multi-process path on fewer)" % (args.gpus, world, ndev))
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    if os.environ.get("MVS_BENCH_FAIL_RANK") == str(rank):     # test hook: one rank of N dies before the rendezvous -> the
+        raise SystemExit("rank %d: MVS_BENCH_FAIL_RANK" % rank)  # launcher tears the others down and the exit code is non-zero
     dev_index = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)

@@ -10,7 +10,11 @@
  *   - every pointer is a DEVICE pointer owned by the caller unless marked [host];
  *   - tensors are float32, channel-last, contiguous: images (H,W,C), volumes (D,H,W,C);
  *   - functions enqueue kernels on `stream` (a hipStream_t passed as void*; NULL = default
- *     stream); they never allocate, never free, never synchronise;
+ *     stream); they never allocate, never free, never synchronise, never create streams or events -- so a
+ *     whole pass captures into a hipGraph.  The exceptions are named where they are declared and are all set-up /
+ *     tear-down / diagnostic calls, never compute calls: mvs_gru_prepare and mvs_gru_release (create / destroy the
+ *     recurrent sweep's side streams and events, synchronise), and the profiling read-outs mvs_profile_dominant_ms /
+ *     mvs_profile_layers_ms (wait for their timing events);
  *   - return value: 0 on success, a positive hipError_t on a HIP failure, a negative
  *     MVS_E_* code on an argument error.  Nothing throws.
  */
@@ -28,7 +32,9 @@ extern "C" {
 
 #define MVS_E_BADARG   (-1)   /* null pointer / non-positive size                         */
 #define MVS_E_SHAPE    (-2)   /* shape not supported by this build (see function comment) */
-#define MVS_E_WORKSPACE (-3)  /* workspace too small                                      */
+#define MVS_E_WORKSPACE (-3)  /* workspace too small (mvs_gru_prepare: all 16 stream sets in use) */
+#define MVS_E_NOT_PREPARED (-4) /* mvs_gru_prepare on a stream under hipGraph capture (it synchronises);
+                                   mvs_gru_stream_layout on a stream without a set */
 
 /* Regulariser implementation selector (mvs_set_conv_impl): the MFMA path is the product;
  * the scalar path is a slow, shape-generic HIP cross-check (never a CPU fallback). */
@@ -277,9 +283,17 @@ int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, int H, int W
  *            out_w, out_b, out_gamma, out_beta   (10 each), then prob_w, prob_b
  *   depth_values [host] depth_num floats (depth of plane d, model.py:706-715)
  *   filters (f1,f2,f3): ConvGRU filter counts (16,4,2 for 'normal')
- * The sweep is a wavefront over (plane, cell) on library-owned side streams forked from / joined to `stream`
- * (one set per caller stream, created on first use); the workspace holds a batch of 16 cost slices, two batches of
- * the hoisted x-part of cell 1 and 8-plane state rings: ~1.0 GB at 400 x 300, C = 32 (mvs_gru_workspace_bytes).
+ * The sweep is a wavefront over (plane, cell) on library-owned side streams forked from / joined to `stream`: the set
+ * mvs_gru_prepare(stream) created for this caller stream.  The sweep itself creates nothing and never synchronises:
+ *   - prepared stream: wavefront on four streams;
+ *   - stream without a set: the same sweep on `stream` alone (same winning planes, ~1.7x the time at 400 x 300), one note on
+ *     stderr per process;
+ *   - `stream` under hipGraph capture: always the one-stream form (prepared or not) -- capturing the cross-stream wavefront
+ *     crashes hipStreamEndCapture of ROCm 7.2 on the host (profiles/r04_gru_wavefront_capture_segfault.log); the captured
+ *     sweep replays to the eager sweep's depth map (tests/test_gpu_pipeline.py);
+ *   - every exit after the fork, error returns included, first makes `stream` wait for the side streams.
+ * The workspace holds a batch of 16 cost slices, two batches of the hoisted x-part of cell 1 and 16-plane state rings:
+ * ~1.0 GB at 400 x 300, C = 32 (mvs_gru_workspace_bytes).
  */
 size_t mvs_gru_workspace_bytes(int H, int W, int C, int f1, int f2, int f3);
 int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms, int view_num,
@@ -302,14 +316,26 @@ int mvs_gru_wta_batch_f32(const float* const* ref, const float* const* src, cons
                           int f3, const float* const* params, const float* depth_values, void* workspace,
                           size_t workspace_bytes, float* depth_out, float* prob_out, void* stream);
 
+/* Set-up of the recurrent sweep for caller stream `stream` on the current device: three side streams, ~30 events, and ONE
+ * ~10-30 ms calibration that finds the compute pipe the caller's hardware queue lives on (csrc/gru.hip) so that the
+ * side streams avoid it.  THE call of this header that creates resources and synchronises (`stream` and the new streams):
+ * call it once per caller stream at start-up (DepthPlan(..., "GRU") does), never inside a latency-critical region or under
+ * hipGraph capture (returns MVS_E_NOT_PREPARED there).  Idempotent.  An inconclusive calibration is reported once on stderr and
+ * the set is still usable.  At most 16 sets per process (MVS_E_WORKSPACE beyond; mvs_gru_release frees one).  Thread-safe. */
+int mvs_gru_prepare(void* stream);
+/* Tear-down: waits for the set's side streams, destroys them and their events (MVS_E_BADARG: no set for this stream).  Call it
+ * before destroying `stream` -- a later stream may receive the same handle on another hardware queue. */
+int mvs_gru_release(void* stream);
+
 /* Formulation of the first ConvGRU cell on the MFMA kernels (csrc/gru.hip): 0 = chosen by view count (default), 1 = hoisted
  * x-part (batched producer launches + 16-channel per-plane kernels), 2 = full 48-channel per-plane kernels.  Same results bit
- * for bit; a tuning / test switch (process-wide, not thread-safe against concurrent sweeps). */
+ * for bit; a tuning / test switch.  Process-wide atomic, read once at the start of each sweep: a sweep keeps the formulation it
+ * started with whatever other threads set meanwhile. */
 int mvs_gru_set_formulation(int form);
 
-/* Diagnostic: the side-stream layout the sweep uses for caller stream `stream` (created and calibrated on first use,
- * csrc/gru.hip): *pipe_of_caller = which of the four candidate pipes the caller's hardware queue was measured on (-1: none
- * stood out), probe_us[8] = the calibration chain times of the eight candidate streams (4 high-, 4 low-priority). */
+/* Diagnostic: the side-stream layout of the set mvs_gru_prepare made for `stream` (MVS_E_NOT_PREPARED without one):
+ * *pipe_of_caller = which of the four candidate pipes the caller's hardware queue was measured on (-1: none stood out),
+ * probe_us[8] = the calibration chain times of the eight candidate streams (4 high-, 4 low-priority). */
 int mvs_gru_stream_layout(void* stream, int* pipe_of_caller, float* probe_us);
 
 /* ---------------------------------------------------------------------------------------------

@@ -84,6 +84,8 @@ SIGNATURES = {
     "mvs_gru_wta_f32": (_i, [_p, _p, _p] + [_i] * 8 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
     "mvs_gru_wta_batch_f32": (_i, [_pp, _pp, _pp] + [_i] * 9 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
     "mvs_gru_set_formulation": (_i, [_i]),
+    "mvs_gru_prepare": (_i, [_p]),
+    "mvs_gru_release": (_i, [_p]),
     "mvs_gru_stream_layout": (_i, [_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }
 
@@ -148,6 +150,28 @@ def f32(t, name="tensor"):
 
 def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_GRU_PREPARED = set()          # (device index, stream handle) pairs mvs_gru_prepare has run for in this process
+
+
+def gru_prepare():
+    """mvs_gru_prepare for torch's CURRENT stream of the current device, once per (device, stream): the only call of the
+    recurrent path that creates streams / events and synchronises (include/mvsnet_hip.h).  Skipped under hipGraph capture:
+    a captured sweep runs on the capture stream alone and needs no set."""
+    key = (torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
+    if key in _GRU_PREPARED or torch.cuda.is_current_stream_capturing():
+        return
+    check(load().mvs_gru_prepare(stream_ptr()), "mvs_gru_prepare")
+    _GRU_PREPARED.add(key)
+
+
+def gru_release():
+    """mvs_gru_release for torch's current stream (before the stream object is dropped)."""
+    key = (torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
+    if key in _GRU_PREPARED:
+        _GRU_PREPARED.discard(key)
+        check(load().mvs_gru_release(stream_ptr()), "mvs_gru_release")
 
 
 def ptr_array(tensors):

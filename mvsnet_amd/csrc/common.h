@@ -27,6 +27,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __device__ __forceinline__ float relu(float v) { return v > 0.f ? v : 0.f; }
 
+// tf.sigmoid / tf.tanh (convgru.py:101-102,117) on the fast transcendental path (v_exp_f32 + v_rcp_f32, ~2 ulp), tanh in the
+// form that does not cancel near 0: t = e^{-2|x|}, (1 - t) / (1 + t) with the sign of x.  Round 3 measured them against libm
+// expf + IEEE divides in cell 1 of the recurrent sweep: the same distance from the float64 fixture (1.169e-3 vs 1.172e-3 worst
+// probability, plane agreement 0.99988 both) -- the distance is float32 summation order, not these forms.  Round 4: cells 2 / 3
+// and the blend kernel use them too (libm expf / tanhf / IEEE division were ~45 % of the small cells' vector instructions).
+__device__ __forceinline__ float mvs_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float mvs_tanh_fast(float x) {
+    const float t = __expf(-2.0f * fabsf(x));
+    return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+}
+
 // XCD-aware block remap (MI355X: 8 XCDs with private 4 MiB L2s, workgroups dealt round-robin over
 // them, so blocks b and b+8 share an L2).  Gives each XCD a contiguous run of the index space so that
 // neighbouring tiles (shared halos, overlapping warp footprints) hit the same L2.  Speed only; the

@@ -9,6 +9,7 @@
 // current cost slice (H*W*C) exists, never the (D,H,W,C) volume.
 #include "common.h"
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
@@ -238,35 +239,34 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
     // LayerNorm moments -> (mean, 1 / sqrt(var + eps)) ONCE per workgroup (two lanes, then LDS): every thread used to run the
     // float64 divisions and square roots itself, per channel -- ~1000 instruction slots per wave at the head of a kernel whose
     // own work is a few hundred (round 3: the four small-cell kernels 43 / 30 / 27 / 15 us per 4-view plane before)
-    __shared__ double lnp[2][2];
+    // Round 4: the per-channel (scale, shift) pairs too -- CB (MODE 2: 2 * CB) lanes do the float64 arithmetic, everybody reads
+    // the float results back as LDS broadcasts (every thread used to redo 4 * CB float64 multiplies and conversions)
+    __shared__ float lna[2][CB][2];
     if (MODE != 0) {
-        if (threadIdx.x < (MODE == 2 ? 2 : 1)) {
+        if (threadIdx.x < (MODE == 2 ? 2 * CB : CB)) {
+            const int k = threadIdx.x / CB, f = threadIdx.x - k * CB;       // k = 0: reset (MODE 1) / update (MODE 2) gate, 1: candidate
             const double cnt = (double)H * W * CB;
-            const double* st = MODE == 1 ? g_stats : (threadIdx.x == 0 ? bl_stats_u : bl_stats_c);
+            const double* st = MODE == 1 ? g_stats : (k == 0 ? bl_stats_u : bl_stats_c);
             const double mean = st[0] / cnt;
             double var = st[1] / cnt - mean * mean;
             if (var < 0.0) var = 0.0;
-            lnp[threadIdx.x][0] = mean;
-            lnp[threadIdx.x][1] = 1.0 / sqrt(var + 1e-12);          // tf.contrib.layers.layer_norm, eps 1e-12
+            const double rstd = 1.0 / sqrt(var + 1e-12);              // tf.contrib.layers.layer_norm, eps 1e-12
+            const float gamma = MODE == 1 ? r_gamma[f] : (k == 0 ? bl.ug[f] : bl.og[f]);
+            const float beta = MODE == 1 ? r_beta[f] : (k == 0 ? bl.ub[f] : bl.ob[f]);
+            const double inv = (double)gamma * rstd;
+            lna[k][f][0] = (float)inv; lna[k][f][1] = (float)((double)beta - mean * inv);
         }
         __syncthreads();
     }
-    auto affine = [&](int k, float gamma, float beta, float& sc, float& sh) {
-        const double inv = (double)gamma * lnp[k][1];
-        sc = (float)inv; sh = (float)((double)beta - lnp[k][0] * inv);
-    };
     float ra[CB], rb[CB];
     if (MODE == 1) {
 #pragma unroll
-        for (int f = 0; f < CB; ++f) affine(0, r_gamma[f], r_beta[f], ra[f], rb[f]);
+        for (int f = 0; f < CB; ++f) { ra[f] = lna[0][f][0]; rb[f] = lna[0][f][1]; }
     }
     float ua[CB], ub_[CB], ca[CB], cb_[CB];
     if (MODE == 2) {
 #pragma unroll
-        for (int f = 0; f < CB; ++f) {
-            affine(0, bl.ug[f], bl.ub[f], ua[f], ub_[f]);
-            affine(1, bl.og[f], bl.ob[f], ca[f], cb_[f]);
-        }
+        for (int f = 0; f < CB; ++f) { ua[f] = lna[0][f][0]; ub_[f] = lna[0][f][1]; ca[f] = lna[1][f][0]; cb_[f] = lna[1][f][1]; }
     }
     const int tiles_x = (W + TS - 1) / TS;
     const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
@@ -287,7 +287,7 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
                 float gr[CB];
                 load_vec<CB>(g + p * 2 * CB, gr);
 #pragma unroll
-                for (int i = 0; i < CB; ++i) vb[i] *= 1.0f / (1.0f + expf(-(gr[i] * ra[i] + rb[i])));
+                for (int i = 0; i < CB; ++i) vb[i] *= mvs_sigmoid_fast(gr[i] * ra[i] + rb[i]);
             }
             if (MODE == 2) {
                 float cv[CB], gu[CB];
@@ -295,8 +295,8 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
                 load_vec<CB>(bl_g + p * 2 * CB + CB, gu);
 #pragma unroll
                 for (int i = 0; i < CB; ++i) {
-                    const float uu = sigmoidf(gu[i] * ua[i] + ub_[i]);
-                    vb[i] = uu * vb[i] + (1.0f - uu) * tanhf(cv[i] * ca[i] + cb_[i]);
+                    const float uu = mvs_sigmoid_fast(gu[i] * ua[i] + ub_[i]);
+                    vb[i] = uu * vb[i] + (1.0f - uu) * mvs_tanh_fast(cv[i] * ca[i] + cb_[i]);
                 }
                 if (r >= 1 && r <= TS && c >= 1 && c <= TS) {
 #pragma unroll
@@ -420,25 +420,32 @@ gru_blend_fused_kernel(const float* __restrict__ c, const double* __restrict__ s
                        const float* h, float* h_out,         // may alias (non-pipelined sweep)
                        size_t vstride) {                     // blockIdx.y = view
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
-    if (i >= (long long)HW * F) return;
     const size_t vo = (size_t)blockIdx.y * vstride;
     c = view_ptr(c, vo); stats_c = view_ptr(stats_c, vo); g = view_ptr(g, vo); stats_u = view_ptr(stats_u, vo);
     h = view_ptr(h, vo); h_out = view_ptr(h_out, vo);
+    // the (scale, shift) pairs of both LayerNorms once per workgroup (2F lanes in float64, then LDS broadcasts): every thread
+    // used to run two float64 square roots and 4 * VEC float64 multiplies (F <= 64: the launcher checks)
+    __shared__ float aff[2][64][2];
+    if (threadIdx.x < 2 * F) {
+        const int k = threadIdx.x / F, f = threadIdx.x - k * F;             // k = 0: update gate, 1: candidate
+        const double n = (double)HW * F;
+        const double* st = k == 0 ? stats_u : stats_c;
+        const double mean = st[0] / n;
+        double var = st[1] / n - mean * mean; if (var < 0.0) var = 0.0;
+        const double inv = (double)(k == 0 ? ug[f] : og[f]) * (1.0 / sqrt(var + 1e-12));
+        aff[k][f][0] = (float)inv; aff[k][f][1] = (float)((double)(k == 0 ? ub[f] : ob[f]) - mean * inv);
+    }
+    __syncthreads();
+    if (i >= (long long)HW * F) return;
     const int f = (int)(i % F);
     const long long pix = i / F;
-    const double n = (double)HW * F;
     float cv[VEC], gv[VEC], hv[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { cv[k] = c[i + k]; gv[k] = g[pix * 2 * F + F + f + k]; hv[k] = h[i + k]; }
-    // the moments are shared by all channels: one mean / inverse deviation per LayerNorm
-    double mu = stats_u[0] / n, vu = stats_u[1] / n - mu * mu; if (vu < 0.0) vu = 0.0;
-    double mc = stats_c[0] / n, vc = stats_c[1] / n - mc * mc; if (vc < 0.0) vc = 0.0;
-    const double iu = 1.0 / sqrt(vu + 1e-12), ic = 1.0 / sqrt(vc + 1e-12);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-        const double au = (double)ug[f + k] * iu, ac = (double)og[f + k] * ic;
-        const float uu = sigmoidf(gv[k] * (float)au + (float)((double)ub[f + k] - mu * au));
-        const float yv = tanhf(cv[k] * (float)ac + (float)((double)ob[f + k] - mc * ac));
+        const float uu = mvs_sigmoid_fast(gv[k] * aff[0][f + k][0] + aff[0][f + k][1]);
+        const float yv = mvs_tanh_fast(cv[k] * aff[1][f + k][0] + aff[1][f + k][1]);
         h_out[i + k] = uu * hv[k] + (1.0f - uu) * yv;
     }
 }
@@ -653,49 +660,96 @@ int pipe_of_caller(hipStream_t caller, GruStreams& g) {
     return mh >= 0 ? mh : ml;                                    // the same pipe by construction; either measurement will do
 }
 
-// One set per caller stream (sweeps of different reference views in flight on different caller streams must not share
-// side streams, or they would serialise behind each other); created and calibrated on first use.
-GruStreams* gru_streams(hipStream_t caller) {
-    struct Slot { int dev; hipStream_t caller; GruStreams g; int state; };
-    static Slot slots[8];
-    static int used = 0;
-    static std::mutex mu;                                // slot creation is per (device, caller stream), thread-safe
-    if (getenv("MVS_GRU_ONE_STREAM") != nullptr) return nullptr;     // test hook (parity of the one-stream sweep), read per sweep
+// One set per (device, caller stream) -- sweeps of different reference views in flight on different caller streams must not
+// share side streams, or they would serialise behind each other.  Sets are created and calibrated by mvs_gru_prepare() ONLY
+// (round 4: the sweep itself used to do this on first use, i.e. create streams and synchronise inside an entry point whose
+// header promises neither, and invalidate a hipGraph capture it was first called under); the sweep looks its set up and never
+// creates one; mvs_gru_release() gives a slot back.
+struct GruSlot { int dev; hipStream_t caller; GruStreams g; int state; };      // state: 0 free, 1 ready
+constexpr int GRU_SLOTS = 16;
+GruSlot g_slots[GRU_SLOTS];
+std::mutex g_slots_mu;
+
+GruStreams* gru_find(hipStream_t caller) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < used; ++i)
-        if (slots[i].dev == dev && slots[i].caller == caller) return slots[i].state == 1 ? &slots[i].g : nullptr;
-    if (used == 8) {                                     // further caller streams run the (slower) one-stream sweep: say so once
-        static bool told = false;
-        if (!told) { told = true; fprintf(stderr, "mvsnet_hip: more than 8 caller streams use the recurrent sweep; the extra ones run it on one stream\n"); }
-        return nullptr;
+    std::lock_guard<std::mutex> lock(g_slots_mu);
+    for (int i = 0; i < GRU_SLOTS; ++i)
+        if (g_slots[i].state == 1 && g_slots[i].dev == dev && g_slots[i].caller == caller) return &g_slots[i].g;
+    return nullptr;
+}
+
+void gru_destroy(GruStreams& g) {                       // whatever of a set exists (also a half-built one)
+    for (int i = 0; i < 8; ++i) if (g.cand[i]) { (void)hipStreamSynchronize(g.cand[i]); (void)hipStreamDestroy(g.cand[i]); g.cand[i] = nullptr; }
+    auto ev = [](hipEvent_t& e) { if (e) { (void)hipEventDestroy(e); e = nullptr; } };
+    ev(g.fork);
+    for (int i = 0; i < 2; ++i) { ev(g.xready[i]); ev(g.xdone[i]); for (int j = 0; j < RG; ++j) { ev(g.ready[i][j]); ev(g.read[i][j]); } }
+    for (int i = 0; i < 3; ++i) { ev(g.join[i]); g.s[i] = nullptr; }
+}
+
+// Creates and calibrates the set of `caller` on the current device (idempotent).  Synchronises `caller` and the new streams.
+int gru_prepare(hipStream_t caller) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(caller, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return MVS_E_NOT_PREPARED;   // prepare synchronises
+    std::lock_guard<std::mutex> lock(g_slots_mu);
+    int free_slot = -1;
+    for (int i = 0; i < GRU_SLOTS; ++i) {
+        if (g_slots[i].state == 1 && g_slots[i].dev == dev && g_slots[i].caller == caller) return 0;
+        if (g_slots[i].state == 0 && free_slot < 0) free_slot = i;
     }
-    Slot& sl = slots[used++];
-    sl.dev = dev; sl.caller = caller; sl.state = -1;
+    if (free_slot < 0) return MVS_E_WORKSPACE;             // GRU_SLOTS caller streams hold a set: release one first
+    GruSlot& sl = g_slots[free_slot];
+    sl = GruSlot{};
+    sl.dev = dev; sl.caller = caller;
     GruStreams& g = sl.g;
-    bool ok = true;
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;   // lo = least urgent: the batch producer yields to the cells
-    for (int i = 0; ok && i < 8; ++i) ok = hipStreamCreateWithPriority(&g.cand[i], hipStreamNonBlocking, i < 4 ? hi : lo) == hipSuccess;
+    e = hipSuccess;
+    for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipStreamCreateWithPriority(&g.cand[i], hipStreamNonBlocking, i < 4 ? hi : lo);
     // first use = hardware queue creation: touch the eight candidates now, in order, with nothing in between
-    for (int i = 0; ok && i < 8; ++i) {
+    for (int i = 0; e == hipSuccess && i < 8; ++i) {
         gru_probe_empty_kernel<<<1, 64, 0, g.cand[i]>>>();
-        ok = hipStreamSynchronize(g.cand[i]) == hipSuccess;
+        e = hipStreamSynchronize(g.cand[i]);
     }
-    auto ev = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
+    auto ev = [&](hipEvent_t* ep) { if (e == hipSuccess) e = hipEventCreateWithFlags(ep, hipEventDisableTiming); };
     ev(&g.fork);
     for (int i = 0; i < 2; ++i) { ev(&g.xready[i]); ev(&g.xdone[i]); for (int j = 0; j < RG; ++j) { ev(&g.ready[i][j]); ev(&g.read[i][j]); } }
     for (int i = 0; i < 3; ++i) ev(&g.join[i]);
-    if (!ok) return nullptr;
+    if (e != hipSuccess) { gru_destroy(g); return (int)e; }
     g.pipe_of_caller = pipe_of_caller(caller, g);
+    if (g.pipe_of_caller < 0) {
+        // no candidate pipe stood out (other work on the GPU during the ~10 ms measurement, or a runtime that deals queues
+        // differently): the sweep still runs as a wavefront, but one of its side streams may share the caller's compute
+        // pipe -- the 2x slow layout of round 2 (profiles/r03_gru_bisect*.log).  Say so, once per process.
+        static bool told = false;
+        if (!told) { told = true; fprintf(stderr, "mvsnet_hip: mvs_gru_prepare: the stream-layout calibration was inconclusive (chains %.0f %.0f %.0f %.0f | %.0f %.0f %.0f %.0f us); "
+                                                  "the recurrent sweep may run up to 2x slower on this stream -- call mvs_gru_release + mvs_gru_prepare again on an idle GPU\n",
+                                          g.probe_us[0], g.probe_us[1], g.probe_us[2], g.probe_us[3], g.probe_us[4], g.probe_us[5], g.probe_us[6], g.probe_us[7]); }
+    }
     int pick[3], n = 0;                                  // the three candidate pipes the caller's queue is NOT on
     for (int m = 0; m < 4 && n < 3; ++m) if (m != g.pipe_of_caller) pick[n++] = m;
     g.s[0] = g.cand[pick[0]]; g.s[1] = g.cand[pick[1]]; g.s[2] = g.cand[4 + pick[2]];
     for (int i = 0; i < 8; ++i)                          // the five candidates that lost go back (their hardware queues with them)
         if (g.cand[i] != g.s[0] && g.cand[i] != g.s[1] && g.cand[i] != g.s[2]) { (void)hipStreamDestroy(g.cand[i]); g.cand[i] = nullptr; }
     sl.state = 1;
-    return &g;
+    return 0;
+}
+
+int gru_release(hipStream_t caller) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lock(g_slots_mu);
+    for (int i = 0; i < GRU_SLOTS; ++i)
+        if (g_slots[i].state == 1 && g_slots[i].dev == dev && g_slots[i].caller == caller) {
+            gru_destroy(g_slots[i].g);                   // waits for the side streams' work
+            g_slots[i].state = 0;
+            return 0;
+        }
+    return MVS_E_BADARG;
 }
 
 __global__ void __launch_bounds__(256)
@@ -723,16 +777,19 @@ extern "C" size_t mvs_gru_workspace_bytes(int H, int W, int C, int f1, int f2, i
 // chain's latency paces a single sweep; full for two or more: B x 950 tiles per launch hide it, and the hoisted form's px
 // tensor -- 46 MB of traffic per plane and view -- and its producer competing for the matrix pipes are what is left to save).
 // Both give the same bits (gru_mfma.hip, SPLIT accumulators).
-static int g_gru_form = 0;
+static std::atomic<int> g_gru_form{0};                 // read ONCE per sweep (a sweep in flight keeps the formulation it started with)
 extern "C" int mvs_gru_set_formulation(int form) {
     if (form < 0 || form > 2) return MVS_E_BADARG;
-    g_gru_form = form;
+    g_gru_form.store(form);
     return 0;
 }
 
+extern "C" int mvs_gru_prepare(void* stream) { return gru_prepare(mvs_stream(stream)); }
+extern "C" int mvs_gru_release(void* stream) { return gru_release(mvs_stream(stream)); }
+
 extern "C" int mvs_gru_stream_layout(void* stream, int* pipe_of_caller_out, float* probe_us_out) {
-    GruStreams* gs = gru_streams(mvs_stream(stream));
-    if (!gs) return MVS_E_BADARG;
+    GruStreams* gs = gru_find(mvs_stream(stream));
+    if (!gs) return MVS_E_NOT_PREPARED;
     if (pipe_of_caller_out) *pipe_of_caller_out = gs->pipe_of_caller;
     if (probe_us_out) for (int i = 0; i < 8; ++i) probe_us_out[i] = gs->probe_us[i];
     return 0;
@@ -746,6 +803,7 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
     MVS_CHECK_ARG(ref && src && transforms && params && depth_values && workspace && depth_out && prob_out);
     MVS_CHECK_ARG(views >= 1 && views <= MAXV);
     MVS_CHECK_ARG(view_num >= 2 && depth_num >= 1 && H > 0 && W > 0 && C > 0 && f1 > 0 && f2 > 0 && f3 > 0);
+    if (f1 > 64 || f2 > 64 || f3 > 64) return MVS_E_SHAPE;     // gru_blend_fused_kernel keeps 2 x F LayerNorm affines in LDS ('fat': 32)
     for (int v = 0; v < views; ++v) MVS_CHECK_ARG(ref[v] && src[v] && transforms[v]);
     GruWs ws = carve((char*)workspace, H, W, C, f1, f2, f3);      // view 0's block; view v's tensors are v * ws.bytes further
     const size_t vstride = ws.bytes;
@@ -768,7 +826,8 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
 
     // cell 1 (90 % of the MACs) runs on the fp32-MFMA kernels when its shape fits their tiling
     bool mfma1 = (mvs_get_conv_impl() != MVS_CONV_IMPL_SCALAR) && C == 32 && f1 == 16;
-    const bool hoist = mfma1 && (g_gru_form == 1 || (g_gru_form == 0 && views == 1));
+    const int form = g_gru_form.load();
+    const bool hoist = mfma1 && (form == 1 || (form == 0 && views == 1));
     if (mfma1) {                                         // prepared weights, shared by the views
         if (hoist) rc = mvs_gru1_split_weights(params[0], params[6], C, f1, ws.wx, ws.wgh, ws.woh, st);
         else rc = mvs_gru1_full_weights(params[0], params[6], C, f1, ws.wfg, ws.wfo, st);
@@ -793,13 +852,32 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
     // Several reference views (views > 1) ride in the SAME launches: every kernel of the sweep takes a view index from its
     // grid, so the ~7 launches per plane, their ~5 us floors and the cross-stream waits are shared by `views` depth maps.
     const int ring = RG * PG;
-    GruStreams* gs = (route[0] && route[1] && route[2] && depth_num > 2 * PG) ? gru_streams(st) : nullptr;
+    const bool wavefront = route[0] && route[1] && route[2] && depth_num > 2 * PG &&
+                           getenv("MVS_GRU_ONE_STREAM") == nullptr;      // test hook (parity of the one-stream sweep), read per sweep
+    // Under hipGraph capture the sweep goes to the caller's stream alone: capturing the four-stream wavefront (the caller's stream
+    // waits on side-stream events in the middle of the capture, events are re-recorded per group) makes hipStreamEndCapture of
+    // ROCm 7.2 crash on the host (profiles/r04_gru_wavefront_capture_segfault.log).  Same results (depth identical), ~1.7x the
+    // eager wavefront's time when replayed.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    GruStreams* gs = (wavefront && !capturing) ? gru_find(st) : nullptr;
+    if (wavefront && !capturing && !gs) {
+        // no side streams for this caller stream: this entry point creates none (mvs_gru_prepare does) -- run the sweep on the
+        // caller's stream alone (same results, ~1.7x the time at 400 x 300) and say so once.
+        static std::atomic<bool> told{false};
+        if (!told.exchange(true))
+            fprintf(stderr, "mvsnet_hip: mvs_gru_wta*_f32 on a stream without mvs_gru_prepare(): the recurrent sweep runs on this stream "
+                            "alone (same results, slower); call mvs_gru_prepare(stream) once per caller stream\n");
+    }
     hipStream_t sk[3] = {st, gs ? gs->s[0] : st, gs ? gs->s[1] : st};
+    const long long hw_ll = (long long)H * W;
+    bool forked = false;
+    auto sweep = [&]() -> int {
     if (gs) {
         if ((e = hipEventRecord(gs->fork, st)) != hipSuccess) return (int)e;
+        forked = true;
         for (int i = 0; i < 3; ++i) if ((e = hipStreamWaitEvent(gs->s[i], gs->fork, 0)) != hipSuccess) return (int)e;
     }
-    const long long hw_ll = (long long)H * W;
 
     // The cost slices of the batch that holds plane d.  Hoisted form: one buffer -- the x-part launches that read it follow the
     // slices' launch on the producer stream, and what the chain reads (px) has two halves.  Full form: the chain reads the
@@ -970,11 +1048,18 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
             }
         }
     }
-    if (gs)
+    return 0;
+    };       // sweep
+    rc = sweep();
+    // Join on EVERY exit after the fork: also when a launch failed half-way the caller's stream must stay ordered
+    // after whatever the side streams were given -- the caller frees or re-uses the feature maps and the workspace in stream order.
+    if (forked)
         for (int i = 0; i < 3; ++i) {
-            if ((e = hipEventRecord(gs->join[i], gs->s[i])) != hipSuccess) return (int)e;
-            if ((e = hipStreamWaitEvent(st, gs->join[i], 0)) != hipSuccess) return (int)e;
+            hipError_t e1 = hipEventRecord(gs->join[i], gs->s[i]);
+            if (e1 == hipSuccess) e1 = hipStreamWaitEvent(st, gs->join[i], 0);
+            if (e1 != hipSuccess && rc == 0) rc = (int)e1;
         }
+    if (rc) return rc;
     wta_finish_views_kernel<<<dim3(mvs_cdiv(hw_ll, 256), views), 256, 0, st>>>(ws.max_prob, ws.exp_sum, ws.depth, H * W, vstride,
                                                                              depth_out, prob_out);
     return (int)hipGetLastError();

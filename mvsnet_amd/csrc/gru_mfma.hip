@@ -210,8 +210,8 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     // libm expf + IEEE divides here cost 1.0 ms per depth map (25.15 against 24.15 ms) and land at the SAME distance from the
     // float64 fixture (probability rel-max 1.169e-3 against 1.172e-3, plane agreement 0.99988 both): the distance the round-2
     // verdict attributed to these forms comes from float32 summation order, not from them.
-    auto sig = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); };
-    auto tanh_ = [](float x) { const float t = __expf(-2.0f * fabsf(x)); return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x); };
+    auto sig = [](float x) { return mvs_sigmoid_fast(x); };           // common.h: the forms every cell of the sweep uses
+    auto tanh_ = [](float x) { return mvs_tanh_fast(x); };
     auto stage_piece = [&](int i, float* buf, int tile_of) __attribute__((always_inline)) {
         float4 v = pre[i];                           // zeros outside the image (SAME padding)
         if (MODE == 1 && i >= NA) {                  // xb = sigmoid(LN(g_r)) * h (convgru.py:97,101,107)

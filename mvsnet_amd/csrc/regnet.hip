@@ -37,6 +37,7 @@ extern "C" const char* mvs_error_string(int code) {
     if (code == MVS_E_BADARG) return "mvsnet_hip: bad argument (null pointer or non-positive size)";
     if (code == MVS_E_SHAPE) return "mvsnet_hip: shape not supported by this kernel";
     if (code == MVS_E_WORKSPACE) return "mvsnet_hip: workspace too small";
+    if (code == MVS_E_NOT_PREPARED) return "mvsnet_hip: no side streams for this caller stream (call mvs_gru_prepare outside hipGraph capture first)";
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "mvsnet_hip: unknown error";
 }

@@ -335,6 +335,7 @@ class DepthPlan:
             f1, f2, f3 = weights.gru.filters
             nbytes = lib.mvs_gru_workspace_bytes(height, width, channels, f1, f2, f3)
             self.workspace = torch.empty(nbytes * self.views, device=dev, dtype=torch.uint8)
+            _lib.gru_prepare()     # side streams + calibration for the current stream: the one call that synchronises
         else:
             raise NotImplementedError(regularization)      # predictlib.py:97-98
 
@@ -374,6 +375,7 @@ class DepthPlan:
 
     def run_gru(self, features, depth_values):
         lib = _lib.load()
+        _lib.gru_prepare()         # no-op for a stream already prepared (a plan may run on another stream than it was built on)
         g = self.weights.gru
         f1, f2, f3 = g.filters
         dv = (C.c_float * self.D)(*[float(v) for v in depth_values])
@@ -389,6 +391,7 @@ class DepthPlan:
         (mvs_gru_wta_batch_f32): features[v] (N,H,W,C), depth_values[v] (D,); cameras set per view with
         set_cameras(..., view=v).  Returns (depth (n,H,W), prob (n,H,W))."""
         lib = _lib.load()
+        _lib.gru_prepare()
         g = self.weights.gru
         f1, f2, f3 = g.filters
         n = len(features)

@@ -234,7 +234,7 @@ def test_eight_ranks_plumbing_over_gloo(tmp_path):
     of config 4's 1078 reference views (22 scans x 49 views), the per-rank gathers and object gather bench.py's record uses,
     8 ranks x 3 processes per GPU folded onto the first 8 devices (MVS_GPUS), and the exit code of ONE failing rank among 8.
     (The GPU box admits at most 6 processes on its card, so the 8-rank case is rehearsed here on the CPU; the GPU suite runs
-    bench.py with 5 ranks on one card, tests/test_gpu_pipeline.py.)"""
+    bench.py with 4 ranks on one card, tests/test_gpu_pipeline.py.)"""
     from mvsnet_amd.shard import launch_ranks
     ok = tmp_path / "ok8.py"
     ok.write_text(

@@ -138,6 +138,79 @@ def test_plan_runs_under_hipgraph_capture(lib_built):
     assert torch.allclose(plan.depth, eager, rtol=1e-6, atol=1e-4)
 
 
+def test_gru_sweep_prepare_capture_and_release(lib_built):
+    """include/mvsnet_hip.h (round 4): mvs_gru_prepare(stream) is the ONE call of the recurrent path that creates streams /
+    events and synchronises; mvs_gru_wta*_f32 never does.  A sweep captured into a hipGraph (it goes to the capture stream
+    alone: the four-stream wavefront cannot be captured on ROCm 7.2) replays to the eager wavefront's depth map; a stream
+    without a set runs the one-stream sweep eagerly with the same winning planes; prepare is refused under capture
+    (MVS_E_NOT_PREPARED = -4); release / prepare recycle the slot."""
+    import ctypes as C
+    from mvsnet_amd import _lib
+    from mvsnet_amd.model import DepthPlan, MVSNetWeights, wta_depth_values
+    lib = _lib.load()
+    base = S.make_workload("c3")
+    Hh, Ww, D = 52, 72, 40                               # ragged tiles, enough planes for the wavefront (D > 8)
+    gp = S.make_gru_params("normal", seed=2, in_channels=base.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
+    feats = t(S.make_features(base.view_num, base.height, base.width, base.channels, seed=11)[:, :Hh, :Ww])
+    end = base.depth_start + (D - 1) * base.depth_interval
+    dv = wta_depth_values(D, base.depth_start, end, False)
+    cams = t(base.cams)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        plan = DepthPlan(base.view_num, D, Hh, Ww, base.channels, weights, "GRU", DEV)       # prepares stream s
+        pc, us = C.c_int(-9), (C.c_float * 8)()
+        assert lib.mvs_gru_stream_layout(_lib.stream_ptr(), C.byref(pc), us) == 0 and -1 <= pc.value <= 3 and min(us) > 0
+        assert lib.mvs_gru_prepare(_lib.stream_ptr()) == 0                                   # idempotent
+        plan.set_cameras(cams, base.depth_start, base.depth_interval, end, False)
+        d, p = plan.run_gru(feats, dv)
+        torch.cuda.synchronize()
+        eager_d, eager_p = d.clone(), p.clone()
+        assert len(torch.unique(eager_d)) > 4
+        g = torch.cuda.CUDAGraph()
+        rcs = []
+        with torch.cuda.graph(g, stream=s):
+            plan.run_gru(feats, dv)
+            rcs.append(lib.mvs_gru_prepare(_lib.stream_ptr()))                               # prepare synchronises: refused under capture
+            rcs.append(lib.mvs_gru_release(C.c_void_p(12345)))                               # no set for this handle
+        assert rcs == [-4, -1]
+    for _ in range(2):                                   # a graph is replayable
+        plan.depth.zero_(); plan.prob.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(plan.depth, eager_d)
+        assert float(((plan.prob - eager_p).abs() / eager_p).max()) < 1e-6
+    # a stream nobody prepared: the one-stream sweep, eagerly and captured alike
+    gw = weights.gru
+    f1, f2, f3 = gw.filters
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    dvc = (C.c_float * D)(*[float(v) for v in dv])
+    with torch.cuda.stream(s2):
+        call = lambda: lib.mvs_gru_wta_f32(_lib.ptr(feats[0]), _lib.ptr(feats[1:]), _lib.ptr(plan.transforms), base.view_num, D, Hh, Ww,
+                                           base.channels, f1, f2, f3, gw.ptrs, dvc, C.c_void_p(plan.workspace.data_ptr()),
+                                           plan.workspace.numel(), _lib.ptr(plan.depth), _lib.ptr(plan.prob), _lib.stream_ptr())
+        assert lib.mvs_gru_stream_layout(_lib.stream_ptr(), None, None) == -4
+        assert lib.mvs_gru_release(_lib.stream_ptr()) == -1                                  # nothing to release
+        plan.depth.zero_()
+        assert call() == 0
+        torch.cuda.synchronize()
+        assert torch.equal(plan.depth, eager_d)                                               # same planes (DESIGN 4.4: depth identical)
+        assert float(((plan.prob - eager_p).abs() / eager_p).max()) < 1e-6
+    # slots are recycled
+    with torch.cuda.stream(s):
+        _lib.gru_release()
+        assert lib.mvs_gru_stream_layout(_lib.stream_ptr(), None, None) == -4
+        _lib.gru_prepare()
+        assert lib.mvs_gru_stream_layout(_lib.stream_ptr(), None, None) == 0
+        d3, _ = plan.run_gru(feats, dv)
+        torch.cuda.synchronize()
+        assert torch.equal(d3, eager_d)
+    assert _lib.load().mvs_error_string(-4).decode().startswith("mvsnet_hip: no side streams")
+
+
 def test_lite_mode_from_images_runs_padded_regulariser_and_torch_towers():
     """network_mode 'lite' end to end: narrow towers stay on the PyTorch module (GroupNorm groups < 8 channels),
     the regulariser runs zero-padded on the MFMA shapes; checked against the oracle composition."""
@@ -252,9 +325,37 @@ def test_bench_and_inference_start_their_own_ranks(tmp_path, lib_built):
     assert r4.returncode == 0, (r4.stdout[-2000:], r4.stderr[-2000:])
     rec4 = json.loads([l for l in r4.stdout.splitlines() if l.startswith("{")][-1])
     assert rec4["ranks"] == 2 and rec4["depth_maps"] == 5 and rec4["depth_maps_per_s"] > 0
+    assert rec4["devices"] == [0, 0]                        # both worker processes on the ONE requested GPU (MVS_GPUS)
     for i in range(5):                                     # same files as the two-rank run above
         a = open(os.path.join(out, "%d_init.pfm" % i), "rb").read()
         assert a == open(os.path.join(out2, "%d_init.pfm" % i), "rb").read()
+
+
+def test_bench_with_four_ranks_on_one_card_and_a_failing_rank(lib_built):
+    """The N-rank record of `bench.py --gpus N` beyond two ranks, rehearsed over gloo with every rank on cuda:0: the GPU box
+    admits six processes on its card (this test process and the launcher count: five ranks were killed by the process guard), so
+    four ranks run here and the 8-rank plumbing (launcher, rendezvous, shard of 1078 views, gathers, exit code) runs on the CPU
+    (tests/test_data_and_sharding.py).  One failing rank out of four must end the whole run with a non-zero exit code and no
+    JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVS_DIST_BACKEND="gloo", MVS_ALLOW_SHARED_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--workload", "small",
+           "--no-extra", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 4 and rec["ranks"]["world_size"] == 4 and rec["ranks"]["backend"] == "gloo"
+    assert [d["rank"] for d in rec["ranks"]["devices"]] == list(range(4))
+    assert len(rec["per_rank_depth_maps_per_s"]["ranks"]) == 4 and rec["scaling"] == "weak"
+    assert abs(rec["value"] - 4 * rec["steps"] / (rec["ms_per_step"] * 1e-3 * rec["steps"])) < 1e-6 * rec["value"]   # whole job / slowest rank
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, MVS_BENCH_FAIL_RANK="2"), cwd=root)
+    assert bad.returncode != 0
+    assert not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
 
 def test_compute_depth_maps_on_an_upstream_pair_txt_project(tmp_path, lib_built):
