@@ -120,38 +120,30 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     static_assert(MODE == 0 || CB > 0, "the reset gate applies to the xb family");
     static_assert(!BATCH || (CB == 0 && MODE == 0 && !ADD), "only the x-part launch is batched over planes");
     const int qb = tid % (CQB ? CQB : 1);            // this thread's channel quad in the xb pieces
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;      // MODE 1: LayerNorm affine of the reset gate
-    if (MODE == 1) {
+    // LayerNorm affines of the reset gate (MODE 1) / of the update gate and the candidate (MODE 2): (scale, shift) per channel,
+    // scale = gamma / sqrt(var + 1e-12), shift = beta - mean * scale in float64 (tf.contrib.layers.layer_norm).
+    // Round 4: CB (2 * CB) lanes work them out and park the float results in LDS; every thread reads its channel quad back
+    // after the barrier that follows the first tile's loads (all 512 threads used to run the float64 divisions and square
+    // roots themselves, at the head of a kernel that sits on the recurrent chain twice per plane).
+    __shared__ float lnaff[2][CB > 0 ? CB : 1][2];
+    if (MODE != 0 && tid < (MODE == 2 ? 2 : 1) * CB) {
+        const int k = tid / (CB > 0 ? CB : 1), f = tid - k * CB;       // k = 0: reset (MODE 1) / update (MODE 2) gate, 1: candidate
         const double cnt = (double)a.H * a.W * CB;
-        double mean = a.g_stats[0] / cnt;
-        double var = a.g_stats[1] / cnt - mean * mean;
+        const double* st = MODE == 1 ? a.g_stats : (k == 0 ? a.stats_u : a.stats_c);
+        const float gamma = MODE == 1 ? a.r_gamma[f] : (k == 0 ? a.u_gamma[f] : a.o_gamma[f]);
+        const float beta = MODE == 1 ? a.r_beta[f] : (k == 0 ? a.u_beta[f] : a.o_beta[f]);
+        const double mean = st[0] / cnt;
+        double var = st[1] / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
-        float s[4], t[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            double inv = (double)a.r_gamma[4 * qb + k] / sqrt(var + 1e-12);
-            s[k] = (float)inv; t[k] = (float)((double)a.r_beta[4 * qb + k] - mean * inv);
-        }
-        ra = make_float4(s[0], s[1], s[2], s[3]); rb = make_float4(t[0], t[1], t[2], t[3]);
+        const double inv = (double)gamma / sqrt(var + 1e-12);
+        lnaff[k][f][0] = (float)inv; lnaff[k][f][1] = (float)((double)beta - mean * inv);
     }
-    float4 ua = ra, ub = ra, ca = ra, cb = ra;      // MODE 2: LayerNorm affines of the update gate and the candidate
-    if (MODE == 2) {
-        const double cnt = (double)a.H * a.W * CB;
-        auto affine = [&](const double* st, const float* gamma, const float* beta, float4& sc, float4& sh) {
-            double mean = st[0] / cnt;
-            double var = st[1] / cnt - mean * mean;
-            if (var < 0.0) var = 0.0;
-            float s4[4], t4[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double inv = (double)gamma[4 * qb + k] / sqrt(var + 1e-12);
-                s4[k] = (float)inv; t4[k] = (float)((double)beta[4 * qb + k] - mean * inv);
-            }
-            sc = make_float4(s4[0], s4[1], s4[2], s4[3]); sh = make_float4(t4[0], t4[1], t4[2], t4[3]);
-        };
-        affine(a.stats_u, a.u_gamma, a.u_beta, ua, ub);
-        affine(a.stats_c, a.o_gamma, a.o_beta, ca, cb);
-    }
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, ua = ra, ub = ra, ca = ra, cb = ra;
+    auto read_affines = [&]() __attribute__((always_inline)) {
+        auto q = [&](int k, int j) { return make_float4(lnaff[k][4 * qb][j], lnaff[k][4 * qb + 1][j], lnaff[k][4 * qb + 2][j], lnaff[k][4 * qb + 3][j]); };
+        if (MODE == 1) { ra = q(0, 0); rb = q(0, 1); }
+        if (MODE == 2) { ua = q(0, 0); ub = q(0, 1); ca = q(1, 0); cb = q(1, 1); }
+    };
     const int bytes_a = a.H * a.W * CA * 4, bytes_b = a.H * a.W * CB * 4;
     const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.xa, 0, bytes_a * (BATCH ? a.planes : 1), 0x00020000);
     const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.xb, 0, bytes_b, 0x00020000);
@@ -260,6 +252,7 @@ conv2d_cat_mfma_kernel(Gru2dArgs a) {
     int tile = first_tile;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) load_piece(i, tile);
+    if (MODE != 0) { __syncthreads(); read_affines(); }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) stage_piece(i, slab, tile);
 #pragma unroll
