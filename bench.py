@@ -224,9 +224,9 @@ def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN", procs_
     """End-to-end throughput of the reference's own loop (mvsnet/inference.py:105-119: load a cluster -> run the graph -> write
     the outputs, 'Depth inference ... sec/step') on a synthetic on-disk session of the metric's shape: `n_images` JPEGs of
     640x512 with cameras and a covisibility file (mvsnet_amd.synthetic.write_session), view_num 5, max_d 192 -> 160x128 feature
-    maps -- configuration 4's per-GPU work, one rank.  compute_depth_maps decodes / resizes / standardises on loader threads,
-    runs the UNetDS2GN towers (HIP library, per-image feature cache) and the hot path, and writes <idx>_init.pfm / _prob.pfm /
-    PNGs / JPG / camera per reference view.  Two passes over the same session: the first pays the lazy one-offs (plans,
+    maps -- configuration 4's per-GPU work, one rank.  compute_depth_maps decodes / resizes / crops in worker processes
+    (mvsnet_amd/host_pool.py), runs the UNetDS2GN towers (HIP library, per-image feature cache) and the hot path in this
+    process, and the workers write <idx>_init.pfm / _prob.pfm / PNGs / JPG / camera per reference view.  Two passes over the same session: the first pays the lazy one-offs (plans,
     code objects, pinned buffers), the second is reported."""
     import shutil
     import tempfile
@@ -248,14 +248,17 @@ def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN", procs_
                    "session_depth_maps_per_s": n / tm["wall"], "sec_per_step": tm["wall"] / max(n, 1),
                    "fraction_of_kernel_only_rate": (n / tm["wall"]) / kernel_rate if kernel_rate else None,
                    "files_written": len(os.listdir(cfg.output_dir)),
+                   "host_workers": tm.get("host_workers"),
+                   "host_cpu_ms_per_depth_map": (1e3 * tm["host_cpu"] / max(n, 1)) if tm.get("host_cpu") is not None else None,
+                   "host_cores": os.cpu_count(),
                    "breakdown_ms_per_depth_map": {
-                       "decode_resize_standardise (loader threads, summed)": 1e3 * tm["load"] / max(n, 1),
+                       "decode_resize_crop (worker processes, summed)": 1e3 * tm["load"] / max(n, 1),
                        "main_thread_waiting_for_loaders": 1e3 * tm["wait_load"] / max(n, 1),
                        "main_thread_enqueueing_gpu_work": 1e3 * tm["host_gpu_submit"] / max(n, 1),
                        "h2d_and_towers (GPU)": 1e3 * tm["towers"] / max(n, 1),
                        "hot_path (GPU)": 1e3 * tm["hot_path"] / max(n, 1),
                        "d2h (GPU, to pinned buffers)": 1e3 * tm["d2h"] / max(n, 1),
-                       "file_writes (writer threads, summed)": 1e3 * tm["write"] / max(n, 1)},
+                       "file_writes (worker processes, summed)": 1e3 * tm["write"] / max(n, 1)},
                    "loader_threads": tm["loader_threads"], "writer_threads": tm["writer_threads"]}
         # the same session with several worker PROCESSES sharing this GPU (python -m mvsnet_amd.inference --procs_per_gpu P): the
         # one-process loop above is bound by its Python main thread, not by the GPU

@@ -1,0 +1,226 @@
+"""Worker PROCESSES for the host side of the session loop (the reference's tf.data prefetch thread,
+mvsnet/predictlib.py:48-51, and its write_output, :162-177).
+
+Round 3 ran decode / rescale / crop of the input images and the encoding of the six output files per reference view on
+THREADS of the GPU-owning process: 12 worker threads and the thread that enqueues the GPU work took turns on one GIL, the
+main thread's 2.4 ms of Python per depth map stretched to 3.9 ms and the loop delivered 0.30 of the kernel-only rate.  Here
+the same functions run in worker processes:
+
+  * `image_task`  -- the per-IMAGE part of cluster_generator.py:234-286 (load -> scale-to-cover -> centre-crop -> output
+    scale), result handed back through a shared-memory slot (multiprocessing.shared_memory; nothing of the 1 MB image
+    goes through a pipe);
+  * `write_task`  -- predictlib.write_output_slice (two .pfm, two 16-bit PNGs, the reference .jpg, the camera .txt).
+
+The pool is started with the `spawn` method: the children are fresh interpreters that import numpy / Pillow and this
+package's host modules only (never torch, never the HIP library), so it is safe to create after the parent has
+initialised the GPU, and nothing of the parent's HIP state is inherited.  One pool per process, kept for the process's
+lifetime (`get_pool`); `workers = 0` keeps everything on threads (round 3's path, still used for upstream-format
+projects).
+"""
+from __future__ import annotations
+
+import atexit
+import os
+import threading
+import time
+from concurrent.futures import Future, ProcessPoolExecutor
+
+import numpy as np
+
+_ATTACHED = {}          # worker side: shared-memory blocks by name
+
+
+def _attach(name):
+    from multiprocessing import shared_memory
+    shm = _ATTACHED.get(name)
+    if shm is None:
+        for old in list(_ATTACHED):                   # the parent replaced its block: drop the mapping of the old one
+            _ATTACHED.pop(old).close()
+        shm = _ATTACHED[name] = shared_memory.SharedMemory(name=name)
+    return shm
+
+
+def prepare_image(path, rescale, width, height, base_image_size, output_scale):
+    """The per-image part of ClusterGenerator.prepare (cluster_generator.py:234-286): BGR decode (mvs_cluster.py:72-76),
+    scale by the cluster's `rescale` (utils.py:107-118), centre-crop (utils.py:121-153), and the output-scaled copy that
+    write_output stores as <idx>.jpg.  Returns (cropped uint8 (h,w,3), output image uint8, original shape)."""
+    from PIL import Image
+    from .mvs_data_generation import crop_mvs_input, scale_image
+    rgb = np.asarray(Image.open(path).convert("RGB"))
+    img = np.ascontiguousarray(rgb[:, :, ::-1])
+    im = scale_image(img, rescale)
+    cr, _ = crop_mvs_input([im], [np.zeros((2, 4, 4))], width, height, base_image_size)
+    cr = np.ascontiguousarray(cr[0])
+    return cr, scale_image(cr, output_scale), img.shape
+
+
+def image_task(path, rescale, width, height, base_image_size, output_scale, shm_name, offset, capacity):
+    """Worker: prepare_image into the shared-memory slot [offset, offset + capacity): cropped image, then output image."""
+    t0 = time.perf_counter()
+    cr, out, shape = prepare_image(path, rescale, width, height, base_image_size, output_scale)
+    if cr.nbytes + out.nbytes > capacity:
+        raise ValueError("image slot too small: %d + %d > %d bytes" % (cr.nbytes, out.nbytes, capacity))
+    buf = _attach(shm_name).buf
+    np.frombuffer(buf, np.uint8, cr.size, offset)[:] = cr.reshape(-1)
+    np.frombuffer(buf, np.uint8, out.size, offset + cr.nbytes)[:] = out.reshape(-1)
+    return cr.shape, out.shape, shape, time.perf_counter() - t0
+
+
+def write_task(output_dir, depth, prob, ref_image, ref_cam, index, visualize, prob_upsample):
+    """Worker: predictlib.write_output_slice (predictlib.py:105-159)."""
+    from . import predictlib as pl
+    t0 = time.perf_counter()
+    pl.write_output_slice(output_dir, depth, prob, ref_image, ref_cam, index, visualize, prob_upsample)
+    return time.perf_counter() - t0
+
+
+def _warm():
+    import PIL.Image            # noqa: F401  (the first task should not pay the imports)
+    from . import mvs_data_generation, predictlib, preprocess   # noqa: F401
+    return os.getpid()
+
+
+class HostPool:
+    """`workers` spawned processes + a ring of shared-memory image slots."""
+
+    def __init__(self, workers, slots=48):
+        import multiprocessing as mp
+        self.workers = int(workers)
+        self.ex = ProcessPoolExecutor(max_workers=self.workers, mp_context=mp.get_context("spawn"))
+        self.slots = int(slots)
+        self.slot_bytes = 0
+        self.shm = None
+        self.free = []
+        self.cv = threading.Condition()
+        # All children start at the first submit (below) and take two things from that moment:
+        #  * the environment -- they are given NO GPU (a worker never needs one);
+        #  * the description of the parent's __main__ module, which the spawn method would re-import in every child (running an
+        #    unguarded main script again: a second copy of the application, GPU work included; and failing outright when the
+        #    parent runs from stdin or an embedded interpreter).  The workers only ever call functions of this module, so they
+        #    are started with an EMPTY __main__: nothing of the application is imported there.
+        import sys
+        import types
+        hide = {"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "", "MVS_HOST_WORKER": "1"}
+        saved = {k: os.environ.get(k) for k in hide}
+        os.environ.update(hide)
+        real_main = sys.modules.get("__main__")
+        sys.modules["__main__"] = types.ModuleType("__main__")
+        try:
+            self.pids = sorted(set(f.result() for f in [self.ex.submit(_warm) for _ in range(4 * self.workers)]))
+        finally:
+            if real_main is not None:
+                sys.modules["__main__"] = real_main
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    def cpu_seconds(self):
+        """user + system CPU time the worker processes have used so far (psutil), or None."""
+        try:
+            import psutil
+            return sum(sum(psutil.Process(pid).cpu_times()[:2]) for pid in self.pids)
+        except Exception:                              # noqa: BLE001
+            return None
+
+    def _ensure_slots(self, nbytes):
+        """(Re)allocates the slot ring when a session needs larger slots; waits until no slot is in use."""
+        from multiprocessing import shared_memory
+        nbytes = (int(nbytes) + 4095) & ~4095
+        with self.cv:
+            if self.shm is not None and nbytes <= self.slot_bytes:
+                return
+            while self.shm is not None and len(self.free) < self.slots:
+                self.cv.wait()
+            if self.shm is not None:
+                self.shm.close(); self.shm.unlink()
+            self.slot_bytes = nbytes
+            self.shm = shared_memory.SharedMemory(create=True, size=self.slots * nbytes)
+            self.free = list(range(self.slots))
+
+    def load_image(self, path, rescale, width, height, base_image_size, output_scale):
+        """-> Future of (cropped uint8 (h,w,3), output image, original shape, worker seconds); private arrays, the slot is
+        free again when the future resolves."""
+        h_cap = max(height, int(np.ceil(height / base_image_size) * base_image_size)) + base_image_size
+        w_cap = max(width, int(np.ceil(width / base_image_size) * base_image_size)) + base_image_size
+        need = h_cap * w_cap * 3
+        need += int(need * max(output_scale, 0.0) ** 2) + 4096
+        self._ensure_slots(need)
+        with self.cv:
+            while not self.free:
+                self.cv.wait()
+            slot = self.free.pop()
+            shm, cap = self.shm, self.slot_bytes
+        out = Future()
+        off = slot * cap
+        inner = self.ex.submit(image_task, path, rescale, width, height, base_image_size, output_scale, shm.name, off, cap)
+
+        def done(f):                                   # executor's management thread: copy out of the slot, free it
+            try:
+                cs, os_, shape, sec = f.result()
+                n1 = int(np.prod(cs)); n2 = int(np.prod(os_))
+                cr = np.frombuffer(shm.buf, np.uint8, n1, off).reshape(cs).copy()
+                oi = np.frombuffer(shm.buf, np.uint8, n2, off + n1).reshape(os_).copy()
+                out.set_result((cr, oi, shape, sec))
+            except BaseException as e:                 # noqa: BLE001  (delivered to the consumer)
+                out.set_exception(e)
+            finally:
+                with self.cv:
+                    self.free.append(slot)
+                    self.cv.notify_all()
+        inner.add_done_callback(done)
+        return out
+
+    def write_outputs(self, output_dir, depth, prob, ref_image, ref_cam, index, visualize=False, prob_upsample=None):
+        """-> Future of the worker's seconds.  The arrays are pickled by the executor's feeder thread: pass private copies."""
+        return self.ex.submit(write_task, output_dir, depth, prob, ref_image, ref_cam, index, visualize, prob_upsample)
+
+    def close(self):
+        try:
+            self.ex.shutdown(wait=True, cancel_futures=True)
+        finally:
+            if self.shm is not None:
+                try:
+                    self.shm.close(); self.shm.unlink()
+                except FileNotFoundError:
+                    pass
+                self.shm = None
+
+
+_POOL = None
+_POOL_LOCK = threading.Lock()
+
+
+def default_workers():
+    """Worker processes per GPU-owning process: the host cores this process may count on (cores / local ranks), less the
+    main thread and its helper threads, at most 12 (450 depth maps/s need ~6 busy cores of decode + encode)."""
+    n = os.cpu_count() or 4
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    return max(2, min(12, n // max(1, local) - 2))
+
+
+def get_pool(workers=None):
+    """The process-wide pool (created on first use; `workers` = 0 -> None: the caller stays on threads)."""
+    global _POOL
+    w = default_workers() if workers is None else int(workers)
+    if w <= 0:
+        return None
+    with _POOL_LOCK:
+        if _POOL is None or _POOL.workers != w:
+            if _POOL is not None:
+                _POOL.close()
+            _POOL = HostPool(w)
+    return _POOL
+
+
+@atexit.register
+def _close_pool():
+    global _POOL
+    if _POOL is not None:
+        _POOL.close()
+        _POOL = None

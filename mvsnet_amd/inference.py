@@ -59,9 +59,12 @@ def center_images_device(u8):
     reductions agree with them to ~1e-7 relative)."""
     import torch
     x = u8.to(torch.float32)
-    x64 = x.double()
-    mean = x64.mean(dim=(1, 2), keepdim=True)
-    var = ((x64 - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+    # float64 ACCUMULATION of float32 terms that are exact (grey levels and their squares are integers below 2^16): the sums are
+    # exact, the moments carry float64 rounding only -- without materialising a float64 copy of the batch (round 3 did: 8 bytes
+    # per element through five elementwise kernels)
+    n = float(x.shape[1] * x.shape[2])
+    mean = x.sum(dim=(1, 2), keepdim=True, dtype=torch.float64) / n
+    var = ((x * x).sum(dim=(1, 2), keepdim=True, dtype=torch.float64) / n - mean * mean).clamp_(min=0.0)
     return ((x - mean.float()) / (var.sqrt().float() + 0.00000001)).contiguous()
 
 
@@ -107,6 +110,62 @@ class FeatureCache:
         return [self.group[k_] for k_ in keys]
 
 
+class SessionLoader:
+    """Clusters of a session-format generator prepared with the per-IMAGE work on worker processes (host_pool.HostPool):
+    `submit(c)` hands the cluster's images that no earlier cluster asked for to the pool and returns at once, `result(handle)`
+    gives what `gen.prepare(c, center=False)` gives -- the same functions, run in the workers -- except that the image stacks
+    come back as LISTS of per-view uint8 arrays (no (N,H,W,3) copy on this thread).  Image sizes (needed for the cluster's
+    scale-to-cover factor before anything is decoded, mvs_cluster.py:178-192) come from the files' headers."""
+
+    def __init__(self, gen, pool, limit=192):
+        from collections import OrderedDict
+        self.gen, self.pool, self.limit = gen, pool, limit
+        self.images = OrderedDict()                  # (session, index, rescale) -> Future of (cropped, output image, shape, seconds)
+        self.sizes = {}
+        self.load_seconds = 0.0
+        self._counted = set()
+
+    def _size(self, c, i):
+        key = (c.session_dir, i)
+        hit = self.sizes.get(key)
+        if hit is None:
+            from PIL import Image
+            with Image.open(c.image_path(i)) as im:  # header only: nothing is decoded
+                hit = self.sizes[key] = (im.size[1], im.size[0], 3)
+        return hit
+
+    def submit(self, c):
+        g = self.gen
+        sizes = [self._size(c, i) for i in c.indices]
+        c.original_image_shape = sizes[0]
+        c.rescale = max(max(float(g.image_height) / s_[0] for s_ in sizes), max(float(g.image_width) / s_[1] for s_ in sizes))
+        futs = []
+        for i in c.indices:
+            key = (c.session_dir, i, round(float(c.rescale), 12))
+            f = self.images.get(key)
+            if f is None:
+                f = self.images[key] = self.pool.load_image(c.image_path(i), c.rescale, g.image_width, g.image_height,
+                                                            g.base_image_size, g.output_scale)
+                while len(self.images) > self.limit:
+                    self.images.popitem(last=False)
+            else:
+                self.images.move_to_end(key)
+            futs.append((key, f))
+        return c, sizes, futs
+
+    def result(self, handle):
+        c, sizes, futs = handle
+        ins, outs = [], []
+        for key, f in futs:
+            cr, oi, _shape, sec = f.result()
+            if key not in self._counted:             # worker seconds, once per decoded image
+                self._counted.add(key)
+                self.load_seconds += sec
+            ins.append(cr); outs.append(oi)
+        full_cams, out_cams = self.gen.cluster_cameras(c, c.cameras(), sizes)
+        return outs, ins, out_cams, full_cams, c.ref_index
+
+
 # Pinned host buffers are expensive to create (~1.5 ms each) and cheap to keep: the staging buffers of the uploads and the result
 # buffers of the downloads live for the process, not for one compute_depth_maps call (a session is one call).
 _PINNED_STAGING = {}
@@ -114,14 +173,16 @@ _PINNED_RESULTS = {}
 
 
 def compute_depth_maps(input_dir, config=None, weights=None, device=None, timings=None, gru_views=4,
-                       feature_cache_limit=256, **kwargs):
+                       feature_cache_limit=256, host_workers=None, **kwargs):
     """mvsnet/inference.py:83-119.  Returns the number of depth maps this rank wrote.
 
     `timings` (a dict) receives the stage breakdown of the run in seconds: wall, load (decode + resize + crop + centre on the
     loader threads, summed over threads), wait_load (this thread blocked on the loaders), towers / hot_path / d2h (GPU time from
     stream events, host -> device copies of the images included in towers), host_gpu_submit (this thread enqueueing), write (file
     writers, summed over threads).  `gru_views`: reference views per recurrent sweep (mvs_gru_wta_batch_f32) with the GRU
-    regulariser."""
+    regulariser.  `host_workers`: worker PROCESSES for image decoding / rescaling and output encoding (host_pool; None = by
+    core count, 0 = round 3's loader / writer threads inside this process); `timings` then also receives host_cpu = CPU
+    seconds of this process and its workers."""
     import threading
     import torch
     from . import predictlib as pl
@@ -175,20 +236,47 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     # the copy's event (round 2 called .cpu() here, which held this thread -- and with it the next reference view's launches
     # -- until the GPU had finished the current one).
     from concurrent.futures import ThreadPoolExecutor
+    from . import host_pool
+    from .mvs_data_generation import Cluster
     n_loaders = max(2, min(8, (os.cpu_count() or 4) // 2))
     n_writers = 4
+    # Round 4: the per-image work of the loaders and the whole of the writers run in worker PROCESSES (host_pool): with them on
+    # threads of this process the thread that feeds the GPU spent more time waiting for the GIL than working.  The loader /
+    # writer threads below remain as the thin ends of that pipe (they wait for futures and copy events), and as the whole
+    # pipe for upstream-format projects and for host_workers = 0.
+    pool = host_pool.get_pool(host_workers) if any(type(c_) is Cluster for c_ in mine) else None
+    session_loader = SessionLoader(gen, pool) if pool is not None else None
+    cpu0 = None
+    if timings is not None:
+        try:
+            import psutil
+            cpu0 = (sum(psutil.Process().cpu_times()[:2]), pool.cpu_seconds() if pool is not None else 0.0)
+        except Exception:                             # noqa: BLE001
+            cpu0 = None
     loader, writer = ThreadPoolExecutor(max_workers=n_loaders), ThreadPoolExecutor(max_workers=n_writers)
-    pending, writes = [], []
+    pending, writes, pool_writes = [], [], []
     ahead = 16
     slots = threading.BoundedSemaphore(8)             # pinned result buffers in flight
     ev_marks = []                                     # per reference view: events at the stage boundaries
 
-    from .mvs_data_generation import Cluster
     device_center = lambda c_: type(c_) is Cluster        # session format: uint8 up, standardised on the device
+
+    class _Handle:                                        # a cluster whose images are on their way through the worker processes
+        def __init__(self, h):
+            self.h = h
+
+        def result(self):
+            return session_loader.result(self.h)
 
     def submit_next(it):
         for c_ in it:
-            if device_center(c_):
+            if device_center(c_) and session_loader is not None:
+                try:
+                    pending.append((c_, _Handle(session_loader.submit(c_))))
+                except Exception as e:                    # an unreadable header: skip-and-log like a failed load
+                    logger.warning("skipping cluster %s/%d: %s", c_.session_dir, c_.ref_index, e)
+                    continue
+            elif device_center(c_):
                 pending.append((c_, loader.submit(timed, "load", gen.prepare, c_, False)))
             else:
                 pending.append((c_, loader.submit(timed, "load", gen.prepare, c_)))
@@ -253,19 +341,34 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
             marks.append(copied)
 
         def write():
+            released = False
+
+            def release():
+                nonlocal released
+                if not released:
+                    released = True
+                    with tm_lock:
+                        pinned[tuple(dh.shape)].append(pair)
+                    slots.release()
             try:
                 copied.synchronize()
-                if config.refinement and config.upsample_before_refinement:      # full-size outputs (predictlib.py:107-115)
+                full = bool(config.refinement and config.upsample_before_refinement)      # full-size outputs (predictlib.py:107-115)
+                if full:
                     from .mvs_data_generation import center_image       # the reference writes the STANDARDISED input image here
-                    img0 = center_image(in_images[0]) if in_images.dtype == np.uint8 else in_images[0]
-                    return timed("write", pl.write_output_slice, output_dir, dh.numpy(), ph.numpy(), img0, full_cams[0],
-                                 index, config.visualize, 1.0 / config.sample_scale)
-                return timed("write", pl.write_output_slice, output_dir, dh.numpy(), ph.numpy(), out_images[0], out_cams[0],
-                             index, config.visualize)
-            finally:
+                    img0 = center_image(in_images[0]) if in_images[0].dtype == np.uint8 else in_images[0]
+                    args = (img0, full_cams[0], index, config.visualize, 1.0 / config.sample_scale)
+                else:
+                    args = (out_images[0], out_cams[0], index, config.visualize, None)
+                if pool is None:
+                    return timed("write", pl.write_output_slice, output_dir, dh.numpy(), ph.numpy(), *args)
+                # private copies (the executor pickles them later, on its feeder thread), then the pinned pair is free again
+                dn, pn = np.array(dh.numpy()), np.array(ph.numpy())
+                release()
+                f_ = pool.write_outputs(output_dir, dn, pn, np.asarray(args[0]), np.asarray(args[1]), *args[2:])
                 with tm_lock:
-                    pinned[tuple(dh.shape)].append(pair)
-                slots.release()
+                    pool_writes.append(f_)
+            finally:
+                release()
         writes.append(writer.submit(write))
 
     def mark():
@@ -367,6 +470,10 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     flush_gru()
     for w_ in writes:
         w_.result()                                   # surfaces write errors; all files are on disk on return
+    for f_ in pool_writes:
+        tm["write"] += f_.result()                    # worker seconds; raises what the worker raised
+    if session_loader is not None:
+        tm["load"] += session_loader.load_seconds
     loader.shutdown(); writer.shutdown()
     if timings is not None:
         torch.cuda.synchronize()
@@ -374,6 +481,11 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
         timings["wall"] = time.perf_counter() - t_wall
         timings["depth_maps"] = done
         timings["loader_threads"], timings["writer_threads"] = n_loaders, n_writers
+        timings["host_workers"] = pool.workers if pool is not None else 0
+        if cpu0 is not None:
+            import psutil
+            timings["host_cpu"] = (sum(psutil.Process().cpu_times()[:2]) - cpu0[0]) + \
+                                  ((pool.cpu_seconds() or 0.0) - (cpu0[1] or 0.0) if pool is not None else 0.0)
         tw = th = td = 0.0
         for m in ev_marks:
             if m[0] is not None and m[1] is not None:
@@ -410,6 +522,9 @@ def main(argv=None):
                     help="worker processes sharing each GPU (ranks = gpus x procs_per_gpu, collectives over gloo): the loop "
                          "load -> towers -> hot path -> write is bound by ONE Python thread per process (DESIGN section 5, "
                          "`session`), several processes per GPU fill it")
+    ap.add_argument("--host_workers", type=int, default=-1,
+                    help="worker processes for image decoding / rescaling and output encoding (mvsnet_amd/host_pool.py); "
+                         "-1 = by core count, 0 = loader / writer threads inside this process")
     ap.add_argument("--passes", type=int, default=1,
                     help="run the whole input this many times and report all passes after the first together (throughput "
                          "measurements: the first pass pays plans, code objects and pinned buffers)")
@@ -454,7 +569,8 @@ def main(argv=None):
                 dist.barrier()                        # the ranks start together: the rate is all maps / the slowest rank
             t0, total = time.perf_counter(), 0
         for d in dirs:
-            total += compute_depth_maps(d, cfg, weights, device, gru_views=args.gru_views)
+            total += compute_depth_maps(d, cfg, weights, device, gru_views=args.gru_views,
+                                        host_workers=None if args.host_workers < 0 else args.host_workers)
         wall = time.perf_counter() - t0
     counts = sh.gather_counts(dist, total, device=device if dist is not None else "cpu")
     walls = sh.gather_counts(dist, wall, device=device if dist is not None else "cpu")

@@ -120,6 +120,21 @@ def crop_mvs_input(images, cams, width, height, base_image_size, depth_image=Non
     return images, cams
 
 
+_CAMERA_JSON = {}          # path -> (mtime_ns, size, parsed): a session's cameras are listed by up to view_num clusters each
+
+
+def _camera_json(path):
+    st = os.stat(path)
+    hit = _CAMERA_JSON.get(path)
+    if hit is None or hit[0] != st.st_mtime_ns or hit[1] != st.st_size:
+        with open(path) as f:
+            hit = (st.st_mtime_ns, st.st_size, json.load(f))
+        if len(_CAMERA_JSON) > 4096:
+            _CAMERA_JSON.clear()
+        _CAMERA_JSON[path] = hit
+    return hit[2]
+
+
 class Cluster:
     """One reference view and its covisible source views (mvs_cluster.py:27-207)."""
 
@@ -173,8 +188,7 @@ class Cluster:
     def load_camera(self, index):
         """(2,4,4): pose (translation metres -> mm), intrinsics, (min, interval, num, max)
         (mvs_cluster.py:91-127)."""
-        with open(self.camera_path(index)) as f:
-            data = json.load(f)
+        data = _camera_json(self.camera_path(index))
         interval = ((self.max_depth - self.min_depth) / (self.depth_num - 1)) * self.interval_scale
         cam = np.zeros((2, 4, 4))
         for i in range(4):
@@ -303,7 +317,8 @@ class ClusterGenerator:
         c.original_image_shape = sizes[0]
         c.rescale = max(max(float(self.image_height) / s_[0] for s_ in sizes), max(float(self.image_width) / s_[1] for s_ in sizes))
         cams = c.cameras()
-        ins, outs, full_cams, out_cams = [], [], [], []
+        full_cams, out_cams = self.cluster_cameras(c, cams, sizes)
+        ins, outs = [], []
         for v, i in enumerate(c.indices):
             key = (c.session_dir, i, round(float(c.rescale), 12), bool(center))
             with self._img_lock:
@@ -318,14 +333,21 @@ class ClusterGenerator:
                     self._img_cache[key] = hit
                     while len(self._img_cache) > self.image_cache_limit:
                         self._img_cache.popitem(last=False)
+            ins.append(hit[0]); outs.append(hit[1])
+        return (np.stack(outs, axis=0), np.stack(ins, axis=0), out_cams, full_cams, c.ref_index)
+
+    def cluster_cameras(self, c, cams, sizes):
+        """Cameras of a cluster after scale-to-cover (c.rescale), centre-crop and output scaling, from the ORIGINAL image
+        sizes alone (crop_mvs_input only shifts the principal point by the crop offset): (full_cams (N,2,4,4), out_cams)."""
+        full_cams, out_cams = [], []
+        for v in range(len(c.indices)):
             _, cm = scale_mvs_input([], [cams[v]], scale=c.rescale)
-            # crop_mvs_input only shifts the principal point by the crop offset: recompute it for the camera from the size
             h0, w0 = int(round(sizes[v][0] * c.rescale)), int(round(sizes[v][1] * c.rescale))
             dummy = [np.empty((h0, w0, 0), np.uint8)]
             _, cc = crop_mvs_input(dummy, cm, self.image_width, self.image_height, self.base_image_size)
             _, oc = scale_mvs_input([], cc, scale=self.output_scale)
-            ins.append(hit[0]); outs.append(hit[1]); full_cams.append(cc[0]); out_cams.append(oc[0])
-        return (np.stack(outs, axis=0), np.stack(ins, axis=0), np.stack(out_cams, axis=0), np.stack(full_cams, axis=0), c.ref_index)
+            full_cams.append(cc[0]); out_cams.append(oc[0])
+        return np.stack(full_cams, axis=0), np.stack(out_cams, axis=0)
 
     def prepare(self, c: Cluster, center=True):
         if self.mode == "inference" and type(c) is Cluster:

@@ -131,6 +131,8 @@ def confidence_to_uint16(image):
 
 
 def write_png16(file, image16):
-    """Greyscale 16-bit PNG via Pillow (imageio.imsave in the reference)."""
+    """Greyscale 16-bit PNG via Pillow (imageio.imsave in the reference).  zlib level 1 (round 4): the same pixels in a
+    ~20 % larger file for a quarter of the encoding time (2.2 -> 0.5 ms per 160 x 128 map; the encoder was 60 % of a
+    reference view's write time)."""
     from PIL import Image
-    Image.fromarray(np.asarray(image16, np.uint16)).save(file)
+    Image.fromarray(np.asarray(image16, np.uint16)).save(file, compress_level=1)

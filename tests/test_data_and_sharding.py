@@ -302,3 +302,56 @@ def test_feature_cache_never_evicts_a_key_of_the_group_in_hand():
     assert list(c.entries) == [7, 8, 5, 9] and c.hits == 3 and c.misses == 10
     with pytest.raises(KeyError):
         c.get([6])                                                                     # not part of the group in hand
+
+
+def test_host_worker_processes_equal_the_in_process_loader_and_writer(tmp_path):
+    """mvsnet_amd/host_pool.py (round 4): the per-image part of the loader (decode -> scale-to-cover -> centre-crop -> output
+    scale) and write_output_slice run in spawned worker PROCESSES; a cluster assembled by inference.SessionLoader equals
+    ClusterGenerator.prepare(c, center=False) array for array, the six files a worker writes equal the in-process writer's
+    byte for byte, the workers see no GPU and import nothing of the application's __main__."""
+    import numpy as np
+    from mvsnet_amd import host_pool, mvs_data_generation as G, predictlib as pl, synthetic as S
+    from mvsnet_amd.inference import SessionLoader
+    sess = S.write_session(str(tmp_path / "s"), n_images=7, height=100, width=132, view_num=5, depth_num=192)
+    mk = lambda: G.make_generator(sess, 5, 128, 96, 192, 1.0, 8, mode="inference", output_scale=0.25)
+    gen = mk()
+    pool = host_pool.get_pool(2)
+    assert pool.workers == 2 and len(pool.pids) >= 1 and os.getpid() not in pool.pids
+    sl = SessionLoader(gen, pool)
+    handles = [sl.submit(c) for c in gen.clusters]                       # 7 images requested once each, 35 uses
+    want = None
+    for c, h in zip(gen.clusters, handles):
+        got = sl.result(h)
+        gen2 = mk()
+        c2 = [x for x in gen2.clusters if x.ref_index == c.ref_index][0]
+        want = gen2.prepare(c2, center=False)
+        assert isinstance(got[0], list) and got[1][0].dtype == np.uint8
+        assert np.array_equal(np.stack(got[0]), want[0]) and np.array_equal(np.stack(got[1]), want[1])
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]) and got[4] == want[4]
+        assert c.rescale == c2.rescale and tuple(c.original_image_shape) == tuple(c2.original_image_shape)
+    assert len(sl.images) == 7 and sl.load_seconds > 0
+    rs = np.random.RandomState(0)
+    depth = (rs.rand(24, 32) * 500 + 425).astype(np.float32)
+    prob = rs.rand(24, 32).astype(np.float32)
+    o1, o2 = str(tmp_path / "o1"), str(tmp_path / "o2")
+    os.makedirs(o1); os.makedirs(o2)
+    assert pool.write_outputs(o1, depth, prob, want[0][0], want[2][0], 7).result() > 0
+    pl.write_output_slice(o2, depth, prob, want[0][0], want[2][0], 7)
+    assert sorted(os.listdir(o1)) == sorted(os.listdir(o2)) == ["7.jpg", "7.txt", "7_depth.png", "7_init.pfm", "7_prob.pfm", "7_prob.png"]
+    for fn in os.listdir(o2):
+        assert open(os.path.join(o1, fn), "rb").read() == open(os.path.join(o2, fn), "rb").read(), fn
+    # a failing task surfaces in the parent as the worker's exception, and the slot it held is free again
+    bad = pool.load_image(str(tmp_path / "missing.jpg"), 1.0, 128, 96, 8, 0.25)
+    with pytest.raises(FileNotFoundError):
+        bad.result()
+    assert len(pool.free) == pool.slots
+    # the workers were started without devices and without the application's main module
+    env = pool.ex.submit(_worker_probe).result()
+    assert env["hip"] == "" and env["worker"] == "1" and env["main_file"] is None and env["torch"] is False
+    assert host_pool.get_pool(0) is None                                  # threads only
+
+
+def _worker_probe():
+    import sys
+    return {"hip": os.environ.get("HIP_VISIBLE_DEVICES"), "worker": os.environ.get("MVS_HOST_WORKER"),
+            "main_file": getattr(sys.modules["__main__"], "__file__", None), "torch": "torch" in sys.modules}
