@@ -379,6 +379,7 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
         return e
 
     gru_batch = []                                    # GRU: reference views waiting to share one sweep
+    tower_marks = []                                  # (start, end) events of tower passes not yet attributed to a flushed sweep
 
     def flush_gru():
         if not gru_batch:
@@ -401,7 +402,12 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
         dd, pp_ = plan.run_gru_batch([g_[0] for g_ in gru_batch], dvs)
         m1 = mark()
         for v, g_ in enumerate(gru_batch):
+            # the tower passes (and uploads) of the groups that fed this sweep: their event pairs ride on its first view
             marks = [None, None, m0, m1] if (timings is not None and v == 0) else None
+            if marks is not None and tower_marks:
+                marks[0], marks[1] = tower_marks.pop(0)
+                ev_marks.extend([[a_, b_, m0, m0] for a_, b_ in tower_marks])      # further groups: towers only (zero-length hot path)
+                tower_marks.clear()
             finish(dd[v], pp_[v], *g_[5], marks)        # copied out in stream order, before the next sweep overwrites the plan's buffers
             if marks is not None:
                 ev_marks.append(marks)
@@ -448,6 +454,8 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
                 flush_gru()                               # a view of another size starts a new batch
                 batched_gru = True
             if batched_gru:
+                if first and timings is not None:
+                    tower_marks.append((m_start, m_towers))
                 gru_batch.append((features, cams, depth_num, depth_start, depth_end, rest))
                 if len(gru_batch) >= gru_views:
                     flush_gru()
