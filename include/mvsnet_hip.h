@@ -317,7 +317,7 @@ int mvs_gru_wta_batch_f32(const float* const* ref, const float* const* src, cons
                           size_t workspace_bytes, float* depth_out, float* prob_out, void* stream);
 
 /* Set-up of the recurrent sweep for caller stream `stream` on the current device: three side streams, ~30 events, and ONE
- * ~10-30 ms calibration that finds the compute pipe the caller's hardware queue lives on (csrc/gru.hip; DESIGN 4.4) so that the
+ * ~10-30 ms calibration that finds the compute pipe the caller's hardware queue lives on (csrc/gru.hip; DESIGN 4.5) so that the
  * side streams avoid it.  THE call of this header that creates resources and synchronises (`stream` and the new streams):
  * call it once per caller stream at start-up (DepthPlan(..., "GRU") does), never inside a latency-critical region or under
  * hipGraph capture (returns MVS_E_NOT_PREPARED there).  Idempotent.  An inconclusive calibration is reported once on stderr and

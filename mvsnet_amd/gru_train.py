@@ -14,7 +14,7 @@ Where the work runs
   * warp + variance of ALL planes and its backward w.r.t. the feature maps: libmvsnet_hip.so
     (`mvs_cost_volume_f32` / `mvs_cost_volume_bwd_gather_f32`), as on the 3D-CNN training path;
   * the three ConvGRU cells: back-propagation through time over `depth_num` planes, restructured the way the
-    inference kernels are (DESIGN §4.4): a cell's convolution over concat([x, h]) is split into an x part and an h
+    inference kernels are (DESIGN §4.5): a cell's convolution over concat([x, h]) is split into an x part and an h
     part, and the network is walked cell by cell instead of plane by plane.  The x part of every plane is then ONE
     batched convolution (planes as the batch dimension), and so are the x-part input gradients and ALL weight / bias
     gradients in the backward pass (ATen / MIOpen, as for the 2D towers).  What is sequential in the plane index —

@@ -542,7 +542,7 @@ def main(argv=None):
     logging.basicConfig(level=os.environ.get("LOG_LEVEL", "INFO"))
     if args.procs_per_gpu > 1 and args.regularization == "GRU":
         # measured (round 3, 160x128, D = 192): 165 depth maps/s with one process, 53 with three -- the recurrent sweep is a
-        # four-queue wavefront, and the queues of several processes share the GPU's four compute pipes (DESIGN 4.4)
+        # four-queue wavefront, and the queues of several processes share the GPU's four compute pipes (DESIGN 4.5)
         logger.warning("--procs_per_gpu %d with the GRU regulariser: the sweeps of different processes share the GPU's compute "
                        "pipes and slow each other down; use --gru_views to put several reference views into one sweep instead",
                        args.procs_per_gpu)

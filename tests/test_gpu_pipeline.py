@@ -197,7 +197,7 @@ def test_gru_sweep_prepare_capture_and_release(lib_built):
         plan.depth.zero_()
         assert call() == 0
         torch.cuda.synchronize()
-        assert torch.equal(plan.depth, eager_d)                                               # same planes (DESIGN 4.4: depth identical)
+        assert torch.equal(plan.depth, eager_d)                                               # same planes (DESIGN 4.5: depth identical)
         assert float(((plan.prob - eager_p).abs() / eager_p).max()) < 1e-6
     # slots are recycled
     with torch.cuda.stream(s):
