@@ -27,7 +27,7 @@ PY
 done
 ls -la gpurun_out/r04/r04*
 # SQ counters of the 4-view recurrent sweep, per kernel and plane
-bash tools/r4_pmc_gru.sh > gpurun_out/r04/r04_gru_pmc_B4.txt 2>&1
+bash tools/gru_pmc.sh > gpurun_out/r04/r04_gru_pmc_B4.txt 2>&1
 # the default bench record of the round (what the driver runs)
 timeout -k 10 600 python bench.py > gpurun_out/r04/r04_bench_default.json 2> gpurun_out/r04/r04_bench_default.err
 ls -la gpurun_out/r04/r04*

@@ -1,12 +1,12 @@
 #!/bin/bash
 # SQ counters of the recurrent sweep at 4 views per launch, summed per kernel over one process (2 warm-up + 2 timed sweeps)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r4_pmc_gru; rm -rf $O; mkdir -p $O
+O=gpurun_out/gru_pmc; rm -rf $O; mkdir -p $O
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/p1 -- python tools/gru_time.py --views 4 --iters 2 > $O/p1.log 2>&1 || echo "pass failed"
 python - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
-for f in glob.glob("gpurun_out/r4_pmc_gru/p1/**/*counter_collection.csv", recursive=True):
+for f in glob.glob("gpurun_out/gru_pmc/p1/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:60]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
