@@ -98,6 +98,7 @@ conv2d_cat_kernel(const float* __restrict__ xa, int Ca, const float* __restrict_
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct LN { float inv_r, mean_r; };
 
 // LayerNorm affine from accumulated moments: y = x*inv[c] + (beta[c] - mean*inv[c]),
@@ -214,7 +215,7 @@ struct SmallArgs {
     size_t vstride;                                   // blockIdx.y = view
 };
 
-template <int CA, int CB, int CO, int MODE>
+template <int CA, int CB, int CO, int MODE, bool MATRIX>
 __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int bid) {
     const int view = blockIdx.y;
     const size_t vo = (size_t)view * sa.vstride;
@@ -236,6 +237,26 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
     cfloat* wsh = (cfloat*)w;
     __shared__ __attribute__((aligned(16))) float tile[PS * PS * CT];
     __shared__ float red[4][2][2];
+    // Round 4: the convolution itself on v_mfma_f32_4x4x1_16B_f32 -- 16 blocks of (4 output channels x 4 pixels), K = 1: a lane
+    // stays one pixel, its B operand is the staged input value it already holds, its four result registers are 4 output
+    // channels of that pixel, and the A operand (lane m: weight of output channel m & 3) is one LDS read per (tap, channel).
+    // Exactly the fused multiply-add chain of the vector form, in the same order: the same bits (tools/small_cell_probe.hip
+    // checks it).  The probe (profiles/r04_small_cell_probe.txt) measured the 20 -> 8 convolution at 82.7 TFLOP/s on this
+    // form against 48.0 on v_pk_fma_f32 with SGPR weights -- the packed FMA issues at half rate on gfx950, so the matrix
+    // instruction is twice the vector ALU's real fp32 rate, without padding for 4- and 8-channel outputs (2 channels: half).
+    // MATRIX is chosen by the launcher: the matrix form for ONE reference view per sweep (same-box A/B, c3: 22.49 -> 22.06 ms),
+    // the vector form for several views per launch (72.4 against 73.1 ms per 4-view sweep: there the kernels are bound by memory
+    // and the sweep by the matrix pipe cell 1 keeps busy; the 5.8 KB weight table costs the 20-channel instances one of their
+    // six workgroups per CU).  Both forms give the same bits.
+    constexpr bool MFMA44 = MATRIX && (CO == 8 || CO == 4 || CO == 2);
+    constexpr int NGRP = CO > 4 ? 2 : 1;               // matrix instructions per (tap, input channel)
+    __shared__ __attribute__((aligned(16))) float wl[MFMA44 ? 9 * CT * 4 * NGRP : 4];      // [tap * CT + ci][m & 3][group]
+    if (MFMA44) {
+        for (int i = threadIdx.x; i < 9 * CT * 4 * NGRP; i += 256) {
+            const int g_ = i % NGRP, r_ = (i / NGRP) & 3, k_ = i / (4 * NGRP), co = r_ + 4 * g_;
+            wl[i] = co < CO ? w[k_ * CO + co] : 0.f;     // visible to the convolution after the staging barrier below
+        }
+    }
     // LayerNorm moments -> (mean, 1 / sqrt(var + eps)) ONCE per workgroup (two lanes, then LDS): every thread used to run the
     // float64 divisions and square roots itself, per channel -- ~1000 instruction slots per wave at the head of a kernel whose
     // own work is a few hundred (round 3: the four small-cell kernels 43 / 30 / 27 / 15 us per 4-view plane before)
@@ -335,17 +356,48 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
     float acc[CO];
 #pragma unroll
     for (int j = 0; j < CO; ++j) acc[j] = bias ? bias[j] : 0.f;
+    if constexpr (MFMA44) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
+        for (int j = 0; j < 4; ++j) { if (j < CO) a0[j] = acc[j]; if (NGRP == 2) a1[j] = acc[CO > 4 ? 4 + j : 0]; }
+        const float* wa = wl + (threadIdx.x & 3) * NGRP;
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            float v[CT];
-            load_vec<CT>(tile + ((ly + kh) * PS + lx + kw) * CT, v);
-            cfloat* wt = wsh + (kh * 3 + kw) * CT * CO;
+        for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
-            for (int ci = 0; ci < CT; ++ci)
+            for (int kw = 0; kw < 3; ++kw) {
+                float v[CT];
+                load_vec<CT>(tile + ((ly + kh) * PS + lx + kw) * CT, v);
+                const float* wt = wa + (kh * 3 + kw) * CT * 4 * NGRP;
 #pragma unroll
-                for (int j = 0; j < CO; ++j) acc[j] += v[ci] * wt[ci * CO + j];
+                for (int ci = 0; ci < CT; ++ci) {
+                    if constexpr (NGRP == 2) {
+                        const float2 wv = *(const float2*)(wt + ci * 8);
+                        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, v[ci], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, v[ci], a1, 0, 0, 0);
+                    } else {
+                        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[ci * 4], v[ci], a0, 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { if (j < CO) acc[j] = a0[j]; if (NGRP == 2) acc[CO > 4 ? 4 + j : 0] = a1[j]; }
+    } else {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                float v[CT];
+                load_vec<CT>(tile + ((ly + kh) * PS + lx + kw) * CT, v);
+                cfloat* wt = wsh + (kh * 3 + kw) * CT * CO;
+#pragma unroll
+                for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+                    for (int j = 0; j < CO; ++j) acc[j] = __builtin_fmaf(v[ci], wt[ci * CO + j], acc[j]);
+                // (explicitly fused: written as acc += v * w the 20 -> 4 instance came out with part of its products on
+                // v_pk_mul_f32 + v_add_f32, i.e. rounded twice -- legal under -ffp-contract=fast, but not the matrix form's
+                // multiply-add chain, and the two forms must give the same bits)
+            }
         }
     }
     if (valid) {
@@ -360,8 +412,8 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
             float sv = 0.f, qv = 0.f;
             if (valid) {
 #pragma unroll
-                for (int j = 0; j < CO; ++j)
-                    if (j / per == gi) { sv += acc[j]; qv += acc[j] * acc[j]; }
+                for (int j = 0; j < CO; ++j)      // explicit fused multiply-add: left to -ffp-contract the matrix and the vector
+                    if (j / per == gi) { sv += acc[j]; qv = __builtin_fmaf(acc[j], acc[j], qv); }      // form of this kernel came out differently (1 ulp in the moments)
             }
             sv = wave_sum(sv); qv = wave_sum(qv);
             if (lane == 0) { red[wv][gi][0] = sv; red[wv][gi][1] = qv; }
@@ -375,9 +427,9 @@ __device__ __forceinline__ void conv2d_small_body(const SmallArgs& sa, const int
     }
 }
 
-template <int CA, int CB, int CO, int MODE>
+template <int CA, int CB, int CO, int MODE, bool MATRIX>
 __global__ void __launch_bounds__(256)
-conv2d_small_kernel(SmallArgs a) { conv2d_small_body<CA, CB, CO, MODE>(a, blockIdx.x); }
+conv2d_small_kernel(SmallArgs a) { conv2d_small_body<CA, CB, CO, MODE, MATRIX>(a, blockIdx.x); }
 
 // cells 2 / 3: gate conv then candidate conv (reset gate folded in); false if the shape has no instance
 // `prev`: the previous plane's blend has not been launched -- its inputs; h then RECEIVES the state entering this plane
@@ -391,19 +443,24 @@ bool launch_small_cell(const float* xin, float* h, const float* const* p, int H,
                        double* sg, double* so, const PrevPlane* prev, Views vw, hipStream_t st, const WtaFold* wta = nullptr) {
     const dim3 grid(((H + 15) / 16) * ((W + 15) / 16), vw.n);     // 16 x 16 pixel tiles x views
     BlendIn none = {};
+    const bool mg = vw.n == 1, mc = vw.n == 1;                      // matrix form for one view per sweep, vector form for several (conv2d_small_body)
     if (prev) {
         BlendIn bl = {c, prev->g, prev->so, prev->sg + 2, p[8], p[9], p[4], p[5], h, nullptr, nullptr, {}, nullptr, nullptr, nullptr};
         if (wta) {
             bl.pw = wta->pw; bl.pbias = wta->pbias; bl.max_prob = wta->max_prob; bl.depth_image = wta->depth_image; bl.exp_sum = wta->exp_sum;
             for (int v = 0; v < MAXV; ++v) bl.depth_value[v] = wta->depth_value[v];
         }
-        conv2d_small_kernel<CA, F, 2 * F, 2><<<grid, 256, 0, st>>>(SmallArgs{xin, prev->h_before, nullptr, nullptr, nullptr, nullptr,
-                                                                             p[0], p[1], H, W, g, sg, 2, bl, vw.stride});
+        const SmallArgs ga{xin, prev->h_before, nullptr, nullptr, nullptr, nullptr, p[0], p[1], H, W, g, sg, 2, bl, vw.stride};
+        if (mg) conv2d_small_kernel<CA, F, 2 * F, 2, true><<<grid, 256, 0, st>>>(ga);
+        else conv2d_small_kernel<CA, F, 2 * F, 2, false><<<grid, 256, 0, st>>>(ga);
     } else {
-        conv2d_small_kernel<CA, F, 2 * F, 0><<<grid, 256, 0, st>>>(SmallArgs{xin, h, nullptr, nullptr, nullptr, nullptr,
-                                                                             p[0], p[1], H, W, g, sg, 2, none, vw.stride});
+        const SmallArgs ga{xin, h, nullptr, nullptr, nullptr, nullptr, p[0], p[1], H, W, g, sg, 2, none, vw.stride};
+        if (mg) conv2d_small_kernel<CA, F, 2 * F, 0, true><<<grid, 256, 0, st>>>(ga);
+        else conv2d_small_kernel<CA, F, 2 * F, 0, false><<<grid, 256, 0, st>>>(ga);
     }
-    conv2d_small_kernel<CA, F, F, 1><<<grid, 256, 0, st>>>(SmallArgs{xin, h, g, sg, p[2], p[3], p[6], p[7], H, W, c, so, 1, none, vw.stride});
+    const SmallArgs ca{xin, h, g, sg, p[2], p[3], p[6], p[7], H, W, c, so, 1, none, vw.stride};
+    if (mc) conv2d_small_kernel<CA, F, F, 1, true><<<grid, 256, 0, st>>>(ca);
+    else conv2d_small_kernel<CA, F, F, 1, false><<<grid, 256, 0, st>>>(ca);
     return true;
 }
 
