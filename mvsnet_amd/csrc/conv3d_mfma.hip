@@ -51,9 +51,27 @@ template <int CIN, int COUT, int TH, int TWG = CONV_TW> struct S1Geom {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int OOB = (int)0x80000000u;      // buffer byte offset with bit 31 set: loads give 0, stores are dropped
 
-template <int CIN, int COUT, int TH, bool HAS_X2, int TWG = CONV_TW, int CR = 1>
+// FUSE2 (round 4): 3dconv1_1 (16 -> 16, stride 1) and 3dconv2_0 (16 -> 32, stride 2) read the same tensor -- BN + ReLU of
+// 3dconv1_0 (mvsnetworks.py:131-132,138-139) -- so the stride-2 layer rides in the stride-1 layer's plane march exactly as
+// 3dconv1_0 rides in 3dconv0_1's (conv3d_c8.hip): the workgroup's staged 10 x 18 slab covers a 4 x 8 patch of stride-2
+// outputs (two 16-voxel column tiles) x 32 output channels (two row tiles); its 55 KB of weights do not fit in LDS next to
+// the slab, so K = (kd, kh, kw, ci) is split four ways by input channel: wave w keeps the A fragments of ci 4w .. 4w+3 for
+// all 27 taps x 32 couts in 54 registers, accumulates its quarter of every output, and the four partial tiles are summed
+// through 12 KB of LDS when an output plane completes (every second input plane).  One read and one normalisation of the
+// input instead of two, one launch instead of two, and the stride-2 layer (0.31 of the MFMA peak as a kernel of its own:
+// 40 tiles, 17 % halo planes) costs its 25 % of extra matrix work inside a kernel that already runs at 0.61.
+struct Fuse2Args {
+    const float* w2;      // stride-2 weights, TensorFlow layout (3,3,3,16,32)
+    float* y2;            // (D/2, H/2, W/2, 32) raw output
+    double* stats2;       // (slots2, 2, 32) float64 sums or null
+    int slots2;
+};
+constexpr int FUSE2_RED_FLOATS = 3 * 2 * 2 * 64 * 4;      // partial tiles of waves 1..3: [wave][row tile][column tile][lane][4]
+
+template <int CIN, int COUT, int TH, bool HAS_X2, int TWG = CONV_TW, int CR = 1, bool FUSE2 = false>
 __global__ void __launch_bounds__(256, (S1Geom<CIN, COUT, TH, TWG>::WGS_PER_CU))
-conv3d_s1_kernel(ConvArgs a) {
+conv3d_s1_kernel(ConvArgs a, Fuse2Args fa) {
+    static_assert(!FUSE2 || (CIN == 16 && COUT == 16 && TH == 8 && TWG == CONV_TW && CR == 1 && !HAS_X2), "the fused stride-2 consumer is built for 3dconv1_1 + 3dconv2_0");
     constexpr int S = S1Geom<CIN, COUT, TH, TWG>::S;
     constexpr int PW = TWG + 2;                    // staged row width with halo
     constexpr int CC = 16 / CR;                    // columns of a 16-voxel MFMA column tile
@@ -75,6 +93,7 @@ conv3d_s1_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;                              // [9 taps][CQ][3 kd][COUT][4]
     float* slab = smem + W_FLOATS;                 // [2][NPOS][S]
+    float* red2 = slab + 2 * SLAB_FLOATS;          // FUSE2: [3 waves][2 row tiles][2 column tiles][64 lanes][4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -262,6 +281,92 @@ conv3d_s1_kernel(ConvArgs a) {
         yoff[v] = (h < a.H && w < a.W) ? ((h * a.W + w) * a.cout_total + co_base) * 4 : OOB;
     }
 
+    // ---- fused stride-2 consumer (FUSE2) -------------------------------------------------------------
+    // Column tile ct, lane column n: output (oh, ow) = (h0/2 + 2ct + (n>>3), w0/2 + (n&7)); input tap (kh, kw) sits at staged
+    // (row 4ct + 2(n>>3) + kh + 1, column 2(n&7) + kw + 1) -- SAME with even sizes pads nothing in front.  This wave's k index kq
+    // is input channel 4*wave + kq (one ds_read_b32 per tap and column tile).
+    constexpr int COUT2 = 32;
+    float wS2[FUSE2 ? 3 : 1][FUSE2 ? 9 : 1][2];   // [kd][tap][row tile]: A fragments, dead (eliminated) when !FUSE2
+    f32x4 cur2[2][2], prv2[2][2];                  // [row tile][column tile]: output planes od_cur / od_cur - 1
+    int s2b[3];
+    float st2_s[2][4], st2_q[2][4];
+    int fin_od = -1;                               // output plane whose partial tiles wait in `red2`
+    const int Ho2 = a.H / 2, Wo2 = a.W / 2;
+    if (FUSE2) {
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+                    wS2[kd][tap][rt] = fa.w2[((size_t)(kd * 9 + tap) * CIN + 4 * wave + kq) * COUT2 + 16 * rt + n];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) s2b[kw] = ((2 * (n >> 3) + 1) * PW + 2 * (n & 7) + kw + 1) * S + 4 * wave + kq;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) { cur2[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; prv2[rt][ct] = cur2[rt][ct]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { st2_s[rt][k] = 0.f; st2_q[rt][k] = 0.f; }
+        }
+    }
+    // The stride-2 layer's 9 taps of one plane, after the stride-1 sweep of that plane; B values requested two taps ahead (an odd
+    // plane's four MFMAs per tap do not cover an LDS read's latency).  (Hanging the taps between the operand groups of the
+    // stride-1 sweep instead was measured slower, round 4: 109-112 us for the fused launch against 100 us.)
+    auto s2_sweep = [&](auto Ec, const float* buf) __attribute__((always_inline)) {
+        constexpr bool EVEN = decltype(Ec)::value;   // even plane: kd 0 -> cur, kd 2 -> prv; odd: kd 1 -> cur
+        float b2[3][2];
+        auto ld = [&](int tap, float (&b)[2]) __attribute__((always_inline)) {
+            const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) b[ct] = buf[s2b[kw] + (4 * ct + kh) * PW * S];
+        };
+        ld(0, b2[0]); ld(1, b2[1]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 2 < 9) ld(tap + 2, b2[(tap + 2) % 3]);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const float bval = b2[tap % 3][ct];
+                    if (EVEN) {
+                        cur2[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wS2[0][tap][rt], bval, cur2[rt][ct], 0, 0, 0);
+                        prv2[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wS2[FUSE2 ? 2 : 0][tap][rt], bval, prv2[rt][ct], 0, 0, 0);
+                    } else {
+                        cur2[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wS2[FUSE2 ? 1 : 0][tap][rt], bval, cur2[rt][ct], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // wave 0: sum the four K-quarters of output plane fin_od, store, BatchNorm sums.  (Spreading this over the four waves --
+    // wave t finishing tile t -- was measured slower, round 4: 108 us for the fused launch against 100 us, with every partial
+    // going through LDS; picking a wave's own partial out of prv2[][] by the wave number put the accumulators in scratch: 134 us.)
+    auto s2_finish = [&]() __attribute__((always_inline)) {
+        if (fin_od >= 0 && wave == 0) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    f32x4 r = prv2[rt][ct];
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) {
+                        const f32x4 p = *(const f32x4*)(red2 + (((w * 2 + rt) * 2 + ct) * 64 + lane) * 4);
+                        r[0] += p[0]; r[1] += p[1]; r[2] += p[2]; r[3] += p[3];
+                    }
+                    const int oh = h0 / 2 + 2 * ct + (n >> 3), ow = w0 / 2 + (n & 7);
+                    if (oh < Ho2 && ow < Wo2) {
+                        float* dst = fa.y2 + ((((size_t)fin_od * Ho2 + oh) * Wo2) + ow) * COUT2 + 16 * rt + 4 * kq;
+                        *(float4*)dst = make_float4(r[0], r[1], r[2], r[3]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { st2_s[rt][k] += r[k]; st2_q[rt][k] += r[k] * r[k]; }
+                    }
+                }
+        }
+        fin_od = -1;
+    };
+
     // ---- plane march -------------------------------------------------------------------------------
     // Plane q is swept while plane q+1 moves registers -> LDS (first half of the operand groups) and
     // plane q+2 is requested from global memory (second half): with one or two waves per SIMD,
@@ -286,7 +391,32 @@ conv3d_s1_kernel(ConvArgs a) {
                 if (NG / 2 + (i * (NG - NG / 2)) / NIT == g) load_piece(i, q + 2);
             }
         };
+        if (FUSE2) s2_finish();
         sweep(Pc, cur, extra);                      // planes outside the volume are staged as zeros
+        if (FUSE2 && q >= d0) {
+            const bool in_vol = q < a.D;
+            if (q & 1) {
+                if (in_vol) s2_sweep(std::false_type{}, cur);
+            } else {
+                // plane q = 2 * od_cur: od_cur starts (kd 0), od_cur - 1 completes (kd 2)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) { prv2[rt][ct] = cur2[rt][ct]; cur2[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                if (in_vol) s2_sweep(std::true_type{}, cur);
+                const int od_prev = q / 2 - 1;
+                if (2 * od_prev >= d0) {
+                    if (wave > 0) {
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct)
+                                *(f32x4*)(red2 + ((((wave - 1) * 2 + rt) * 2 + ct) * 64 + lane) * 4) = prv2[rt][ct];
+                    }
+                    fin_od = od_prev;
+                }
+            }
+        }
         retire(Pc, q - 1);
         __syncthreads();
     };
@@ -294,6 +424,26 @@ conv3d_s1_kernel(ConvArgs a) {
         plane(std::integral_constant<int, 0>{}, t);
         if (t + 1 < T) plane(std::integral_constant<int, 1>{}, t + 1);
         if (t + 2 < T) plane(std::integral_constant<int, 2>{}, t + 2);
+    }
+
+    if (FUSE2) {
+        s2_finish();
+        if (fa.stats2 && wave == 0) {
+            double* s2p = fa.stats2 + (size_t)((blockIdx.x + gridDim.x * blockIdx.z) % (fa.slots2 > 1 ? fa.slots2 : 1)) * 2 * COUT2;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float sv = st2_s[rt][k], qv = st2_q[rt][k];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }
+                    if (n == 0) {
+                        atomicAdd(&s2p[16 * rt + 4 * kq + k], (double)sv);
+                        atomicAdd(&s2p[COUT2 + 16 * rt + 4 * kq + k], (double)qv);
+                    }
+                }
+        }
+        __syncthreads();      // (stats_commit below re-uses the slab)
     }
 
     // ---- BatchNorm statistics ----------------------------------------------------------------------
@@ -320,8 +470,35 @@ int launch_s1(const ConvArgs& a0, int Cout, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess) return (int)e;
         attr_done = true;
     }
-    if (a.x2) conv3d_s1_kernel<CIN, COUT, TH, true, TWG, CR><<<grid, 256, smem, st>>>(a);
-    else conv3d_s1_kernel<CIN, COUT, TH, false, TWG, CR><<<grid, 256, smem, st>>>(a);
+    if (a.x2) conv3d_s1_kernel<CIN, COUT, TH, true, TWG, CR><<<grid, 256, smem, st>>>(a, Fuse2Args{});
+    else conv3d_s1_kernel<CIN, COUT, TH, false, TWG, CR><<<grid, 256, smem, st>>>(a, Fuse2Args{});
+    return (int)hipGetLastError();
+}
+
+// 3dconv1_1 + 3dconv2_0 in one pass (FUSE2 above).  Even D, H, W only; MVS_E_SHAPE otherwise (the caller runs the two layers apart).
+int launch_s1_fuse2(const ConvArgs& a0, const Fuse2Args& fa, hipStream_t st) {
+    ConvArgs a = a0;
+    if ((a.D & 1) || (a.H & 1) || (a.W & 1) || a.x2 || a.cout_total != 16) return MVS_E_SHAPE;
+    if ((long long)a.D * a.H * a.W * 16 * 4 >= (1LL << 31)) return MVS_E_SHAPE;                      // 32-bit buffer offsets
+    const int tiles = ((a.H + 7) / 8) * ((a.W + CONV_TW - 1) / CONV_TW);
+    // chunks start on even planes so that stride-2 output planes never straddle workgroups
+    int best = 2; long long best_cost = 1LL << 60;
+    for (int dr = 2; dr <= a.D; dr += 2) {
+        const long long wgs = (long long)tiles * ((a.D + dr - 1) / dr);
+        const long long cost = ((wgs + 255) / 256) * (dr + 3);
+        if (cost < best_cost) { best_cost = cost; best = dr; }
+    }
+    a.planes_per_wg = best;
+    dim3 grid(tiles, 1, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
+    const size_t smem = (size_t)S1Geom<16, 16, 8>::LDS_BYTES + FUSE2_RED_FLOATS * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3d_s1_kernel<16, 16, 8, false, CONV_TW, 1, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    conv3d_s1_kernel<16, 16, 8, false, CONV_TW, 1, true><<<grid, 256, smem, st>>>(a, fa);
     return (int)hipGetLastError();
 }
 
@@ -383,6 +560,13 @@ int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const
                          float* y, double* stats, hipStream_t st, int stats_slots) {
     ConvArgs a{x, nullptr, nullptr, x2, nullptr, nullptr, w, y, stats, D, H, W, Cout, 0, 0, 0, 0, bn, bn2, wprep, nullptr, stats_slots};
     return mvs_deconv3d_mfma_launch(a, Cin, Cout, st);
+}
+
+// 3dconv1_1 (x -> y, 16 -> 16, stride 1) and 3dconv2_0 (x -> y2, 16 -> 32, stride 2) over the same BN + ReLU input in one pass
+int mvs_conv3d_s1s2_16_bn(const float* x, const BnSrc& bn, const float* w, const float* wprep, int D, int H, int W, float* y,
+                          double* stats, const float* w2, float* y2, double* stats2, hipStream_t st, int stats_slots) {
+    ConvArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, w, y, stats, D, H, W, 16, 0, 0, 0, 0, bn, BnSrc{}, wprep, nullptr, stats_slots};
+    return launch_s1_fuse2(a, Fuse2Args{w2, y2, stats2, stats_slots}, st);
 }
 
 // ---- weight pre-layout (run once per weight set, mvs_regnet_prepare_f32) ---------------------------

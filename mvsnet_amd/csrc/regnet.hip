@@ -20,6 +20,8 @@ int mvs_deconv3d_mfma(const float*, const float*, const float*, const float*, co
                       const float*, const float*, int, int, int, int, int, float*, double*,
                       hipStream_t);
 // same, taking the producers' raw BatchNorm sums instead of a finalised (scale, shift)
+int mvs_conv3d_s1s2_16_bn(const float* x, const BnSrc& bn, const float* w, const float* wprep, int D, int H, int W, float* y,
+                          double* stats, const float* w2, float* y2, double* stats2, hipStream_t st, int stats_slots);
 int mvs_conv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const BnSrc& bn2,
                        const float* w, const float* wprep, const unsigned short* wprep_bf, int D, int H,
                        int W, int Cin, int Cout, int stride, float* y, double* stats, hipStream_t st, int stats_slots);
@@ -394,8 +396,24 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
     // The same-resolution branches 3dconv1_1 / 3dconv2_1 (mvsnetworks.py:138-141) are only needed by the decoder.  (Round 1 ran
     // them on a side stream beside the encoder's tail; with the block kernels of conv3d_os.hip a layer running beside the
     // chain slows it by more than it hides -- 826 depth maps/s with the fork, 837 without -- so everything is one stream.)
-    RUN(layer(false, L10, -1, L11, D1, H1, W1, 2 * b, 2 * b, 1, hs));
-    RUN(layer(false, L10, -1, L20, D1, H1, W1, 2 * b, 4 * b, 2, hs));
+    // 3dconv1_1 (stride 1) and 3dconv2_0 (stride 2) read the same tensor, BN + ReLU of 3dconv1_0: one fused pass when the
+    // shape is the one conv3d_mfma.hip builds it for (round 4), as for the two consumers of the cost volume above.
+    bool pair2_done = false;
+    if (all_mfma && !(D1 & 1) && !(H1 & 1) && !(W1 & 1)) {
+        RUN(lp_mark(L11, 0, hs));
+        for (int bi = 0; bi < batch; ++bi) {
+            const size_t wo = (size_t)bi * ws_floats1;
+            rc = mvs_conv3d_s1s2_16_bn(ws.y[L10] + wo, bn_of(L10), weights[L11], prepared ? prepared + lay.off[L11] : nullptr,
+                                       D1, H1, W1, ws.y[L11] + wo, st(L11), weights[L20], ws.y[L20] + wo, st(L20), hs, SL);
+            if (rc) break;
+        }
+        if (rc == 0) { RUN(lp_mark(L11, 1, hs)); pair2_done = true; }
+        else if (rc != MVS_E_SHAPE) return rc;
+    }
+    if (!pair2_done) {
+        RUN(layer(false, L10, -1, L11, D1, H1, W1, 2 * b, 2 * b, 1, hs));
+        RUN(layer(false, L10, -1, L20, D1, H1, W1, 2 * b, 4 * b, 2, hs));
+    }
     RUN(layer(false, L20, -1, L21, D2, H2, W2, 4 * b, 4 * b, 1, hs));
     RUN(layer(false, L20, -1, L30, D2, H2, W2, 4 * b, 8 * b, 2, hs));
     RUN(layer(false, L30, -1, L31, D3, H3, W3, 8 * b, 8 * b, 1, hs));
