@@ -66,6 +66,13 @@ def image_task(path, rescale, width, height, base_image_size, output_scale, shm_
     return cr.shape, out.shape, shape, time.perf_counter() - t0
 
 
+def image_task_pickled(path, rescale, width, height, base_image_size, output_scale):
+    """Worker: prepare_image with the result returned through the pool's pipe (when /dev/shm cannot hold a slot ring)."""
+    t0 = time.perf_counter()
+    cr, out, shape = prepare_image(path, rescale, width, height, base_image_size, output_scale)
+    return cr, out, shape, time.perf_counter() - t0
+
+
 def write_task(output_dir, depth, prob, ref_image, ref_cam, index, visualize, prob_upsample):
     """Worker: predictlib.write_output_slice (predictlib.py:105-159)."""
     from . import predictlib as pl
@@ -87,7 +94,7 @@ class HostPool:
         import multiprocessing as mp
         self.workers = int(workers)
         self.ex = ProcessPoolExecutor(max_workers=self.workers, mp_context=mp.get_context("spawn"))
-        self.slots = int(slots)
+        self.slots = self.max_slots = int(slots)
         self.slot_bytes = 0
         self.shm = None
         self.free = []
@@ -125,19 +132,38 @@ class HostPool:
             return None
 
     def _ensure_slots(self, nbytes):
-        """(Re)allocates the slot ring when a session needs larger slots; waits until no slot is in use."""
+        """(Re)allocates the slot ring when a session needs larger slots; waits until no slot is in use.  The ring takes at most
+        a quarter of what /dev/shm has free (a tmpfs that runs full kills the writer with SIGBUS: containers often give it
+        64 MB, and a 1600 x 1200 slot is 6 MB); with room for fewer than 4 slots the pool hands images back through its pipe
+        instead (returns False)."""
         from multiprocessing import shared_memory
         nbytes = (int(nbytes) + 4095) & ~4095
         with self.cv:
             if self.shm is not None and nbytes <= self.slot_bytes:
-                return
+                return True
+            if self.shm is None and self.slot_bytes == -1:
+                return False                              # no room was found before: stay on the pipe
             while self.shm is not None and len(self.free) < self.slots:
                 self.cv.wait()
             if self.shm is not None:
-                self.shm.close(); self.shm.unlink()
-            self.slot_bytes = nbytes
-            self.shm = shared_memory.SharedMemory(create=True, size=self.slots * nbytes)
-            self.free = list(range(self.slots))
+                self.shm.close(); self.shm.unlink(); self.shm = None
+            try:
+                vfs = os.statvfs("/dev/shm")
+                room = vfs.f_bavail * vfs.f_frsize // 4
+            except OSError:
+                room = 0
+            slots = min(self.max_slots, room // nbytes)
+            if slots < 4:
+                self.slot_bytes = -1
+                return False
+            try:
+                self.shm = shared_memory.SharedMemory(create=True, size=slots * nbytes)
+            except OSError:
+                self.slot_bytes = -1
+                return False
+            self.slots, self.slot_bytes = slots, nbytes
+            self.free = list(range(slots))
+            return True
 
     def load_image(self, path, rescale, width, height, base_image_size, output_scale):
         """-> Future of (cropped uint8 (h,w,3), output image, original shape, worker seconds); private arrays, the slot is
@@ -146,7 +172,8 @@ class HostPool:
         w_cap = max(width, int(np.ceil(width / base_image_size) * base_image_size)) + base_image_size
         need = h_cap * w_cap * 3
         need += int(need * max(output_scale, 0.0) ** 2) + 4096
-        self._ensure_slots(need)
+        if not self._ensure_slots(need):
+            return self.ex.submit(image_task_pickled, path, rescale, width, height, base_image_size, output_scale)
         with self.cv:
             while not self.free:
                 self.cv.wait()

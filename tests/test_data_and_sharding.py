@@ -349,6 +349,23 @@ def test_host_worker_processes_equal_the_in_process_loader_and_writer(tmp_path):
     env = pool.ex.submit(_worker_probe).result()
     assert env["hip"] == "" and env["worker"] == "1" and env["main_file"] is None and env["torch"] is False
     assert host_pool.get_pool(0) is None                                  # threads only
+    # a /dev/shm without room for a slot ring (containers often give it 64 MB): images come back through the pool's pipe, same arrays
+    import collections
+    small = host_pool.HostPool(1, slots=8)
+    try:
+        fake = collections.namedtuple("vfs", "f_bavail f_frsize")(16, 4096)
+        real = os.statvfs
+        os.statvfs = lambda path_: fake if path_ == "/dev/shm" else real(path_)
+        try:
+            img = os.path.join(sess, "images", "3.jpg")
+            cr, oi, shape, sec = small.load_image(img, 1.0, 128, 96, 8, 0.25).result()
+        finally:
+            os.statvfs = real
+        assert small.shm is None and small.slot_bytes == -1
+        want_cr, want_oi, want_shape = host_pool.prepare_image(img, 1.0, 128, 96, 8, 0.25)
+        assert np.array_equal(cr, want_cr) and np.array_equal(oi, want_oi) and tuple(shape) == tuple(want_shape) and sec > 0
+    finally:
+        small.close()
 
 
 def _worker_probe():
