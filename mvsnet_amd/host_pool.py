@@ -81,6 +81,17 @@ def write_task(output_dir, depth, prob, ref_image, ref_cam, index, visualize, pr
     return time.perf_counter() - t0
 
 
+def _worker_init(parent_pid):
+    """Runs once in every worker: a daemon thread that ends the worker when its parent is gone (a killed parent would leave
+    the workers blocked on their task queue for good)."""
+    def watch():
+        while True:
+            time.sleep(2.0)
+            if os.getppid() != parent_pid:
+                os._exit(0)
+    threading.Thread(target=watch, daemon=True).start()
+
+
 def _warm():
     import PIL.Image            # noqa: F401  (the first task should not pay the imports)
     from . import mvs_data_generation, predictlib, preprocess   # noqa: F401
@@ -93,7 +104,8 @@ class HostPool:
     def __init__(self, workers, slots=48):
         import multiprocessing as mp
         self.workers = int(workers)
-        self.ex = ProcessPoolExecutor(max_workers=self.workers, mp_context=mp.get_context("spawn"))
+        self.ex = ProcessPoolExecutor(max_workers=self.workers, mp_context=mp.get_context("spawn"),
+                                      initializer=_worker_init, initargs=(os.getpid(),))
         self.slots = self.max_slots = int(slots)
         self.slot_bytes = 0
         self.shm = None
