@@ -265,6 +265,16 @@ def test_session_pipeline_equals_the_per_reference_view_calls(tmp_path, lib_buil
     tm = {}
     n = compute_depth_maps(sess, cfg, weights, torch.device("cuda", 0), timings=tm, gru_views=3)
     assert n == 7 and tm["depth_maps"] == 7 and tm["wall"] > 0 and tm["hot_path"] > 0
+    assert tm["host_workers"] >= 2 and tm["load"] > 0 and tm["write"] > 0 and tm["towers"] > 0       # worker processes (host_pool)
+    # the same session with the loaders / writers on threads of this process (host_workers = 0): the same files, byte for byte
+    cfg0 = pl.InferenceConfig(input_dir=sess, view_num=3, max_d=24, width=128, height=96, base_image_size=8,
+                              regularization=regularization, output_dir=str(tmp_path / "out_threads"))
+    tm0 = {}
+    assert compute_depth_maps(sess, cfg0, weights, torch.device("cuda", 0), timings=tm0, gru_views=3, host_workers=0) == 7
+    assert tm0["host_workers"] == 0
+    for fn in sorted(os.listdir(cfg.output_dir)):
+        assert open(os.path.join(cfg.output_dir, fn), "rb").read() == open(os.path.join(cfg0.output_dir, fn), "rb").read(), fn
+    assert len(os.listdir(cfg0.output_dir)) == 42
     gen = make_generator(sess, 3, 128, 96, 24, 1.0, 8, mode="inference", output_scale=0.25)
     for c in sorted(gen.clusters, key=lambda c_: c_.ref_index):
         out_images, in_images, out_cams, full_cams, index = gen.prepare(c)          # float32, standardised on the host
