@@ -592,13 +592,21 @@ def main():
             lf = layer_flops(w.channels, S.base_filter(args.network_mode), w.depth_num * w.height * w.width)
             fused = layer_ms[LAYERS.index("3dconv1_0")] == 0.0 and layer_ms[LAYERS.index("3dconv0_1")] > 0.0
             fused2 = layer_ms[LAYERS.index("3dconv2_0")] == 0.0 and layer_ms[LAYERS.index("3dconv1_1")] > 0.0      # round 4: 3dconv2_0 rides in 3dconv1_1's launch
+            # round 4: 3dconv2_1's blocks ride as fillers in the launches of 3dconv3_0 / 3_1 / 4_0 (no launch of its own)
+            shares = (ctypes.c_int * 3)()
+            _lib.check(lib.mvs_regnet_filler_shares(shares), "mvs_regnet_filler_shares")
+            filled = layer_ms[LAYERS.index("3dconv2_1")] == 0.0 and layer_ms[LAYERS.index("3dconv3_1")] > 0.0 and sum(shares) == 1000
+            share_of = dict(zip(("3dconv3_0", "3dconv3_1", "3dconv4_0"), (x / 1000.0 for x in shares))) if filled else {}
             for li, name in enumerate(LAYERS):
                 ms = layer_ms[li]
                 if ms <= 0.0:
                     continue
                 rider = "3dconv1_0" if (fused and name == "3dconv0_1") else "3dconv2_0" if (fused2 and name == "3dconv1_1") else None
-                fl = lf[name] + (lf[rider] if rider else 0.0)
-                row = {"kernel": "%s%s (in-pipeline, HIP events around the launch)" % (name, " + %s fused" % rider if rider else ""),
+                fl = lf[name] + (lf[rider] if rider else 0.0) + share_of.get(name, 0.0) * lf["3dconv2_1"]
+                label = name + (" + %s fused" % rider if rider else "")
+                if name in share_of:
+                    label += " + %.2f of 3dconv2_1's blocks as filler workgroups" % share_of[name]
+                row = {"kernel": "%s (in-pipeline, HIP events around the launch)" % label,
                        "ms": ms, "algorithmic_flops": fl, "launches_timed": layer_n.value}
                 if name == "3dconv6_2":                     # 8 -> 1 channels: reads two 8-channel volumes, writes one channel
                     by = w.depth_num * w.height * w.width * (2 * 8 + 1) * 4
@@ -633,6 +641,8 @@ def main():
         chain = ["3dconv2_0", "3dconv3_0", "3dconv3_1", "3dconv4_0", "3dconv5_0"]
         if layer_n.value > 0:
             out["low_resolution_chain_us"] = 1e3 * sum(layer_ms[LAYERS.index(n_)] for n_ in chain)     # (3dconv2_0 counts 0 when it rides in 3dconv1_1's launch)
+            if layer_ms[LAYERS.index("3dconv2_1")] == 0.0:
+                out["low_resolution_chain_includes"] = "3dconv2_1 (its blocks ride in the launches of 3dconv3_0 / 3_1 / 4_0)"
         if block_rates:
             out["repeat_blocks"] = {"blocks": len(block_rates), "steps_per_block": args.steps,
                                     "median": float(np.median(block_rates)), "min": min(block_rates), "max": max(block_rates),

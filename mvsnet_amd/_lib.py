@@ -87,6 +87,7 @@ SIGNATURES = {
     "mvs_gru_prepare": (_i, [_p]),
     "mvs_gru_release": (_i, [_p]),
     "mvs_gru_stream_layout": (_i, [_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "mvs_regnet_filler_shares": (_i, [C.POINTER(C.c_int)]),
 }
 
 CONV_IMPL = {"auto": 0, "scalar": 1, "mfma": 2, "bf16x3": 3}

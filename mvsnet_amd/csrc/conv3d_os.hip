@@ -57,15 +57,14 @@ __host__ __device__ constexpr int tap_kd(int t) { return t / 9; }
 __host__ __device__ constexpr int tap_kh(int t) { return (t / 3) % 3; }
 __host__ __device__ constexpr int tap_kw(int t) { return t % 3; }
 
+// One workgroup's block.  `blk` of `nblk` = the block's index in the layer's block grid (a launch's blockIdx.x of gridDim.x, or
+// a slice of another layer's launch: conv3d_os_filled_kernel), `cog` = the group of 16 * NCW output channels (blockIdx.y).
 template <int KIND, int CIN, int NCW, int VT, int BD, int BHT, int BWT, bool HAS_X2, bool PREP>
-__global__ void __launch_bounds__(256, 2)
-conv3d_os_kernel(ConvArgs a, int nbh, int nbw) {
+__device__ __forceinline__ void os_block(const ConvArgs& a, int nbh, int nbw, int blk, int nblk, int cog, float* lds) {
     using Gm = OsGeom<KIND, CIN, NCW, VT, BD, BHT, BWT>;
     constexpr int S = Gm::S, PH = Gm::PH, PW = Gm::PW, CQ = Gm::CQ, NIT = Gm::NIT, G = Gm::G, NS = Gm::NS;
     constexpr int NACC = Gm::NACC;
     constexpr int PF = 8;                                   // weight loads in flight per wave (K steps ahead; 4 / 8 / 12 measured: 8)
-
-    extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,10 +72,10 @@ conv3d_os_kernel(ConvArgs a, int nbh, int nbw) {
     const int ct = wave % NCW, wv = wave / NCW;             // cout tile / voxel-tile group of this wave
 
     // block -> origin in OUTPUT voxels (S1, S2) or INPUT voxels (transposed)
-    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int bid = xcd_swizzle(blk, nblk);
     const int bx = bid % nbw, by = (bid / nbw) % nbh, bz = bid / (nbw * nbh);
     const int z0 = bz * BD, y0 = by * Gm::BH, x0 = bx * Gm::BW;
-    const int co_base = (blockIdx.y * NCW + ct) * 16;       // first output channel of this wave's tile
+    const int co_base = (cog * NCW + ct) * 16;              // first output channel of this wave's tile
     // input coordinate of staged position (0,0,0)
     const int iz0 = KIND == OS_S1 ? z0 - 1 : KIND == OS_S2 ? 2 * z0 - a.pd : z0 - 1;
     const int iy0 = KIND == OS_S1 ? y0 - 1 : KIND == OS_S2 ? 2 * y0 - a.ph : y0 - 1;
@@ -84,7 +83,7 @@ conv3d_os_kernel(ConvArgs a, int nbh, int nbw) {
 
     // ---- weights: this wave's stream of A fragments -------------------------------------------------------------
     // prepared: [cout tile][step][lane][4] floats, lane (r = lane&15, q) <-> w[tap][16g + 4q + i][16*tile + r]
-    const float* wp = PREP ? a.wprep + ((size_t)(blockIdx.y * NCW + ct) * NS) * 256 + lane * 4 : nullptr;
+    const float* wp = PREP ? a.wprep + ((size_t)(cog * NCW + ct) * NS) * 256 + lane * 4 : nullptr;
     auto load_a = [&](int s) __attribute__((always_inline)) -> float4 {
         if (PREP) return *reinterpret_cast<const float4*>(wp + (size_t)s * 256);
         const int tap = s / G, g = s - tap * G;
@@ -280,9 +279,72 @@ conv3d_os_kernel(ConvArgs a, int nbh, int nbw) {
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < Gm::NVW; ++w) tot += (double)red[((w * NCW + t) * 2 + kk) * 16 + c];
-            atomicAdd(&conv_stats_row(a)[(size_t)kk * a.cout_total + (blockIdx.y * NCW + t) * 16 + c], tot);
+            atomicAdd(&conv_stats_row(a)[(size_t)kk * a.cout_total + (cog * NCW + t) * 16 + c], tot);
         }
     }
+}
+
+template <int KIND, int CIN, int NCW, int VT, int BD, int BHT, int BWT, bool HAS_X2, bool PREP>
+__global__ void __launch_bounds__(256, 2)
+conv3d_os_kernel(ConvArgs a, int nbh, int nbw) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    os_block<KIND, CIN, NCW, VT, BD, BHT, BWT, HAS_X2, PREP>(a, nbh, nbw, blockIdx.x, gridDim.x, blockIdx.y, lds);
+}
+
+// A chain layer of the 1/8 level + FILLER blocks of 3dconv2_1.  3dconv3_0, 3_1 and 4_0 (mvsnetworks.py:133-147) are 240
+// workgroups each -- one per CU, four waves -- that spend half of their 16-23 us in fixed cost (BatchNorm sums, staging, the
+// atomics tail) with the matrix pipe idle, and 3dconv2_1 (960 blocks, 3.4 GFLOP), which only the decoder's 3dconv5_0 needs,
+// used to run alone before them.  Here every launch of the chain carries a slice of 3dconv2_1's blocks behind its own: the
+// first `na` workgroups are layer A's blocks, the rest blocks [b_first, b_first + gridDim.x - na) of layer B's `nb`.
+template <class CA, class CB>
+__global__ void __launch_bounds__(256, 2)
+conv3d_os_filled_kernel(ConvArgs a, int nbh_a, int nbw_a, int na, ConvArgs b, int nbh_b, int nbw_b, int nb, int b_first) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x < na)
+        os_block<CA::KIND, CA::CIN, CA::NCW, CA::VT, CA::BD, CA::BHT, CA::BWT, false, true>(a, nbh_a, nbw_a, blockIdx.x, na, 0, lds);
+    else
+        os_block<CB::KIND, CB::CIN, CB::NCW, CB::VT, CB::BD, CB::BHT, CB::BWT, false, true>(b, nbh_b, nbw_b, b_first + blockIdx.x - na, nb, 0, lds);
+}
+
+template <int KIND_, int CIN_, int NCW_, int VT_, int BD_, int BHT_, int BWT_>
+struct OsCfg {
+    static constexpr int KIND = KIND_, CIN = CIN_, NCW = NCW_, VT = VT_, BD = BD_, BHT = BHT_, BWT = BWT_;
+    using Gm = OsGeom<KIND_, CIN_, NCW_, VT_, BD_, BHT_, BWT_>;
+    // block grid over OUTPUT voxels (S1, S2) or INPUT voxels (transposed)
+    static void grid(const ConvArgs& a, int& nbd, int& nbh, int& nbw) {
+        const int Dg = KIND == OS_S2 ? (a.D + 1) / 2 : a.D, Hg = KIND == OS_S2 ? (a.H + 1) / 2 : a.H,
+                  Wg = KIND == OS_S2 ? (a.W + 1) / 2 : a.W;
+        nbd = (Dg + BD - 1) / BD; nbh = (Hg + Gm::BH - 1) / Gm::BH; nbw = (Wg + Gm::BW - 1) / Gm::BW;
+    }
+};
+using Os21 = OsCfg<OS_S1, 32, 2, 2, 2, 1, 2>;           // 3dconv2_1
+using Os30 = OsCfg<OS_S2, 32, 4, 2, 2, 1, 1>;           // 3dconv3_0
+using Os31 = OsCfg<OS_S1, 64, 4, 2, 2, 1, 1>;           // 3dconv3_1
+using Os40 = OsCfg<OS_DECONV, 64, 2, 1, 2, 1, 1>;       // 3dconv4_0
+
+template <class CA, class CB>
+int launch_os_filled(const ConvArgs& a, int CoutA, const ConvArgs& b, int CoutB, int b_first, int b_count, hipStream_t st) {
+    if (CoutA != 16 * CA::NCW || CoutB != 16 * CB::NCW) return MVS_E_SHAPE;          // one output-channel group each
+    if (!a.wprep || !b.wprep || a.x2 || b.x2) return MVS_E_SHAPE;
+    const long long via = (long long)a.D * a.H * a.W, voa = CA::KIND == OS_DECONV ? 8 * via : via, vb = (long long)b.D * b.H * b.W;
+    if (via * CA::CIN * 4 >= (1LL << 31) || voa * CoutA * 4 >= (1LL << 31) || vb * CB::CIN * 4 >= (1LL << 31) ||
+        vb * CoutB * 4 >= (1LL << 31)) return MVS_E_SHAPE;                            // 32-bit offsets
+    int nbd, nbh_a, nbw_a, nbh_b, nbw_b;
+    CA::grid(a, nbd, nbh_a, nbw_a);
+    const int na = nbd * nbh_a * nbw_a;
+    CB::grid(b, nbd, nbh_b, nbw_b);
+    const int nb = nbd * nbh_b * nbw_b;
+    if (b_first < 0 || b_count < 0 || b_first + b_count > nb) return MVS_E_SHAPE;
+    const size_t smem = CA::Gm::LDS_BYTES > CB::Gm::LDS_BYTES ? CA::Gm::LDS_BYTES : CB::Gm::LDS_BYTES;
+    static bool attr_done = false;
+    auto* kern = conv3d_os_filled_kernel<CA, CB>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    kern<<<dim3(na + b_count), 256, smem, st>>>(a, nbh_a, nbw_a, na, b, nbh_b, nbw_b, nb, b_first);
+    return (int)hipGetLastError();
 }
 
 template <int KIND, int CIN, int NCW, int VT, int BD, int BHT, int BWT>
@@ -356,6 +418,29 @@ int mvs_conv3d_os_weight_layout(const float* w, int kind, int Cin, int Cout, flo
     const int total = 27 * Cin * Cout;
     os_weight_layout_kernel<<<mvs_cdiv(total, 256), 256, 0, st>>>(w, kind == 2, Cin, Cout, out);
     return (int)hipGetLastError();
+}
+
+// Blocks of the 3dconv2_1-shaped layer (32 -> 32, stride 1) a caller can deal out as fillers.
+int mvs_conv3d_os_filler_blocks(int D, int H, int W) {
+    ConvArgs b{}; b.D = D; b.H = H; b.W = W;
+    int nbd, nbh, nbw;
+    Os21::grid(b, nbd, nbh, nbw);
+    return nbd * nbh * nbw;
+}
+
+// Layer A (kind / Cin / Cout of 3dconv3_0, 3_1 or 4_0) with blocks [b_first, b_first + b_count) of the 32 -> 32 stride-1 layer b.
+// MVS_E_SHAPE: not one of the three pairs (the caller launches the layers apart).
+int mvs_conv3d_os_filled_launch(const ConvArgs& a0, int kind, int Cin, int Cout, const ConvArgs& b, int b_first, int b_count,
+                                hipStream_t st) {
+    ConvArgs a = a0;
+    if (kind == 1) {
+        auto pad_before = [](int n) { int o = (n + 1) / 2; int t = (o - 1) * 2 + 3 - n; return t < 0 ? 0 : t / 2; };
+        a.pd = pad_before(a.D); a.ph = pad_before(a.H); a.pw = pad_before(a.W);
+    }
+    if (kind == 1 && Cin == 32 && Cout == 64) return launch_os_filled<Os30, Os21>(a, Cout, b, 32, b_first, b_count, st);
+    if (kind == 0 && Cin == 64 && Cout == 64) return launch_os_filled<Os31, Os21>(a, Cout, b, 32, b_first, b_count, st);
+    if (kind == 2 && Cin == 64 && Cout == 32) return launch_os_filled<Os40, Os21>(a, Cout, b, 32, b_first, b_count, st);
+    return MVS_E_SHAPE;
 }
 
 int mvs_conv3d_os_launch(const ConvArgs& a, int kind, int Cin, int Cout, hipStream_t st) {

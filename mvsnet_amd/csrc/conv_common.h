@@ -209,6 +209,11 @@ int mvs_conv3d_c8_s2_launch(const ConvArgs& a, const float* w2, float* y2, doubl
 bool mvs_conv3d_os_covers(int kind, int Cin, int Cout);
 int mvs_conv3d_os_weight_layout(const float* w, int kind, int Cin, int Cout, float* out, hipStream_t st);
 int mvs_conv3d_os_launch(const ConvArgs& a, int kind, int Cin, int Cout, hipStream_t st);
+// a chain layer of the 1/8 level (3dconv3_0 / 3_1 / 4_0) + blocks [b_first, b_first + b_count) of the 32 -> 32 stride-1 layer b
+// (3dconv2_1) in one launch; mvs_conv3d_os_filler_blocks = how many blocks that layer has at (D, H, W)
+int mvs_conv3d_os_filler_blocks(int D, int H, int W);
+int mvs_conv3d_os_filled_launch(const ConvArgs& a, int kind, int Cin, int Cout, const ConvArgs& b, int b_first, int b_count,
+                                hipStream_t st);
 // opt-in split-precision stride-1 path (conv3d_bf16x3.hip)
 bool mvs_conv3d_bf16x3_supported(int Cin, int Cout);
 int mvs_conv3d_s1_bf16x3(const ConvArgs& a, int Cin, int Cout, hipStream_t st);

@@ -155,6 +155,22 @@ extern "C" int mvs_profile_layers_ms(double* avg_ms11, int* count) {
 
 // ---- RegNetUS0 -----------------------------------------------------------------------------------
 
+#ifndef MVS_FILL0
+#define MVS_FILL0 250        // share (1/1000) of 3dconv2_1's blocks that ride with 3dconv3_0 / 3dconv3_1 (the rest with 3dconv4_0)
+#endif
+#ifndef MVS_FILL1
+#define MVS_FILL1 500
+#endif
+
+extern "C" int mvs_regnet_filler_shares(int* permille3) {
+    MVS_CHECK_ARG(permille3);
+    const bool on = MVS_FILL0 >= 0;
+    permille3[0] = on ? MVS_FILL0 : 0;
+    permille3[1] = on ? MVS_FILL1 : 0;
+    permille3[2] = on ? 1000 - MVS_FILL0 - MVS_FILL1 : 0;
+    return 0;
+}
+
 namespace {
 
 constexpr int N_BN = 10;   // layers with BatchNorm, order: 1_0 2_0 3_0 0_1 1_1 2_1 3_1 4_0 5_0 6_0
@@ -414,11 +430,39 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
         RUN(layer(false, L10, -1, L11, D1, H1, W1, 2 * b, 2 * b, 1, hs));
         RUN(layer(false, L10, -1, L20, D1, H1, W1, 2 * b, 4 * b, 2, hs));
     }
-    RUN(layer(false, L20, -1, L21, D2, H2, W2, 4 * b, 4 * b, 1, hs));
-    RUN(layer(false, L20, -1, L30, D2, H2, W2, 4 * b, 8 * b, 2, hs));
-    RUN(layer(false, L30, -1, L31, D3, H3, W3, 8 * b, 8 * b, 1, hs));
-    // decoder with additive skips (mvsnetworks.py:146-157)
-    RUN(layer(true, L31, -1, L40, D3, H3, W3, 8 * b, 4 * b, 2, hs));
+    // 3dconv2_1 (only the decoder's 3dconv5_0 reads it) rides as filler blocks in the launches of the 1/8-resolution chain
+    // 3dconv3_0 -> 3_1 -> 4_0 (conv3d_os.hip, conv3d_os_filled_kernel; round 4) when every layer has its block kernel.
+    bool filled = false;
+    if (MVS_FILL0 >= 0 && all_mfma && prepared && lay.ok[L21] && lay.ok[L30] && lay.ok[L31] && lay.ok[L40]) {
+        const int nfill = mvs_conv3d_os_filler_blocks(D2, H2, W2);
+        // share of 3dconv2_1's blocks per chain launch, in 1/1000 (multiples of 8 blocks: one per XCD)
+        const int f0 = (nfill * MVS_FILL0 / 1000) & ~7, f1 = (nfill * MVS_FILL1 / 1000) & ~7;
+        const int first[3] = {0, f0, f0 + f1}, count[3] = {f0, f1, nfill - f0 - f1};
+        const int outs[3] = {L30, L31, L40}, prods[3] = {L20, L30, L31}, kinds[3] = {1, 0, 2};
+        const int dd[3] = {D2, D3, D3}, hh[3] = {H2, H3, H3}, ww[3] = {W2, W3, W3};
+        auto os_args = [&](int bi, int p1, int out, int d, int h, int w) {
+            const size_t wo = (size_t)bi * ws_floats1;
+            return ConvArgs{ws.y[p1] + wo, nullptr, nullptr, nullptr, nullptr, nullptr, weights[out], ws.y[out] + wo, st(out),
+                            d, h, w, lay.co[out], 0, 0, 0, 0, bn_of(p1), bn_of(-1), prepared + lay.off[out], nullptr, SL};
+        };
+        rc = 0;
+        for (int k = 0; k < 3 && rc == 0; ++k) {
+            RUN(lp_mark(outs[k], 0, hs));
+            for (int bi = 0; bi < batch && rc == 0; ++bi)
+                rc = mvs_conv3d_os_filled_launch(os_args(bi, prods[k], outs[k], dd[k], hh[k], ww[k]), kinds[k], lay.ci[outs[k]],
+                                                 lay.co[outs[k]], os_args(bi, L20, L21, D2, H2, W2), first[k], count[k], hs);
+            if (rc == 0) RUN(lp_mark(outs[k], 1, hs));
+            else if (!(rc == MVS_E_SHAPE && k == 0)) return rc;
+        }
+        filled = rc == 0;
+    }
+    if (!filled) {
+        RUN(layer(false, L20, -1, L21, D2, H2, W2, 4 * b, 4 * b, 1, hs));
+        RUN(layer(false, L20, -1, L30, D2, H2, W2, 4 * b, 8 * b, 2, hs));
+        RUN(layer(false, L30, -1, L31, D3, H3, W3, 8 * b, 8 * b, 1, hs));
+        // decoder with additive skips (mvsnetworks.py:146-157)
+        RUN(layer(true, L31, -1, L40, D3, H3, W3, 8 * b, 4 * b, 2, hs));
+    }
     RUN(layer(true, L40, L21, L50, D2, H2, W2, 4 * b, 2 * b, 2, hs));
     RUN(layer(true, L50, L11, L60, D1, H1, W1, 2 * b, b, 2, hs));
     // output conv, no BN / ReLU / bias (mvsnetworks.py:158)

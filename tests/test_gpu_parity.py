@@ -323,6 +323,35 @@ def test_regnet_auto_mode_on_small_odd_volumes(shape):
     np.testing.assert_allclose(got, exp, rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("shape", [(32, 32, 64), (48, 40, 72), (192, 128, 160)])
+def test_regnet_filler_launches_equal_the_layers_apart(shape):
+    """Round 4: with prepared weights 3dconv2_1 has no launch of its own -- its blocks ride as filler workgroups behind
+    the blocks of 3dconv3_0 / 3_1 / 4_0 (conv3d_os.hip, conv3d_os_filled_kernel; shares: mvs_regnet_filler_shares).
+    Without prepared weights (mvs_regnet_us0_f32) the four layers are launched apart.  Same arithmetic per block, so the
+    two agree to the order of the float64 BatchNorm atomics; both against the oracle at the small sizes."""
+    import ctypes as C
+    from mvsnet_amd import _lib as L
+    from mvsnet_amd.model import BN_EPSILON, RegNetWeights, regnet_us0
+    lib = L.load()
+    shares = (C.c_int * 3)()
+    assert lib.mvs_regnet_filler_shares(shares) == 0 and sum(shares) == 1000 and min(shares) >= 0
+    D, H, W = shape
+    params = S.make_regnet_params("normal", seed=31, random_affine=True)
+    cost = t(np.abs(np.random.RandomState(32).standard_normal((D, H, W, 32))).astype(np.float32))
+    wts = RegNetWeights(params, DEV)
+    filled = regnet_us0(cost, wts)
+    apart = torch.empty_like(filled)
+    ws = torch.empty(lib.mvs_regnet_workspace_bytes(D, H, W, 32, wts.base), device=DEV, dtype=torch.uint8)
+    L.check(lib.mvs_regnet_us0_f32(L.ptr(cost), D, H, W, 32, wts.base, wts.w_ptrs, wts.g_ptrs, wts.b_ptrs, BN_EPSILON,
+                                   C.c_void_p(ws.data_ptr()), ws.numel(), L.ptr(apart), L.stream_ptr()), "mvs_regnet_us0_f32")
+    torch.cuda.synchronize()
+    scale = float(apart.abs().max())
+    assert float((filled - apart).abs().max()) <= 2e-5 * scale
+    if D * H * W <= 48 * 40 * 72:
+        exp = O.regnet_us0(n(cost), params, np.float64)
+        assert rel_l1(n(filled), exp) < 2e-5
+
+
 def test_batch_of_two_shares_batchnorm_statistics():
     """FLAGS.batch_size > 1 (model.py:28,350,431,479): towers / homographies / cost volumes / soft-argmin per sample,
     RegNetUS0's BatchNorm over the whole batch (network.py:496-506) -- against the batched oracle, and NOT equal to
