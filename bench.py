@@ -415,7 +415,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # MVS_BENCH_FORCE_DIST=1: a world of ONE rank still goes through the process group (RCCL on a one-GPU box: the barriers,
+    # the MAX all-reduce and the gathers of the N > 1 path on the real backend; tests/test_gpu_pipeline.py)
+    if world > 1 or os.environ.get("MVS_BENCH_FORCE_DIST"):
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

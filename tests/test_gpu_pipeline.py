@@ -385,3 +385,60 @@ def test_compute_depth_maps_on_an_upstream_pair_txt_project(tmp_path, lib_built)
         assert d.shape == (24, 32) and np.isfinite(d).all() and d.min() >= 425.0 - 1e-3
         for suffix in ("_prob.pfm", "_depth.png", "_prob.png", ".jpg", ".txt"):
             assert os.path.exists(os.path.join(out, "%d%s" % (idx, suffix)))
+
+
+def test_rccl_single_rank_runs_every_collective_of_the_multi_gpu_paths(lib_built):
+    """N > 1 on hardware is the driver's run, on a node this box does not have.  What CAN be checked on one GPU:
+    that RCCL (torch.distributed backend "nccl") initialises on this image the way bench.py / shard.py / train.py do it
+    (device_id given) and accepts every collective those paths issue, with their dtypes and reduce ops, on device tensors --
+    a world of one rank, in a child process (a process group is per process)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MVS_TEST_PORT", "29631"))
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+dist.barrier(); torch.cuda.synchronize()
+tt = torch.tensor([1.25], device=dev, dtype=torch.float64)                 # bench.py: per-rank seconds
+every = [torch.zeros_like(tt)]
+dist.all_gather(every, tt); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+assert float(every[0]) == 1.25 and float(tt) == 1.25
+objs = [None]; dist.all_gather_object(objs, {"rank": 0, "device": torch.cuda.get_device_name(0)})     # bench.py: device names
+assert objs[0]["rank"] == 0
+g = torch.randn(1 << 20, device=dev); ref = g.clone()                       # train.py / backward.py: gradient buckets, sync-BN sums
+dist.all_reduce(g); assert torch.equal(g, ref)
+h = torch.randn(257, device=dev, dtype=torch.float64); ref = h.clone()
+dist.all_reduce(h); assert torch.equal(h, ref)
+n = torch.tensor([7], device=dev); dist.all_reduce(n, op=dist.ReduceOp.MIN); assert int(n) == 7       # train.py: common step count
+f = torch.tensor([0], device=dev); dist.all_reduce(f, op=dist.ReduceOp.MAX); assert int(f) == 0       # train.py: stop flag
+from mvsnet_amd import shard
+assert shard.gather_counts(dist, 3.5, device=dev) == [3.5]
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_over_rccl_with_a_world_of_one_rank(lib_built):
+    """bench.py's N > 1 code path (barrier, timed steps, barrier, all_gather + MAX all-reduce of the seconds on DEVICE
+    tensors, all_gather_object of the device names) on the backend the driver's 8-GPU run uses -- RCCL -- with the one rank
+    a one-GPU box can give it (MVS_BENCH_FORCE_DIST=1)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29633",
+               MVS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MVS_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["ranks"]["world_size"] == 1 and rec["ranks"]["backend"] == "nccl (RCCL)" and rec["n_gpus"] == 1
+    assert rec["ranks"]["devices"][0]["rank"] == 0 and rec["value"] > 100
