@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel trace of the UNetDS2GN towers on the HIP library (5 views of 512x640): per-launch durations in layer order
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/unetprof; rm -rf $O
+O=gpurun_out/unetprof${TAG:-}; rm -rf $O; export UNETPROF_DIR=$O
 cat > /tmp/unet_only.py <<'PY'
 import os, sys, torch
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
@@ -14,10 +14,10 @@ for _ in range(6):
     out = net(img)
 torch.cuda.synchronize()
 PY
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O -- python /tmp/unet_only.py > gpurun_out/unetprof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O -- python /tmp/unet_only.py > gpurun_out/unetprof${TAG:-}.log 2>&1
 python - <<'PY'
 import csv, glob
-f = glob.glob("gpurun_out/unetprof/*/*kernel_trace.csv")[0]
+f = glob.glob(__import__("os").environ.get("UNETPROF_DIR","gpurun_out/unetprof") + "/*/*kernel_trace.csv")[0]
 rows = [r for r in csv.DictReader(open(f)) if "conv2d_gn_kernel" in r["Kernel_Name"] or "deconv2d" in r["Kernel_Name"] and "layout" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 per = len(rows) // 6
