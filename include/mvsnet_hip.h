@@ -209,8 +209,9 @@ int mvs_profile_layers_ms(double* avg_ms11, int* count);
 /* Launch plan of the 1/8-resolution chain.  With prepared weights and the metric's channel widths 3dconv2_1 (read only by
  * the decoder's 3dconv5_0, mvsnetworks.py:139,148-150) has no launch of its own: its blocks ride as filler workgroups behind
  * the blocks of 3dconv3_0, 3dconv3_1 and 3dconv4_0 (240 workgroups each, half of their time fixed cost with the matrix pipe
- * idle).  [host] permille3 receives the share of 3dconv2_1's blocks in each of those three launches, in 1/1000 (0 0 0 = the
- * four layers are launched apart); mvs_profile_layers_ms then reports 0 under 3dconv2_1.  Compile-time constants. */
+ * idle).  [host] permille3 receives the share of 3dconv2_1's blocks in each of those three launches, in 1/1000
+ * (compile-time constants); mvs_profile_layers_ms then reports 0 under 3dconv2_1.  Without prepared weights, or for other
+ * channel widths / volumes of 2 GB and more, the four layers are launched apart whatever this call says. */
 int mvs_regnet_filler_shares(int* permille3);
 /* The whole 3D-CNN path after the feature towers in ONE call (inference_mem, model.py:408-502): plane homographies ->
  * fused warp + variance cost volume -> RegNetUS0 -> softmax / soft-argmin / probability map; 14 launches, none of them for

@@ -155,19 +155,14 @@ extern "C" int mvs_profile_layers_ms(double* avg_ms11, int* count) {
 
 // ---- RegNetUS0 -----------------------------------------------------------------------------------
 
-#ifndef MVS_FILL0
-#define MVS_FILL0 250        // share (1/1000) of 3dconv2_1's blocks that ride with 3dconv3_0 / 3dconv3_1 (the rest with 3dconv4_0)
-#endif
-#ifndef MVS_FILL1
-#define MVS_FILL1 500
-#endif
+// Share (1/1000) of 3dconv2_1's blocks that ride as filler workgroups in the launches of 3dconv3_0 and 3dconv3_1 (the rest in
+// 3dconv4_0's).  Measured at the metric workload (profiles/r04_filler_ab.txt, depth maps/s): layers apart 912-915; 250/500
+// 920-923; 200/400 916; 300/550 913; 0/600 913; 330/340 905.
+constexpr int FILL_3_0 = 250, FILL_3_1 = 500;
 
 extern "C" int mvs_regnet_filler_shares(int* permille3) {
     MVS_CHECK_ARG(permille3);
-    const bool on = MVS_FILL0 >= 0;
-    permille3[0] = on ? MVS_FILL0 : 0;
-    permille3[1] = on ? MVS_FILL1 : 0;
-    permille3[2] = on ? 1000 - MVS_FILL0 - MVS_FILL1 : 0;
+    permille3[0] = FILL_3_0; permille3[1] = FILL_3_1; permille3[2] = 1000 - FILL_3_0 - FILL_3_1;
     return 0;
 }
 
@@ -433,10 +428,10 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
     // 3dconv2_1 (only the decoder's 3dconv5_0 reads it) rides as filler blocks in the launches of the 1/8-resolution chain
     // 3dconv3_0 -> 3_1 -> 4_0 (conv3d_os.hip, conv3d_os_filled_kernel; round 4) when every layer has its block kernel.
     bool filled = false;
-    if (MVS_FILL0 >= 0 && all_mfma && prepared && lay.ok[L21] && lay.ok[L30] && lay.ok[L31] && lay.ok[L40]) {
+    if (all_mfma && prepared && lay.ok[L21] && lay.ok[L30] && lay.ok[L31] && lay.ok[L40]) {
         const int nfill = mvs_conv3d_os_filler_blocks(D2, H2, W2);
         // share of 3dconv2_1's blocks per chain launch, in 1/1000 (multiples of 8 blocks: one per XCD)
-        const int f0 = (nfill * MVS_FILL0 / 1000) & ~7, f1 = (nfill * MVS_FILL1 / 1000) & ~7;
+        const int f0 = (nfill * FILL_3_0 / 1000) & ~7, f1 = (nfill * FILL_3_1 / 1000) & ~7;
         const int first[3] = {0, f0, f0 + f1}, count[3] = {f0, f1, nfill - f0 - f1};
         const int outs[3] = {L30, L31, L40}, prods[3] = {L20, L30, L31}, kinds[3] = {1, 0, 2};
         const int dd[3] = {D2, D3, D3}, hh[3] = {H2, H3, H3}, ww[3] = {W2, W3, W3};
