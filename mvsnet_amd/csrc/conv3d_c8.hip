@@ -66,9 +66,14 @@ struct FuseArgs {
     // consumers' bn_affine4 adds up (regnet.hip: 8 rows for 3dconv0_1, 4 for 3dconv1_0 -- what fits the layer's
     // 128-double statistics slab).
     int slots1, slots2;
+    // SPAN schedule (conv3d_c8_kernel<.., SPAN = true>): groups of `span_g` tiles are cut into `span_m` plane ranges over the
+    // tiles' concatenated depth; range k of a group is planes [span_b[k], span_b[k+1]) of that sequence and may cross ONE tile
+    // boundary (two segments).  See launch_c8.
+    int span_g, span_m;
+    int span_b[17];
 };
 
-template <bool FUSE, bool AFF>
+template <bool FUSE, bool AFF, bool SPAN = false>
 __global__ void __launch_bounds__(256, 2)
 conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -82,12 +87,28 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     const int n = lane & 15, kq = lane >> 4;
 
     const int tiles_w = (a.W + TW - 1) / TW;
-    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_h = bid / tiles_w, tile_w = bid - tile_h * tiles_w;
-    const int h0 = tile_h * TH, w0 = tile_w * TW;
-    const int d0 = blockIdx.z * a.planes_per_wg;
-    const int d1 = min(d0 + a.planes_per_wg, a.D);
-    const int T = d1 - d0 + 2;                     // input planes d0-1 .. d1
+    // What this workgroup marches: one (tile, plane range), or with SPAN up to two -- the end of one tile's depth and the
+    // start of the next tile's.
+    int seg_tile[2], seg_d0[2], seg_d1[2], nseg = 1;
+    if (SPAN) {
+        // workgroup w -> XCD w % 8 (round-robin dispatch): an XCD works through consecutive groups, i.e. neighbouring tiles
+        const int per_xcd = gridDim.x >> 3, j = blockIdx.x >> 3, x = blockIdx.x & 7;
+        const int lin = (gridDim.x & 7) ? (int)blockIdx.x : x * per_xcd + j;
+        const int grp = lin / fa.span_m, k = lin - grp * fa.span_m;
+        const int lo = fa.span_b[k], hi_ = fa.span_b[k + 1];
+        const int t0 = lo / a.D, t1 = (hi_ - 1) / a.D;
+        seg_tile[0] = grp * fa.span_g + t0; seg_d0[0] = lo - t0 * a.D; seg_d1[0] = min(hi_, (t0 + 1) * a.D) - t0 * a.D;
+        seg_tile[1] = grp * fa.span_g + t1; seg_d0[1] = 0; seg_d1[1] = hi_ - t1 * a.D;
+        nseg = t1 != t0 ? 2 : 1;
+    } else {
+        seg_tile[0] = xcd_swizzle(blockIdx.x, gridDim.x);
+        seg_d0[0] = blockIdx.z * a.planes_per_wg;
+        seg_d1[0] = min(seg_d0[0] + a.planes_per_wg, a.D);
+        seg_tile[1] = 0; seg_d0[1] = 0; seg_d1[1] = 0;
+    }
+    int h0 = (seg_tile[0] / tiles_w) * TH, w0 = (seg_tile[0] % tiles_w) * TW;
+    int d0 = seg_d0[0], d1 = seg_d1[0];
+    int T = d1 - d0 + 2;                           // input planes d0-1 .. d1
 
     if (a.wprep) load_prepared_weights(wl, a.wprep, W_FLOATS);
     else for (int i = tid; i < W_FLOATS; i += 256) {
@@ -108,17 +129,20 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
 
     float4 pre[NIT];
     int goff[NIT], loff[NIT];
+    auto set_goff = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        int f = tid + 256 * i;
-        if (f >= NF4) f -= 256;                    // spare threads of the last piece redo their previous one
-        int pos = f / CQ;
-        int r = pos / PW, c = pos - r * PW;
-        int gh = h0 - 1 + r, gw = w0 - 1 + c;
-        bool inb = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        goff[i] = inb ? ((gh * a.W + gw) * CIN + 4 * c4) * 4 : OOB;      // byte offset inside a plane
-        loff[i] = slab_off(r, c, c4);
-    }
+        for (int i = 0; i < NIT; ++i) {
+            int f = tid + 256 * i;
+            if (f >= NF4) f -= 256;                // spare threads of the last piece redo their previous one
+            int pos = f / CQ;
+            int r = pos / PW, c = pos - r * PW;
+            int gh = h0 - 1 + r, gw = w0 - 1 + c;
+            bool inb = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+            goff[i] = inb ? ((gh * a.W + gw) * CIN + 4 * c4) * 4 : OOB;      // byte offset inside a plane
+            loff[i] = slab_off(r, c, c4);
+        }
+    };
+    set_goff();
     // Buffer addressing (the launcher guarantees < 2 GB tensors): 32-bit byte offsets, and an offset
     // with bit 31 set is out of range -> loads return 0 (= SAME padding), stores are dropped.
     const int plane_bytes = a.H * a.W * CIN * 4;
@@ -210,13 +234,14 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     // store + zero the block that has just received kd = 2 (block (P+1)%3), output plane o
     // per-lane byte offsets inside an output plane: rows r, r+1 (blocks 0|1) and r + (kq>>1) (block 2)
     int yoff[3];
-    {
+    auto set_yoff = [&]() __attribute__((always_inline)) {
         const int w = w0 + n, co = 4 * (kq & 1);
         const int hs[3] = {h0 + 2 * wave, h0 + 2 * wave + 1, h0 + 2 * wave + (kq >> 1)};
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             yoff[i] = (hs[i] < a.H && w < a.W) ? ((hs[i] * a.W + w) * COUT + co) * 4 : OOB;
-    }
+    };
+    set_yoff();
     const int yplane_bytes = a.H * a.W * COUT * 4;
     auto retire = [&](auto Pc, int o) __attribute__((always_inline)) {
         constexpr int P = decltype(Pc)::value;
@@ -320,13 +345,15 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
     // from global memory (steps 14..19).  The two workgroups of a CU fall into lock-step (the one that
     // is behind gets the whole matrix pipe while the other waits at its barrier), so whatever is NOT
     // hidden under the MFMAs is idle time for both: only the retire stores and the barrier are left.
+    auto prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) load_piece(i, d0 - 1);
+        for (int i = 0; i < NIT; ++i) load_piece(i, d0 - 1);
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) stage_piece(i, d0 - 1, slab);
+        for (int i = 0; i < NIT; ++i) stage_piece(i, d0 - 1, slab);
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) load_piece(i, d0);
-    __syncthreads();
+        for (int i = 0; i < NIT; ++i) load_piece(i, d0);
+        __syncthreads();
+    };
 
     auto plane = [&](auto Pc, int t) __attribute__((always_inline)) {
         const int q = d0 - 1 + t;
@@ -362,10 +389,27 @@ conv3d_c8_kernel(ConvArgs a, FuseArgs fa) {
         retire(Pc, q - 1);
         __syncthreads();
     };
-    for (int t = 0; t < T; t += 3) {
-        plane(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < T) plane(std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < T) plane(std::integral_constant<int, 2>{}, t + 2);
+    for (int sg = 0; sg < (SPAN ? nseg : 1); ++sg) {
+        if (SPAN && sg > 0) {
+            // second segment: another tile, its first planes.  Whatever the first march left in the accumulators belongs to
+            // planes past its range; the last stride-2 plane of the first range is flushed before its partials are overwritten.
+            if (FUSE) s2_finish();
+            h0 = (seg_tile[1] / tiles_w) * TH; w0 = (seg_tile[1] % tiles_w) * TW;
+            d0 = seg_d0[1]; d1 = seg_d1[1]; T = d1 - d0 + 2;
+            set_goff(); set_yoff();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (FUSE) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) { cur[ct] = (f32x4){0.f, 0.f, 0.f, 0.f}; prv[ct] = cur[ct]; }
+            }
+        }
+        prologue();
+        for (int t = 0; t < T; t += 3) {
+            plane(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < T) plane(std::integral_constant<int, 1>{}, t + 1);
+            if (t + 2 < T) plane(std::integral_constant<int, 2>{}, t + 2);
+        }
     }
     if (FUSE) {
         s2_finish();
@@ -416,8 +460,43 @@ int launch_c8(const ConvArgs& a0, const FuseArgs& fa, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3d_c8_kernel<FUSE, true>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if constexpr (FUSE) {
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3d_c8_kernel<true, false, true>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        }
         if (e != hipSuccess) return (int)e;
         attr_done = true;
+    }
+    if constexpr (FUSE) {
+        // SPAN schedule (round 4): groups of G tiles share M workgroups that cut the tiles' concatenated depth into M equal
+        // ranges; a range may cross one tile boundary (the workgroup then marches the end of one tile and the start of the
+        // next: two more halo planes and a second prologue).  Taken when it costs fewer plane steps than whole chunks: at the
+        // metric workload 160 tiles x 192 planes meet 512 workgroup slots -- three chunks of 64 leave 32 slots idle (64 + 3
+        // steps), 5 tiles / 16 workgroups fill every slot with ranges of 60 (60 + 3, + 2 across a boundary): 581 -> 565 us,
+        // 921 -> 935 depth maps/s on one box.  Ranges 8 planes shorter across a boundary (62 / 54) and a pairing of long with
+        // short ranges on a CU measured the same (profiles/r04_pair_span_ab.txt).
+        if (!aff) {
+            const long long chunk_cost = (((long long)tiles * grid.z + 511) / 512) * (a.planes_per_wg + 3);
+            int bg = 0, bm = 0; long long bcost = chunk_cost;
+            for (int G = 1; G <= 8; ++G) {
+                if (tiles % G) continue;
+                for (int M = G; M <= 16; ++M) {
+                    const int total = G * a.D;
+                    if (total % M || (long long)(tiles / G) * M > 512) continue;
+                    const int L = total / M;
+                    if ((L & 1) || L < 32 || L > a.D) continue;          // even starts (stride-2 planes), at most one boundary per range
+                    const long long cost = L + 3 + ((a.D % L) ? 2 : 0);
+                    if (cost < bcost) { bcost = cost; bg = G; bm = M; }
+                }
+            }
+            if (bg) {
+                FuseArgs f2 = fa;
+                f2.span_g = bg; f2.span_m = bm;
+                for (int k = 0; k <= bm; ++k) f2.span_b[k] = k * (bg * a.D / bm);
+                conv3d_c8_kernel<true, false, true><<<dim3((tiles / bg) * bm), 256, smem, st>>>(a, f2);
+                return (int)hipGetLastError();
+            }
+        }
     }
     if (aff) conv3d_c8_kernel<FUSE, true><<<grid, 256, smem, st>>>(a, fa);
     else conv3d_c8_kernel<FUSE, false><<<grid, 256, smem, st>>>(a, fa);
