@@ -15,7 +15,6 @@ for r in rows:
     r["n"] = n.split("(")[0][:46]
 rows.sort(key=lambda r: r["s"])
 # the last sweep = after the last wta_finish / zero kernel gap: take the last 1/k of the gate-convolution launches of cell 1
-chain = [r for r in rows if "conv2d_cat_mfma_kernel" in r["n"] and ", 2, " in r["n"] or ("conv2d_cat_mfma_kernel" in r["n"] and "32, 0, " in r["n"] and False)]
 gates = [r for r in rows if "conv2d_cat_mfma_kernel" in r["n"] and r["n"].rstrip(">").split(", ")[3] in ("0", "2") and "true>" not in r["n"].split(", ")[-1]]
 D = 256
 sweeps = len(gates) // D
