@@ -38,6 +38,16 @@ int mvs_gru1_gates_full_blend_mfma(const float* x, const float* h_before, const 
 int mvs_gru1_out_full_mfma(const float* x, const float* h, const float* g, const double* g_stats, const float* r_gamma,
                            const float* r_beta, const float* wo, const float* bias, int H, int W, float* c, double* stats,
                            int views, size_t vstride, hipStream_t st);
+// the fused two-launches-per-plane sweep (gru_fused.hip)
+struct GruFusedWs {
+    float* x; float* S[3][2]; float* G[3][2]; float* Cb[3]; double* stats;
+    float *max_prob, *depth, *exp_sum;
+    float *w1g, *w1c, *wsg, *wsc;
+};
+constexpr int GRU_FUSED_RING = 64;       // LayerNorm-sum rows of the fused sweep: plane p uses row p % 64
+int mvs_gru_fused_prepare_weights(const float* const* params, const GruFusedWs& ws, hipStream_t st);
+int mvs_gru_fused_step(const GruFusedWs& ws, const float* const* params, int t, int depth_num, const float* x_t, int H, int W,
+                       int views, size_t vstride, const float* depth_values, hipStream_t st);
 namespace {
 
 template <int CO>
@@ -610,6 +620,8 @@ struct GruWs {
     float *x, *g[3], *g2[3], *c[3], *rh, *u, *h[3][8 * 4], *reg, *max_prob, *exp_sum, *depth;   // h: ring of RG*PG states (RG <= 8); g2: the gate buffer of odd planes (cells whose blend is folded into the next plane's gate convolution)
     float *px, *wx, *wgh, *woh;        // hoisted x-part of cell 1: (2, XB, H, W, 3*f1) and its prepared weights
     float *wfg, *wfo;                  // cell 1 unhoisted: prepared weights of the full 48-channel convolutions
+    float *wsg, *wsc;                  // fused sweep: small-cell tables of the gates / output launch (gru_fused.hip)
+    double* fstats;                    // fused sweep: GRU_FUSED_RING planes x 3 cells x 6 LayerNorm sums
     double* stats;     // per plane of a batch: 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
     size_t bytes;
 };
@@ -646,6 +658,8 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     w.wx = take((size_t)9 * C * 3 * f1); w.wgh = take((size_t)9 * f1 * 2 * f1); w.woh = take((size_t)9 * f1 * f1);
     w.wfg = take((size_t)9 * (C + f1) * 2 * f1); w.wfo = take((size_t)9 * (C + f1) * f1);
     w.stats = (double*)(base ? base + off : nullptr); off += align256((size_t)(SB + 1) * XB * 18 * 8);   // SB + 1 batches deep
+    w.wsg = take(2 * 720 + 288); w.wsc = take(720 + 288);
+    w.fstats = (double*)(base ? base + off : nullptr); off += align256((size_t)GRU_FUSED_RING * 18 * 8);
     w.bytes = off;
     return w;
 }
@@ -837,7 +851,7 @@ extern "C" size_t mvs_gru_workspace_bytes(int H, int W, int C, int f1, int f2, i
 // Both give the same bits (gru_mfma.hip, SPLIT accumulators).
 static std::atomic<int> g_gru_form{0};                 // read ONCE per sweep (a sweep in flight keeps the formulation it started with)
 extern "C" int mvs_gru_set_formulation(int form) {
-    if (form < 0 || form > 2) return MVS_E_BADARG;
+    if (form < 0 || form > 3) return MVS_E_BADARG;
     g_gru_form.store(form);
     return 0;
 }
@@ -885,6 +899,37 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
     // cell 1 (90 % of the MACs) runs on the fp32-MFMA kernels when its shape fits their tiling
     bool mfma1 = (mvs_get_conv_impl() != MVS_CONV_IMPL_SCALAR) && C == 32 && f1 == 16;
     const int form = g_gru_form.load();
+    // The fused sweep (gru_fused.hip): the reference's filter counts (model.py:641-660, 'normal' mode) at 32 feature channels --
+    // all three cells, prob_conv and the winner-take-all update in two launches per plane on the caller's stream alone.
+    const bool fused = mfma1 && f2 == 4 && f3 == 2 && (form == 0 || form == 3);
+    if (fused) {
+        GruFusedWs fw;
+        fw.x = ws.x;
+        for (int k = 0; k < 3; ++k) { fw.S[k][0] = ws.h[k][0]; fw.S[k][1] = ws.h[k][1]; fw.G[k][0] = ws.g[k]; fw.G[k][1] = ws.g2[k]; fw.Cb[k] = ws.c[k]; }
+        fw.stats = ws.fstats; fw.max_prob = ws.max_prob; fw.depth = ws.depth; fw.exp_sum = ws.exp_sum;
+        fw.w1g = ws.wfg; fw.w1c = ws.wfo; fw.wsg = ws.wsg; fw.wsc = ws.wsc;
+        if ((rc = mvs_gru1_full_weights(params[0], params[6], C, f1, ws.wfg, ws.wfo, st))) return rc;
+        if ((rc = mvs_gru_fused_prepare_weights(params, fw, st))) return rc;
+        for (int k = 0; k < 3; ++k) if ((rc = zero(ws.h[k][1], hw * F[k]))) return rc;      // s(-1) = 0 lives in S[k][1]; S[k][0] zeroed above
+        if ((rc = zero((float*)ws.fstats, (size_t)GRU_FUSED_RING * 18 * 2))) return rc;
+        for (int t = 0; t < depth_num + 3; ++t) {
+            if (t % XB == 0) {
+                if (t < depth_num) {                     // the -variance slices of planes t .. t + XB - 1 (model.py:680-693,698)
+                    const int nb = depth_num - t < XB ? depth_num - t : XB;
+                    for (int v = 0; v < views; ++v)
+                        if ((rc = mvs_cost_volume_f32(ref[v], src[v], transforms[v], view_num, depth_num, t, nb, H, W, C, /*variant*/ 1,
+                                                      /*negate*/ 1, /*border*/ 0, vp(ws.x, v), st))) return rc;
+                }
+                // LayerNorm-sum rows of planes t + XB .. t + 2 XB - 1 (their previous users, planes 64 earlier, are long done)
+                if (t > 0 && (rc = zero((float*)(ws.fstats + (size_t)((t + XB) % GRU_FUSED_RING) * 18), (size_t)XB * 18 * 2))) return rc;
+            }
+            const int tx = t < depth_num ? t : depth_num - 1;
+            if ((rc = mvs_gru_fused_step(fw, params, t, depth_num, ws.x + (size_t)(tx % XB) * hw * C, H, W, views, vstride, depth_values, st))) return rc;
+        }
+        wta_finish_views_kernel<<<dim3(mvs_cdiv((long long)hw, 256), views), 256, 0, st>>>(ws.max_prob, ws.exp_sum, ws.depth, H * W, vstride,
+                                                                                         depth_out, prob_out);
+        return (int)hipGetLastError();
+    }
     const bool hoist = mfma1 && (form == 1 || (form == 0 && views == 1));
     if (mfma1) {                                         // prepared weights, shared by the views
         if (hoist) rc = mvs_gru1_split_weights(params[0], params[6], C, f1, ws.wx, ws.wgh, ws.woh, st);

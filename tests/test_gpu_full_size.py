@@ -168,16 +168,25 @@ def test_gru_batch_of_reference_views_equals_the_single_view_sweeps(lib_built, s
     # views of a batch are independent: view 0 alone in a batch-capable plan gives the same again
     d1, p1 = batch.run_gru_batch(feats[:1], dvs[:1])
     assert (d1.cpu().numpy()[0] == outs[0][0]).all()
-    # the two formulations of cell 1 (hoisted x-part: the single-view default; full 48-channel kernels: the multi-view default)
-    # accumulate the x and h halves separately and combine them in the same order: same bits
+    # The round-2..4 wavefront over HIP streams (formulations 1 / 2 of cell 1: hoisted x-part; full 48-channel kernels) against the
+    # fused two-launches-per-plane sweep (formulation 0 / 3, the default): the two wavefront formulations give the same bits as
+    # each other (x and h halves in separate accumulators, combined in the same order); the fused sweep runs the same
+    # multiply-add chains and differs only in how the LayerNorm sums are grouped before they reach float64 -- a rounding-level
+    # difference that may flip the winner of a near-tie on a handful of pixels.
     from mvsnet_amd import _lib
     try:
-        for form in (1, 2):
+        got = {}
+        for form in (1, 2, 3):
             _lib.check(_lib.load().mvs_gru_set_formulation(form), "mvs_gru_set_formulation")
             df, pf = batch.run_gru_batch(feats, dvs)
-            df, pf = df.cpu().numpy(), pf.cpu().numpy()
-            print("%s formulation %d: depth equal %s, prob max abs diff %.2e" % (size, form, bool((df == db).all()), float(np.abs(pf - pb).max())))
-            assert (df == db).all() and float(np.max(np.abs(pf - pb) / np.maximum(pb, 1e-30))) <= 1e-6
+            got[form] = (df.cpu().numpy().copy(), pf.cpu().numpy().copy())
+        assert (got[1][0] == got[2][0]).all() and float(np.max(np.abs(got[1][1] - got[2][1]) / np.maximum(got[2][1], 1e-30))) <= 1e-6
+        assert (got[3][0] == db).all() and (got[3][1] == pb).all()              # formulation 3 IS the default
+        flips = float((got[2][0] != db).mean())
+        same = got[2][0] == db
+        rel = float(np.max(np.abs(got[2][1][same] - pb[same]) / np.maximum(pb[same], 1e-30)))
+        print("%s wavefront vs fused sweep: planes differing %.2e, prob rel max %.2e on the others" % (size, flips, rel))
+        assert flips <= 2e-4 and rel <= 2e-3, (flips, rel)
     finally:
         _lib.check(_lib.load().mvs_gru_set_formulation(0), "mvs_gru_set_formulation")
 

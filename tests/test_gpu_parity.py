@@ -623,5 +623,5 @@ def test_gru_batch_entry_point_argument_checks_and_ragged_batches():
                                                              _lib.ptr(plan.prob_v), _lib.stream_ptr())
     assert call(9, plan.workspace.numel()) == -1 and call(0, plan.workspace.numel()) == -1        # MVS_E_BADARG
     assert call(nv, plan.workspace.numel() // nv * (nv - 1)) == -3                                   # MVS_E_WORKSPACE
-    assert lib.mvs_gru_set_formulation(3) == -1
+    assert lib.mvs_gru_set_formulation(4) == -1
     torch.cuda.synchronize()

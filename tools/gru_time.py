@@ -16,7 +16,7 @@ from mvsnet_amd.model import DepthPlan, MVSNetWeights, wta_depth_values  # noqa:
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--views", type=int, nargs="+", default=[1])
-ap.add_argument("--form", type=int, default=0, help="cell-1 formulation: 0 by view count, 1 hoisted x-part, 2 full 48-channel kernels")
+ap.add_argument("--form", type=int, default=0, help="0 / 3 fused two-launch sweep (default), 1 wavefront with hoisted x-part, 2 wavefront with full 48-channel kernels")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
