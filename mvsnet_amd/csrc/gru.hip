@@ -40,6 +40,7 @@ int mvs_gru1_out_full_mfma(const float* x, const float* h, const float* g, const
                            int views, size_t vstride, hipStream_t st);
 // the fused two-launches-per-plane sweep (gru_fused.hip)
 struct GruFusedWs {
+    char* base;
     float* x; float* S[3][2]; float* G[3][2]; float* Cb[3]; double* stats;
     float *max_prob, *depth, *exp_sum;
     float *w1g, *w1c, *wsg, *wsc;
@@ -658,7 +659,7 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     w.wx = take((size_t)9 * C * 3 * f1); w.wgh = take((size_t)9 * f1 * 2 * f1); w.woh = take((size_t)9 * f1 * f1);
     w.wfg = take((size_t)9 * (C + f1) * 2 * f1); w.wfo = take((size_t)9 * (C + f1) * f1);
     w.stats = (double*)(base ? base + off : nullptr); off += align256((size_t)(SB + 1) * XB * 18 * 8);   // SB + 1 batches deep
-    w.wsg = take(2 * 720 + 288); w.wsc = take(720 + 288);
+    w.wsg = take(2 * 720 + 288 + 20); w.wsc = take(720 + 288);
     w.fstats = (double*)(base ? base + off : nullptr); off += align256((size_t)GRU_FUSED_RING * 18 * 8);
     w.bytes = off;
     return w;
@@ -904,7 +905,7 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
     const bool fused = mfma1 && f2 == 4 && f3 == 2 && (form == 0 || form == 3);
     if (fused) {
         GruFusedWs fw;
-        fw.x = ws.x;
+        fw.base = (char*)workspace; fw.x = ws.x;
         for (int k = 0; k < 3; ++k) { fw.S[k][0] = ws.h[k][0]; fw.S[k][1] = ws.h[k][1]; fw.G[k][0] = ws.g[k]; fw.G[k][1] = ws.g2[k]; fw.Cb[k] = ws.c[k]; }
         fw.stats = ws.fstats; fw.max_prob = ws.max_prob; fw.depth = ws.depth; fw.exp_sum = ws.exp_sum;
         fw.w1g = ws.wfg; fw.w1c = ws.wfo; fw.wsg = ws.wsg; fw.wsc = ws.wsc;
