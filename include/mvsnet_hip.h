@@ -340,6 +340,12 @@ int mvs_gru_release(void* stream);
  * started with whatever other threads set meanwhile. */
 int mvs_gru_set_formulation(int form);
 
+/* Diagnostic (csrc/gru_fused.hip): per-workgroup time stamps of the fused two-launches-per-plane sweep.  `buffer` = caller-owned
+ * device memory of (1 + 8 * capacity) int64, zeroed by the caller; every workgroup of every fused launch appends one record
+ * [launch << 32 | phase << 16 | workgroup, entry, first tile staged, first tile done, loop done, exit (100 MHz ticks), tiles,
+ * HW_ID].  null switches it off (the default).  Not thread-safe; tools/gru_fused_trace.py. */
+int mvs_gru_fused_trace(void* buffer, int capacity);
+
 /* Diagnostic: the side-stream layout of the set mvs_gru_prepare made for `stream` (MVS_E_NOT_PREPARED without one):
  * *pipe_of_caller = which of the four candidate pipes the caller's hardware queue was measured on (-1: none stood out),
  * probe_us[8] = the calibration chain times of the eight candidate streams (4 high-, 4 low-priority). */

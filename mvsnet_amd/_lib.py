@@ -84,6 +84,7 @@ SIGNATURES = {
     "mvs_gru_wta_f32": (_i, [_p, _p, _p] + [_i] * 8 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
     "mvs_gru_wta_batch_f32": (_i, [_pp, _pp, _pp] + [_i] * 9 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
     "mvs_gru_set_formulation": (_i, [_i]),
+    "mvs_gru_fused_trace": (_i, [_p, _i]),
     "mvs_gru_prepare": (_i, [_p]),
     "mvs_gru_release": (_i, [_p]),
     "mvs_gru_stream_layout": (_i, [_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]),

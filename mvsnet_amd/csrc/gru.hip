@@ -913,20 +913,65 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
         if ((rc = mvs_gru_fused_prepare_weights(params, fw, st))) return rc;
         for (int k = 0; k < 3; ++k) if ((rc = zero(ws.h[k][1], hw * F[k]))) return rc;      // s(-1) = 0 lives in S[k][1]; S[k][0] zeroed above
         if ((rc = zero((float*)ws.fstats, (size_t)GRU_FUSED_RING * 18 * 2))) return rc;
-        for (int t = 0; t < depth_num + 3; ++t) {
-            if (t % XB == 0) {
-                if (t < depth_num) {                     // the -variance slices of planes t .. t + XB - 1 (model.py:680-693,698)
-                    const int nb = depth_num - t < XB ? depth_num - t : XB;
-                    for (int v = 0; v < views; ++v)
-                        if ((rc = mvs_cost_volume_f32(ref[v], src[v], transforms[v], view_num, depth_num, t, nb, H, W, C, /*variant*/ 1,
-                                                      /*negate*/ 1, /*border*/ 0, vp(ws.x, v), st))) return rc;
-                }
-                // LayerNorm-sum rows of planes t + XB .. t + 2 XB - 1 (their previous users, planes 64 earlier, are long done)
-                if (t > 0 && (rc = zero((float*)(ws.fstats + (size_t)((t + XB) % GRU_FUSED_RING) * 18), (size_t)XB * 18 * 2))) return rc;
+        // The -variance cost slices (model.py:680-693,698) come in batches of XB planes from one depth-sweep launch per view.  With a
+        // stream set (mvs_gru_prepare) the producer runs ONE BATCH AHEAD on the set's low-priority stream, into the other half of
+        // a two-batch buffer (the px tensor of the wavefront formulations, unused here): its waves fill the issue slots the
+        // recurrent launches leave idle instead of standing in line with them (31 of 287 us per plane at four views).  Without a
+        // set, and under hipGraph capture, everything stays on the caller's stream.
+        hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+        const bool capturing0 = hipStreamIsCapturing(st, &cs0) == hipSuccess && cs0 != hipStreamCaptureStatusNone;
+        GruStreams* pg = (!capturing0 && depth_num > XB && getenv("MVS_GRU_ONE_STREAM") == nullptr) ? gru_find(st) : nullptr;
+        const hipStream_t sx = pg ? pg->s[2] : st;
+        auto xhalf = [&](int bidx) -> float* { return pg ? ws.px + (size_t)(bidx & 1) * XB * hw * C : ws.x; };
+        auto produce = [&](int bidx, hipStream_t s) -> int {
+            const int t0 = bidx * XB, nb = depth_num - t0 < XB ? depth_num - t0 : XB;
+            for (int v = 0; v < views; ++v) {
+                const int r2 = mvs_cost_volume_f32(ref[v], src[v], transforms[v], view_num, depth_num, t0, nb, H, W, C, /*variant*/ 1,
+                                                   /*negate*/ 1, /*border*/ 0, vp(xhalf(bidx), v), s);
+                if (r2) return r2;
             }
-            const int tx = t < depth_num ? t : depth_num - 1;
-            if ((rc = mvs_gru_fused_step(fw, params, t, depth_num, ws.x + (size_t)(tx % XB) * hw * C, H, W, views, vstride, depth_values, st))) return rc;
+            return 0;
+        };
+        bool forked0 = false;
+        auto run = [&]() -> int {
+            hipError_t e0;
+            if (pg) {
+                if ((e0 = hipEventRecord(pg->fork, st)) != hipSuccess) return (int)e0;
+                forked0 = true;
+                if ((e0 = hipStreamWaitEvent(sx, pg->fork, 0)) != hipSuccess) return (int)e0;
+                if ((rc = produce(0, sx))) return rc;
+                if ((e0 = hipEventRecord(pg->xready[0], sx)) != hipSuccess) return (int)e0;
+            }
+            for (int t = 0; t < depth_num + 3; ++t) {
+                if (t % XB == 0) {
+                    const int bidx = t / XB;
+                    if (t < depth_num) {
+                        if (!pg) { if ((rc = produce(bidx, st))) return rc; }
+                        else {
+                            if ((e0 = hipStreamWaitEvent(st, pg->xready[bidx & 1], 0)) != hipSuccess) return (int)e0;
+                            if ((bidx + 1) * XB < depth_num) {       // the next batch into the other half, once its readers (batch bidx - 1) are done
+                                if (bidx >= 1 && ((e0 = hipEventRecord(pg->xdone[(bidx + 1) & 1], st)) != hipSuccess ||
+                                                  (e0 = hipStreamWaitEvent(sx, pg->xdone[(bidx + 1) & 1], 0)) != hipSuccess)) return (int)e0;
+                                if ((rc = produce(bidx + 1, sx))) return rc;
+                                if ((e0 = hipEventRecord(pg->xready[(bidx + 1) & 1], sx)) != hipSuccess) return (int)e0;
+                            }
+                        }
+                    }
+                    // LayerNorm-sum rows of planes t + XB .. t + 2 XB - 1 (their previous users, planes 64 earlier, are long done)
+                    if (t > 0 && (rc = zero((float*)(ws.fstats + (size_t)((t + XB) % GRU_FUSED_RING) * 18), (size_t)XB * 18 * 2))) return rc;
+                }
+                const int tx = t < depth_num ? t : depth_num - 1;
+                if ((rc = mvs_gru_fused_step(fw, params, t, depth_num, xhalf(tx / XB) + (size_t)(tx % XB) * hw * C, H, W, views, vstride, depth_values, st))) return rc;
+            }
+            return 0;
+        };
+        rc = run();
+        if (forked0) {                                   // join on every exit after the fork
+            hipError_t e1 = hipEventRecord(pg->join[2], sx);
+            if (e1 == hipSuccess) e1 = hipStreamWaitEvent(st, pg->join[2], 0);
+            if (e1 != hipSuccess && rc == 0) rc = (int)e1;
         }
+        if (rc) return rc;
         wta_finish_views_kernel<<<dim3(mvs_cdiv((long long)hw, 256), views), 256, 0, st>>>(ws.max_prob, ws.exp_sum, ws.depth, H * W, vstride,
                                                                                          depth_out, prob_out);
         return (int)hipGetLastError();

@@ -37,71 +37,79 @@ constexpr int FMAXV = 8;                 // reference views per launch (mvs_gru_
 constexpr int FNT = 512, FTH = 8, FTW = 16, FPW = FTW + 2, FNPOS = (FTH + 2) * FPW;      // 180 staged positions per tile
 
 struct FusedCell {
-    const float* h;         // G: the state BEFORE the blend (entered plane p-1), or the state itself when !blend;  C: the state s(p-1)
-    const float* c;         // G: raw candidate convolution of plane p-1 (H,W,F)
-    const float* g;         // G: raw gate convolution of plane p-1 (update half read);  C: of plane p (reset half read)   (H,W,2F)
-    const double* st_in;    // 6 doubles [reset s,q | update s,q | candidate s,q]: G of plane p-1, C of plane p
+    // byte offsets inside the view's workspace block (every activation tensor of the sweep lives in it)
+    unsigned h;             // G: the state BEFORE the blend (entered plane p-1), or the state itself when !blend;  C: the state s(p-1)
+    unsigned c;             // G: raw candidate convolution of plane p-1 (H,W,F)
+    unsigned g;             // G: raw gate convolution of plane p-1 (update half read);  C: of plane p (reset half read)   (H,W,2F)
+    unsigned h_out;         // G: receives s(p-1) on the tile's own pixels
+    unsigned y;             // the output: G raw gates of plane p (H,W,2F);  C raw candidate of plane p (H,W,F)
+    const double* st_in;    // 6 doubles [reset s,q | update s,q | candidate s,q]: G of plane p-1, C of plane p (view 0's block)
     double* st_out;         // 6 doubles of plane p: G adds [0..3], C adds [4..5]
     const float* bias;
     const float *ga, *gb, *oa, *ob;      // G: update gamma / beta, candidate gamma / beta;  C: reset gamma / beta (ga, gb)
-    unsigned h_out;         // G: byte offset (in the view's workspace block) of the tensor that receives s(p-1) on the tile's own pixels
-    unsigned y;             // byte offset of the output: G raw gates of plane p (H,W,2F);  C raw candidate of plane p (H,W,F)
     int conv, blend;        // this cell's convolution is live (its plane exists) / the blend of plane p-1 is formed on load
 };
 struct FusedArgs {
-    const float* x;         // (H,W,32) cost slice of cell 1's plane
+    unsigned x;             // (H,W,32) cost slice of cell 1's plane (byte offset in the block)
     FusedCell cell[3];
     const float* w1;        // cell-1 weights of this phase, [tap9][12][COUT][4] (gru_weight_slice_kernel)
     const float* wsmall;    // small-cell tables of this phase (gru_small_table_kernel)
-    char* ws;               // view 0's workspace block: every tensor this kernel WRITES lives in it (one buffer resource per view)
+    char* ws;               // view 0's workspace block; view v's is v * vstride bytes further (one buffer resource per view)
     unsigned max_prob, depth_image, exp_sum; int wta;    // winner-take-all accumulators (G): byte offsets in the block, live flag
     int H, W, tiles_h, tiles_w, wg_per_view;
     size_t vstride;         // bytes between the workspace blocks of consecutive views (< 2^31)
+    long long* trace;       // diagnostic (null in the product): [0] = record counter, then 8 x int64 per workgroup (mvs_gru_fused_trace)
+    int trace_cap, launch_id;
 };
 struct FusedDepth { float v[FMAXV]; };   // depth value of the WTA plane, per view (its own kernel argument: indexed on the kernarg)
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+// Every activation tensor is addressed through ONE buffer resource over the view's workspace block: `voff` = byte offset in the
+// block (tensor offset included), or FBAD = nothing to do for this lane (out of range: a load returns 0, a store is dropped).
+// The instruction's SGPR offset stays 0 -- on purpose: with a register in the soffset field the compiler's hazard recognizer
+// assumes that the "store of more than 64 bits followed by a VALU write of its data registers" hazard does not exist and
+// schedules such a write right behind the store; on gfx950 it does exist (first build of this file: the x component of a float4
+// store, overwritten by the next instruction, reached memory corrupted for the last lanes of each row of 16 -- run-to-run
+// differences at 16 x 16 pixels; tools/store_hazard_probe.hip reproduces it in isolation, tools/store_hazard_scan.py and
+// tests/test_abi_and_io.py watch every build of the library for it).
+constexpr int FBAD = (int)0x80000000;
 __device__ __forceinline__ float4 ld_b128(__amdgpu_buffer_rsrc_t rsrc, int voff) {
     u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
-// Stores (and the WTA loads) address a tensor inside the view's workspace block: `toff` = the tensor's byte offset in the block,
-// `voff` = the lane's byte offset in the tensor, or negative = nothing to do for this lane (the offset is pushed out of range and
-// the hardware drops the lane).  The tensor offset is ADDED INTO THE VGPR OFFSET, the instruction's SGPR offset stays 0 -- on
-// purpose: with a register in the soffset field the compiler's hazard recognizer assumes that the "store of more than 64 bits
-// followed by a VALU write of its data registers" hazard does not exist and schedules such a write right behind the store; on
-// gfx950 it does exist (first build of this file: the x component of a float4 store, overwritten by the next instruction,
-// reached memory corrupted for the last lanes of each row -- run-to-run differences at 16 x 16 pixels;
-// tools/store_hazard_probe.hip reproduces it in isolation).
-constexpr int FBAD = (int)0x80000000;
-__device__ __forceinline__ int fold(int voff, int toff) { return voff < 0 ? FBAD : voff + toff; }
-__device__ __forceinline__ float ld_b32(__amdgpu_buffer_rsrc_t rsrc, int voff, int toff) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, fold(voff, toff), 0, 0));
+__device__ __forceinline__ float ld_b32(__amdgpu_buffer_rsrc_t rsrc, int voff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));
 }
-__device__ __forceinline__ void st_b128(__amdgpu_buffer_rsrc_t rsrc, int voff, int toff, float x, float y, float z, float w) {
-    __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)}, rsrc, fold(voff, toff), 0, 0);
+__device__ __forceinline__ void st_b128(__amdgpu_buffer_rsrc_t rsrc, int voff, float x, float y, float z, float w) {
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)}, rsrc, voff, 0, 0);
 }
-__device__ __forceinline__ void st_b64(__amdgpu_buffer_rsrc_t rsrc, int voff, int toff, float x, float y) {
-    __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){__float_as_uint(x), __float_as_uint(y)}, rsrc, fold(voff, toff), 0, 0);
+__device__ __forceinline__ void st_b64(__amdgpu_buffer_rsrc_t rsrc, int voff, float x, float y) {
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){__float_as_uint(x), __float_as_uint(y)}, rsrc, voff, 0, 0);
 }
-__device__ __forceinline__ void st_b32(__amdgpu_buffer_rsrc_t rsrc, int voff, int toff, float x) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsrc, fold(voff, toff), 0, 0);
+__device__ __forceinline__ void st_b32(__amdgpu_buffer_rsrc_t rsrc, int voff, float x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsrc, voff, 0, 0);
 }
 
 // PHASE 0 = gates launch G(t), PHASE 1 = output launch C(t).  Slab channel map (floats per staged position):
 //   G (S = 56): x 0..31 | s1 32..47 | s2 48..51 | s3 52..53 | 54,55 unused          (56 = 48 + the conflict-free pad of gru_mfma.hip)
 //   C (S = 72): x 0..31 | r1*s1 32..47 | s1 48..63 | r2*s2 64..67 | s2 68..71 ;  r3*s3 in a 4-float side slab
+// STEADY: an interior plane step -- every cell live and blending, the WTA update on: the flags are compile-time constants (the
+// first and last three steps of a sweep take the general instantiation).
 //
 // Memory operations and the wait counters.  On gfx950 loads AND stores retire in order through one counter (vmcnt), and the
 // compiler can only count what it sees on every path: a store inside `if (own pixel)` makes it wait for ALL outstanding memory
 // operations before the next staged piece is consumed -- i.e. for the acknowledgement of stores issued a few instructions
 // earlier, between the matrix instructions of the sweep (first build of this kernel: 11.3 us per tile against 6.5 us of matrix
-// time).  So every memory operation inside the tile loop is issued by every lane of every wave on a straight line: stores and
-// the WTA loads go through ONE buffer resource over the view's workspace block with the lane's offset pushed out of range
-// when the lane has nothing to write / read (the hardware drops such lanes; st_b128 and friends below), LDS reads never sit inside a branch either, and
+// time).  So every memory operation inside the tile loop is issued by every lane of every wave on a straight line, with the
+// lane's offset pushed out of range when the lane has nothing to write / read; LDS reads never sit inside a branch either, and
 // the wave-specific small jobs (branches) contain matrix / vector instructions and LDS reads only.
-template <int PHASE>
+//
+// Vector instructions are what the tile loop has to save: fp32 vector and fp32 matrix instructions share the SIMD's multipliers
+// (DESIGN 4), so every one of them adds to the 6.5 us of matrix time of a tile.  Hence: per-thread byte offsets of every load and
+// store computed once (a tile costs one add + one select per memory operation), the blend as ONE division per channel with
+// LayerNorm affines pre-scaled for v_exp_f32, per-lane float64 moment sums instead of wave reductions per tile.
+template <int PHASE, bool STEADY>
 __global__ void __launch_bounds__(FNT, 1)
 gru_fused_kernel(FusedArgs a, FusedDepth dv) {
     constexpr int S = PHASE == 0 ? 56 : 72;
@@ -112,25 +120,24 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
     constexpr int SLAB = FNPOS * S;
     constexpr int XA2 = PHASE == 0 ? 32 : 48;                       // first channel of cell 2's input [s1 | (r2*)s2] in the slab
     constexpr int XA3 = PHASE == 0 ? 48 : 68;                       // first channel of cell 3's xa = s2
-    constexpr int BAD = (int)0x80000000;                            // a byte offset outside every buffer
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;                                // cell-1 weights
     float* wsm = wl + W1_FLOATS;                     // small tables
     float* slab = wsm + WS_FLOATS;                   // [2][FNPOS][S]
     float* mini = slab + 2 * SLAB;                   // C: [2][FNPOS][4] r3*s3 (.xy), then [FNPOS][4] that absorbs the stores a wave has no use for
-    // LayerNorm (scale, shift) quads: G: 0-3 s1 update, 4-7 s1 candidate, 8 s2 update, 9 s2 candidate, 10 s3 update (2), 11 s3 candidate (2)
-    //                                 C: 0-3 s1 reset, 4 s2 reset, 5 s3 reset (2)
+    // LayerNorm (scale, shift) quads, pre-scaled for v_exp_f32 (see the prologue):
+    //   G: 0-3 s1 update, 4-7 s1 candidate, 8 s2 update, 9 s2 candidate, 10 s3 update (2), 11 s3 candidate (2);  C: 0-3 s1 reset, 4 s2 reset, 5 s3 reset (2)
     __shared__ __attribute__((aligned(16))) float lnS[12][4], lnT[12][4];
     __shared__ double red[8][8];
     __builtin_amdgcn_s_setprio(3);
 
+    const long long tr0 = a.trace ? wall_clock64() : 0;
+    long long tr1 = 0, tr2 = 0, tr3 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
     const int view = blockIdx.x / a.wg_per_view, j = blockIdx.x - view * a.wg_per_view;
-    // view v's tensors live v * vstride bytes after view 0's.  (No modified copy of `a`: a struct that is written to and then
-    // indexed with a runtime cell number would live in scratch memory; the kernel arguments stay in SGPRs.)
-    const size_t vo = (size_t)view * a.vstride;
+    const size_t vo = (size_t)view * a.vstride;      // view v's block (no modified copy of `a`: it would live in scratch memory)
     auto vp = [vo](auto* p) { return p ? (decltype(p))((const char*)p + vo) : p; };
     auto cell_sel = [&](int k, auto f) { return k == 0 ? f(a.cell[0]) : k == 1 ? f(a.cell[1]) : f(a.cell[2]); };
     // this workgroup's tiles: an XCD (workgroups b, b+8, ... share an L2) takes a contiguous band of the view's tiles, so that
@@ -142,27 +149,21 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         first = xcd * tb + (j >> 3); stride = a.wg_per_view >> 3; end = min(tiles, (xcd + 1) * tb);
     } else { first = j; stride = a.wg_per_view; end = tiles; }
 
-    // ---- staging pieces (global -> registers -> LDS), hung between the matrix instructions of the sweep ---------------------
-    // pieces 0-2: x (1440 float4 per tile), pieces 3-4: s1 (720 channel quads), piece 5: s2 (waves 0-3) / s3 (waves 4-7), 180 each
-    const int HW4 = a.H * a.W * 4;
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)vp(a.x), 0, HW4 * 32, 0x00020000);
-    const auto rs_h1 = __builtin_amdgcn_make_buffer_rsrc((void*)vp(a.cell[0].h), 0, HW4 * 16, 0x00020000);
-    const auto rs_g1 = __builtin_amdgcn_make_buffer_rsrc((void*)vp(a.cell[0].g), 0, HW4 * 32, 0x00020000);
-    const auto rs_c1 = __builtin_amdgcn_make_buffer_rsrc((void*)vp(PHASE == 0 ? a.cell[0].c : a.cell[0].h), 0, HW4 * 16, 0x00020000);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)vp(a.ws), 0, (int)a.vstride, 0x00020000);
     const bool lo = wave < 4;                        // wave-uniform: this wave's small piece is s2 (else s3)
     const int FS = lo ? 4 : 2;                       // channels of the small family
-    const auto rs_hs = __builtin_amdgcn_make_buffer_rsrc((void*)vp(lo ? a.cell[1].h : a.cell[2].h), 0, HW4 * FS, 0x00020000);
-    const auto rs_gs = __builtin_amdgcn_make_buffer_rsrc((void*)vp(lo ? a.cell[1].g : a.cell[2].g), 0, HW4 * 2 * FS, 0x00020000);
-    const auto rs_cs = __builtin_amdgcn_make_buffer_rsrc((void*)vp(PHASE == 0 ? (lo ? a.cell[1].c : a.cell[2].c) : (lo ? a.cell[1].h : a.cell[2].h)), 0, HW4 * FS, 0x00020000);
-    const auto rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)vp(a.ws), 0, (int)a.vstride, 0x00020000);      // everything this kernel writes
-    const int blend1 = a.cell[0].blend, blend_s = lo ? a.cell[1].blend : a.cell[2].blend;
-    const int so_hout1 = (int)a.cell[0].h_out, so_hout_s = (int)(lo ? a.cell[1].h_out : a.cell[2].h_out);
-    const int so_y1 = (int)a.cell[0].y;
-    const int live1 = a.cell[0].conv, live2 = a.cell[1].conv, live3 = a.cell[2].conv;
+    const bool blend1 = STEADY || a.cell[0].blend, blend_s = STEADY || (lo ? a.cell[1].blend : a.cell[2].blend);
+    const bool live1 = STEADY || a.cell[0].conv, live2 = STEADY || a.cell[1].conv, live3 = STEADY || a.cell[2].conv;
 
+    // ---- staging pieces (global -> registers -> LDS), hung between the matrix instructions of the sweep ---------------------
+    // pieces 0-2: x (1440 float4 per tile), pieces 3-4: s1 (720 channel quads), piece 5: s2 (waves 0-3) / s3 (waves 4-7), 180 each.
+    // Per thread and memory operation: the byte offset for the tile whose staged window starts at pixel 0 (tensor offset, position
+    // in the window, channel quad); a tile adds (pixel index of its window origin) * (bytes per pixel of the tensor).
     const int q8 = tid & 7, q4 = tid & 3;
     const int spos = min(tid & 255, FNPOS - 1);      // the small piece's position
-    int ppix[6], prc[6], loff[6];                    // pixel offset inside the staged window, (row | col << 8), LDS float offset
+    int prc[6], loff[6], lx[3], lh[2], lg[2], lc[PHASE == 0 ? 2 : 1], so1[PHASE == 0 ? 2 : 1];
+    int lhs, lgs, lcs = 0, sos = 0;
+    unsigned ownbits = 0;                            // bit i: piece i's position is one of the tile's own pixels
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         int pos;
@@ -170,70 +171,91 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         else if (i < 5) { int f = tid + FNT * (i - 3); if (f >= FNPOS * 4) f -= FNT; pos = f >> 2; loff[i] = pos * S + 32 + 4 * q4; }
         else { pos = spos; loff[i] = pos * S + (PHASE == 0 ? (lo ? 48 : 52) : 64); }
         const int r = pos / FPW, c = pos - r * FPW;
-        ppix[i] = r * a.W + c; prc[i] = r | (c << 8);
+        const int ppix = r * a.W + c;
+        prc[i] = ((r - 1) & 0xffff) | ((c - 1) << 16);         // row / column relative to the tile's first pixel (-1 .. 8 / -1 .. 16), two 16-bit fields
+        if (r >= 1 && r <= FTH && c >= 1 && c <= FTW) ownbits |= 1u << i;
+        if (i < 3) lx[i] = (int)a.x + ppix * 128 + 16 * q8;
+        else if (i < 5) {
+            lh[i - 3] = (int)a.cell[0].h + ppix * 64 + 16 * q4;
+            // G: update gate = channels [16,32) of the previous plane's gates; C: reset gate = channels [0,16) of this plane's
+            lg[i - 3] = (int)a.cell[0].g + ppix * 128 + 16 * q4 + (PHASE == 0 ? 64 : 0);
+            if (PHASE == 0) { lc[i - 3] = (int)a.cell[0].c + ppix * 64 + 16 * q4; so1[i - 3] = (int)a.cell[0].h_out + ppix * 64 + 16 * q4; }
+        } else {
+            lhs = (int)(lo ? a.cell[1].h : a.cell[2].h) + ppix * (4 * FS);       // s3: two floats of this pixel, two of the next (unused)
+            lgs = (int)(lo ? a.cell[1].g : a.cell[2].g) + ppix * (8 * FS) + (PHASE == 0 ? 4 * FS : 0);
+            if (PHASE == 0) { lcs = (int)(lo ? a.cell[1].c : a.cell[2].c) + ppix * (4 * FS); sos = (int)(lo ? a.cell[1].h_out : a.cell[2].h_out) + ppix * (4 * FS); }
+        }
     }
     float4 pre[6], preg[3], prec[PHASE == 0 ? 3 : 1];
-    unsigned inside = 0;                             // bit i: piece i's position lies inside the image (G: the blend of a padded position is 0)
+    unsigned inside = 0;                             // bit i: piece i's position of the tile in flight lies inside the image
     auto load_piece = [&](int i, int tile) __attribute__((always_inline)) {
         const int tg = tile < end ? tile : 0;        // past the end: a harmless reload of tile 0
         const int th = tg / a.tiles_w, h0 = th * FTH, w0 = (tg - th * a.tiles_w) * FTW;
-        const int r = prc[i] & 255, c = prc[i] >> 8;
-        const bool ok = (unsigned)(w0 - 1 + c) < (unsigned)a.W;      // rows above / below the image fall outside the buffers and read 0
-        const int pix = (h0 - 1) * a.W + (w0 - 1) + ppix[i];          // may be negative: out of range as an unsigned byte offset
-        if (i < 3) pre[i] = ld_b128(rs_x, ok ? pix * 128 + 16 * q8 : BAD);
+        const int bp = (h0 - 1) * a.W + (w0 - 1);    // pixel index of the staged window's origin (scalar; may be negative)
+        const int rr = (prc[i] << 16) >> 16, cc = prc[i] >> 16;
+        const bool in = (unsigned)(h0 + rr) < (unsigned)a.H && (unsigned)(w0 + cc) < (unsigned)a.W;      // SAME padding: zeros outside
+        if (i < 3) pre[i] = ld_b128(rs, in ? lx[i] + bp * 128 : FBAD);
         else if (i < 5) {
-            pre[i] = ld_b128(rs_h1, ok ? pix * 64 + 16 * q4 : BAD);
-            // G: update gate = channels [16,32) of the previous plane's gates; C: reset gate = channels [0,16) of this plane's
-            preg[i - 3] = ld_b128(rs_g1, ok ? pix * 128 + 16 * q4 + (PHASE == 0 ? 64 : 0) : BAD);
-            if (PHASE == 0) prec[i - 3] = ld_b128(rs_c1, ok ? pix * 64 + 16 * q4 : BAD);
+            pre[i] = ld_b128(rs, in ? lh[i - 3] + bp * 64 : FBAD);
+            preg[i - 3] = ld_b128(rs, in ? lg[i - 3] + bp * 128 : FBAD);
+            if (PHASE == 0) prec[i - 3] = ld_b128(rs, in ? lc[i - 3] + bp * 64 : FBAD);
         } else {
-            pre[5] = ld_b128(rs_hs, ok ? pix * (4 * FS) : BAD);      // s3: two floats of this pixel, two of the next (unused)
-            preg[2] = ld_b128(rs_gs, ok ? pix * (8 * FS) + (PHASE == 0 ? 4 * FS : 0) : BAD);
-            if (PHASE == 0) prec[2] = ld_b128(rs_cs, ok ? pix * (4 * FS) : BAD);
+            pre[5] = ld_b128(rs, in ? lhs + bp * (4 * FS) : FBAD);
+            preg[2] = ld_b128(rs, in ? lgs + bp * (8 * FS) : FBAD);
+            if (PHASE == 0) prec[2] = ld_b128(rs, in ? lcs + bp * (4 * FS) : FBAD);
         }
-        if (PHASE == 0 && i >= 3) {
-            const bool in = ok && (unsigned)(h0 - 1 + r) < (unsigned)a.H;
-            inside = in ? inside | (1u << i) : inside & ~(1u << i);
-        }
+        if (PHASE == 0 && i >= 3) inside = in ? inside | (1u << i) : inside & ~(1u << i);
     };
-    auto sig = [](float x) { return mvs_sigmoid_fast(x); };
-    auto tanh_ = [](float x) { return mvs_tanh_fast(x); };
+    // One channel of the blend u*h + (1-u)*tanh(y), u = sigmoid(gate) (convgru.py:98,102,114-120) as ONE division:
+    //   A = e^-gate, B = e^-2|y|:   u = 1/(1+A),  tanh(y) = sgn(y) (1-B)/(1+B)   =>   h' = (h (1+B) + A sgn(y) (1-B)) / ((1+A)(1+B))
+    // with the exponents taken straight from the pre-scaled LayerNorm affines (ga = -scale*log2(e), ...): two v_exp_f32 and one
+    // v_rcp_f32 per channel (the separate sigmoid and tanh of rounds 3-4: two of each).  A is capped at 2^64 (u < 6e-20 there) so
+    // that the product of the denominators stays finite.
+    auto blend1ch = [](float h, float g, float c, float ga, float gb, float ca, float cb) __attribute__((always_inline)) -> float {
+        const float A = __builtin_amdgcn_exp2f(fminf(__builtin_fmaf(g, ga, gb), 64.0f));
+        const float ty = __builtin_fmaf(c, ca, cb);                  // = 2 log2(e) * y
+        const float B = __builtin_amdgcn_exp2f(-fabsf(ty));
+        const float p2 = 1.0f + B;
+        const float rd = __builtin_amdgcn_rcpf((1.0f + A) * p2);
+        const float ynum = copysignf(1.0f - B, ty);
+        return __builtin_fmaf(A, ynum, h * p2) * rd;
+    };
     auto stage_piece = [&](int i, float* buf, float* mbuf, int tile_of) __attribute__((always_inline)) {
         float4 v = pre[i];                           // zeros outside the image (SAME padding)
         if (i < 3) { *(float4*)(buf + loff[i]) = v; return; }
         const int gi = i < 5 ? i - 3 : 2;
         const float4 gq = preg[gi];
         if (PHASE == 0) {
-            // the state entering this cell's plane: u*h + (1-u)*tanh(LN c) of the plane before (convgru.py:98,102,114-120);
-            // evaluated on every path (first plane of a cell: the loaded zeros are kept)
+            // the state entering this cell's plane: the blend of the plane before; evaluated on every path (first plane of a
+            // cell: the loaded zeros are kept)
             const bool bl = i < 5 ? blend1 : blend_s;
             const float4 cq = prec[gi];
             const int uq = i < 5 ? q4 : (lo ? 8 : 10), oq = i < 5 ? 4 + q4 : (lo ? 9 : 11);
             const float4 ua = *(const float4*)lnS[uq], ub = *(const float4*)lnT[uq], ca = *(const float4*)lnS[oq], cb = *(const float4*)lnT[oq];
-            const float u0 = sig(gq.x * ua.x + ub.x), u1 = sig(gq.y * ua.y + ub.y), u2 = sig(gq.z * ua.z + ub.z), u3 = sig(gq.w * ua.w + ub.w);
             float4 b;
-            b.x = u0 * v.x + (1.0f - u0) * tanh_(cq.x * ca.x + cb.x); b.y = u1 * v.y + (1.0f - u1) * tanh_(cq.y * ca.y + cb.y);
-            b.z = u2 * v.z + (1.0f - u2) * tanh_(cq.z * ca.z + cb.z); b.w = u3 * v.w + (1.0f - u3) * tanh_(cq.w * ca.w + cb.w);
+            b.x = blend1ch(v.x, gq.x, cq.x, ua.x, ub.x, ca.x, cb.x); b.y = blend1ch(v.y, gq.y, cq.y, ua.y, ub.y, ca.y, cb.y);
+            b.z = blend1ch(v.z, gq.z, cq.z, ua.z, ub.z, ca.z, cb.z); b.w = blend1ch(v.w, gq.w, cq.w, ua.w, ub.w, ca.w, cb.w);
             const bool in = (inside >> i) & 1u;
-            if (bl) v = in ? b : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (STEADY || bl) v = in ? b : make_float4(0.f, 0.f, 0.f, 0.f);
             // the tile's own pixels keep the state: the output launch, the next cell and the next plane read it
-            const int r = prc[i] & 255, c = prc[i] >> 8;
-            const bool own = bl && tile_of < end && r >= 1 && r <= FTH && c >= 1 && c <= FTW && in;
+            const bool own = (STEADY || bl) && tile_of < end && ((ownbits >> i) & 1u) && in;
             const int th = tile_of / a.tiles_w, h0 = th * FTH, w0 = (tile_of - th * a.tiles_w) * FTW;
-            const int p = (h0 - 1 + r) * a.W + (w0 - 1 + c);
-            if (i < 5) st_b128(rs_ws, own ? p * 64 + 16 * q4 : BAD, so_hout1, v.x, v.y, v.z, v.w);
+            const int bp = (h0 - 1) * a.W + (w0 - 1);
+            if (i < 5) st_b128(rs, own ? so1[i - 3] + bp * 64 : FBAD, v.x, v.y, v.z, v.w);
             else {
-                st_b128(rs_ws, own && lo ? p * 16 : BAD, so_hout_s, v.x, v.y, v.z, v.w);
-                st_b64(rs_ws, own && !lo ? p * 8 : BAD, so_hout_s, v.x, v.y);
+                st_b128(rs, own && lo ? sos + bp * 16 : FBAD, v.x, v.y, v.z, v.w);
+                st_b64(rs, own && !lo ? sos + bp * 8 : FBAD, v.x, v.y);
             }
             *(float4*)(buf + loff[i]) = v;           // (s3: floats 54, 55 of the position receive two unused values)
         } else {
-            // xb = sigmoid(LN(g_r)) * h (convgru.py:97,101,107); the next cell's xa is the state itself
+            // xb = sigmoid(LN(g_r)) * h (convgru.py:97,101,107) = h / (1 + e^-gate); the next cell's xa is the state itself
             const int rq = i < 5 ? q4 : (lo ? 4 : 5);
             const float4 ra = *(const float4*)lnS[rq], rb = *(const float4*)lnT[rq];
             float4 rv;
-            rv.x = v.x * sig(gq.x * ra.x + rb.x); rv.y = v.y * sig(gq.y * ra.y + rb.y);
-            rv.z = v.z * sig(gq.z * ra.z + rb.z); rv.w = v.w * sig(gq.w * ra.w + rb.w);
+            rv.x = v.x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.x, ra.x, rb.x)));
+            rv.y = v.y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.y, ra.y, rb.y)));
+            rv.z = v.z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.z, ra.z, rb.z)));
+            rv.w = v.w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.w, ra.w, rb.w)));
             if (i < 5) { *(float4*)(buf + loff[i]) = rv; *(float4*)(buf + loff[i] + 16) = v; }
             else {       // s2: r2*s2 at 64, s2 at 68;  s3: r3*s3 into the side slab, the state itself is nobody's operand
                 float* da = lo ? buf + loff[5] : mbuf + 4 * spos;
@@ -245,7 +267,7 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
 
     // ---- prologue: everything that comes from memory is requested before anything is waited for ------------------------------
     constexpr int NAFF = PHASE == 0 ? 44 : 22;
-    double ln_s0 = 0.0, ln_s1 = 1.0; float ln_g = 0.f, ln_b = 0.f; int ln_quad = 0, ln_sub = 0; double ln_cnt = 1.0;
+    double ln_s0 = 0.0, ln_s1 = 1.0; float ln_g = 0.f, ln_b = 0.f; int ln_quad = 0, ln_sub = 0, ln_kind = 0; double ln_cnt = 1.0;
     if (tid < NAFF) {   // LayerNorm sums and parameters of (cell, gate, channel)
         int k, idx;
         if (PHASE == 0) { k = tid < 32 ? 0 : tid < 40 ? 1 : 2; idx = tid - (k == 0 ? 0 : k == 1 ? 32 : 40); }
@@ -255,12 +277,11 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         const double* st = vp(cell_sel(k, [](const FusedCell& c_) { return c_.st_in; })) + (PHASE == 0 ? (kind == 0 ? 2 : 4) : 0);
         const float* gp = kind == 0 ? cell_sel(k, [](const FusedCell& c_) { return c_.ga; }) : cell_sel(k, [](const FusedCell& c_) { return c_.oa; });
         const float* bp = kind == 0 ? cell_sel(k, [](const FusedCell& c_) { return c_.gb; }) : cell_sel(k, [](const FusedCell& c_) { return c_.ob; });
-        ln_s0 = st[0]; ln_s1 = st[1];
-        ln_g = gp[f]; ln_b = bp[f];
+        ln_s0 = st[0]; ln_s1 = st[1]; ln_g = gp[f]; ln_b = bp[f];
         ln_cnt = (double)a.H * a.W * F;
         if (PHASE == 0) ln_quad = k == 0 ? 4 * kind + (f >> 2) : k == 1 ? 8 + kind : 10 + kind;
         else ln_quad = k == 0 ? (f >> 2) : k == 1 ? 4 : 5;
-        ln_sub = f & 3;
+        ln_sub = f & 3; ln_kind = kind;
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) load_piece(i, first);
@@ -279,12 +300,17 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
 #pragma unroll
         for (int k = 0; k < K2; ++k) reinterpret_cast<f32x4*>(wsm)[min(tid + FNT * k, NS4 - 1)] = t2[k];
     }
-    if (tid < NAFF) {   // scale = gamma / sqrt(var + 1e-12), shift = beta - mean * scale in float64 (tf.contrib.layers.layer_norm)
+    if (tid < NAFF) {
+        // scale = gamma / sqrt(var + 1e-12), shift = beta - mean * scale in float64 (tf.contrib.layers.layer_norm), then folded
+        // with the constant of the exponential that consumes it: gates -> e^-x = 2^(-log2(e) x), candidate -> e^-2|y| = 2^-|2 log2(e) y|
         const double mean = ln_s0 / ln_cnt;
         double var = ln_s1 / ln_cnt - mean * mean;
         if (var < 0.0) var = 0.0;
         const double inv = (double)ln_g / sqrt(var + 1e-12);
-        lnS[ln_quad][ln_sub] = (float)inv; lnT[ln_quad][ln_sub] = (float)((double)ln_b - mean * inv);
+        const double shift = (double)ln_b - mean * inv;
+        const double L2E = 1.4426950408889634;
+        const double f = (PHASE == 0 && ln_kind == 1) ? 2.0 * L2E : -L2E;
+        lnS[ln_quad][ln_sub] = (float)(inv * f); lnT[ln_quad][ln_sub] = (float)(shift * f);
     }
     if (tid >= 64 && tid < 64 + 8) {                 // the unused halves of the 2-channel quads
         const int q = PHASE == 0 ? 10 + ((tid - 64) >> 2) : 5, sub = 2 + ((tid - 64) & 1);
@@ -308,6 +334,18 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nb) sbias[e] = bp[b0 + e];
     }
+    // where this wave's results go: cell 1's row (8 floats per lane of the gates, 4 of the candidate), the small job's quad
+    const int sy1 = (int)a.cell[0].y + ((wave * a.W + n) * COUT + 4 * kq) * 4;
+    int sy_small = FBAD, small_px = 0; bool small_live = false, small_b64 = false;
+    if (PHASE == 0) {
+        if (wave < 4) { sy_small = (int)a.cell[1].y + (srow * a.W + scol) * 32 + 16 * (wave >> 1); small_px = 32; small_live = live2; }
+        else if (wave < 6) { sy_small = (int)a.cell[2].y + (srow * a.W + scol) * 16; small_px = 16; small_live = live3; }
+    } else {
+        if (wave < 2) { sy_small = (int)a.cell[1].y + (srow * a.W + scol) * 16; small_px = 16; small_live = live2; }
+        else if (wave < 4) { sy_small = (int)a.cell[2].y + (srow * a.W + scol) * 8; small_px = 8; small_live = live3; small_b64 = true; }
+    }
+    const bool wta_wave = PHASE == 0 && wave >= 6 && (STEADY || a.wta);
+    const int swta = (srow * a.W + scol) * 4;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 6; ++i) stage_piece(i, slab, mini, first);
@@ -315,21 +353,13 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
     for (int i = 0; i < 6; ++i) load_piece(i, first + stride);
     __syncthreads();
 
-    // LayerNorm moments: float within a tile (fixed lane -> pixel map), double across the tiles of a workgroup
+    // LayerNorm moments: float within a tile (fixed lane -> pixel map), float64 per lane across the tiles of a workgroup (the
+    // sums do not depend on which workgroup swept which tile: a batch of views gives the single view's bits)
     double st_s[MT], st_q[MT], sm_s[2] = {0.0, 0.0}, sm_q[2] = {0.0, 0.0};
 #pragma unroll
     for (int m = 0; m < MT; ++m) { st_s[m] = 0.0; st_q[m] = 0.0; }
-    // where this wave's small job stores (offset of the tensor in the block, bytes per pixel, first byte inside the pixel)
-    int so_small = 0, small_px = 0, small_b0 = 0; bool small_live = false, small_b64 = false;
-    if (PHASE == 0) {
-        if (wave < 4) { so_small = (int)a.cell[1].y; small_px = 32; small_b0 = 16 * (wave >> 1); small_live = live2; }
-        else if (wave < 6) { so_small = (int)a.cell[2].y; small_px = 16; small_live = live3; }
-    } else {
-        if (wave < 2) { so_small = (int)a.cell[1].y; small_px = 16; small_live = live2; }
-        else if (wave < 4) { so_small = (int)a.cell[2].y; small_px = 8; small_live = live3; small_b64 = true; }
-    }
-    const bool wta_wave = PHASE == 0 && wave >= 6 && a.wta;
 
+    if (a.trace) tr1 = wall_clock64();               // first tile staged, second requested
     int it = 0;
     for (int tile = first; tile < end; tile += stride, ++it) {
         const float* cur = slab + (it & 1) * SLAB;
@@ -337,14 +367,14 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         const float* mcur = mini + (it & 1) * FNPOS * 4;
         float* mnxt = mini + ((it + 1) & 1) * FNPOS * 4;
         const int th = tile / a.tiles_w, h0 = th * FTH, w0 = (tile - th * a.tiles_w) * FTW;
-        const int sh = h0 + srow, sw = w0 + scol;
-        const bool svalid = sh < a.H && sw < a.W;
-        const int spix = sh * a.W + sw;
+        const int tp = h0 * a.W + w0;                // the tile's first pixel
+        const bool svalid = h0 + srow < a.H && w0 + scol < a.W;
         // the winner-take-all accumulators of this tile's pixels, requested now (waves 6, 7 of G; out of range elsewhere)
         float wta_mp = 0.f, wta_es = 0.f;
         if (PHASE == 0) {
-            wta_mp = ld_b32(rs_ws, wta_wave && svalid ? spix * 4 : BAD, (int)a.max_prob);
-            wta_es = ld_b32(rs_ws, wta_wave && svalid ? spix * 4 : BAD, (int)a.exp_sum);
+            const int wo = wta_wave && svalid ? swta + tp * 4 : FBAD;
+            wta_mp = ld_b32(rs, wo == FBAD ? FBAD : wo + (int)a.max_prob);
+            wta_es = ld_b32(rs, wo == FBAD ? FBAD : wo + (int)a.exp_sum);
         }
 
         // ---- cell 1: x channels and state channels in separate accumulators, combined as (h part) + ((x part) + bias): what
@@ -384,13 +414,13 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
             }
         }
         {   // store (+ bias) and LayerNorm moments (gates: tile 0 = reset, tile 1 = update)
-            const int h = h0 + wave, w = w0 + n;
-            const bool ok1 = live1 && h < a.H && w < a.W;
+            const bool ok1 = live1 && h0 + wave < a.H && w0 + n < a.W;
+            const int o1 = ok1 ? sy1 + tp * (COUT * 4) : FBAD;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const f32x4 r = acc[m], rx = accx[m];
                 const float4 o = make_float4(r[0] + (rx[0] + bias4[m][0]), r[1] + (rx[1] + bias4[m][1]), r[2] + (rx[2] + bias4[m][2]), r[3] + (rx[3] + bias4[m][3]));
-                st_b128(rs_ws, ok1 ? (h * a.W + w) * (COUT * 4) + (m * 16 + 4 * kq) * 4 : BAD, so_y1, o.x, o.y, o.z, o.w);
+                st_b128(rs, ok1 ? o1 + m * 64 : FBAD, o.x, o.y, o.z, o.w);
                 const float ts = (o.x + o.y) + (o.z + o.w), tq = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
                 st_s[m] += ok1 ? (double)ts : 0.0;
                 st_q[m] += ok1 ? (double)tq : 0.0;
@@ -455,32 +485,31 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         }
         {   // the small job's store and LayerNorm moments, the winner-take-all update: straight-line for every wave
             const bool sok = small_live && svalid;
-            st_b128(rs_ws, sok && !small_b64 ? spix * small_px + small_b0 : BAD, so_small, sr[0], sr[1], sr[2], sr[3]);
-            if (PHASE == 1) st_b64(rs_ws, sok && small_b64 ? spix * small_px : BAD, so_small, sr[0], sr[1]);
+            const int os = sok ? sy_small + tp * small_px : FBAD;
+            st_b128(rs, small_b64 ? FBAD : os, sr[0], sr[1], sr[2], sr[3]);
+            if (PHASE == 1) st_b64(rs, small_b64 ? os : FBAD, sr[0], sr[1]);
             // moments: group 0 = all four channels (cell 2, one group per wave; C: the candidate) or channels 0,1 (cell 3);
             // group 1 = channels 2,3 (cell 3 gates: the update group)
             const bool pair = PHASE == 0 ? (wave >= 4) : (wave >= 2);      // cell 3: channel pairs
-            float s0, q0, s1, q1;
-            if (pair) { s0 = sr[0] + sr[1]; q0 = __builtin_fmaf(sr[1], sr[1], sr[0] * sr[0]); s1 = sr[2] + sr[3]; q1 = __builtin_fmaf(sr[3], sr[3], sr[2] * sr[2]); }
-            else {
-                s0 = 0.f; q0 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { s0 += sr[e]; q0 = __builtin_fmaf(sr[e], sr[e], q0); }
-                s1 = 0.f; q1 = 0.f;
-            }
-            if (!sok) { s0 = 0.f; q0 = 0.f; s1 = 0.f; q1 = 0.f; }
-            s0 = wave_sum(s0); q0 = wave_sum(q0); s1 = wave_sum(s1); q1 = wave_sum(q1);
-            sm_s[0] += (double)s0; sm_q[0] += (double)q0; sm_s[1] += (double)s1; sm_q[1] += (double)q1;
+            const float s01 = sr[0] + sr[1], q01 = __builtin_fmaf(sr[1], sr[1], sr[0] * sr[0]);
+            const float s23 = sr[2] + sr[3], q23 = __builtin_fmaf(sr[3], sr[3], sr[2] * sr[2]);
+            // (the four-channel group in the order of conv2d_small_body: s = ((r0 + r1) + r2) + r3, q = fma chain)
+            const float s4 = (s01 + sr[2]) + sr[3], q4s = __builtin_fmaf(sr[3], sr[3], __builtin_fmaf(sr[2], sr[2], q01));
+            const float s0 = pair ? s01 : s4, q0 = pair ? q01 : q4s;
+            sm_s[0] += sok ? (double)s0 : 0.0; sm_q[0] += sok ? (double)q0 : 0.0;
+            sm_s[1] += sok && pair ? (double)s23 : 0.0; sm_q[1] += sok && pair ? (double)q23 : 0.0;
             if (PHASE == 0) {   // winner-take-all update (model.py:721-731; strict '<' keeps the first maximum)
-                const bool wok = wta_wave && svalid;
-                const bool better = wok && wta_mp < pr;
-                st_b32(rs_ws, better ? spix * 4 : BAD, (int)a.max_prob, pr);
-                st_b32(rs_ws, better ? spix * 4 : BAD, (int)a.depth_image, dv.v[view]);
-                st_b32(rs_ws, wok ? spix * 4 : BAD, (int)a.exp_sum, wta_es + pr);
+                const int wo = wta_wave && svalid ? swta + tp * 4 : FBAD;
+                const bool better = wo != FBAD && wta_mp < pr;
+                st_b32(rs, better ? wo + (int)a.max_prob : FBAD, pr);
+                st_b32(rs, better ? wo + (int)a.depth_image : FBAD, dv.v[view]);
+                st_b32(rs, wo == FBAD ? FBAD : wo + (int)a.exp_sum, wta_es + pr);
             }
         }
         __syncthreads();
+        if (a.trace && it == 0) tr2 = wall_clock64();   // first tile done
     }
+    if (a.trace) tr3 = wall_clock64();
 
     // ---- LayerNorm sums of this workgroup -> float64 atomics.  red[wave][0..3] : cell 1 (MT groups x 2), [4..7] the small job (2 x 2)
 #pragma unroll
@@ -488,7 +517,10 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         const double s = wave_sum(st_s[m]), q = wave_sum(st_q[m]);
         if (lane == 0) { red[wave][2 * m] = s; red[wave][2 * m + 1] = q; }
     }
-    if (lane == 0) { red[wave][4] = sm_s[0]; red[wave][5] = sm_q[0]; red[wave][6] = sm_s[1]; red[wave][7] = sm_q[1]; }
+    {
+        const double s0 = wave_sum(sm_s[0]), q0 = wave_sum(sm_q[0]), s1 = wave_sum(sm_s[1]), q1 = wave_sum(sm_q[1]);
+        if (lane == 0) { red[wave][4] = s0; red[wave][5] = q0; red[wave][6] = s1; red[wave][7] = q1; }
+    }
     __syncthreads();
     if (PHASE == 0) {
         // cell 1: [0..3] = reset s,q | update s,q.  cell 2: reset = waves 0,1 ; update = waves 2,3.  cell 3: waves 4,5 (both groups)
@@ -499,6 +531,14 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         if (tid < 2 && live1) { double t = 0.0; for (int w = 0; w < 8; ++w) t += red[w][tid]; atomicAdd(&vp(a.cell[0].st_out)[4 + tid], t); }
         else if (tid >= 2 && tid < 4 && live2) { const int e = tid - 2; atomicAdd(&vp(a.cell[1].st_out)[4 + e], red[0][4 + e] + red[1][4 + e]); }
         else if (tid >= 4 && tid < 6 && live3) { const int e = tid - 4; atomicAdd(&vp(a.cell[2].st_out)[4 + e], red[2][4 + e] + red[3][4 + e]); }
+    }
+    if (a.trace && tid == 0) {
+        const long long slot = (long long)atomicAdd((unsigned long long*)a.trace, 1ULL);
+        if (slot < a.trace_cap) {
+            long long* r = a.trace + 1 + slot * 8;
+            r[0] = ((long long)a.launch_id << 32) | (PHASE << 16) | blockIdx.x; r[1] = tr0; r[2] = tr1; r[3] = tr2; r[4] = tr3; r[5] = wall_clock64();
+            r[6] = it; r[7] = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 4);      // tiles swept; HW_ID (CU / SE / XCC bits)
+        }
     }
 }
 
@@ -512,8 +552,19 @@ __global__ void gru_small_table_kernel(const float* __restrict__ w, int CT, int 
     out[i] = (ci < CT && co < CO) ? w[((size_t)tap * CT + ci) * CO + co] : 0.f;
 }
 
+template <int PHASE, bool STEADY>
+int launch_fused2(const FusedArgs& a, const FusedDepth& dv, int grid, size_t smem, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gru_fused_kernel<PHASE, STEADY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    gru_fused_kernel<PHASE, STEADY><<<grid, FNT, smem, st>>>(a, dv);
+    return (int)hipGetLastError();
+}
 template <int PHASE>
-int launch_fused(const FusedArgs& a0, const FusedDepth& dv, int views, hipStream_t st) {
+int launch_fused(const FusedArgs& a0, const FusedDepth& dv, int views, bool steady, hipStream_t st) {
     FusedArgs a = a0;
     a.tiles_h = (a.H + FTH - 1) / FTH;
     a.tiles_w = (a.W + FTW - 1) / FTW;
@@ -527,14 +578,7 @@ int launch_fused(const FusedArgs& a0, const FusedDepth& dv, int views, hipStream
     constexpr int COUT = PHASE == 0 ? 32 : 16;
     constexpr int WS_FLOATS = PHASE == 0 ? 2 * 720 + 288 + 20 : 720 + 288;
     const size_t smem = (size_t)(9 * 48 * COUT + WS_FLOATS + 2 * FNPOS * S + (PHASE == 1 ? 3 * FNPOS * 4 : 0)) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gru_fused_kernel<PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
-    gru_fused_kernel<PHASE><<<per * views, FNT, smem, st>>>(a, dv);
-    return (int)hipGetLastError();
+    return steady ? launch_fused2<PHASE, true>(a, dv, per * views, smem, st) : launch_fused2<PHASE, false>(a, dv, per * views, smem, st);
 }
 
 }  // namespace
@@ -569,24 +613,34 @@ int mvs_gru_fused_prepare_weights(const float* const* params, const GruFusedWs& 
     return (int)hipGetLastError();
 }
 
+// Diagnostic: per-workgroup time stamps of the fused launches (100 MHz wall clock: entry, first tile staged, first tile done, loop
+// done, exit) appended to a caller-owned device buffer of 1 + 8 * capacity int64 (tools/gru_fused_trace.py).  Off (null) by default.
+static long long* g_fused_trace = nullptr; static int g_fused_trace_cap = 0; static int g_fused_launch = 0;
+extern "C" int mvs_gru_fused_trace(void* buffer, int capacity) {
+    g_fused_trace = (long long*)buffer; g_fused_trace_cap = buffer ? capacity : 0; g_fused_launch = 0;
+    return 0;
+}
+
 // one plane step of the pipeline: G(t) then C(t).  t runs 0 .. depth_num + 2.
 int mvs_gru_fused_step(const GruFusedWs& ws, const float* const* params, int t, int depth_num, const float* x_t, int H, int W,
                        int views, size_t vstride, const float* depth_values /* host, (views, depth_num) */, hipStream_t st) {
     if (vstride >= ((size_t)1 << 31)) return MVS_E_SHAPE;            // the kernels address a view's block with 32-bit byte offsets
     auto off = [&](const void* p) { return (unsigned)((const char*)p - ws.base); };
     FusedArgs g = {}, c = {};
-    g.x = c.x = x_t;
+    g.x = c.x = off(x_t);
     g.ws = c.ws = ws.base;
     g.H = c.H = H; g.W = c.W = W; g.vstride = c.vstride = vstride;
+    bool steady = true;                              // every cell live and blending, the WTA update on
     for (int k = 0; k < 3; ++k) {
         const int p = t - k;                         // this cell's plane
         const float* const* pp = params + 10 * k;
         const bool conv = p >= 0 && p < depth_num, blend = p >= 1 && p <= depth_num;
+        steady = steady && conv && blend;
         const int pc = p < 0 ? 0 : p, pm = p < 1 ? 0 : p - 1;        // clamped plane indices for the stats rows of dead cells
         FusedCell& gc = g.cell[k];
         // s(q) lives in S[k][q & 1] (s(-1) = 0 in S[k][1]); G forms s(p-1) from s(p-2)
-        gc.h = blend ? ws.S[k][p & 1] : ws.S[k][(p - 1) & 1];
-        gc.c = ws.Cb[k]; gc.g = ws.G[k][(p - 1) & 1];
+        gc.h = off(blend ? ws.S[k][p & 1] : ws.S[k][(p - 1) & 1]);
+        gc.c = off(ws.Cb[k]); gc.g = off(ws.G[k][(p - 1) & 1]);
         gc.st_in = ws.stats + ((size_t)(pm % GRU_FUSED_RING) * 3 + k) * 6;
         gc.h_out = off(ws.S[k][(p - 1) & 1]);
         gc.y = off(ws.G[k][p & 1]);
@@ -594,7 +648,7 @@ int mvs_gru_fused_step(const GruFusedWs& ws, const float* const* params, int t, 
         gc.bias = pp[1]; gc.ga = pp[4]; gc.gb = pp[5]; gc.oa = pp[8]; gc.ob = pp[9];
         gc.conv = conv; gc.blend = blend;
         FusedCell& cc = c.cell[k];
-        cc.h = ws.S[k][(p - 1) & 1]; cc.c = nullptr; cc.g = ws.G[k][p & 1];
+        cc.h = off(ws.S[k][(p - 1) & 1]); cc.c = 0; cc.g = off(ws.G[k][p & 1]);
         cc.st_in = ws.stats + ((size_t)(pc % GRU_FUSED_RING) * 3 + k) * 6;
         cc.h_out = 0; cc.y = off(ws.Cb[k]); cc.st_out = ws.stats + ((size_t)(pc % GRU_FUSED_RING) * 3 + k) * 6;
         cc.bias = pp[7]; cc.ga = pp[2]; cc.gb = pp[3]; cc.oa = pp[2]; cc.ob = pp[3];
@@ -604,10 +658,13 @@ int mvs_gru_fused_step(const GruFusedWs& ws, const float* const* params, int t, 
     g.max_prob = off(ws.max_prob); g.depth_image = off(ws.depth); g.exp_sum = off(ws.exp_sum);
     const int q = t - 3;
     g.wta = q >= 0 && q < depth_num;
+    steady = steady && g.wta;
     FusedDepth dv = {};
     for (int v = 0; v < views && v < FMAXV; ++v) dv.v[v] = g.wta ? depth_values[(size_t)v * depth_num + q] : 0.f;
-    int rc = launch_fused<0>(g, dv, views, st);
+    g.trace = c.trace = g_fused_trace; g.trace_cap = c.trace_cap = g_fused_trace_cap;
+    g.launch_id = g_fused_launch++; c.launch_id = g_fused_launch++;
+    int rc = launch_fused<0>(g, dv, views, steady, st);
     if (rc) return rc;
     if (t > depth_num + 1) return 0;                 // the last output launch is C(depth_num + 1): cell 3's plane depth_num - 1
-    return launch_fused<1>(c, dv, views, st);
+    return launch_fused<1>(c, dv, views, steady, st);
 }
