@@ -91,6 +91,19 @@ __device__ __forceinline__ void st_b32(__amdgpu_buffer_rsrc_t rsrc, int voff, fl
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsrc, voff, 0, 0);
 }
 
+// Sum over the 64 lanes of a wave on the DPP path; LANE 63 receives the total (the other lanes partial sums): inclusive row
+// shifts by 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (lanes a shift
+// leaves without a source, and rows a broadcast does not address, add 0).  18 vector instructions per float64 against the 12
+// ds_bpermute round trips of the shuffle form; eight of these close every launch (tail 3.0 -> 1.6 us, profiles/r05_gru_fused_trace.txt).
+__device__ __forceinline__ double wave_sum_dpp63(double v) {
+#define MVS_DPP_ADD(ctrl, rmask) { const int lo_ = __double2loint(v), hi_ = __double2hiint(v); \
+        const int l2_ = __builtin_amdgcn_update_dpp(0, lo_, ctrl, rmask, 0xf, false), h2_ = __builtin_amdgcn_update_dpp(0, hi_, ctrl, rmask, 0xf, false); \
+        v += __hiloint2double(h2_, l2_); }
+    MVS_DPP_ADD(0x111, 0xf) MVS_DPP_ADD(0x112, 0xf) MVS_DPP_ADD(0x114, 0xf) MVS_DPP_ADD(0x118, 0xf)      // row_shr:1, 2, 4, 8
+    MVS_DPP_ADD(0x142, 0xa) MVS_DPP_ADD(0x143, 0xc)                                                      // row_bcast:15, row_bcast:31
+#undef MVS_DPP_ADD
+    return v;
+}
 // PHASE 0 = gates launch G(t), PHASE 1 = output launch C(t).  Slab channel map (floats per staged position):
 //   G (S = 56): x 0..31 | s1 32..47 | s2 48..51 | s3 52..53 | 54,55 unused          (56 = 48 + the conflict-free pad of gru_mfma.hip)
 //   C (S = 72): x 0..31 | r1*s1 32..47 | s1 48..63 | r2*s2 64..67 | s2 68..71 ;  r3*s3 in a 4-float side slab
@@ -133,7 +146,8 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
     __builtin_amdgcn_s_setprio(3);
 
     const long long tr0 = a.trace ? wall_clock64() : 0;
-    long long tr1 = 0, tr2 = 0, tr3 = 0;
+    const long long cy0 = a.trace ? clock64() : 0;         // shader clocks (s_memtime) next to the 100 MHz wall clock: the launch's real frequency
+    long long tr1 = 0, tr2 = 0, tr3 = 0, tpa = 0, tpb = 0, tpc = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
     const int view = blockIdx.x / a.wg_per_view, j = blockIdx.x - view * a.wg_per_view;
@@ -285,20 +299,19 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) load_piece(i, first);
-    {   // prepared weights -> LDS: all loads of a thread in flight at once (one round trip instead of three)
-        constexpr int N4 = W1_FLOATS / 4, NS4 = WS_FLOATS / 4;
-        constexpr int K1 = (N4 + FNT - 1) / FNT, K2 = (NS4 + FNT - 1) / FNT;
+    // prepared weights: all loads of a thread in flight at once (one round trip instead of three); they are written to LDS AFTER
+    // the first tile has been staged -- its loads were issued before these and return first, so the blend arithmetic of tile 0
+    // runs while the weights are still on their way
+    constexpr int N4 = W1_FLOATS / 4, NS4 = WS_FLOATS / 4;
+    constexpr int K1 = (N4 + FNT - 1) / FNT, K2 = (NS4 + FNT - 1) / FNT;
+    f32x4 wt1[K1], wt2[K2];
+    {
         const f32x4* s4 = reinterpret_cast<const f32x4*>(a.w1);
         const f32x4* t4 = reinterpret_cast<const f32x4*>(a.wsmall);
-        f32x4 t1[K1], t2[K2];
 #pragma unroll
-        for (int k = 0; k < K1; ++k) t1[k] = s4[min(tid + FNT * k, N4 - 1)];
+        for (int k = 0; k < K1; ++k) wt1[k] = s4[min(tid + FNT * k, N4 - 1)];
 #pragma unroll
-        for (int k = 0; k < K2; ++k) t2[k] = t4[min(tid + FNT * k, NS4 - 1)];
-#pragma unroll
-        for (int k = 0; k < K1; ++k) reinterpret_cast<f32x4*>(wl)[min(tid + FNT * k, N4 - 1)] = t1[k];       // (the clamped lanes rewrite the last quad)
-#pragma unroll
-        for (int k = 0; k < K2; ++k) reinterpret_cast<f32x4*>(wsm)[min(tid + FNT * k, NS4 - 1)] = t2[k];
+        for (int k = 0; k < K2; ++k) wt2[k] = t4[min(tid + FNT * k, NS4 - 1)];
     }
     if (tid < NAFF) {
         // scale = gamma / sqrt(var + 1e-12), shift = beta - mean * scale in float64 (tf.contrib.layers.layer_norm), then folded
@@ -347,10 +360,17 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
     const bool wta_wave = PHASE == 0 && wave >= 6 && (STEADY || a.wta);
     const int swta = (srow * a.W + scol) * 4;
     __syncthreads();
+    if (a.trace) tpa = wall_clock64();             // affines in LDS, everybody through the first barrier
 #pragma unroll
     for (int i = 0; i < 6; ++i) stage_piece(i, slab, mini, first);
+    if (a.trace) tpb = wall_clock64();             // first tile staged (this wave)
+#pragma unroll
+    for (int k = 0; k < K1; ++k) reinterpret_cast<f32x4*>(wl)[min(tid + FNT * k, N4 - 1)] = wt1[k];       // (the clamped lanes rewrite the last quad)
+#pragma unroll
+    for (int k = 0; k < K2; ++k) reinterpret_cast<f32x4*>(wsm)[min(tid + FNT * k, NS4 - 1)] = wt2[k];
 #pragma unroll
     for (int i = 0; i < 6; ++i) load_piece(i, first + stride);
+    if (a.trace) tpc = wall_clock64();             // weights in LDS, second tile requested (this wave)
     __syncthreads();
 
     // LayerNorm moments: float within a tile (fixed lane -> pixel map), float64 per lane across the tiles of a workgroup (the
@@ -514,12 +534,12 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
     // ---- LayerNorm sums of this workgroup -> float64 atomics.  red[wave][0..3] : cell 1 (MT groups x 2), [4..7] the small job (2 x 2)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const double s = wave_sum(st_s[m]), q = wave_sum(st_q[m]);
-        if (lane == 0) { red[wave][2 * m] = s; red[wave][2 * m + 1] = q; }
+        const double s = wave_sum_dpp63(st_s[m]), q = wave_sum_dpp63(st_q[m]);
+        if (lane == 63) { red[wave][2 * m] = s; red[wave][2 * m + 1] = q; }
     }
     {
-        const double s0 = wave_sum(sm_s[0]), q0 = wave_sum(sm_q[0]), s1 = wave_sum(sm_s[1]), q1 = wave_sum(sm_q[1]);
-        if (lane == 0) { red[wave][4] = s0; red[wave][5] = q0; red[wave][6] = s1; red[wave][7] = q1; }
+        const double s0 = wave_sum_dpp63(sm_s[0]), q0 = wave_sum_dpp63(sm_q[0]), s1 = wave_sum_dpp63(sm_s[1]), q1 = wave_sum_dpp63(sm_q[1]);
+        if (lane == 63) { red[wave][4] = s0; red[wave][5] = q0; red[wave][6] = s1; red[wave][7] = q1; }
     }
     __syncthreads();
     if (PHASE == 0) {
@@ -537,7 +557,7 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         if (slot < a.trace_cap) {
             long long* r = a.trace + 1 + slot * 8;
             r[0] = ((long long)a.launch_id << 32) | (PHASE << 16) | blockIdx.x; r[1] = tr0; r[2] = tr1; r[3] = tr2; r[4] = tr3; r[5] = wall_clock64();
-            r[6] = it; r[7] = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 4);      // tiles swept; HW_ID (CU / SE / XCC bits)
+            r[6] = it | ((tpa - tr0) << 16) | ((tpb - tr0) << 32) | ((tpc - tr0) << 48); r[7] = clock64() - cy0;      // tiles swept + three prologue stamps (ticks since entry, 16 bits each); shader clocks between entry and exit
         }
     }
 }

@@ -53,11 +53,13 @@ for ph, name in ((0, "G"), (1, "C")):
             continue
         p, q = per[L], per[L - 1]
         r = p["r"]
-        tiles = np.maximum(r[:, 6], 1)
+        tiles = np.maximum(r[:, 6] & 0xffff, 1)
+        pa, pb, pc = (r[:, 6] >> 16) & 0xffff, (r[:, 6] >> 32) & 0xffff, (r[:, 6] >> 48) & 0xffff
         rest = np.where(tiles > 1, (r[:, 4] - r[:, 3]) / np.maximum(tiles - 1, 1), np.nan)
         rows.append([us(p["first"] - q["last"]), us(np.median(r[:, 1]) - p["first"]), us(np.median(r[:, 2] - r[:, 1])),
                      us(np.median(r[:, 3] - r[:, 2])), us(np.nanmedian(rest)), us(np.median(r[:, 5] - r[:, 4])),
-                     us(p["last"] - p["first"]), tiles.max(), us(np.median(r[:, 5]) - p["first"]), us(np.percentile(r[:, 1], 95) - p["first"])])
+                     us(p["last"] - p["first"]), tiles.max(), us(np.median(r[:, 5]) - p["first"]), us(np.percentile(r[:, 1], 95) - p["first"]),
+                     us(np.median(pa)), us(np.median(pb)), us(np.median(pc)), np.median(r[:, 7] / np.maximum(r[:, 5] - r[:, 1], 1)) * 100.0])
     m = np.median(np.array(rows), axis=0)
     print("%s launch, %d view(s): gap %.1f | ramp (median entry) %.1f, 95%% entry %.1f | prologue %.1f | first tile %.1f | later tiles %.2f each (max %d tiles) | tail %.1f | "
-          "median exit at %.1f | span %.1f us" % (name, B, m[0], m[1], m[9], m[2], m[3], m[4], int(m[7]), m[5], m[8], m[6]))
+          "median exit at %.1f | span %.1f us\n      prologue, since entry: first barrier passed (affines) %.1f, first tile staged %.1f, weights in LDS + second tile requested %.1f; shader clock during the launch %.0f MHz" % (name, B, m[0], m[1], m[9], m[2], m[3], m[4], int(m[7]), m[5], m[8], m[6], m[10], m[11], m[12], m[13]))
