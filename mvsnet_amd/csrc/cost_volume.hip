@@ -224,20 +224,20 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
 template <int NSRC>
 void launch_sweep(const float* ref, const float* src, const float* transforms, int depth_total,
                   int d_begin, int d_count, int H, int W, int C, int variant, int negate,
-                  float* cost, hipStream_t st) {
+                  float* cost, hipStream_t st, int threads = 256) {
     const int ppb = d_count < 16 ? d_count : 16;          // planes per block
     // Q = 2 (8 channels per lane) halves the per-lane bookkeeping per channel but needs 236 VGPRs
     // (2 waves/SIMD instead of 3): measured 0.258 ms vs 0.243 ms at the metric config, so it stays off.
     const bool wide = false;
     const int lg = wide ? C / 8 : C / 4;
     long long total = (long long)H * W * lg;
-    dim3 grid(mvs_cdiv(total, 256), mvs_cdiv(d_count, ppb));
-    const size_t smem = (size_t)4 * 64 * NSRC * 2 * sizeof(float4);     // bookkeeping table, 2 KB per wave and view
+    dim3 grid(mvs_cdiv(total, threads), mvs_cdiv(d_count, ppb));
+    const size_t smem = (size_t)(threads / 64) * 64 * NSRC * 2 * sizeof(float4);     // bookkeeping table, 2 KB per wave and view
     if (wide)
-        cost_volume_sweep_kernel<NSRC, 2><<<grid, 256, smem, st>>>(ref, src, transforms, depth_total, d_begin,
+        cost_volume_sweep_kernel<NSRC, 2><<<grid, threads, smem, st>>>(ref, src, transforms, depth_total, d_begin,
                                                                 d_count, ppb, H, W, C, variant, negate, cost);
     else
-        cost_volume_sweep_kernel<NSRC, 1><<<grid, 256, smem, st>>>(ref, src, transforms, depth_total, d_begin,
+        cost_volume_sweep_kernel<NSRC, 1><<<grid, threads, smem, st>>>(ref, src, transforms, depth_total, d_begin,
                                                                 d_count, ppb, H, W, C, variant, negate, cost);
 }
 
@@ -258,10 +258,12 @@ warp_kernel(const float* __restrict__ img, const float* __restrict__ t, int H, i
 
 }  // namespace
 
-extern "C" int mvs_cost_volume_f32(const float* ref, const float* src, const float* transforms,
-                                   int view_num, int depth_total, int d_begin, int d_count,
-                                   int H, int W, int C, int variant, int negate, int border,
-                                   float* cost, void* stream) {
+// `threads` per workgroup of the depth sweep (64-thread multiples up to 256).  The recurrent sweep's producer stream asks for 128:
+// such a workgroup needs 16 KB of LDS and fits on a CU beside a 141-144 KB workgroup of the fused ConvGRU launches (gru.hip).
+int mvs_cost_volume_threads_f32(const float* ref, const float* src, const float* transforms,
+                                int view_num, int depth_total, int d_begin, int d_count,
+                                int H, int W, int C, int variant, int negate, int border,
+                                float* cost, int threads, void* stream) {
     MVS_CHECK_ARG(ref && src && transforms && cost);
     MVS_CHECK_ARG(view_num >= 2 && depth_total >= 1 && d_begin >= 0 && d_count >= 1 &&
                   d_begin + d_count <= depth_total && H > 0 && W > 0 && C > 0);
@@ -277,7 +279,7 @@ extern "C" int mvs_cost_volume_f32(const float* ref, const float* src, const flo
     const bool u24 = H < (1 << 24) && W < (1 << 24) && (long long)W * C * 4 < (1 << 24);     // the sweep's 24-bit offset multiplies
     if (border == 0 && view_num <= 8 && cq_pow2 && off32 && u24) {      // depth sweep with register tap reuse
         hipStream_t st = mvs_stream(stream);
-#define MVS_SWEEP(NS) case NS: launch_sweep<NS>(ref, src, transforms, depth_total, d_begin, d_count, H, W, C, variant, negate, cost, st); break;
+#define MVS_SWEEP(NS) case NS: launch_sweep<NS>(ref, src, transforms, depth_total, d_begin, d_count, H, W, C, variant, negate, cost, st, threads); break;
         switch (view_num - 1) {
             MVS_SWEEP(1) MVS_SWEEP(2) MVS_SWEEP(3) MVS_SWEEP(4) MVS_SWEEP(5) MVS_SWEEP(6) MVS_SWEEP(7)
         }
@@ -291,6 +293,14 @@ extern "C" int mvs_cost_volume_f32(const float* ref, const float* src, const flo
         cost_volume_kernel<1><<<grid, 256, 0, mvs_stream(stream)>>>(
             ref, src, transforms, view_num - 1, depth_total, d_begin, H, W, C, variant, negate, cost);
     MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_cost_volume_f32(const float* ref, const float* src, const float* transforms,
+                                   int view_num, int depth_total, int d_begin, int d_count,
+                                   int H, int W, int C, int variant, int negate, int border,
+                                   float* cost, void* stream) {
+    return mvs_cost_volume_threads_f32(ref, src, transforms, view_num, depth_total, d_begin, d_count, H, W, C, variant, negate, border,
+                                       cost, 256, stream);
 }
 
 extern "C" int mvs_warp_f32(const float* image, const float* transform8, int H, int W, int C,

@@ -38,6 +38,8 @@ int mvs_gru1_gates_full_blend_mfma(const float* x, const float* h_before, const 
 int mvs_gru1_out_full_mfma(const float* x, const float* h, const float* g, const double* g_stats, const float* r_gamma,
                            const float* r_beta, const float* wo, const float* bias, int H, int W, float* c, double* stats,
                            int views, size_t vstride, hipStream_t st);
+int mvs_cost_volume_threads_f32(const float* ref, const float* src, const float* transforms, int view_num, int depth_total, int d_begin,
+                                int d_count, int H, int W, int C, int variant, int negate, int border, float* cost, int threads, void* stream);
 // the fused two-launches-per-plane sweep (gru_fused.hip)
 struct GruFusedWs {
     char* base;
@@ -922,12 +924,14 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
         const bool capturing0 = hipStreamIsCapturing(st, &cs0) == hipSuccess && cs0 != hipStreamCaptureStatusNone;
         GruStreams* pg = (!capturing0 && depth_num > XB && getenv("MVS_GRU_ONE_STREAM") == nullptr) ? gru_find(st) : nullptr;
         const hipStream_t sx = pg ? pg->s[2] : st;
+        static const int small_wg = getenv("MVS_GRU_PRODUCER_THREADS") ? atoi(getenv("MVS_GRU_PRODUCER_THREADS")) : 128;      // A/B hook
         auto xhalf = [&](int bidx) -> float* { return pg ? ws.px + (size_t)(bidx & 1) * XB * hw * C : ws.x; };
         auto produce = [&](int bidx, hipStream_t s) -> int {
             const int t0 = bidx * XB, nb = depth_num - t0 < XB ? depth_num - t0 : XB;
             for (int v = 0; v < views; ++v) {
-                const int r2 = mvs_cost_volume_f32(ref[v], src[v], transforms[v], view_num, depth_num, t0, nb, H, W, C, /*variant*/ 1,
-                                                   /*negate*/ 1, /*border*/ 0, vp(xhalf(bidx), v), s);
+                // (on the producer stream: 128-thread workgroups, 16 KB of LDS -- they fit beside a fused workgroup)
+                const int r2 = mvs_cost_volume_threads_f32(ref[v], src[v], transforms[v], view_num, depth_num, t0, nb, H, W, C, /*variant*/ 1,
+                                                           /*negate*/ 1, /*border*/ 0, vp(xhalf(bidx), v), (pg && s == sx) ? small_wg : 256, s);
                 if (r2) return r2;
             }
             return 0;

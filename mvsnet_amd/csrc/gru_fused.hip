@@ -451,7 +451,11 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         // the job's channel quad, the lane's own staged value is the B operand): acc = bias, then fma per (tap, input channel)
         // in the order [xa | xb] -- conv2d_small_body's chain.  LDS reads and matrix instructions only (see the header).
         auto job20 = [&](const float* tab) __attribute__((always_inline)) -> f32x4 {
-            f32x4 r = {sbias[0], sbias[1], sbias[2], sbias[3]};
+            // FOUR independent chains (input channels 4q + e: one chain per e), summed at the end.  One chain of 180 instructions waits
+            // on itself -- ~20 clk per 8-cycle instruction with every wave of the workgroup in its small job at the end of a tile:
+            // 1.5 us of a 9.5 us G tile (profiles/r05_gru_fused_wave_roles.txt).  The sum order differs from conv2d_small_body's
+            // single chain in the last bits (batch = single view still holds: the same kernel either way).
+            f32x4 r4[4] = {(f32x4){sbias[0], sbias[1], sbias[2], sbias[3]}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
             const float* ap = tab + (lane & 3) * 4;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -461,13 +465,13 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
                     const f32x4 bq = *(const f32x4*)(bt + 4 * q);
                     const f32x4 aq = *(const f32x4*)(ap + (tap * 5 + q) * 16);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) r = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[e], bq[e], r, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) r4[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[e], bq[e], r4[e], 0, 0, 0);
                 }
             }
-            return r;
+            return (r4[0] + r4[1]) + (r4[2] + r4[3]);
         };
         auto job6 = [&](const float* tab) __attribute__((always_inline)) -> f32x4 {
-            f32x4 r = {sbias[0], sbias[1], sbias[2], sbias[3]};
+            f32x4 r4[4] = {(f32x4){sbias[0], sbias[1], sbias[2], sbias[3]}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
             const float* ap = tab + (lane & 3) * 4;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -478,11 +482,11 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
                 else b1 = *(const float2*)(mcur + 4 * (srow * FPW + scol + po));
                 const f32x4 a0 = *(const f32x4*)(ap + (tap * 2) * 16), a1 = *(const f32x4*)(ap + (tap * 2 + 1) * 16);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[e], b0[e], r, 0, 0, 0);
-                r = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[0], b1.x, r, 0, 0, 0);
-                r = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[1], b1.y, r, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) r4[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[e], b0[e], r4[e], 0, 0, 0);
+                r4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[0], b1.x, r4[0], 0, 0, 0);
+                r4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[1], b1.y, r4[1], 0, 0, 0);
             }
-            return r;
+            return (r4[0] + r4[1]) + (r4[2] + r4[3]);
         };
         f32x4 sr = {0.f, 0.f, 0.f, 0.f};             // the small job's four output channels of this lane's pixel
         float pr = 0.f;                              // waves 6, 7 of G: exp(prob_conv)
