@@ -32,9 +32,11 @@ extern "C" {
 
 #define MVS_E_BADARG   (-1)   /* null pointer / non-positive size                         */
 #define MVS_E_SHAPE    (-2)   /* shape not supported by this build (see function comment) */
-#define MVS_E_WORKSPACE (-3)  /* workspace too small (mvs_gru_prepare: all 16 stream sets in use) */
+#define MVS_E_WORKSPACE (-3)  /* workspace too small                                      */
 #define MVS_E_NOT_PREPARED (-4) /* mvs_gru_prepare on a stream under hipGraph capture (it synchronises);
                                    mvs_gru_stream_layout on a stream without a set */
+#define MVS_E_NO_SLOT  (-5)   /* mvs_gru_prepare: all 16 stream sets of the process are in use (mvs_gru_release frees one).
+                                   Not fatal for the sweep: without a set it runs on the caller's stream alone */
 
 /* Regulariser implementation selector (mvs_set_conv_impl): the MFMA path is the product;
  * the scalar path is a slow, shape-generic HIP cross-check (never a CPU fallback). */
@@ -328,16 +330,23 @@ int mvs_gru_wta_batch_f32(const float* const* ref, const float* const* src, cons
  * side streams avoid it.  THE call of this header that creates resources and synchronises (`stream` and the new streams):
  * call it once per caller stream at start-up (DepthPlan(..., "GRU") does), never inside a latency-critical region or under
  * hipGraph capture (returns MVS_E_NOT_PREPARED there).  Idempotent.  An inconclusive calibration is reported once on stderr and
- * the set is still usable.  At most 16 sets per process (MVS_E_WORKSPACE beyond; mvs_gru_release frees one).  Thread-safe. */
+ * the set is still usable.  At most 16 sets per process (MVS_E_NO_SLOT beyond; mvs_gru_release frees one).  Thread-safe.
+ * Optional since round 5: without a set the sweep runs as the fused two-launches-per-plane pipeline on the caller's stream alone
+ * (csrc/gru_fused.hip), which needs none; the round-4 four-stream wavefront (mvs_gru_set_formulation 1 / 2) still does. */
 int mvs_gru_prepare(void* stream);
 /* Tear-down: waits for the set's side streams, destroys them and their events (MVS_E_BADARG: no set for this stream).  Call it
  * before destroying `stream` -- a later stream may receive the same handle on another hardware queue. */
 int mvs_gru_release(void* stream);
 
-/* Formulation of the first ConvGRU cell on the MFMA kernels (csrc/gru.hip): 0 = chosen by view count (default), 1 = hoisted
- * x-part (batched producer launches + 16-channel per-plane kernels), 2 = full 48-channel per-plane kernels.  Same results bit
- * for bit; a tuning / test switch.  Process-wide atomic, read once at the start of each sweep: a sweep keeps the formulation it
- * started with whatever other threads set meanwhile. */
+/* Formulation of the recurrent sweep at the reference's shape (32 feature channels, filters 16 / 4 / 2):
+ *   0 (default) = 3 = the FUSED sweep (csrc/gru_fused.hip): two launches per plane on the caller's stream alone carry all three
+ *       cells, prob_conv and the winner-take-all update; no stream set needed, captures into a hipGraph;
+ *   1 = the round-4 wavefront over a stream set (mvs_gru_prepare) with cell 1's x-part hoisted into batched producer launches,
+ *   2 = the same wavefront with full 48-channel per-plane kernels.
+ * 1 and 2 give the same bits as each other; the fused sweep runs the same multiply-add chains for cell 1 and differs from them
+ * in the last bits (LayerNorm partial sums, the small cells' four partial chains).  Within a formulation a batch of views gives
+ * the single view's bits.  Other shapes take the wavefront / generic routes whatever is set.  A tuning / test switch: process-wide
+ * atomic, read once at the start of each sweep -- a sweep keeps the formulation it started with. */
 int mvs_gru_set_formulation(int form);
 
 /* Diagnostic (csrc/gru_fused.hip): per-workgroup time stamps of the fused two-launches-per-plane sweep.  `buffer` = caller-owned

@@ -154,25 +154,52 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_GRU_PREPARED = set()          # (device index, stream handle) pairs mvs_gru_prepare has run for in this process
+_GRU_PREPARED = {}             # (device index, stream handle) -> number of live users (DepthPlan objects) of the set mvs_gru_prepare made
+MVS_E_NO_SLOT = -5
 
 
 def gru_prepare():
     """mvs_gru_prepare for torch's CURRENT stream of the current device, once per (device, stream): the only call of the
     recurrent path that creates streams / events and synchronises (include/mvsnet_hip.h).  Skipped under hipGraph capture:
-    a captured sweep runs on the capture stream alone and needs no set."""
+    a captured sweep runs on the capture stream alone and needs no set.  Returns the key to hand to gru_unref() (or None).
+    When all 16 sets of the process are taken (MVS_E_NO_SLOT) it warns once and carries on: the sweep runs without a set."""
     key = (torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
-    if key in _GRU_PREPARED or torch.cuda.is_current_stream_capturing():
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    if key not in _GRU_PREPARED:
+        rc = load().mvs_gru_prepare(stream_ptr())
+        if rc == MVS_E_NO_SLOT:
+            import warnings
+            warnings.warn("mvsnet_amd: all 16 stream sets of mvs_gru_prepare are in use; the recurrent sweep of this stream runs on the "
+                          "stream alone (drop DepthPlan objects of streams you no longer use, or call _lib.gru_release())", RuntimeWarning)
+            return None
+        check(rc, "mvs_gru_prepare")
+        _GRU_PREPARED[key] = 0
+    _GRU_PREPARED[key] += 1
+    return key
+
+
+def gru_unref(key):
+    """One user of the (device, stream) set less; the last one releases it (mvs_gru_release waits for the side streams).  Called by
+    DepthPlan.close() / its finalizer: a set must not outlive the stream it was calibrated for (a later stream may receive the
+    same handle on another hardware queue)."""
+    if key is None or key not in _GRU_PREPARED:
         return
-    check(load().mvs_gru_prepare(stream_ptr()), "mvs_gru_prepare")
-    _GRU_PREPARED.add(key)
+    _GRU_PREPARED[key] -= 1
+    if _GRU_PREPARED[key] <= 0:
+        del _GRU_PREPARED[key]
+        try:
+            with torch.cuda.device(key[0]):
+                load().mvs_gru_release(C.c_void_p(key[1]))
+        except Exception:       # interpreter shutdown: the library or torch may be gone
+            pass
 
 
 def gru_release():
-    """mvs_gru_release for torch's current stream (before the stream object is dropped)."""
+    """mvs_gru_release for torch's current stream, whatever its user count (before the stream object is dropped)."""
     key = (torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
     if key in _GRU_PREPARED:
-        _GRU_PREPARED.discard(key)
+        del _GRU_PREPARED[key]
         check(load().mvs_gru_release(stream_ptr()), "mvs_gru_release")
 
 

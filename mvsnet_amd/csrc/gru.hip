@@ -775,7 +775,7 @@ int gru_prepare(hipStream_t caller) {
         if (g_slots[i].state == 1 && g_slots[i].dev == dev && g_slots[i].caller == caller) return 0;
         if (g_slots[i].state == 0 && free_slot < 0) free_slot = i;
     }
-    if (free_slot < 0) return MVS_E_WORKSPACE;             // GRU_SLOTS caller streams hold a set: release one first
+    if (free_slot < 0) return MVS_E_NO_SLOT;               // GRU_SLOTS caller streams hold a set: release one first
     GruSlot& sl = g_slots[free_slot];
     sl = GruSlot{};
     sl.dev = dev; sl.caller = caller;
@@ -904,6 +904,10 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
     const int form = g_gru_form.load();
     // The fused sweep (gru_fused.hip): the reference's filter counts (model.py:641-660, 'normal' mode) at 32 feature channels --
     // all three cells, prob_conv and the winner-take-all update in two launches per plane on the caller's stream alone.
+    // Formulation 0 takes it whenever the shape fits -- also for ONE eager view on a stream that has a stream set, where the round-4
+    // wavefront with the hoisted x-part (formulation 1) is still 3-4 % faster (c3, same box: 21.8 against 22.6 ms): a batch of views
+    // must give the single view's bits, and from two views per sweep on, and under hipGraph capture (23.4 against 37 ms), the fused
+    // sweep is the faster or equal one (profiles/r05_gru_ab_forms.txt).
     const bool fused = mfma1 && f2 == 4 && f3 == 2 && (form == 0 || form == 3);
     if (fused) {
         GruFusedWs fw;

@@ -39,6 +39,7 @@ extern "C" const char* mvs_error_string(int code) {
     if (code == MVS_E_BADARG) return "mvsnet_hip: bad argument (null pointer or non-positive size)";
     if (code == MVS_E_SHAPE) return "mvsnet_hip: shape not supported by this kernel";
     if (code == MVS_E_WORKSPACE) return "mvsnet_hip: workspace too small";
+    if (code == MVS_E_NO_SLOT) return "mvsnet_hip: all 16 stream sets of mvs_gru_prepare are in use (mvs_gru_release frees one); the sweep still runs, on the caller's stream alone";
     if (code == MVS_E_NOT_PREPARED) return "mvsnet_hip: no side streams for this caller stream (call mvs_gru_prepare outside hipGraph capture first)";
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "mvsnet_hip: unknown error";

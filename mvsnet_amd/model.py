@@ -10,6 +10,7 @@ streams and the 2D feature extractor.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -335,9 +336,30 @@ class DepthPlan:
             f1, f2, f3 = weights.gru.filters
             nbytes = lib.mvs_gru_workspace_bytes(height, width, channels, f1, f2, f3)
             self.workspace = torch.empty(nbytes * self.views, device=dev, dtype=torch.uint8)
-            _lib.gru_prepare()     # side streams + calibration for the current stream: the one call that synchronises
+            # side streams + calibration for the current stream: the one call that synchronises.  The set is shared by the plans of a
+            # stream and released with the last of them (close() or garbage collection).
+            self._gru_keys = [_lib.gru_prepare()]
+            self._finalizer = weakref.finalize(self, DepthPlan._drop_sets, self._gru_keys)
         else:
             raise NotImplementedError(regularization)      # predictlib.py:97-98
+
+    @staticmethod
+    def _drop_sets(keys):
+        while keys:
+            _lib.gru_unref(keys.pop())
+
+    def close(self):
+        """Gives the stream sets of the recurrent sweep back (mvs_gru_release when this was their last user)."""
+        if getattr(self, "_finalizer", None) is not None:
+            self._finalizer()
+
+    def _gru_prepare_here(self):
+        """A plan may run on another stream than it was built on: that stream gets (a share of) a set too."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        key = (torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
+        if key not in [k for k in self._gru_keys if k is not None]:
+            self._gru_keys.append(_lib.gru_prepare())
 
     def set_cameras(self, cams, depth_start, depth_interval, depth_end, inverse_depth, view=0):
         lib = _lib.load()
@@ -375,7 +397,7 @@ class DepthPlan:
 
     def run_gru(self, features, depth_values):
         lib = _lib.load()
-        _lib.gru_prepare()         # no-op for a stream already prepared (a plan may run on another stream than it was built on)
+        self._gru_prepare_here()
         g = self.weights.gru
         f1, f2, f3 = g.filters
         dv = (C.c_float * self.D)(*[float(v) for v in depth_values])
@@ -391,7 +413,7 @@ class DepthPlan:
         (mvs_gru_wta_batch_f32): features[v] (N,H,W,C), depth_values[v] (D,); cameras set per view with
         set_cameras(..., view=v).  Returns (depth (n,H,W), prob (n,H,W))."""
         lib = _lib.load()
-        _lib.gru_prepare()
+        self._gru_prepare_here()
         g = self.weights.gru
         f1, f2, f3 = g.filters
         n = len(features)

@@ -139,12 +139,14 @@ def test_plan_runs_under_hipgraph_capture(lib_built):
 
 
 def test_gru_sweep_prepare_capture_and_release(lib_built):
-    """include/mvsnet_hip.h (round 4): mvs_gru_prepare(stream) is the ONE call of the recurrent path that creates streams /
-    events and synchronises; mvs_gru_wta*_f32 never does.  A sweep captured into a hipGraph (it goes to the capture stream
-    alone: the four-stream wavefront cannot be captured on ROCm 7.2) replays to the eager wavefront's depth map; a stream
-    without a set runs the one-stream sweep eagerly with the same winning planes; prepare is refused under capture
-    (MVS_E_NOT_PREPARED = -4); release / prepare recycle the slot."""
+    """include/mvsnet_hip.h: mvs_gru_prepare(stream) is the ONE call of the recurrent path that creates streams / events and
+    synchronises; mvs_gru_wta*_f32 never does.  Round 5: the default sweep is the fused two-launches-per-plane pipeline on the
+    caller's stream alone (csrc/gru_fused.hip) -- it needs no set, captures into a hipGraph as it is and replays to the eager
+    result bit for bit; the round-4 four-stream wavefront (formulation 1, needs a set) gives the same planes up to near-ties.  prepare is
+    refused under capture (MVS_E_NOT_PREPARED = -4); release / prepare recycle the slot; the 17th set of a process is
+    MVS_E_NO_SLOT = -5, a warning in Python, and the sweep carries on; DepthPlan.close() gives a set back."""
     import ctypes as C
+    import warnings
     from mvsnet_amd import _lib
     from mvsnet_amd.model import DepthPlan, MVSNetWeights, wta_depth_values
     lib = _lib.load()
@@ -164,14 +166,24 @@ def test_gru_sweep_prepare_capture_and_release(lib_built):
         assert lib.mvs_gru_stream_layout(_lib.stream_ptr(), C.byref(pc), us) == 0 and -1 <= pc.value <= 3 and min(us) > 0
         assert lib.mvs_gru_prepare(_lib.stream_ptr()) == 0                                   # idempotent
         plan.set_cameras(cams, base.depth_start, base.depth_interval, end, False)
-        d, p = plan.run_gru(feats, dv)
+        try:
+            _lib.check(lib.mvs_gru_set_formulation(1), "mvs_gru_set_formulation")
+            d, p = plan.run_gru(feats, dv)                                                   # the round-4 wavefront over the set's streams
+            torch.cuda.synchronize()
+            wave_d, wave_p = d.clone(), p.clone()
+        finally:
+            _lib.check(lib.mvs_gru_set_formulation(0), "mvs_gru_set_formulation")
+        d, p = plan.run_gru(feats, dv)                                                       # the default: the fused sweep
         torch.cuda.synchronize()
         eager_d, eager_p = d.clone(), p.clone()
         assert len(torch.unique(eager_d)) > 4
+        same = wave_d == eager_d
+        assert float((~same).float().mean()) <= 2e-4
+        assert float(((wave_p - eager_p).abs() / eager_p)[same].max()) < 2e-3
         g = torch.cuda.CUDAGraph()
         rcs = []
         with torch.cuda.graph(g, stream=s):
-            plan.run_gru(feats, dv)
+            plan.run_gru(feats, dv)                                                          # under capture: the fused sweep
             rcs.append(lib.mvs_gru_prepare(_lib.stream_ptr()))                               # prepare synchronises: refused under capture
             rcs.append(lib.mvs_gru_release(C.c_void_p(12345)))                               # no set for this handle
         assert rcs == [-4, -1]
@@ -180,9 +192,8 @@ def test_gru_sweep_prepare_capture_and_release(lib_built):
         torch.cuda.synchronize()
         g.replay()
         torch.cuda.synchronize()
-        assert torch.equal(plan.depth, eager_d)
-        assert float(((plan.prob - eager_p).abs() / eager_p).max()) < 1e-6
-    # a stream nobody prepared: the one-stream sweep, eagerly and captured alike
+        assert torch.equal(plan.depth, eager_d) and torch.equal(plan.prob, eager_p)
+    # a stream nobody prepared: the fused sweep, the same bits
     gw = weights.gru
     f1, f2, f3 = gw.filters
     s2 = torch.cuda.Stream()
@@ -197,8 +208,7 @@ def test_gru_sweep_prepare_capture_and_release(lib_built):
         plan.depth.zero_()
         assert call() == 0
         torch.cuda.synchronize()
-        assert torch.equal(plan.depth, eager_d)                                               # same planes (depth identical)
-        assert float(((plan.prob - eager_p).abs() / eager_p).max()) < 1e-6
+        assert torch.equal(plan.depth, eager_d) and torch.equal(plan.prob, eager_p)
     # slots are recycled
     with torch.cuda.stream(s):
         _lib.gru_release()
@@ -209,6 +219,29 @@ def test_gru_sweep_prepare_capture_and_release(lib_built):
         torch.cuda.synchronize()
         assert torch.equal(d3, eager_d)
     assert _lib.load().mvs_error_string(-4).decode().startswith("mvsnet_hip: no side streams")
+    # the 17th stream set: its own error code, a warning in Python, and the plan still works
+    streams, plans = [torch.cuda.Stream() for _ in range(17)], []
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for st_ in streams:
+            with torch.cuda.stream(st_):
+                plans.append(DepthPlan(base.view_num, D, Hh, Ww, base.channels, weights, "GRU", DEV))
+    assert any("stream sets" in str(w_.message) for w_ in rec)
+    assert lib.mvs_error_string(-5).decode().startswith("mvsnet_hip: all 16 stream sets")
+    with torch.cuda.stream(streams[-1]):
+        plans[-1].set_cameras(cams, base.depth_start, base.depth_interval, end, False)
+        d17, p17 = plans[-1].run_gru(feats, dv)
+        torch.cuda.synchronize()
+        assert torch.equal(d17, eager_d) and torch.equal(p17, eager_p)                       # no set: the fused sweep
+    n_before = len(_lib._GRU_PREPARED)
+    plans[0].close()                                                                          # gives its set back ...
+    assert len(_lib._GRU_PREPARED) == n_before - 1
+    with torch.cuda.stream(streams[-1]):
+        assert _lib.gru_prepare() is not None                                                 # ... and the 17th stream gets it
+        _lib.gru_release()
+    for pl in plans:
+        pl.close()
+    plan.close()
 
 
 def test_lite_mode_from_images_runs_padded_regulariser_and_torch_towers():
