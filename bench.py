@@ -106,7 +106,24 @@ def pmc_traffic():
     return out
 
 
-def cpu_baseline(workload, rp, budget_s=20.0, gpu_depth=None):
+def gru_pmc_per_plane():
+    """Matrix-pipe busy and vector-active microseconds per plane of the 4-view recurrent sweep from the committed SQ counter summary
+    (profiles/rNN_gru_pmc_B4.txt, tools/gru_pmc.sh: its TOTAL line), sourced the way roofline.traffic is; {} without a file."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gru_pmc_B4.txt")))
+    if not files:
+        return {}
+    m = None
+    for line in open(files[-1]):
+        m = re.search(r"TOTAL per plane: active_any ([\d.]+) us, valu ([\d.]+) us, mfma_busy ([\d.]+) us", line) or m
+    if not m:
+        return {}
+    return {"mfma_busy_us": float(m.group(3)), "valu_active_us": float(m.group(2)), "active_any_us": float(m.group(1)),
+            "source": os.path.basename(files[-1]) + " (SQ_VALU_MFMA_BUSY_CYCLES / SQ_ACTIVE_INST_VALU per SIMD at 2.4 GHz, summed over the sweep's kernels)"}
+
+
+def cpu_baseline(workload, rp, budget_s=20.0, gpu_depth=None, max_maps=8):
     """CPU restatement (oracle/torch_restatement.py, fp32, all host cores) timed on a bounded
     sample of the same workload: whole depth maps until ~budget_s have elapsed (at least one)."""
     from oracle import torch_restatement as TR       # measurement only; never on the product path
@@ -129,7 +146,7 @@ def cpu_baseline(workload, rp, budget_s=20.0, gpu_depth=None):
         cpu_depth, _ = TR.inference_mem_from_features(w.features, w.cams, w.depth_num, w.depth_start, w.depth_interval, rp)
         n_done += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n_done >= 8:
+        if el > budget_s or n_done >= max_maps:
             break
     extra = {}
     if gpu_depth is not None:      # the metric's "abs-rel vs ref" at full size, against the CPU restatement
@@ -137,6 +154,14 @@ def cpu_baseline(workload, rp, budget_s=20.0, gpu_depth=None):
     return {**extra, "value": n_done / el, "unit": "depth maps/s", "cores": cores, "kind": "port",
             "sample": "%d whole depth map(s) of workload %s (features->depth, torch-CPU fp32 restatement "
                       "of the reference; TensorFlow reference not runnable offline) in %.1f s" % (n_done, w.name, el)}
+
+
+def rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        return None
 
 
 def timed_block(step, steps):
@@ -223,7 +248,49 @@ def extra_config_gru(name, dev, steps=5, views=1):
     return out
 
 
-def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN", procs_per_gpu=3):
+def gru_formulations(dev, name="c3", steps=3):
+    """The same sweep (one reference view) under each formulation of the recurrent path: the fused two-launches-per-plane pipeline
+    (the default), the round-4 wavefront over a stream set with cell 1's x-part hoisted, and the fused sweep replayed from a hipGraph."""
+    from mvsnet_amd import _lib, synthetic as S
+    from mvsnet_amd.model import DepthPlan, MVSNetWeights, wta_depth_values
+    w = S.make_workload(name)
+    gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=dev)
+    cams = torch.as_tensor(w.cams).to(dev)
+    feats = torch.as_tensor(w.features).to(dev)
+    dv = wta_depth_values(w.depth_num, w.depth_start, w.depth_end, False)
+    out = {}
+    lib = _lib.load()
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        plan = DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "GRU", dev)
+        plan.set_cameras(cams, w.depth_start, w.depth_interval, w.depth_end, False)
+
+        def timed(fn):
+            fn(); st.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            st.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+        try:
+            for form, tag in ((3, "fused (default)"), (1, "wavefront, hoisted x-part (round 4)")):
+                _lib.check(lib.mvs_gru_set_formulation(form), "mvs_gru_set_formulation")
+                out[tag] = timed(lambda: plan.run_gru(feats, dv))
+        finally:
+            _lib.check(lib.mvs_gru_set_formulation(0), "mvs_gru_set_formulation")
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                plan.run_gru(feats, dv)
+            out["fused, replayed from a hipGraph"] = timed(g.replay)
+        except Exception as e:                             # informative
+            out["fused, replayed from a hipGraph"] = repr(e)[:200]
+    plan.close()
+    return out
+
+
+def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN", procs_per_gpu=3, width=640, height=512):
     """End-to-end throughput of the reference's own loop (mvsnet/inference.py:105-119: load a cluster -> run the graph -> write
     the outputs, 'Depth inference ... sec/step') on a synthetic on-disk session of the metric's shape: `n_images` JPEGs of
     640x512 with cameras and a covisibility file (mvsnet_amd.synthetic.write_session), view_num 5, max_d 192 -> 160x128 feature
@@ -238,8 +305,8 @@ def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN", procs_
     from mvsnet_amd.predictlib import InferenceConfig
     root = tempfile.mkdtemp(prefix="mvs_session_")
     try:
-        S.write_session(root, n_images=n_images, height=512, width=640, view_num=5, depth_num=192)
-        cfg = InferenceConfig(input_dir=root, view_num=5, max_d=192, width=640, height=512, sample_scale=0.25,
+        S.write_session(root, n_images=n_images, height=height, width=width, view_num=5, depth_num=192)
+        cfg = InferenceConfig(input_dir=root, view_num=5, max_d=192, width=width, height=height, sample_scale=0.25,
                               regularization=regularization)
         weights = build_weights(cfg, dev)
         out = {}
@@ -247,7 +314,7 @@ def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN", procs_
             tm = {}
             cfg.output_dir = os.path.join(root, "out%d" % attempt)
             n = compute_depth_maps(root, cfg, weights, dev, timings=tm)
-            out = {"session": "%d JPEGs 640x512 + cameras, N=5, D=192, %s; %d reference views, second pass" % (n_images, regularization, n),
+            out = {"session": "%d JPEGs %dx%d + cameras, N=5, D=192, %s; %d reference views, second pass" % (n_images, width, height, regularization, n),
                    "session_depth_maps_per_s": n / tm["wall"], "sec_per_step": tm["wall"] / max(n, 1),
                    "fraction_of_kernel_only_rate": (n / tm["wall"]) / kernel_rate if kernel_rate else None,
                    "files_written": len(os.listdir(cfg.output_dir)),
@@ -377,7 +444,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("MVS_BENCH_STREAMS", "1")),
-                    help="independent depth maps in flight per GPU (one plan + HIP stream each)")
+                    help="independent depth maps in flight per GPU (one plan + HIP stream each).  Keep 1: since the round-4 schedules "
+                         "fill every CU with one depth map, two in flight get in each other's way (877 against 929 depth maps/s)")
     ap.add_argument("--regularization", default="3DCNN", choices=["3DCNN", "GRU"],
                     help="GRU = R-MVSNet recurrent sweep (config 3); reported as an extra, not the metric")
     ap.add_argument("--gru-views", type=int, default=1, help="reference views per recurrent sweep (--regularization GRU)")
@@ -509,7 +577,11 @@ def main():
         rank_rates = [args.steps / float(e.item()) for e in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    rank_devices = [{"rank": rank, "device_index": dev_index, "device": torch.cuda.get_device_name(dev_index)}]
+    props = torch.cuda.get_device_properties(dev_index)
+    pci = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xff, getattr(props, "pci_device_id", 0) & 0xff) \
+        if hasattr(props, "pci_bus_id") else None
+    rank_devices = [{"rank": rank, "device_index": dev_index, "device": torch.cuda.get_device_name(dev_index), "pci_bus_id": pci,
+                     "uuid": str(getattr(props, "uuid", "")) or None, "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES")}]
     if dist:
         every_dev = [None] * world
         dist.all_gather_object(every_dev, rank_devices[0])
@@ -638,6 +710,7 @@ def main():
             "depth_checksum": float(np.float64(depth_np).sum()),
             "per_rank_depth_maps_per_s": {"min": min(rank_rates), "max": max(rank_rates), "ranks": rank_rates},
             "ranks": {"world_size": dist.get_world_size() if dist else 1, "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if dist else None,
+                      "rccl_version": rccl_version(), "distinct_pci_bus_ids": len({d_.get("pci_bus_id") for d_ in rank_devices}),
                       "devices": rank_devices},
         }
         chain = ["3dconv2_0", "3dconv3_0", "3dconv3_1", "3dconv4_0", "3dconv5_0"]
@@ -670,24 +743,6 @@ def main():
             torch.cuda.synchronize()
             out["images_to_depth_maps_per_s"] = args.steps / (time.perf_counter() - t1)
             out["extractor"] = args.extractor
-        if world == 1 and n_streams == 1 and not args.no_extra:
-            # informative only (never `value`): the same work with two depth maps in flight per GPU --
-            # the small, latency-bound layers of one map overlap the large kernels of the other
-            p2 = [plan, DepthPlan(w.view_num, w.depth_num, w.height, w.width, w.channels, weights, "3DCNN", dev)]
-            s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
-
-            def step2(i):
-                with torch.cuda.stream(s2[i % 2]):
-                    p2[i % 2].run_depth(feats, cams, w.depth_start, w.depth_interval, end, False)
-            n2 = max(40, 2 * args.steps)          # the overlap needs a few steps to build up: 20 steps read ~8 % low
-            for i in range(8):
-                step2(i)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for i in range(n2):
-                step2(i)
-            torch.cuda.synchronize()
-            out["depth_maps_per_s_two_streams"] = n2 / (time.perf_counter() - t2)
         if world == 1 and n_streams == 1 and not args.no_extra and args.workload == "M" and args.network_mode == "normal":
             # BASELINE.json configs[1] and configs[2] on this GPU, each with its distance from the committed fixture
             t_x = [time.perf_counter()]
@@ -697,14 +752,22 @@ def main():
                 print("bench extra %-28s %6.1f s" % (tag, t_x[-1] - t_x[-2]), file=sys.stderr, flush=True)
             out["config_c2"] = extra_config_3dcnn("c2", dev); lap("config_c2")
             out["config_c3_gru"] = extra_config_gru("c3", dev, 5, 1); lap("config_c3_gru")
+            out["config_c3_gru"]["formulations_ms_per_depth_map"] = gru_formulations(dev); lap("c3 formulations")
             out["config_c3_gru"]["fresh_process"] = gru_config_in_child("c3"); lap("c3 fresh process")
             out["config_c3_gru_4_views"] = extra_config_gru("c3", dev, 3, 4); lap("config_c3_gru_4_views")
+            out["config_c3_gru_4_views"]["per_plane_counters"] = gru_pmc_per_plane()
             out["config_c3_gru_from_images"] = gru_production_order(dev); lap("config_c3_gru_from_images")
             out["session"] = session_record(dev, out["value"]); lap("session")
+            # configuration 2's image size (1152 x 864 JPEGs: ~3x the host decode work per image; 288 x 216 feature maps)
+            out["session_config2_images"] = session_record(dev, out["config_c2"].get("depth_maps_per_s"), n_images=24, procs_per_gpu=0,
+                                                           width=1152, height=864); lap("session_config2_images")
             out["training"] = training_record(dev, configs=(("3dcnn_d192", "3DCNN", 192), ("3dcnn_d128_config5", "3DCNN", 128), ("gru_d192", "GRU", 192))
                                               if args.training_all else (("3dcnn_d128_config5", "3DCNN", 128),)); lap("training")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, rp, args.cpu_budget, depth_np)
+            if args.workload == "M":       # configs[0]: the configuration BASELINE.json defines AS the CPU run (N=3, D=32, 160x128 features)
+                w1 = S.make_workload("c1", args.network_mode, seed=0)
+                out["cpu_baseline_c1"] = cpu_baseline(w1, rp, 5.0, None, max_maps=4)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

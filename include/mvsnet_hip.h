@@ -294,12 +294,14 @@ int mvs_wta_finish_f32(const float* max_prob, const float* exp_sum, int H, int W
  *   filters (f1,f2,f3): ConvGRU filter counts (16,4,2 for 'normal')
  * The sweep is a wavefront over (plane, cell) on library-owned side streams forked from / joined to `stream`: the set
  * mvs_gru_prepare(stream) created for this caller stream.  The sweep itself creates nothing and never synchronises:
- *   - prepared stream: wavefront on four streams;
- *   - stream without a set: the same sweep on `stream` alone (same winning planes, ~1.7x the time at 400 x 300), one note on
- *     stderr per process;
- *   - `stream` under hipGraph capture: always the one-stream form (prepared or not) -- capturing the cross-stream wavefront
- *     crashes hipStreamEndCapture of ROCm 7.2 on the host (profiles/r04_gru_wavefront_capture_segfault.log); the captured
- *     sweep replays to the eager sweep's depth map (tests/test_gpu_pipeline.py);
+ *   - default formulation at the reference's shape (mvs_gru_set_formulation 0 / 3): the fused sweep, two launches per plane on
+ *     `stream` alone, with or without a set, eagerly or under hipGraph capture -- the same bits every time;
+ *   - wavefront formulations (1 / 2) on a prepared stream: four streams; on a stream without a set: the same sweep on `stream`
+ *     alone (same winning planes, ~1.7x the time at 400 x 300), one note on stderr per process;
+ *   - wavefront formulations under hipGraph capture: always the one-stream form -- hip::Stream::EndCapture of the HIP runtime the
+ *     PyTorch wheel bundles (7.0.70002) recurses without bound when captured streams wait on each other in both directions (root
+ *     cause, native backtrace and a stand-alone reproducer: profiles/r05_capture_wavefront_root_cause.txt,
+ *     tools/capture_wavefront_repro.hip; ROCm 7.2's own runtime does not have the defect);
  *   - every exit after the fork, error returns included, first makes `stream` wait for the side streams.
  * The workspace holds a batch of 16 cost slices, two batches of the hoisted x-part of cell 1 and 16-plane state rings:
  * ~1.0 GB at 400 x 300, C = 32 (mvs_gru_workspace_bytes).

@@ -1011,13 +1011,17 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
     const int ring = RG * PG;
     const bool wavefront = route[0] && route[1] && route[2] && depth_num > 2 * PG &&
                            getenv("MVS_GRU_ONE_STREAM") == nullptr;      // test hook (parity of the one-stream sweep), read per sweep
-    // Under hipGraph capture the sweep goes to the caller's stream alone: capturing the four-stream wavefront (the caller's stream
-    // waits on side-stream events in the middle of the capture, events are re-recorded per group) makes hipStreamEndCapture of
-    // ROCm 7.2 crash on the host (profiles/r04_gru_wavefront_capture_segfault.log).  Same results (depth identical), ~1.7x the
-    // eager wavefront's time when replayed.
+    // Under hipGraph capture the WAVEFRONT formulations go to the caller's stream alone.  Root cause of the round-4 host crash
+    // (profiles/r05_capture_wavefront_root_cause.txt): hip::Stream::EndCapture() of the HIP runtime the PyTorch wheel bundles
+    // (libamdhip64 7.0.70002, the runtime every Python process of this library runs on) recurses without bound once two captured
+    // streams wait on each other's events in BOTH directions -- which the ring's backward waits (`read`) do from the fifth group on;
+    // tools/capture_wavefront_repro.hip reproduces it with empty kernels (stack overflow from 40 planes on with that runtime, clean
+    // with /opt/rocm 7.2's; stream flags, priorities, event re-use and capture mode do not matter).  Nothing in this event graph is
+    // illegal.  The default formulation (gru_fused.hip) has no cross-stream pattern and is captured at full speed.
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-    GruStreams* gs = (wavefront && !capturing) ? gru_find(st) : nullptr;
+    static const bool capture_wavefront = getenv("MVS_GRU_CAPTURE_WAVEFRONT") != nullptr;      // diagnostic hook (tools/capture_wavefront_lib.py)
+    GruStreams* gs = (wavefront && (!capturing || capture_wavefront)) ? gru_find(st) : nullptr;
     if (wavefront && !capturing && !gs) {
         // no side streams for this caller stream: this entry point creates none (mvs_gru_prepare does) -- run the sweep on the
         // caller's stream alone (same results, ~1.7x the time at 400 x 300) and say so once.

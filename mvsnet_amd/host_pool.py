@@ -92,9 +92,12 @@ def _worker_init(parent_pid):
     threading.Thread(target=watch, daemon=True).start()
 
 
-def _warm():
+def _warm(hold=0.0):
     import PIL.Image            # noqa: F401  (the first task should not pay the imports)
     from . import mvs_data_generation, predictlib, preprocess   # noqa: F401
+    if hold:
+        import time
+        time.sleep(hold)        # keeps this worker busy so that the executor has to start another one for the next task
     return os.getpid()
 
 
@@ -111,12 +114,16 @@ class HostPool:
         self.shm = None
         self.free = []
         self.cv = threading.Condition()
-        # All children start at the first submit (below) and take two things from that moment:
+        # The children take two things from the moment they are started:
         #  * the environment -- they are given NO GPU (a worker never needs one);
         #  * the description of the parent's __main__ module, which the spawn method would re-import in every child (running an
         #    unguarded main script again: a second copy of the application, GPU work included; and failing outright when the
         #    parent runs from stdin or an embedded interpreter).  The workers only ever call functions of this module, so they
         #    are started with an EMPTY __main__: nothing of the application is imported there.
+        # ProcessPoolExecutor starts its workers ON DEMAND (Python 3.9+: one per submit while no worker is idle), so the window in
+        # which the parent's environment / __main__ are swapped stays open until all `workers` processes exist: every warm-up task
+        # holds its worker for a moment, and the loop runs until the executor's own process table is full (a fast
+        # first task used to let later workers start outside the window, with the GPU visible and the real __main__).
         import sys
         import types
         hide = {"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "", "MVS_HOST_WORKER": "1"}
@@ -125,7 +132,15 @@ class HostPool:
         real_main = sys.modules.get("__main__")
         sys.modules["__main__"] = types.ModuleType("__main__")
         try:
-            self.pids = sorted(set(f.result() for f in [self.ex.submit(_warm) for _ in range(4 * self.workers)]))
+            futs = []
+            for _ in range(8):                               # normally one round
+                futs += [self.ex.submit(_warm, 0.2) for _ in range(self.workers)]
+                for f in futs:
+                    f.result()
+                if len(getattr(self.ex, "_processes", {}) or {}) >= self.workers:
+                    break
+            procs = getattr(self.ex, "_processes", None)
+            self.pids = sorted(procs.keys()) if procs else sorted(set(f.result() for f in futs))
         finally:
             if real_main is not None:
                 sys.modules["__main__"] = real_main
@@ -159,11 +174,10 @@ class HostPool:
                 self.cv.wait()
             if self.shm is not None:
                 self.shm.close(); self.shm.unlink(); self.shm = None
-            try:
-                vfs = os.statvfs("/dev/shm")
-                room = vfs.f_bavail * vfs.f_frsize // 4
-            except OSError:
-                room = 0
+            # a quarter of what /dev/shm has free NOW -- per NODE, not per process: the ranks of one node start together and
+            # each would otherwise see (and reserve a quarter of) the same free space, eight ranks twice what exists; the first
+            # page touched past the tmpfs limit is a SIGBUS
+            room = shm_room()
             slots = min(self.max_slots, room // nbytes)
             if slots < 4:
                 self.slot_bytes = -1
@@ -229,6 +243,18 @@ class HostPool:
 
 _POOL = None
 _POOL_LOCK = threading.Lock()
+
+
+def shm_room(statvfs=os.statvfs):
+    """Bytes of /dev/shm this process may reserve for its image slots: a quarter of the free space, shared between the
+    LOCAL_WORLD_SIZE ranks of the node."""
+    try:
+        vfs = statvfs("/dev/shm")
+        room = vfs.f_bavail * vfs.f_frsize // 4
+    except OSError:
+        return 0
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    return room // max(1, local)
 
 
 def default_workers():

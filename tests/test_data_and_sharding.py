@@ -372,3 +372,41 @@ def _worker_probe():
     import sys
     return {"hip": os.environ.get("HIP_VISIBLE_DEVICES"), "worker": os.environ.get("MVS_HOST_WORKER"),
             "main_file": getattr(sys.modules["__main__"], "__file__", None), "torch": "torch" in sys.modules}
+
+
+def test_host_pool_shares_dev_shm_between_the_ranks_of_a_node(monkeypatch):
+    """the image-slot ring of host_pool takes a quarter of what /dev/shm has free -- per NODE: with
+    LOCAL_WORLD_SIZE ranks starting together each may reserve 1/LOCAL_WORLD_SIZE of that quarter, so eight ranks against a
+    64 MB tmpfs ask for 16 MB in total, not 128."""
+    from mvsnet_amd import host_pool
+
+    class FakeVfs:
+        f_bavail, f_frsize = 64 * 256, 4096                   # 64 MB free
+    fake = lambda path: FakeVfs()
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert host_pool.shm_room(fake) == 16 * 2 ** 20
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    rooms = [host_pool.shm_room(fake) for _ in range(8)]      # eight pools, one per rank
+    assert all(r == 2 * 2 ** 20 for r in rooms) and sum(rooms) <= 64 * 2 ** 20 // 4
+    # a 640 x 512 session needs 0.94 MB per slot: 2 slots < the pool's minimum of 4 -> it goes back to the pipe instead of SIGBUS
+    assert rooms[0] // (640 * 512 * 3) < 4
+
+
+def test_host_pool_starts_every_worker_without_a_gpu_and_with_an_empty_main():
+    """all `workers` processes must be started inside the window in which the parent hides the GPU and its __main__
+    (ProcessPoolExecutor starts workers on demand); the pool's pid list is the executor's own process table."""
+    from mvsnet_amd import host_pool
+    pool = host_pool.HostPool(3, slots=8)
+    try:
+        assert len(pool.pids) == 3 == len(pool.ex._processes)
+        envs = [pool.ex.submit(_worker_env).result() for _ in range(12)]
+        assert {e[0] for e in envs} <= set(pool.pids)
+        assert all(e[1] == "" and e[2] == "1" and e[3] is False for e in envs)       # no GPU, marked as a worker, no application __main__
+    finally:
+        pool.ex.shutdown(wait=True)
+
+
+def _worker_env():
+    import sys
+    main = sys.modules.get("__main__")
+    return (os.getpid(), os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("MVS_HOST_WORKER"), hasattr(main, "test_host_pool_starts_every_worker_without_a_gpu_and_with_an_empty_main"))

@@ -395,6 +395,9 @@ def test_bench_with_four_ranks_on_one_card_and_a_failing_rank(lib_built):
     assert rec["n_gpus"] == 4 and rec["ranks"]["world_size"] == 4 and rec["ranks"]["backend"] == "gloo"
     assert [d["rank"] for d in rec["ranks"]["devices"]] == list(range(4))
     assert len(rec["per_rank_depth_maps_per_s"]["ranks"]) == 4 and rec["scaling"] == "weak"
+    # what a SCALE record needs to prove N distinct GPUs: per rank the device's PCI bus id, per job the RCCL version
+    assert all(d.get("pci_bus_id") for d in rec["ranks"]["devices"]) and rec["ranks"]["distinct_pci_bus_ids"] == 1      # four ranks folded onto ONE card here
+    assert "rccl_version" in rec["ranks"] and 0 < rec["per_rank_depth_maps_per_s"]["min"] <= rec["per_rank_depth_maps_per_s"]["max"]
     assert abs(rec["value"] - 4 * rec["steps"] / (rec["ms_per_step"] * 1e-3 * rec["steps"])) < 1e-6 * rec["value"]   # whole job / slowest rank
     bad = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, MVS_BENCH_FAIL_RANK="2"), cwd=root)
     assert bad.returncode != 0
