@@ -245,11 +245,11 @@ _POOL = None
 _POOL_LOCK = threading.Lock()
 
 
-def shm_room(statvfs=os.statvfs):
+def shm_room(statvfs=None):
     """Bytes of /dev/shm this process may reserve for its image slots: a quarter of the free space, shared between the
     LOCAL_WORLD_SIZE ranks of the node."""
     try:
-        vfs = statvfs("/dev/shm")
+        vfs = (statvfs or os.statvfs)("/dev/shm")
         room = vfs.f_bavail * vfs.f_frsize // 4
     except OSError:
         return 0
