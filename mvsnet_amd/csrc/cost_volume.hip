@@ -65,12 +65,16 @@ cost_volume_kernel(const float* __restrict__ ref, const float* __restrict__ src,
 // neighbourhood is kept in registers and re-fetched only when floor(sx) or floor(sy) changes:
 // tap traffic to L1/L2 drops from 16 x 16 B per voxel-lane to a few, the kernel becomes bound by
 // the coalesced HBM write of the volume.  Zero fill per tap exactly as warp_sample<0>.
-template <int NSRC, int Q>       // Q float4 per lane: 4*Q channels per lane, C/(4*Q) lanes per pixel
+// VN = 2 * variant + negate is a template parameter: as kernel arguments both forms of the variance and both signs were
+// computed for every voxel and selected (12 packed + 8 select instructions per plane where 6 packed do, in a kernel that is
+// bound by vector issue) -- *r5*.
+template <int NSRC, int Q, int VN>       // Q float4 per lane: 4*Q channels per lane, C/(4*Q) lanes per pixel
 __global__ void __launch_bounds__(256)
 cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict__ src,
                          const float* __restrict__ transforms, int depth_total, int d_begin,
-                         int d_count, int planes_per_block, int H, int W, int C, int variant,
-                         int negate, float* __restrict__ cost) {
+                         int d_count, int planes_per_block, int H, int W, int C, float* __restrict__ cost) {
+    constexpr int variant = VN >> 1;
+    constexpr bool negate = (VN & 1) != 0;
     const int lg = C / (4 * Q);                           // lanes per pixel: power of two (host-checked)
     const long long total = (long long)H * W * lg;
     long long idx = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
@@ -91,13 +95,20 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
         rr[2 * k] = (f32x2){r.x, r.y}; rr[2 * k + 1] = (f32x2){r.z, r.w};
         rq[2 * k] = rr[2 * k] * rr[2 * k]; rq[2 * k + 1] = rr[2 * k + 1] * rr[2 * k + 1];
     }
-    int c00[NSRC], c11[NSRC];                             // cached tap identity (byte offsets of taps 00 / 11)
+    // The 2x2 block a view reads is ONE table entry and ONE address (*r5*): its top-left tap is clamped so that the whole block
+    // lies inside the image (rows rb, rb+1 in [0,H), columns cb, cb+1 in [0,W)), the other three taps are the same voffset with
+    // the pixel / row / row+pixel stride in the instruction's scalar offset, and where the clamp moved the block (sample point in
+    // the one-pixel band around the image) the separable weights move with it -- the tap that fell outside carries weight 0 as
+    // before, the products and the order of the four multiply-adds that carry a non-zero weight are unchanged.  Per plane and
+    // view that is 1 compare + 1 add + 1 move where four separately clamped offsets cost 2 + 4 + 2, and 5 table dwords for 8.
+    int cur[NSRC];                                        // cached block identity (byte offset of its top-left tap)
     float4 t00[NSRC][Q], t01[NSRC][Q], t10[NSRC][Q], t11[NSRC][Q];
     const auto srsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, NSRC * H * W * C * 4, 0x00020000);
     const int pix_bytes = C * 4, row_bytes = W * C * 4, img_bytes = H * W * C * 4, lane_bytes = c * 4;
+    const int diag_bytes = row_bytes + pix_bytes;
 #pragma unroll
     for (int v = 0; v < NSRC; ++v) {
-        c00[v] = -1; c11[v] = -1;
+        cur[v] = -1;
 #pragma unroll
         for (int k = 0; k < Q; ++k) t00[v][k] = t01[v][k] = t10[v][k] = t11[v][k] = z4;
     }
@@ -108,13 +119,15 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
 
     // Plane-vectorised bookkeeping.  The kernel is VALU-bound and everything except the blend itself
     // is identical for the lg lanes of a pixel, so lane `sub` does ALL the per-view bookkeeping of
-    // plane (batch + sub): projective map, floor, clamped tap offsets, zero-fill-masked bilinear
-    // weights (already multiplied out to one weight per tap).  The 8 numbers per (plane, pixel, view)
+    // plane (batch + sub): projective map, floor, the clamped block offset, zero-fill-masked bilinear
+    // weights (already multiplied out to one weight per tap).  The 5 numbers per (plane, pixel, view)
     // go through a wave-private LDS table: while sweeping plane p every lane of the pixel reads them
-    // back with two broadcast ds_read_b128 per view and only pays for the loads and the blend.
+    // back with broadcast ds_read_b128 (one per view for the weights, one per four views for the offsets)
+    // and only pays for the loads and the blend.
     extern __shared__ __attribute__((aligned(16))) float4 book_all[];
+    constexpr int NOF = (NSRC + 3) / 4, ENT = NSRC + NOF;    // float4 per (plane, pixel): NSRC weight quads, then the offsets
     const int ppw = 64 / lg;                                 // pixels per wave
-    float4* book = book_all + (size_t)(threadIdx.x >> 6) * (64 * NSRC * 2);      // [lg planes][ppw pixels][NSRC][2]
+    float4* book = book_all + (size_t)(threadIdx.x >> 6) * (64 * ENT);      // [lg planes][ppw pixels][ENT]
     const int pixl = (threadIdx.x & 63) / lg;
 
     float* dstp = cost + ((size_t)dl0 * H * W + pix) * C + c;          // this lane's 16 bytes of plane dl0; walks plane by plane
@@ -122,50 +135,59 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
     for (int dlb = dl0; dlb < dl1; dlb += lg) {
         {
             const int dmy = d_begin + min(dlb + sub, dl1 - 1);
-            float4* mine = book + ((size_t)sub * ppw + pixl) * (NSRC * 2);
+            float4* mine = book + ((size_t)sub * ppw + pixl) * ENT;
+            int ob[NOF * 4];
+#pragma unroll
+            for (int v = NSRC; v < NOF * 4; ++v) ob[v] = 0;
 #pragma unroll
             for (int v = 0; v < NSRC; ++v) {
                 const float* t = transforms + ((size_t)v * depth_total + dmy) * 8;
                 const float4 ta = ld4(t), tb = ld4(t + 4);
                 float proj = tb.z * xf + tb.w * yf + 1.0f;
-                float inv = __builtin_amdgcn_rcpf(proj);        // v_rcp_f32: 1 ulp, exact for proj = 1
+                // v_rcp_f32 (1 ulp, exact for proj = 1) and a multiply where the reference divides: the sample point can differ
+                // from the quotient in its last bit, which moves a blend weight by the same amount (oracle parity 1e-5 covers it)
+                float inv = __builtin_amdgcn_rcpf(proj);
                 float sx = (ta.x * xf + ta.y * yf + ta.z) * inv;
                 float sy = (ta.w * xf + tb.x * yf + tb.y) * inv;
                 float x0 = floorf(sx), y0 = floorf(sy);
                 int ix0 = (int)x0, iy0 = (int)y0;                // v_cvt saturates, NaN -> 0
-                int jx0 = min(max(ix0, 0), W - 1), jx1 = min(max(ix0 + 1, 0), W - 1);
-                int jy0 = min(max(iy0, 0), H - 1), jy1 = min(max(iy0 + 1, 0), H - 1);
-                // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): clamped indices and the strides are < 2^24 (host-checked)
-                const int r0 = v * img_bytes + (int)__umul24(jy0, row_bytes), r1 = v * img_bytes + (int)__umul24(jy1, row_bytes);
-                const int cx0 = (int)__umul24(jx0, pix_bytes), cx1 = (int)__umul24(jx1, pix_bytes);
-                const int o00 = r0 + cx0, o01 = r0 + cx1;
-                const int o10 = r1 + cx0, o11 = r1 + cx1;
                 // per-tap zero fill folded into the separable weights: a tap is dropped iff its row or
                 // its column is outside the image, exactly as reading 0 for it (w * finite = 0)
                 const float wx1 = (ix0 >= 0 && ix0 < W) ? (x0 + 1.0f) - sx : 0.0f;
                 const float wx0 = (ix0 + 1 >= 0 && ix0 + 1 < W) ? sx - x0 : 0.0f;
                 const float wy1 = (iy0 >= 0 && iy0 < H) ? (y0 + 1.0f) - sy : 0.0f;
                 const float wy0 = (iy0 + 1 >= 0 && iy0 + 1 < H) ? sy - y0 : 0.0f;
-                mine[2 * v] = make_float4(__int_as_float(o00), __int_as_float(o01), __int_as_float(o10), __int_as_float(o11));
-                mine[2 * v + 1] = make_float4(wy1 * wx1, wy1 * wx0, wy0 * wx1, wy0 * wx0);
+                // the block that is read: top-left tap clamped to [0, W-2] x [0, H-2] (host-checked: H, W >= 2)
+                const int cb = min(max(ix0, 0), W - 2), rb = min(max(iy0, 0), H - 2);
+                // weight of the block's first / second column: unmoved block -> (wx1, wx0); block moved right (ix0 = -1) -> its
+                // first column is the sample's second tap; moved left (ix0 = W-1) -> its second column is the sample's first tap
+                const float ax = ix0 == cb ? wx1 : (ix0 < cb ? wx0 : 0.0f), bx = ix0 == cb ? wx0 : (ix0 > cb ? wx1 : 0.0f);
+                const float ay = iy0 == rb ? wy1 : (iy0 < rb ? wy0 : 0.0f), by = iy0 == rb ? wy0 : (iy0 > rb ? wy1 : 0.0f);
+                // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): clamped indices and the strides are < 2^24 (host-checked)
+                ob[v] = v * img_bytes + (int)__umul24(rb, row_bytes) + (int)__umul24(cb, pix_bytes);
+                mine[v] = make_float4(ay * ax, ay * bx, by * ax, by * bx);
             }
+#pragma unroll
+            for (int k = 0; k < NOF; ++k)
+                mine[NSRC + k] = make_float4(__int_as_float(ob[4 * k]), __int_as_float(ob[4 * k + 1]), __int_as_float(ob[4 * k + 2]),
+                                             __int_as_float(ob[4 * k + 3]));
         }
         const int np = min(lg, dl1 - dlb);
-        // one plane: refill the register tap cache where the taps moved, blend, reduce, store
-        auto plane = [&](int p, const float4 (&ofs)[NSRC], const float4 (&wts)[NSRC]) __attribute__((always_inline)) {
+        // one plane: refill the register tap cache where the block moved, blend, reduce, store
+        auto plane = [&](const float4 (&ofq)[NOF], const float4 (&wts)[NSRC]) __attribute__((always_inline)) {
             // phase A: all views' loads are issued before the first one is consumed.
 #pragma unroll
             for (int v = 0; v < NSRC; ++v) {
-                const float4 of = ofs[v];
-                const int o00 = __float_as_int(of.x), o11 = __float_as_int(of.w);
-                if (o00 != c00[v] || o11 != c11[v]) {
-                    const int o01 = __float_as_int(of.y), o10 = __float_as_int(of.z);
+                const float4 q = ofq[v >> 2];
+                const int o = __float_as_int((v & 3) == 0 ? q.x : (v & 3) == 1 ? q.y : (v & 3) == 2 ? q.z : q.w);
+                if (o != cur[v]) {
+                    const int vo = o + lane_bytes;
 #pragma unroll
                     for (int k = 0; k < Q; ++k) {
-                        t00[v][k] = ldb(srsrc, o00 + lane_bytes + 16 * k); t01[v][k] = ldb(srsrc, o01 + lane_bytes + 16 * k);
-                        t10[v][k] = ldb(srsrc, o10 + lane_bytes + 16 * k); t11[v][k] = ldb(srsrc, o11 + lane_bytes + 16 * k);
+                        t00[v][k] = ldbs(srsrc, vo + 16 * k, 0); t01[v][k] = ldbs(srsrc, vo + 16 * k, pix_bytes);
+                        t10[v][k] = ldbs(srsrc, vo + 16 * k, row_bytes); t11[v][k] = ldbs(srsrc, vo + 16 * k, diag_bytes);
                     }
-                    c00[v] = o00; c11[v] = o11;
+                    cur[v] = o;
                 }
             }
             // phase B: bilinear blend + running sums, two channels per packed instruction
@@ -192,31 +214,36 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
                 f32x2 o0, o1;
+                // the negated forms are the same fused multiply-adds with the signs of the operands exchanged: same bits, sign flipped
                 if (variant == 0) {
-                    o0 = Qs[2 * k] * inv_n - (S[2 * k] * S[2 * k]) * inv_nn;
-                    o1 = Qs[2 * k + 1] * inv_n - (S[2 * k + 1] * S[2 * k + 1]) * inv_nn;
+                    const f32x2 s0 = (S[2 * k] * S[2 * k]) * inv_nn, s1 = (S[2 * k + 1] * S[2 * k + 1]) * inv_nn;
+                    if (negate) { o0 = s0 - Qs[2 * k] * inv_n; o1 = s1 - Qs[2 * k + 1] * inv_n; }
+                    else { o0 = Qs[2 * k] * inv_n - s0; o1 = Qs[2 * k + 1] * inv_n - s1; }
                 } else {
-                    f32x2 m0 = S[2 * k] * inv_n, m1 = S[2 * k + 1] * inv_n;
-                    o0 = Qs[2 * k] * inv_n - m0 * m0; o1 = Qs[2 * k + 1] * inv_n - m1 * m1;
+                    const f32x2 m0 = S[2 * k] * inv_n, m1 = S[2 * k + 1] * inv_n;
+                    const f32x2 s0 = m0 * m0, s1 = m1 * m1;
+                    if (negate) { o0 = s0 - Qs[2 * k] * inv_n; o1 = s1 - Qs[2 * k + 1] * inv_n; }
+                    else { o0 = Qs[2 * k] * inv_n - s0; o1 = Qs[2 * k + 1] * inv_n - s1; }
                 }
-                if (negate) { o0 = -o0; o1 = -o1; }
                 // non-temporal: the 503 MB volume streams out and must not push the 13 MB of feature maps, which every plane
                 // re-reads, out of the L2 (199.7 -> 185.6 us inside a depth map, 246 -> 228 us alone)
                 __builtin_nontemporal_store((f32x4_nt){o0[0], o0[1], o1[0], o1[1]}, reinterpret_cast<f32x4_nt*>(dst + 4 * k));
             }
         };
-        auto fetch = [&](int p, float4 (&ofs)[NSRC], float4 (&wts)[NSRC]) __attribute__((always_inline)) {
-            const float4* bk = book + ((size_t)min(p, lg - 1) * ppw + pixl) * (NSRC * 2);
+        auto fetch = [&](int p, float4 (&ofq)[NOF], float4 (&wts)[NSRC]) __attribute__((always_inline)) {
+            const float4* bk = book + ((size_t)min(p, lg - 1) * ppw + pixl) * ENT;
 #pragma unroll
-            for (int v = 0; v < NSRC; ++v) { ofs[v] = bk[2 * v]; wts[v] = bk[2 * v + 1]; }
+            for (int v = 0; v < NSRC; ++v) wts[v] = bk[v];
+#pragma unroll
+            for (int k = 0; k < NOF; ++k) ofq[k] = bk[NSRC + k];
         };
         // (reading plane p+1's entries during plane p costs a second register set and an occupancy
         // step: measured slower)
         for (int p = 0; p < np; ++p) {
-            float4 ofs[NSRC], wts[NSRC];
-            fetch(p, ofs, wts);
+            float4 ofq[NOF], wts[NSRC];
+            fetch(p, ofq, wts);
             __builtin_amdgcn_sched_barrier(0);
-            plane(p, ofs, wts);
+            plane(ofq, wts);
         }
     }
 }
@@ -227,18 +254,16 @@ void launch_sweep(const float* ref, const float* src, const float* transforms, i
                   float* cost, hipStream_t st, int threads = 256) {
     const int ppb = d_count < 16 ? d_count : 16;          // planes per block
     // Q = 2 (8 channels per lane) halves the per-lane bookkeeping per channel but needs 236 VGPRs
-    // (2 waves/SIMD instead of 3): measured 0.258 ms vs 0.243 ms at the metric config, so it stays off.
-    const bool wide = false;
-    const int lg = wide ? C / 8 : C / 4;
+    // (2 waves/SIMD instead of 3): measured 0.258 ms vs 0.243 ms at the metric config, so only Q = 1 is instantiated.
+    const int lg = C / 4;
     long long total = (long long)H * W * lg;
     dim3 grid(mvs_cdiv(total, threads), mvs_cdiv(d_count, ppb));
-    const size_t smem = (size_t)(threads / 64) * 64 * NSRC * 2 * sizeof(float4);     // bookkeeping table, 2 KB per wave and view
-    if (wide)
-        cost_volume_sweep_kernel<NSRC, 2><<<grid, threads, smem, st>>>(ref, src, transforms, depth_total, d_begin,
-                                                                d_count, ppb, H, W, C, variant, negate, cost);
-    else
-        cost_volume_sweep_kernel<NSRC, 1><<<grid, threads, smem, st>>>(ref, src, transforms, depth_total, d_begin,
-                                                                d_count, ppb, H, W, C, variant, negate, cost);
+    const size_t smem = (size_t)(threads / 64) * 64 * (NSRC + (NSRC + 3) / 4) * sizeof(float4);     // bookkeeping table: 1 KB per wave and view + 1 KB per four views
+#define MVS_SWEEP_VN(VN) case VN: cost_volume_sweep_kernel<NSRC, 1, VN><<<grid, threads, smem, st>>>(ref, src, transforms, depth_total, d_begin, d_count, ppb, H, W, C, cost); break;
+    switch ((variant == 0 ? 0 : 2) + (negate ? 1 : 0)) {
+        MVS_SWEEP_VN(0) MVS_SWEEP_VN(1) MVS_SWEEP_VN(2) MVS_SWEEP_VN(3)
+    }
+#undef MVS_SWEEP_VN
 }
 
 template <int BORDER>
@@ -277,7 +302,7 @@ int mvs_cost_volume_threads_f32(const float* ref, const float* src, const float*
     // (Two other forms of this kernel were built, are exact, and measured no faster: the LDS-staged sweep and the MFMA-blend
     // sweeps.  They live under csrc/lab/ with their own entry points and tests -- DESIGN 4.1 -- not in this library.)
     const bool u24 = H < (1 << 24) && W < (1 << 24) && (long long)W * C * 4 < (1 << 24);     // the sweep's 24-bit offset multiplies
-    if (border == 0 && view_num <= 8 && cq_pow2 && off32 && u24) {      // depth sweep with register tap reuse
+    if (border == 0 && view_num <= 8 && cq_pow2 && off32 && u24 && H >= 2 && W >= 2) {      // depth sweep with register tap reuse
         hipStream_t st = mvs_stream(stream);
 #define MVS_SWEEP(NS) case NS: launch_sweep<NS>(ref, src, transforms, depth_total, d_begin, d_count, H, W, C, variant, negate, cost, st, threads); break;
         switch (view_num - 1) {

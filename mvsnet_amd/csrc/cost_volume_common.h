@@ -13,6 +13,12 @@ __device__ __forceinline__ float4 ldb(R rsrc, int byte_off) {      // buffer_loa
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
 
+template <typename R>
+__device__ __forceinline__ float4 ldbs(R rsrc, int byte_off, int uniform_off) {      // buffer_load_dwordx4 ... , s_off offen
+    u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, uniform_off, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
 __device__ __forceinline__ float4 fma4(float w, float4 a, float4 acc) {
     acc.x += w * a.x; acc.y += w * a.y; acc.z += w * a.z; acc.w += w * a.w;
     return acc;

@@ -141,6 +141,40 @@ def test_cost_volume_identical_views_is_zero_and_padding_views():
     assert got.shape == (5, 8, 8, 32) and not got.any()
 
 
+@pytest.mark.parametrize("variant", ["mem", "eager"])
+def test_cost_volume_border_bands_are_exact(variant):
+    """The depth sweep reads ONE clamped 2x2 block per (pixel, view, plane) and moves the bilinear weights with it where
+    the sample point lies in the one-pixel band around the image.  Integer features and shifts on a 1/4-pixel grid make
+    every product exact, so the volume must equal the oracle's bit for bit: every plane puts the three source views in a
+    different band (left / right / top / bottom / corners / two pixels out / far out), homography_warping.py:251-252."""
+    from mvsnet_amd.model import cost_volume
+    rs = np.random.RandomState(31)
+    H, W, C = 6, 10, 32
+    ref = rs.randint(-4, 5, size=(H, W, C)).astype(np.float32)
+    src = rs.randint(-4, 5, size=(3, H, W, C)).astype(np.float32)
+    shifts = [(-0.5, 0.0), (0.0, -0.5), (-0.75, -0.25), (-1.0, -1.0), (-1.25, 0.5), (0.25, -1.75), (-2.0, 0.0), (0.0, -2.5),
+              (W - 1.5, 0.0), (W - 1.0, 0.25), (W - 0.75, H - 0.75), (0.5, H - 1.0), (0.0, H - 0.5), (W - 0.25, -0.25),
+              (-0.25, H - 0.25), (W + 0.5, 0.0), (0.0, H + 1.0), (300.0, -300.0), (0.0, 0.0), (1.5, 2.25), (-9.0, -9.0),
+              (W - 1.25, H - 1.25), (-1.0, H - 1.0), (W - 1.0, -1.0)]
+    D = len(shifts)
+    T = np.zeros((3, D, 8), np.float32)
+    T[:, :, 0] = 1; T[:, :, 4] = 1
+    for d in range(D):
+        for v in range(3):
+            sx, sy = shifts[(d + 7 * v) % D]
+            T[v, d, 2] = sx - (v == 2) * (d % 5); T[v, d, 5] = sy + (v == 1) * (d % 3)
+    got = n(cost_volume(t(ref), t(src), t(T), variant=variant))
+    fn = O.variance_cost_mem if variant == "mem" else O.variance_cost_eager
+    for d in range(D):
+        warped = [O.image_projective_transform_bilinear(src[v], T[v, d].astype(np.float64), np.float64) for v in range(3)]
+        exp = fn(ref, warped, 4, np.float64)
+        # sums of at most 4 exact products of small integers and 1/16ths: exact in fp32; the 1/N scalings round once each
+        np.testing.assert_allclose(got[d], exp, rtol=0, atol=2e-5, err_msg="plane %d" % d)
+        # and a launch of that plane alone gives the same numbers
+        one = n(cost_volume(t(ref), t(src), t(T), d_begin=d, d_count=1, variant=variant))
+        np.testing.assert_allclose(got[d], one[0], rtol=0, atol=2e-5, err_msg="plane %d" % d)
+
+
 # ---- R4 conv / deconv / BN -----------------------------------------------------------------------------
 CONV_CASES = [  # D,H,W,Cin,Cout,stride
     (8, 8, 16, 32, 8, 1), (8, 8, 16, 32, 16, 2), (4, 8, 8, 16, 16, 1), (4, 4, 8, 16, 32, 2),
