@@ -72,19 +72,48 @@ template <int NSRC, int Q, int VN>       // Q float4 per lane: 4*Q channels per 
 __global__ void __launch_bounds__(256)
 cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict__ src,
                          const float* __restrict__ transforms, int depth_total, int d_begin,
-                         int d_count, int planes_per_block, int H, int W, int C, float* __restrict__ cost) {
+                         int d_count, int planes_per_block, int H, int W, int C, int ty_log2,
+                         float* __restrict__ cost) {
     constexpr int variant = VN >> 1;
     constexpr bool negate = (VN & 1) != 0;
     const int lg = C / (4 * Q);                           // lanes per pixel: power of two (host-checked)
-    const long long total = (long long)H * W * lg;
-    long long idx = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+    // A wave's 64/lg pixels are a TY x TX tile, the workgroup's waves sit side by side along x (*r5*).  What a wave pays for
+    // vector memory is the number of load INSTRUCTIONS (16 clocks per 16-byte-per-lane load on the CU's texture path whether
+    // all lanes, one lane or none is active: tools/exec0_vmem_probe.hip), i.e. the number of (plane, view) in which ANY of its
+    // pixels' blocks moved.  Pixels across the epipolar direction cross tap boundaries on the same plane; pixels along it do
+    // not.  At the metric workload (horizontal baselines) a pixel's block moves on 23 % of the (plane, view); a wave of 8 pixels
+    // along x has a move on 44 %, 4 rows x 2 columns on 26 %, a column of 8 on 23 %: 174 / 154-159 / 149-151 us, 945 / 964 / 973 depth maps/s.
+    const int ppw = 64 / lg;                                 // pixels per wave
+    if (ty_log2 < 0) {
+        // The shape is voted here, the same in every workgroup: the sample point of the image centre moves by (mx, my) source
+        // pixels over the whole sweep, summed over the views; mostly along x -> a column of pixels, mostly along y -> a row,
+        // otherwise the squarer shape that is longer across the stronger direction.
+        float mx = 0.0f, my = 0.0f;
+        const float cx = 0.5f * (float)W, cy = 0.5f * (float)H;
+#pragma unroll
+        for (int v = 0; v < NSRC; ++v) {
+            const float* t0 = transforms + (size_t)v * depth_total * 8;
+            const float* t1 = t0 + (size_t)(depth_total - 1) * 8;
+            const float i0 = __builtin_amdgcn_rcpf(t0[6] * cx + t0[7] * cy + 1.0f), i1 = __builtin_amdgcn_rcpf(t1[6] * cx + t1[7] * cy + 1.0f);
+            mx += fabsf((t1[0] * cx + t1[1] * cy + t1[2]) * i1 - (t0[0] * cx + t0[1] * cy + t0[2]) * i0);
+            my += fabsf((t1[3] * cx + t1[4] * cy + t1[5]) * i1 - (t0[3] * cx + t0[4] * cy + t0[5]) * i0);
+        }
+        ty_log2 = mx >= 2.0f * my ? 3 : my >= 2.0f * mx ? 0 : mx >= my ? 2 : 1;
+        while ((1 << ty_log2) > ppw) --ty_log2;
+    }
+    const int ty_mask = (1 << ty_log2) - 1;
+    const int tiles_x = (W + (int)(blockDim.x >> 6) * (ppw >> ty_log2) - 1) / ((int)(blockDim.x >> 6) * (ppw >> ty_log2));
+    const int blk = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_y = blk / tiles_x, tile_x = blk - tile_y * tiles_x;      // (the grid covers the shape with the most tiles)
+    const int pixl = (threadIdx.x & 63) / lg;                // pixel slot inside the wave: rows first
+    const int y = (tile_y << ty_log2) + (pixl & ty_mask);
+    const int x = (tile_x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (ppw >> ty_log2) + (pixl >> ty_log2);
+    if (y >= H || x >= W) return;
     const int dl0 = blockIdx.y * planes_per_block;
     const int dl1 = min(dl0 + planes_per_block, d_count);
     const int sub = threadIdx.x & (lg - 1);
     const int c = sub * 4 * Q;                            // first channel of this lane
-    const long long pix = idx / lg;
-    const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+    const long long pix = (long long)y * W + x;
     const float xf = (float)x, yf = (float)y;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -126,9 +155,7 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
     // and only pays for the loads and the blend.
     extern __shared__ __attribute__((aligned(16))) float4 book_all[];
     constexpr int NOF = (NSRC + 3) / 4, ENT = NSRC + NOF;    // float4 per (plane, pixel): NSRC weight quads, then the offsets
-    const int ppw = 64 / lg;                                 // pixels per wave
     float4* book = book_all + (size_t)(threadIdx.x >> 6) * (64 * ENT);      // [lg planes][ppw pixels][ENT]
-    const int pixl = (threadIdx.x & 63) / lg;
 
     float* dstp = cost + ((size_t)dl0 * H * W + pix) * C + c;          // this lane's 16 bytes of plane dl0; walks plane by plane
     const size_t plane_elems = (size_t)H * W * C;
@@ -255,11 +282,22 @@ void launch_sweep(const float* ref, const float* src, const float* transforms, i
     const int ppb = d_count < 16 ? d_count : 16;          // planes per block
     // Q = 2 (8 channels per lane) halves the per-lane bookkeeping per channel but needs 236 VGPRs
     // (2 waves/SIMD instead of 3): measured 0.258 ms vs 0.243 ms at the metric config, so only Q = 1 is instantiated.
-    const int lg = C / 4;
-    long long total = (long long)H * W * lg;
-    dim3 grid(mvs_cdiv(total, threads), mvs_cdiv(d_count, ppb));
+    const int lg = C / 4, ppw = 64 / lg, nw = threads / 64;
+    // wave tile: rows x columns of pixels, voted in the kernel from the transforms (ty_log2 = -1); MVS_CV_TILE_ROWS_LOG2 = 0..3 forces
+    // a shape (tests, measurements).  The grid covers the shape that needs the most workgroups; the others return early.
+    const char* ty_env = getenv("MVS_CV_TILE_ROWS_LOG2");
+    int ty_log2 = ty_env ? atoi(ty_env) : -1;
+    if (ty_log2 > 3) ty_log2 = 3;
+    while (ty_log2 >= 0 && (1 << ty_log2) > ppw) --ty_log2;
+    int blocks = 0;
+    for (int t = 0; t <= 3 && (1 << t) <= ppw; ++t) {
+        if (ty_log2 >= 0 && t != ty_log2) continue;
+        const int b = mvs_cdiv(W, nw * (ppw >> t)) * mvs_cdiv(H, 1 << t);
+        if (b > blocks) blocks = b;
+    }
+    dim3 grid(blocks, mvs_cdiv(d_count, ppb));
     const size_t smem = (size_t)(threads / 64) * 64 * (NSRC + (NSRC + 3) / 4) * sizeof(float4);     // bookkeeping table: 1 KB per wave and view + 1 KB per four views
-#define MVS_SWEEP_VN(VN) case VN: cost_volume_sweep_kernel<NSRC, 1, VN><<<grid, threads, smem, st>>>(ref, src, transforms, depth_total, d_begin, d_count, ppb, H, W, C, cost); break;
+#define MVS_SWEEP_VN(VN) case VN: cost_volume_sweep_kernel<NSRC, 1, VN><<<grid, threads, smem, st>>>(ref, src, transforms, depth_total, d_begin, d_count, ppb, H, W, C, ty_log2, cost); break;
     switch ((variant == 0 ? 0 : 2) + (negate ? 1 : 0)) {
         MVS_SWEEP_VN(0) MVS_SWEEP_VN(1) MVS_SWEEP_VN(2) MVS_SWEEP_VN(3)
     }

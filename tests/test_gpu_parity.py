@@ -175,6 +175,34 @@ def test_cost_volume_border_bands_are_exact(variant):
         np.testing.assert_allclose(got[d], one[0], rtol=0, atol=2e-5, err_msg="plane %d" % d)
 
 
+@pytest.mark.parametrize("C", [16, 32, 64])
+def test_cost_volume_wave_tile_shapes_give_the_same_bits(C, monkeypatch):
+    """The sweep lays a wave's pixels out as a rows x columns tile voted from the transforms (cost_volume.hip); every shape, forced
+    through MVS_CV_TILE_ROWS_LOG2, and the voted one compute each voxel with the same instructions: bit-identical volumes,
+    ragged image sizes included (tiles hanging over the right and bottom edges)."""
+    from mvsnet_amd.homography_warping import homography_transforms
+    from mvsnet_amd.model import cost_volume
+    w = S.make_workload("small")
+    rs = np.random.RandomState(41)
+    H, Wd = 11, 13
+    feats = rs.standard_normal((w.view_num, H, Wd, C)).astype(np.float32)
+    T = homography_transforms(t(w.cams), w.depth_num, w.depth_start, w.depth_interval)
+    T = T * t(np.array([1, 1, Wd / w.width, 1, 1, H / w.height, 1, 1], np.float32))      # keep the samples inside the smaller image
+    monkeypatch.delenv("MVS_CV_TILE_ROWS_LOG2", raising=False)
+    voted = n(cost_volume(t(feats[0]), t(feats[1:]), T))
+    assert np.isfinite(voted).all() and voted.any()
+    for rows_log2 in range(4):
+        monkeypatch.setenv("MVS_CV_TILE_ROWS_LOG2", str(rows_log2))
+        got = n(cost_volume(t(feats[0]), t(feats[1:]), T))
+        assert np.array_equal(got, voted), rows_log2
+    # a sweep along y instead of x (transposed geometry) votes another shape: same bits as a forced one again
+    Tt = T.clone(); Tt[..., [0, 1, 2, 3, 4, 5]] = T[..., [4, 3, 5, 1, 0, 2]]
+    monkeypatch.setenv("MVS_CV_TILE_ROWS_LOG2", "0")
+    forced = n(cost_volume(t(feats[0]), t(feats[1:]), Tt))
+    monkeypatch.delenv("MVS_CV_TILE_ROWS_LOG2")
+    assert np.array_equal(n(cost_volume(t(feats[0]), t(feats[1:]), Tt)), forced)
+
+
 # ---- R4 conv / deconv / BN -----------------------------------------------------------------------------
 CONV_CASES = [  # D,H,W,Cin,Cout,stride
     (8, 8, 16, 32, 8, 1), (8, 8, 16, 32, 16, 2), (4, 8, 8, 16, 16, 1), (4, 4, 8, 16, 32, 2),
