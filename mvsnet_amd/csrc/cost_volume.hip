@@ -85,18 +85,18 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
     // along x has a move on 44 %, 4 rows x 2 columns on 26 %, a column of 8 on 23 %: 174 / 154-159 / 149-151 us, 945 / 964 / 973 depth maps/s.
     const int ppw = 64 / lg;                                 // pixels per wave
     if (ty_log2 < 0) {
-        // The shape is voted here, the same in every workgroup: the sample point of the image centre moves by (mx, my) source
-        // pixels over the whole sweep, summed over the views; mostly along x -> a column of pixels, mostly along y -> a row,
-        // otherwise the squarer shape that is longer across the stronger direction.
+        // The shape is voted here, the same in every workgroup: the sample point of the image centre moves by about (mx, my)
+        // source pixels over the whole sweep, summed over the views (numerators only: a direction is all that is needed, and every
+        // wave pays for these instructions); mostly along x -> a column of pixels, mostly along y -> a row, otherwise the
+        // squarer shape that is longer across the stronger direction.
         float mx = 0.0f, my = 0.0f;
         const float cx = 0.5f * (float)W, cy = 0.5f * (float)H;
 #pragma unroll
         for (int v = 0; v < NSRC; ++v) {
             const float* t0 = transforms + (size_t)v * depth_total * 8;
             const float* t1 = t0 + (size_t)(depth_total - 1) * 8;
-            const float i0 = __builtin_amdgcn_rcpf(t0[6] * cx + t0[7] * cy + 1.0f), i1 = __builtin_amdgcn_rcpf(t1[6] * cx + t1[7] * cy + 1.0f);
-            mx += fabsf((t1[0] * cx + t1[1] * cy + t1[2]) * i1 - (t0[0] * cx + t0[1] * cy + t0[2]) * i0);
-            my += fabsf((t1[3] * cx + t1[4] * cy + t1[5]) * i1 - (t0[3] * cx + t0[4] * cy + t0[5]) * i0);
+            mx += fabsf((t1[0] - t0[0]) * cx + (t1[1] - t0[1]) * cy + (t1[2] - t0[2]));
+            my += fabsf((t1[3] - t0[3]) * cx + (t1[4] - t0[4]) * cy + (t1[5] - t0[5]));
         }
         ty_log2 = mx >= 2.0f * my ? 3 : my >= 2.0f * mx ? 0 : mx >= my ? 2 : 1;
         while ((1 << ty_log2) > ppw) --ty_log2;
