@@ -321,6 +321,10 @@ int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms,
  *   depth_values [host] views x depth_num floats
  *   workspace    views x mvs_gru_workspace_bytes(...) bytes (one block per view)
  *   depth_out / prob_out (views, H, W)
+ * Shape limits (both entry points): f1, f2, f3 <= 64, MVS_E_SHAPE otherwise (the blend kernels keep 2 x F LayerNorm affines per
+ * cell in LDS and the staging code is written for at most 64 state channels; the reference uses 16 / 4 / 2, the 'fat' variant
+ * 32 / 8 / 4); views in 1..8 (MVS_E_BADARG); C as mvs_cost_volume_f32 accepts it.  The fused two-launch sweep covers C = 32 with 16 / 4 / 2; every other accepted shape
+ * runs the wavefront kernels.
  */
 int mvs_gru_wta_batch_f32(const float* const* ref, const float* const* src, const float* const* transforms,
                           int views, int view_num, int depth_num, int H, int W, int C, int f1, int f2,
