@@ -414,6 +414,34 @@ def test_regnet_filler_launches_equal_the_layers_apart(shape):
         assert rel_l1(n(filled), exp) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(192, 128, 160), (104, 48, 64), (40, 24, 48)])
+def test_regnet_span_and_fused_pair_equal_the_plain_schedules(shape, monkeypatch):
+    """The dominant launch's SPAN schedule (conv3d_c8.hip: workgroups own depth ranges that may cross a tile boundary) against the
+    whole-chunk schedule it replaced, and the fused 3dconv1_1 + 3dconv2_0 launch (conv3d_mfma.hip, FUSE2) against the two layers
+    apart -- forced through the library's test hooks MVS_CONV_NO_SPAN / MVS_CONV_NO_FUSE2, at the metric size (where SPAN is
+    taken) and at sizes whose half-resolution depth (52, 20) is not a multiple of the planes a workgroup marches (short last
+    chunk).  Same arithmetic per voxel; the float64 BatchNorm atomics arrive in another order: 2e-5 of the output's scale."""
+    from mvsnet_amd.model import RegNetWeights, regnet_us0
+    D, H, W = shape
+    params = S.make_regnet_params("normal", seed=33, random_affine=True)
+    cost = t(np.abs(np.random.RandomState(34).standard_normal((D, H, W, 32))).astype(np.float32))
+    wts = RegNetWeights(params, DEV)
+    for k in ("MVS_CONV_NO_SPAN", "MVS_CONV_NO_FUSE2"):
+        monkeypatch.delenv(k, raising=False)
+    default = regnet_us0(cost, wts).clone()
+    scale = float(default.abs().max())
+    assert scale > 0 and bool(torch.isfinite(default).all())
+    for hooks in (("MVS_CONV_NO_SPAN",), ("MVS_CONV_NO_FUSE2",), ("MVS_CONV_NO_SPAN", "MVS_CONV_NO_FUSE2")):
+        for k in hooks:
+            monkeypatch.setenv(k, "1")
+        plain = regnet_us0(cost, wts).clone()
+        for k in hooks:
+            monkeypatch.delenv(k)
+        assert float((plain - default).abs().max()) <= 2e-5 * scale, hooks
+    if D * H * W <= 48 * 40 * 72:
+        assert rel_l1(n(default), O.regnet_us0(n(cost), params, np.float64)) < 2e-5
+
+
 def test_batch_of_two_shares_batchnorm_statistics():
     """FLAGS.batch_size > 1 (model.py:28,350,431,479): towers / homographies / cost volumes / soft-argmin per sample,
     RegNetUS0's BatchNorm over the whole batch (network.py:496-506) -- against the batched oracle, and NOT equal to
