@@ -175,7 +175,7 @@ def test_cost_volume_border_bands_are_exact(variant):
         np.testing.assert_allclose(got[d], one[0], rtol=0, atol=2e-5, err_msg="plane %d" % d)
 
 
-@pytest.mark.parametrize("C", [16, 32, 64])
+@pytest.mark.parametrize("C", [4, 8, 16, 32, 64])
 def test_cost_volume_wave_tile_shapes_give_the_same_bits(C, monkeypatch):
     """The sweep lays a wave's pixels out as a rows x columns tile voted from the transforms (cost_volume.hip); every shape, forced
     through MVS_CV_TILE_ROWS_LOG2, and the voted one compute each voxel with the same instructions: bit-identical volumes,
