@@ -751,6 +751,18 @@ def main():
                 t_x.append(time.perf_counter())
                 print("bench extra %-28s %6.1f s" % (tag, t_x[-1] - t_x[-2]), file=sys.stderr, flush=True)
             out["config_c2"] = extra_config_3dcnn("c2", dev); lap("config_c2")
+            if args.conv_impl == "auto":
+                # Opt-in split precision, reported BESIDE `value` and never as it: every fp32 product of 3dconv0_1 as three bf16
+                # MFMAs on hi / lo halves (16 significant bits per operand), all other layers and all accumulation in fp32.
+                _lib.set_conv_impl("bf16x3")
+                try:
+                    r = extra_config_3dcnn("M", dev, steps=50)
+                    r["dtype"] = "fp32 operands split into two bf16 halves for 3dconv0_1 (conv_impl='bf16x3'), fp32 accumulate; everything else as `value`"
+                    r["note"] = "opt-in (mvs_set_conv_impl / --conv-impl bf16x3); `value` is measured with exact fp32 MFMA"
+                    out["split_precision_bf16x3"] = r
+                finally:
+                    _lib.set_conv_impl(args.conv_impl)
+                lap("split_precision_bf16x3")
             out["config_c3_gru"] = extra_config_gru("c3", dev, 5, 1); lap("config_c3_gru")
             out["config_c3_gru"]["formulations_ms_per_depth_map"] = gru_formulations(dev); lap("c3 formulations")
             out["config_c3_gru"]["fresh_process"] = gru_config_in_child("c3"); lap("c3 fresh process")

@@ -301,8 +301,10 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
     // producers' atomic tails but every consumer thread adds the rows up again
     constexpr int slots_env = 2;
     // (volumes of 2 GB and more leave the 32-bit-offset MFMA kernels for the generic ones: one row there)
-    const bool all_mfma = (g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA) && cin == 32 && b == 8 &&
-                          (long long)D * H * W * cin * 4 < (1LL << 31);
+    // (the opt-in split-precision mode keeps every fused / filled fp32 launch of the default mode and uses its bf16 kernel for the one
+    //  layer where it is faster, 3dconv0_1: 32 -> 8 over the whole volume -- round 5; before, it ran all eleven layers apart)
+    const bool all_mfma = (g_conv_impl == MVS_CONV_IMPL_AUTO || g_conv_impl == MVS_CONV_IMPL_MFMA || g_conv_impl == MVS_CONV_IMPL_BF16X3) &&
+                          cin == 32 && b == 8 && (long long)D * H * W * cin * 4 < (1LL << 31);
     const int SL = all_mfma ? (slots_env < 1 ? 1 : slots_env > MVS_BN_SLOTS_MAX ? MVS_BN_SLOTS_MAX : slots_env) : 1;
     bool finalised[N_BN] = {false};
     bool pair_done = false;
@@ -343,7 +345,7 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
         if (g_conv_impl != MVS_CONV_IMPL_SCALAR) {
             const float* wp = (prepared && lay.ok[out]) ? prepared + lay.off[out] : nullptr;
             // opt-in split-precision path: bf16 hi|lo weights live behind the fp32 layouts
-            const unsigned short* wbf = (prepared && g_conv_impl == MVS_CONV_IMPL_BF16X3 && lay.bf[out])
+            const unsigned short* wbf = (prepared && g_conv_impl == MVS_CONV_IMPL_BF16X3 && lay.bf[out] && (!all_mfma || out == L01))
                 ? reinterpret_cast<const unsigned short*>(prepared + lay.total + lay.off[out]) : nullptr;
             int r = deconv ? mvs_deconv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, d, h, w, ci, co, y, so, hs, SL)
                            : mvs_conv3d_mfma_bn(x, bn_of(p1), x2, bn_of(p2), weights[out], wp, wbf, d, h, w, ci, co, stride, y, so, hs, SL);
