@@ -756,7 +756,7 @@ def main():
                 # MFMAs on hi / lo halves (16 significant bits per operand), all other layers and all accumulation in fp32.
                 _lib.set_conv_impl("bf16x3")
                 try:
-                    r = extra_config_3dcnn("M", dev, steps=50)
+                    r = extra_config_3dcnn("M", dev, steps=200)
                     r["dtype"] = "fp32 operands split into two bf16 halves for 3dconv0_1 (conv_impl='bf16x3'), fp32 accumulate; everything else as `value`"
                     r["note"] = "opt-in (mvs_set_conv_impl / --conv-impl bf16x3); `value` is measured with exact fp32 MFMA"
                     out["split_precision_bf16x3"] = r
