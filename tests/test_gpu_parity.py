@@ -606,6 +606,38 @@ def test_gru_wta_matches_oracle(inverse, mode):
     np.testing.assert_allclose(prob[same], ep[same], rtol=2e-4)
 
 
+@pytest.mark.parametrize("hw", [(27, 41), (9, 47), (31, 17)])
+def test_gru_wta_ragged_image_sizes_match_oracle(hw):
+    """Image sizes that are not multiples of the fused sweep's 8 x 16 pixel tiles (gru_fused.hip): partial tiles on the right and
+    bottom edges, a single tile row, a tile column narrower than a tile -- masked lanes read zeros and drop their stores, the
+    LayerNorm sums count own pixels only.  Same cameras, cropped feature maps, against the float64 oracle (convgru.py:82-122)."""
+    from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
+    w = S.make_workload("small")
+    H, Wd = hw
+    feats = np.ascontiguousarray(w.features[:, :H, :Wd])
+    gp = S.make_gru_params("normal", seed=7, in_channels=w.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
+    depth, prob = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end,
+                                            weights=weights, features=t(feats))
+    ed, ep = O.inference_winner_take_all_from_features(feats, w.cams, w.depth_num, w.depth_start, w.depth_end, gp, False, np.float64)
+    depth, prob = n(depth)[0, :, :, 0], n(prob)[0, :, :, 0]
+    assert depth.shape == (H, Wd)
+    same = np.abs(depth - ed) <= 1e-6 * np.abs(ed)
+    assert same.mean() > 0.97, same.mean()
+    np.testing.assert_allclose(prob[same], ep[same], rtol=5e-4)
+    # the wavefront kernels of rounds 3-4 on the same input: the same planes up to ties
+    import ctypes as C
+    from mvsnet_amd import _lib as L
+    lib = L.load()
+    L.check(lib.mvs_gru_set_formulation(1), "mvs_gru_set_formulation")
+    try:
+        d1, _p1 = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end,
+                                            weights=weights, features=t(feats))
+    finally:
+        L.check(lib.mvs_gru_set_formulation(0), "mvs_gru_set_formulation")
+    assert (n(d1)[0, :, :, 0] == depth).mean() > 0.97
+
+
 # ---- R10 end to end -------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,inverse,mode", [("toy", False, "normal"), ("toy", True, "normal"), ("small", False, "normal"),
                                                ("toy", False, "lite"), ("small", False, "semilite-py3")])
