@@ -191,6 +191,10 @@ def test_cost_volume_wave_tile_shapes_give_the_same_bits(C, monkeypatch):
     monkeypatch.delenv("MVS_CV_TILE_ROWS_LOG2", raising=False)
     voted = n(cost_volume(t(feats[0]), t(feats[1:]), T))
     assert np.isfinite(voted).all() and voted.any()
+    To = n(T).astype(np.float64)
+    exp = np.stack([O.variance_cost_mem(feats[0], [O.image_projective_transform_bilinear(feats[v + 1], To[v, d], np.float64)
+                                                   for v in range(w.view_num - 1)], w.view_num, np.float64) for d in range(w.depth_num)])
+    assert rel_l1(voted, exp) < 1e-5 and (np.abs(voted - exp) > 1e-4).mean() < 2e-3      # tap flips at near-integer samples
     for rows_log2 in range(4):
         monkeypatch.setenv("MVS_CV_TILE_ROWS_LOG2", str(rows_log2))
         got = n(cost_volume(t(feats[0]), t(feats[1:]), T))
