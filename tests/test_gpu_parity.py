@@ -207,6 +207,27 @@ def test_cost_volume_wave_tile_shapes_give_the_same_bits(C, monkeypatch):
     assert np.array_equal(n(cost_volume(t(feats[0]), t(feats[1:]), Tt)), forced)
 
 
+@pytest.mark.parametrize("hw", [(2, 2), (2, 9), (7, 2), (1, 6), (5, 1)])
+def test_cost_volume_smallest_images(hw):
+    """Two rows / two columns is the smallest image the one-block sweep takes (its clamped 2x2 block needs both); a single
+    row or column goes to the per-plane kernel.  Exact against the oracle on a 1/4-pixel grid, as the border-band test."""
+    from mvsnet_amd.model import cost_volume
+    rs = np.random.RandomState(51)
+    H, W = hw
+    ref = rs.randint(-4, 5, size=(H, W, 32)).astype(np.float32)
+    src = rs.randint(-4, 5, size=(2, H, W, 32)).astype(np.float32)
+    shifts = [(0.0, 0.0), (-0.5, 0.25), (0.75, -0.75), (-1.25, 1.0), (1.5, 1.5), (-2.0, -2.0), (0.25, 0.5), (3.0, 0.0)]
+    T = np.zeros((2, len(shifts), 8), np.float32)
+    T[:, :, 0] = 1; T[:, :, 4] = 1
+    for d, (sx, sy) in enumerate(shifts):
+        T[0, d, 2], T[0, d, 5] = sx, sy
+        T[1, d, 2], T[1, d, 5] = -sy, sx
+    got = n(cost_volume(t(ref), t(src), t(T)))
+    for d in range(len(shifts)):
+        warped = [O.image_projective_transform_bilinear(src[v], T[v, d].astype(np.float64), np.float64) for v in range(2)]
+        np.testing.assert_allclose(got[d], O.variance_cost_mem(ref, warped, 3, np.float64), rtol=0, atol=2e-5, err_msg="plane %d" % d)
+
+
 # ---- R4 conv / deconv / BN -----------------------------------------------------------------------------
 CONV_CASES = [  # D,H,W,Cin,Cout,stride
     (8, 8, 16, 32, 8, 1), (8, 8, 16, 32, 16, 2), (4, 8, 8, 16, 16, 1), (4, 4, 8, 16, 32, 2),
