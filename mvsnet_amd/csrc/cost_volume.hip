@@ -279,7 +279,20 @@ template <int NSRC>
 void launch_sweep(const float* ref, const float* src, const float* transforms, int depth_total,
                   int d_begin, int d_count, int H, int W, int C, int variant, int negate,
                   float* cost, hipStream_t st, int threads = 256) {
-    const int ppb = d_count < 16 ? d_count : 16;          // planes per block
+    // Planes per workgroup: whole rounds of the chip's 1024 workgroup slots (four 4-wave workgroups per CU at 117 VGPRs) -- a
+    // workgroup costs its planes + ~1.5 planes of start-up (reference features, vote, first table block).  At the metric workload
+    // 16 / 24 / 32 / 48 planes are 7.5 / 5.0 / 3.75 / 2.5 rounds: 967 / 971 / 970 / 970 depth maps/s (8, 12: 955, 952; 96: 958).
+    int ppb = d_count;
+    if (d_count > 16) {
+        const int lg0 = C / 4, ppw0 = 64 / lg0, nw0 = threads / 64;
+        const long long wgs_per_chunk = (long long)mvs_cdiv(W, nw0 * ppw0) * H;      // about the same for every wave tile shape
+        double best = 1e30;
+        for (int cand = 16; cand <= 48; cand += 8) {
+            const long long wgs = wgs_per_chunk * mvs_cdiv(d_count, cand);
+            const double cost = (double)((wgs + 1023) / 1024) * (cand + 1.5);
+            if (cost < best) { best = cost; ppb = cand; }
+        }
+    }
     // Q = 2 (8 channels per lane) halves the per-lane bookkeeping per channel but needs 236 VGPRs
     // (2 waves/SIMD instead of 3): measured 0.258 ms vs 0.243 ms at the metric config, so only Q = 1 is instantiated.
     const int lg = C / 4, ppw = 64 / lg, nw = threads / 64;
