@@ -178,18 +178,16 @@ cost_volume_sweep_kernel(const float* __restrict__ ref, const float* __restrict_
                 float sy = (ta.w * xf + tb.x * yf + tb.y) * inv;
                 float x0 = floorf(sx), y0 = floorf(sy);
                 int ix0 = (int)x0, iy0 = (int)y0;                // v_cvt saturates, NaN -> 0
-                // per-tap zero fill folded into the separable weights: a tap is dropped iff its row or
-                // its column is outside the image, exactly as reading 0 for it (w * finite = 0)
-                const float wx1 = (ix0 >= 0 && ix0 < W) ? (x0 + 1.0f) - sx : 0.0f;
-                const float wx0 = (ix0 + 1 >= 0 && ix0 + 1 < W) ? sx - x0 : 0.0f;
-                const float wy1 = (iy0 >= 0 && iy0 < H) ? (y0 + 1.0f) - sy : 0.0f;
-                const float wy0 = (iy0 + 1 >= 0 && iy0 + 1 < H) ? sy - y0 : 0.0f;
-                // the block that is read: top-left tap clamped to [0, W-2] x [0, H-2] (host-checked: H, W >= 2)
+                // The block that is read: top-left tap clamped to [0, W-2] x [0, H-2] (host-checked: H, W >= 2).  Per-tap zero fill is
+                // folded into the separable weights -- a tap is dropped iff its row or its column is outside the image, exactly as
+                // reading 0 for it (w * finite = 0) -- and the weights move with the block: unmoved (ix0 = cb) -> the block's columns
+                // carry (1 - fx, fx); block moved right (ix0 = -1) -> its first column is the sample's second tap; moved left
+                // (ix0 = W-1) -> its second column is the sample's first tap; further out both taps are outside.
                 const int cb = min(max(ix0, 0), W - 2), rb = min(max(iy0, 0), H - 2);
-                // weight of the block's first / second column: unmoved block -> (wx1, wx0); block moved right (ix0 = -1) -> its
-                // first column is the sample's second tap; moved left (ix0 = W-1) -> its second column is the sample's first tap
-                const float ax = ix0 == cb ? wx1 : (ix0 < cb ? wx0 : 0.0f), bx = ix0 == cb ? wx0 : (ix0 > cb ? wx1 : 0.0f);
-                const float ay = iy0 == rb ? wy1 : (iy0 < rb ? wy0 : 0.0f), by = iy0 == rb ? wy0 : (iy0 > rb ? wy1 : 0.0f);
+                const int dx = ix0 - cb, dy = iy0 - rb;                          // (no overflow: cb, rb >= 0, saturated ix0 / iy0 included)
+                const float fx1 = (x0 + 1.0f) - sx, fx0 = sx - x0, fy1 = (y0 + 1.0f) - sy, fy0 = sy - y0;
+                const float ax = dx == 0 ? fx1 : (dx == -1 ? fx0 : 0.0f), bx = dx == 0 ? fx0 : (dx == 1 ? fx1 : 0.0f);
+                const float ay = dy == 0 ? fy1 : (dy == -1 ? fy0 : 0.0f), by = dy == 0 ? fy0 : (dy == 1 ? fy1 : 0.0f);
                 // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): clamped indices and the strides are < 2^24 (host-checked)
                 ob[v] = v * img_bytes + (int)__umul24(rb, row_bytes) + (int)__umul24(cb, pix_bytes);
                 mine[v] = make_float4(ay * ax, ay * bx, by * ax, by * bx);
