@@ -663,6 +663,27 @@ def test_gru_wta_ragged_image_sizes_match_oracle(hw):
     assert (n(d1)[0, :, :, 0] == depth).mean() > 0.97
 
 
+def test_gru_two_group_kernel_matches_the_default_sweep(monkeypatch):
+    """gru_fused2_kernel (gru_fused.hip; opt-in through MVS_GRU_TWO_GROUPS, measured 5 % slower than the default): two groups of four
+    waves with their own slabs, tiles dealt to whichever group asks first.  Same arithmetic per pixel; the float64 LayerNorm sums are
+    added in another order: the same planes up to ties, probabilities to 1e-4."""
+    from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
+    w = S.make_workload("small")
+    gp = S.make_gru_params("normal", seed=9, in_channels=w.channels, random_affine=True)
+    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
+    for hw in ((32, 48), (27, 41)):
+        feats = np.ascontiguousarray(w.features[:, :hw[0], :hw[1]])
+        monkeypatch.delenv("MVS_GRU_TWO_GROUPS", raising=False)
+        d0, p0 = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end, weights=weights, features=t(feats))
+        d0, p0 = n(d0).copy(), n(p0).copy()
+        monkeypatch.setenv("MVS_GRU_TWO_GROUPS", "1")
+        d1, p1 = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end, weights=weights, features=t(feats))
+        monkeypatch.delenv("MVS_GRU_TWO_GROUPS")
+        same = n(d1) == d0
+        assert same.mean() > 0.995, same.mean()
+        np.testing.assert_allclose(n(p1)[same], p0[same], rtol=1e-4)
+
+
 # ---- R10 end to end -------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,inverse,mode", [("toy", False, "normal"), ("toy", True, "normal"), ("small", False, "normal"),
                                                ("toy", False, "lite"), ("small", False, "semilite-py3")])
