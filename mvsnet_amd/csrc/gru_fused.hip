@@ -579,10 +579,11 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
 // the same arithmetic per pixel -- in two phases per tile: S = stage the tile (the pieces of virtual wave w were requested during
 // the previous tile's matrix phase, those of w + 4 are requested and waited for here, behind the other group's matrix work),
 // M = the two row sweeps and the two small jobs from the group's slab.
-// MEASURED (c3, same box): exact (parity suite, full-size fixtures, batch = single view) and 5 % SLOWER than gru_fused_kernel: 73.3
-// against 69.3 ms per 4-view sweep, 23.8 against 22.7 ms at one view.  Per-phase clock sums (-DGRU2_TIMERS prints them for one
+// MEASURED (c3, same box): exact (parity suite, full-size fixtures, batch = single view) and 3 % SLOWER than gru_fused_kernel: 71.6
+// against 69.3 ms per 4-view sweep, 23.65 against 22.66 ms at one view (73.3 / 23.8 before the second half's loads were moved behind
+// the second sweep).  Per-phase clock sums (-DGRU2_TIMERS prints them for one
 // workgroup): the matrix pipe is busy 76 % of a G launch (one-group kernel: 72 %), but a group spends a third of its tile in the S
-// phase -- 4 k clocks of it waiting for the second half's loads, which 256 VGPRs leave no room to prefetch -- and a tenth at its
+// phase and a tenth at its
 // two barriers; the SIMD serves its older wave first, so waves 4-7 run ~1.6x slower than waves 0-3 while both are busy (tiles are
 // dealt to whichever group asks first).  Opt-in (MVS_GRU_TWO_GROUPS=1): kept for the next step, which is a shorter S phase
 // (x pieces straight into LDS, offsets recomputed instead of kept) -- profiles/r05_gru_two_groups.txt.
@@ -669,10 +670,13 @@ gru_fused2_kernel(FusedArgs a, FusedDepth dv) {
             }
         }
     }
-    float4 pre[6], preg[3], prec[PHASE == 0 ? 3 : 1];
-    unsigned inside = 0;
+    // two register sets: the pieces of virtual wave wg (requested at the end of the S phase, in flight during the whole M phase) and
+    // those of wg + 4 (requested behind the second sweep of the M phase, when the sweep's accumulators and operand buffers are dead)
+    float4 pre_[2][6], preg_[2][3], prec_[2][PHASE == 0 ? 3 : 1];
+    unsigned inside_[2] = {0, 0};
     auto load_piece = [&](auto kc, int i, int tile) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
+        float4 (&pre)[6] = pre_[k]; float4 (&preg)[3] = preg_[k]; float4 (&prec)[PHASE == 0 ? 3 : 1] = prec_[k]; unsigned& inside = inside_[k];
         constexpr int FS = k == 0 ? 4 : 2;
         const int tg = tile < end ? tile : 0;
         const int th = tg / a.tiles_w, h0 = th * FTH, w0 = (tg - th * a.tiles_w) * FTW;
@@ -703,6 +707,7 @@ gru_fused2_kernel(FusedArgs a, FusedDepth dv) {
     auto stage_piece = [&](auto kc, int i, int tile_of) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         constexpr bool lo = k == 0;
+        const float4 (&pre)[6] = pre_[k]; const float4 (&preg)[3] = preg_[k]; const float4 (&prec)[PHASE == 0 ? 3 : 1] = prec_[k]; const unsigned inside = inside_[k];
         const bool blend_s = STEADY || (lo ? a.cell[1].blend : a.cell[2].blend);
         float4 v = pre[i];
         if (i < 3) { *(float4*)(slab + loff[k][i]) = v; return; }
@@ -766,6 +771,8 @@ gru_fused2_kernel(FusedArgs a, FusedDepth dv) {
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) load_piece(K0{}, i, gfirst);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) load_piece(K1{}, i, gfirst);
     constexpr int N4 = W1_FLOATS / 4, NS4 = WS_FLOATS / 4;
     constexpr int K1N = (N4 + FNT - 1) / FNT, K2N = (NS4 + FNT - 1) / FNT;
     {
@@ -861,8 +868,6 @@ gru_fused2_kernel(FusedArgs a, FusedDepth dv) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) stage_piece(K0{}, i, tile);
         GRU2_T(0)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) load_piece(K1{}, i, tile);
         // the winner-take-all accumulators of this tile's pixels (virtual waves 6, 7 of G)
         float wta_mp = 0.f, wta_es = 0.f;
         const bool svalid1 = h0 + srow[1] < a.H && w0 + scol < a.W;
@@ -925,6 +930,10 @@ gru_fused2_kernel(FusedArgs a, FusedDepth dv) {
                 }
             }
             GRU2_T(3 + k)
+            if (k == 1) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) load_piece(K1{}, i, next_tile);      // the next tile's second half: lands behind job 1, the barrier and stage A
+            }
             auto job20 = [&](const float* tab) __attribute__((always_inline)) -> f32x4 {
                 f32x4 r4[4] = {(f32x4){sbias[k][0], sbias[k][1], sbias[k][2], sbias[k][3]}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
                 const float* ap = tab + (lane & 3) * 4;
@@ -1060,7 +1069,7 @@ int launch_fused2(const FusedArgs& a, const FusedDepth& dv, int grid, size_t sme
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    // the two-group kernel is an experiment (5 % slower than the one-group kernel, see its header): opt-in, read per launch so that
+    // the two-group kernel is an experiment (3 % slower than the one-group kernel, see its header): opt-in, read per launch so that
     // a test can run both in one process
     if (getenv("MVS_GRU_TWO_GROUPS") != nullptr && !a.trace) gru_fused2_kernel<PHASE, STEADY><<<grid, FNT, smem, st>>>(a, dv);
     else gru_fused_kernel<PHASE, STEADY><<<grid, FNT, smem, st>>>(a, dv);

@@ -664,7 +664,7 @@ def test_gru_wta_ragged_image_sizes_match_oracle(hw):
 
 
 def test_gru_two_group_kernel_matches_the_default_sweep(monkeypatch):
-    """gru_fused2_kernel (gru_fused.hip; opt-in through MVS_GRU_TWO_GROUPS, measured 5 % slower than the default): two groups of four
+    """gru_fused2_kernel (gru_fused.hip; opt-in through MVS_GRU_TWO_GROUPS, measured 3 % slower than the default): two groups of four
     waves with their own slabs, tiles dealt to whichever group asks first.  Same arithmetic per pixel; the float64 LayerNorm sums are
     added in another order: the same planes up to ties, probabilities to 1e-4."""
     from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
