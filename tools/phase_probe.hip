@@ -104,7 +104,73 @@ void run(const char* what) {
     hipFree(out);
 }
 
+
+// NGRP groups of four waves (wave w, w + 4, w + 8 share a SIMD), each group alternating a vector phase and a matrix phase with a GROUP
+// barrier (LDS counter) after each: how busy does the matrix pipe get with two and with three waves per SIMD?
+template <int NGRP, int NM, int NV, int NT>
+__global__ void __launch_bounds__(256 * NGRP, 1) groups_kernel(int iters, long long* out, float seed) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int grp = wave >> 2;
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){seed, seed, seed, seed};
+    float v[16];
+    for (int i = 0; i < 16; ++i) v[i] = seed + i + lane;
+    const float a = seed * lane, b = seed + lane, m = 1.0f + seed * 1e-7f, c = seed * 1e-9f;
+    __shared__ unsigned gcount[4];
+    if (threadIdx.x < 4) gcount[threadIdx.x] = 0;
+    unsigned gtarget = 0;
+    auto group_sync = [&]() __attribute__((always_inline)) {
+        gtarget += 4;
+        if (lane == 0) __hip_atomic_fetch_add(&gcount[grp], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&gcount[grp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < gtarget) __builtin_amdgcn_s_sleep(1);
+    };
+    __syncthreads();
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        for (int r = 0; r < NV / 16; ++r) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(v[i], m, c);
+        }
+        for (int r = 0; r < NT / 16; ++r) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = __builtin_amdgcn_exp2f(v[i]) * 1e-30f + v[i];
+        }
+        group_sync();
+        for (int r = 0; r < NM / 8; ++r) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        }
+        group_sync();
+    }
+    const long long t1 = clock64();
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+    for (int i = 0; i < 16; ++i) s += v[i];
+    if (s == 12345.678f) out[4000] = 1;
+    if (lane == 0) out[blockIdx.x * 16 + wave] = t1 - t0;
+}
+template <int NGRP, int NM, int NV, int NT>
+void run_groups(const char* what) {
+    long long* out; hipMalloc(&out, 8192 * 8);
+    const int iters = 200;
+    static long long h[4096];
+    groups_kernel<NGRP, NM, NV, NT><<<256, 256 * NGRP>>>(iters, out, 1.0f);
+    groups_kernel<NGRP, NM, NV, NT><<<256, 256 * NGRP>>>(iters, out, 1.0f);
+    hipDeviceSynchronize();
+    hipMemcpy(h, out, sizeof(long long) * 4096, hipMemcpyDeviceToHost);
+    double s = 0; int cnt = 0;
+    for (int b2 = 0; b2 < 256; ++b2) for (int w = 0; w < 4 * NGRP; ++w) { s += (double)h[b2 * 16 + w]; ++cnt; }
+    const double per_iter = s / cnt / iters, pipe = (double)NGRP * NM * 32;
+    printf("%-58s %d waves per SIMD: %8.0f clocks per iteration of every group; matrix pipe needs %6.0f -> %.0f %% busy\n", what, NGRP, per_iter, pipe, 100.0 * pipe / per_iter);
+    hipFree(out);
+}
+
 int main() {
+    run_groups<2, 432, 1280, 96>("two groups: 432 matrix | 1280 vector + 96 exp2 per wave");
+    run_groups<3, 216, 768, 56>("three groups: 216 matrix | 768 vector + 56 exp2 per wave");
+    run_groups<3, 216, 1024, 64>("three groups: 216 matrix | 1024 vector + 64 exp2 per wave");
+    run_groups<2, 216, 768, 56>("two groups: 216 matrix | 768 vector + 56 exp2 per wave");
+    run_groups<1, 216, 768, 56>("one group: 216 matrix | 768 vector + 56 exp2 per wave");
     // matrix pipe per wave and phase: NM * 32 clk; vector: NV * 4 clk (+ NT * 16)
     run<216, 512, 0>("216 matrix | 512 vector (2048 clk)");
     run<216, 1024, 0>("216 matrix | 1024 vector (4096 clk)");
