@@ -176,32 +176,46 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
     // in the window, channel quad); a tile adds (pixel index of its window origin) * (bytes per pixel of the tensor).
     const int q8 = tid & 7, q4 = tid & 3;
     const int spos = min(tid & 255, FNPOS - 1);      // the small piece's position
-    int prc[6], loff[6], lx[3], lh[2], lg[2], lc[PHASE == 0 ? 2 : 1], so1[PHASE == 0 ? 2 : 1];
+    // Seven piece slots per thread: 0-3 x, 4-5 s1, 6 the small one.  The split is UNEVEN on purpose: waves 0-3 take four x pieces and two
+    // s1 pieces (items 0-1023 of 1440, 0-511 of 720), waves 4-7 two and one (the rest; slots 2, 3 and 5 are empty for them).  The SIMD serves
+    // its older wave first: with an even split waves 4-7 took twice as long over their staging as waves 0-3 (7.2 k against 3.6 k clocks of a
+    // 23 k-clock G tile), and waves 0-3 waited 3.8 k clocks at the tile's barrier (device stamps, profiles/r05_gru_uneven_staging.txt).
+    const bool front = wave < 4;                     // wave-uniform
+    const int nxp = front ? 4 : 2, nhp = front ? 2 : 1;
+    auto slot_live = [&](int i) { return i < 4 ? i < nxp : i < 6 ? i - 4 < nhp : true; };
+    int prc[7], loff[7], lx[4], lh[2], lg[2], lc[PHASE == 0 ? 2 : 1], so1[PHASE == 0 ? 2 : 1];
     int lhs, lgs, lcs = 0, sos = 0;
-    unsigned ownbits = 0;                            // bit i: piece i's position is one of the tile's own pixels
+    unsigned ownbits = 0;                            // bit i: slot i's position is one of the tile's own pixels
+    const int t4 = tid & 255;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 7; ++i) {
         int pos;
-        if (i < 3) { int f = tid + FNT * i; if (f >= FNPOS * 8) f -= FNT; pos = f >> 3; loff[i] = pos * S + 4 * q8; }
-        else if (i < 5) { int f = tid + FNT * (i - 3); if (f >= FNPOS * 4) f -= FNT; pos = f >> 2; loff[i] = pos * S + 32 + 4 * q4; }
-        else { pos = spos; loff[i] = pos * S + (PHASE == 0 ? (lo ? 48 : 52) : 64); }
+        if (i < 4) {
+            int f = front ? t4 + 256 * i : 1024 + t4 + 256 * (i & 1);
+            if (f >= FNPOS * 8) f -= 256;
+            pos = f >> 3; loff[i] = pos * S + 4 * q8;
+        } else if (i < 6) {
+            int f = front ? t4 + 256 * (i - 4) : 512 + t4;
+            if (f >= FNPOS * 4) f -= 256;
+            pos = f >> 2; loff[i] = pos * S + 32 + 4 * q4;
+        } else { pos = spos; loff[i] = pos * S + (PHASE == 0 ? (lo ? 48 : 52) : 64); }
         const int r = pos / FPW, c = pos - r * FPW;
         const int ppix = r * a.W + c;
         prc[i] = ((r - 1) & 0xffff) | ((c - 1) << 16);         // row / column relative to the tile's first pixel (-1 .. 8 / -1 .. 16), two 16-bit fields
         if (r >= 1 && r <= FTH && c >= 1 && c <= FTW) ownbits |= 1u << i;
-        if (i < 3) lx[i] = (int)a.x + ppix * 128 + 16 * q8;
-        else if (i < 5) {
-            lh[i - 3] = (int)a.cell[0].h + ppix * 64 + 16 * q4;
+        if (i < 4) lx[i] = (int)a.x + ppix * 128 + 16 * q8;
+        else if (i < 6) {
+            lh[i - 4] = (int)a.cell[0].h + ppix * 64 + 16 * q4;
             // G: update gate = channels [16,32) of the previous plane's gates; C: reset gate = channels [0,16) of this plane's
-            lg[i - 3] = (int)a.cell[0].g + ppix * 128 + 16 * q4 + (PHASE == 0 ? 64 : 0);
-            if (PHASE == 0) { lc[i - 3] = (int)a.cell[0].c + ppix * 64 + 16 * q4; so1[i - 3] = (int)a.cell[0].h_out + ppix * 64 + 16 * q4; }
+            lg[i - 4] = (int)a.cell[0].g + ppix * 128 + 16 * q4 + (PHASE == 0 ? 64 : 0);
+            if (PHASE == 0) { lc[i - 4] = (int)a.cell[0].c + ppix * 64 + 16 * q4; so1[i - 4] = (int)a.cell[0].h_out + ppix * 64 + 16 * q4; }
         } else {
             lhs = (int)(lo ? a.cell[1].h : a.cell[2].h) + ppix * (4 * FS);       // s3: two floats of this pixel, two of the next (unused)
             lgs = (int)(lo ? a.cell[1].g : a.cell[2].g) + ppix * (8 * FS) + (PHASE == 0 ? 4 * FS : 0);
             if (PHASE == 0) { lcs = (int)(lo ? a.cell[1].c : a.cell[2].c) + ppix * (4 * FS); sos = (int)(lo ? a.cell[1].h_out : a.cell[2].h_out) + ppix * (4 * FS); }
         }
     }
-    float4 pre[6], preg[3], prec[PHASE == 0 ? 3 : 1];
+    float4 pre[7], preg[3], prec[PHASE == 0 ? 3 : 1];
     unsigned inside = 0;                             // bit i: piece i's position of the tile in flight lies inside the image
     auto load_piece = [&](int i, int tile) __attribute__((always_inline)) {
         const int tg = tile < end ? tile : 0;        // past the end: a harmless reload of tile 0
@@ -209,17 +223,17 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         const int bp = (h0 - 1) * a.W + (w0 - 1);    // pixel index of the staged window's origin (scalar; may be negative)
         const int rr = (prc[i] << 16) >> 16, cc = prc[i] >> 16;
         const bool in = (unsigned)(h0 + rr) < (unsigned)a.H && (unsigned)(w0 + cc) < (unsigned)a.W;      // SAME padding: zeros outside
-        if (i < 3) pre[i] = ld_b128(rs, in ? lx[i] + bp * 128 : FBAD);
-        else if (i < 5) {
-            pre[i] = ld_b128(rs, in ? lh[i - 3] + bp * 64 : FBAD);
-            preg[i - 3] = ld_b128(rs, in ? lg[i - 3] + bp * 128 : FBAD);
-            if (PHASE == 0) prec[i - 3] = ld_b128(rs, in ? lc[i - 3] + bp * 64 : FBAD);
+        if (i < 4) pre[i] = ld_b128(rs, in ? lx[i] + bp * 128 : FBAD);
+        else if (i < 6) {
+            pre[i] = ld_b128(rs, in ? lh[i - 4] + bp * 64 : FBAD);
+            preg[i - 4] = ld_b128(rs, in ? lg[i - 4] + bp * 128 : FBAD);
+            if (PHASE == 0) prec[i - 4] = ld_b128(rs, in ? lc[i - 4] + bp * 64 : FBAD);
         } else {
-            pre[5] = ld_b128(rs, in ? lhs + bp * (4 * FS) : FBAD);
+            pre[6] = ld_b128(rs, in ? lhs + bp * (4 * FS) : FBAD);
             preg[2] = ld_b128(rs, in ? lgs + bp * (8 * FS) : FBAD);
             if (PHASE == 0) prec[2] = ld_b128(rs, in ? lcs + bp * (4 * FS) : FBAD);
         }
-        if (PHASE == 0 && i >= 3) inside = in ? inside | (1u << i) : inside & ~(1u << i);
+        if (PHASE == 0 && i >= 4) inside = in ? inside | (1u << i) : inside & ~(1u << i);
     };
     // One channel of the blend u*h + (1-u)*tanh(y), u = sigmoid(gate) (convgru.py:98,102,114-120) as ONE division:
     //   A = e^-gate, B = e^-2|y|:   u = 1/(1+A),  tanh(y) = sgn(y) (1-B)/(1+B)   =>   h' = (h (1+B) + A sgn(y) (1-B)) / ((1+A)(1+B))
@@ -237,15 +251,15 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
     };
     auto stage_piece = [&](int i, float* buf, float* mbuf, int tile_of) __attribute__((always_inline)) {
         float4 v = pre[i];                           // zeros outside the image (SAME padding)
-        if (i < 3) { *(float4*)(buf + loff[i]) = v; return; }
-        const int gi = i < 5 ? i - 3 : 2;
+        if (i < 4) { *(float4*)(buf + loff[i]) = v; return; }
+        const int gi = i < 6 ? i - 4 : 2;
         const float4 gq = preg[gi];
         if (PHASE == 0) {
             // the state entering this cell's plane: the blend of the plane before; evaluated on every path (first plane of a
             // cell: the loaded zeros are kept)
-            const bool bl = i < 5 ? blend1 : blend_s;
+            const bool bl = i < 6 ? blend1 : blend_s;
             const float4 cq = prec[gi];
-            const int uq = i < 5 ? q4 : (lo ? 8 : 10), oq = i < 5 ? 4 + q4 : (lo ? 9 : 11);
+            const int uq = i < 6 ? q4 : (lo ? 8 : 10), oq = i < 6 ? 4 + q4 : (lo ? 9 : 11);
             const float4 ua = *(const float4*)lnS[uq], ub = *(const float4*)lnT[uq], ca = *(const float4*)lnS[oq], cb = *(const float4*)lnT[oq];
             float4 b;
             b.x = blend1ch(v.x, gq.x, cq.x, ua.x, ub.x, ca.x, cb.x); b.y = blend1ch(v.y, gq.y, cq.y, ua.y, ub.y, ca.y, cb.y);
@@ -256,7 +270,7 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
             const bool own = (STEADY || bl) && tile_of < end && ((ownbits >> i) & 1u) && in;
             const int th = tile_of / a.tiles_w, h0 = th * FTH, w0 = (tile_of - th * a.tiles_w) * FTW;
             const int bp = (h0 - 1) * a.W + (w0 - 1);
-            if (i < 5) st_b128(rs, own ? so1[i - 3] + bp * 64 : FBAD, v.x, v.y, v.z, v.w);
+            if (i < 6) st_b128(rs, own ? so1[i - 4] + bp * 64 : FBAD, v.x, v.y, v.z, v.w);
             else {
                 st_b128(rs, own && lo ? sos + bp * 16 : FBAD, v.x, v.y, v.z, v.w);
                 st_b64(rs, own && !lo ? sos + bp * 8 : FBAD, v.x, v.y);
@@ -264,17 +278,17 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
             *(float4*)(buf + loff[i]) = v;           // (s3: floats 54, 55 of the position receive two unused values)
         } else {
             // xb = sigmoid(LN(g_r)) * h (convgru.py:97,101,107) = h / (1 + e^-gate); the next cell's xa is the state itself
-            const int rq = i < 5 ? q4 : (lo ? 4 : 5);
+            const int rq = i < 6 ? q4 : (lo ? 4 : 5);
             const float4 ra = *(const float4*)lnS[rq], rb = *(const float4*)lnT[rq];
             float4 rv;
             rv.x = v.x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.x, ra.x, rb.x)));
             rv.y = v.y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.y, ra.y, rb.y)));
             rv.z = v.z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.z, ra.z, rb.z)));
             rv.w = v.w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.w, ra.w, rb.w)));
-            if (i < 5) { *(float4*)(buf + loff[i]) = rv; *(float4*)(buf + loff[i] + 16) = v; }
+            if (i < 6) { *(float4*)(buf + loff[i]) = rv; *(float4*)(buf + loff[i] + 16) = v; }
             else {       // s2: r2*s2 at 64, s2 at 68;  s3: r3*s3 into the side slab, the state itself is nobody's operand
-                float* da = lo ? buf + loff[5] : mbuf + 4 * spos;
-                float* db = lo ? buf + loff[5] + 4 : mini + 2 * FNPOS * 4 + 4 * spos;
+                float* da = lo ? buf + loff[6] : mbuf + 4 * spos;
+                float* db = lo ? buf + loff[6] + 4 : mini + 2 * FNPOS * 4 + 4 * spos;
                 *(float4*)da = rv; *(float4*)db = v;
             }
         }
@@ -299,7 +313,7 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         ln_sub = f & 3; ln_kind = kind;
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) load_piece(i, first);
+    for (int i = 0; i < 7; ++i) if (slot_live(i)) load_piece(i, first);
     // prepared weights: all loads of a thread in flight at once (one round trip instead of three); they are written to LDS AFTER
     // the first tile has been staged -- its loads were issued before these and return first, so the blend arithmetic of tile 0
     // runs while the weights are still on their way
@@ -363,14 +377,14 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
     __syncthreads();
     if (a.trace) tpa = wall_clock64();             // affines in LDS, everybody through the first barrier
 #pragma unroll
-    for (int i = 0; i < 6; ++i) stage_piece(i, slab, mini, first);
+    for (int i = 0; i < 7; ++i) if (slot_live(i)) stage_piece(i, slab, mini, first);
     if (a.trace) tpb = wall_clock64();             // first tile staged (this wave)
 #pragma unroll
     for (int k = 0; k < K1; ++k) reinterpret_cast<f32x4*>(wl)[min(tid + FNT * k, N4 - 1)] = wt1[k];       // (the clamped lanes rewrite the last quad)
 #pragma unroll
     for (int k = 0; k < K2; ++k) reinterpret_cast<f32x4*>(wsm)[min(tid + FNT * k, NS4 - 1)] = wt2[k];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) load_piece(i, first + stride);
+    for (int i = 0; i < 7; ++i) if (slot_live(i)) load_piece(i, first + stride);
     if (a.trace) tpc = wall_clock64();             // weights in LDS, second tile requested (this wave)
     __syncthreads();
 
@@ -419,9 +433,9 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
                 if (g + 1 < NG) load_grp(g + 1, bv[(g + 1) & 1], av[(g + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    if ((i * (NG / 2)) / 6 == g) stage_piece(i, nxt, mnxt, tile + stride);
-                    if (NG / 2 + (i * (NG - NG / 2)) / 6 == g) load_piece(i, tile + 2 * stride);
+                for (int i = 0; i < 7; ++i) {
+                    if ((i * (NG / 2)) / 7 == g && slot_live(i)) stage_piece(i, nxt, mnxt, tile + stride);
+                    if (NG / 2 + (i * (NG - NG / 2)) / 7 == g && slot_live(i)) load_piece(i, tile + 2 * stride);
                 }
                 const bool xgroup = (g % 3) < 2;     // compile-time after unrolling
 #pragma unroll
