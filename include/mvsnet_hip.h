@@ -53,6 +53,21 @@ const char* mvs_error_string(int code);
 int mvs_set_conv_impl(int impl);
 int mvs_get_conv_impl(void);
 
+/* Test / measurement hooks.  The library reads NOTHING from the environment: every switch that lets a test reach a schedule the
+ * launchers would not pick by themselves is one of these process-wide integers (atomic; read at launch time, so set them while
+ * no call of the library is in flight).  Results never depend on them except where stated; 0 (or the stated default) = the
+ * product behaviour.  mvs_set_test_hook returns MVS_E_BADARG for an unknown id or a value outside the hook's range and leaves
+ * the hook unchanged; mvs_get_test_hook returns the current value (or MVS_E_BADARG). */
+#define MVS_HOOK_CV_TILE_ROWS_LOG2    0  /* warp + variance: force the wave tile to 2^v rows (v = 0..3); -1 (default) = voted from the transforms.  Same bits */
+#define MVS_HOOK_CONV_NO_SPAN         1  /* 1: 3dconv0_1 + 1_0 launch walks whole depth chunks instead of SPAN ranges.  Same bits */
+#define MVS_HOOK_CONV_NO_FUSE2        2  /* 1: 3dconv1_1 and 2_0 run as two launches instead of the fused one.  Same bits */
+#define MVS_HOOK_S2_PLANES            3  /* >= 1: output planes per workgroup of the stride-2 plane-march kernel; 0 = the launcher's choice.  Same bits */
+#define MVS_HOOK_GRU_ONE_STREAM       4  /* 1: the wavefront formulations of the recurrent sweep stay on the caller's stream.  Same bits */
+#define MVS_HOOK_GRU_PRODUCER_THREADS 5  /* threads per workgroup of the wavefront's producer launches: 64, 128 (default), 192 or 256.  Same bits */
+#define MVS_HOOK_COUNT                6
+int mvs_set_test_hook(int id, int value);
+int mvs_get_test_hook(int id);
+
 /* ---------------------------------------------------------------------------------------------
  * R1/R1' + R2 prep: plane-induced homographies and their tf.contrib.image.transform 8-vectors.
  * Replaces get_homographies (mvsnet/homography_warping.py:10-58), get_homographies_inv_depth
@@ -323,9 +338,12 @@ int mvs_gru_wta_f32(const float* ref, const float* src, const float* transforms,
  *   depth_out / prob_out (views, H, W)
  * Shape limits (both entry points): f1, f2, f3 <= 64, MVS_E_SHAPE otherwise (the blend kernels keep 2 x F LayerNorm affines per
  * cell in LDS and the staging code is written for at most 64 state channels; the reference uses 16 / 4 / 2, the 'fat' variant
- * 32 / 8 / 4); views in 1..8 (MVS_E_BADARG); C as mvs_cost_volume_f32 accepts it.  The fused two-launch sweep covers C = 32 with 16 / 4 / 2; every other accepted shape
- * runs the wavefront kernels.
+ * 32 / 8 / 4); views in 1..8 (MVS_E_BADARG); C as mvs_cost_volume_f32 accepts it.  The fused two-launch sweep covers C = 32 with 16 / 4 / 2 while a view's
+ * workspace block (mvs_gru_workspace_bytes, ~10.2 KB per pixel) stays below 2 GiB -- its kernels address the block with 32-bit
+ * byte offsets -- i.e. feature maps up to ~210 k pixels; larger maps (e.g. 576 x 384) and every other accepted shape run the
+ * wavefront kernels.  mvs_gru_fused_route is that predicate (1 = fused), decided before anything is enqueued.
  */
+int mvs_gru_fused_route(int C, int f1, int f2, int f3, size_t view_block_bytes);
 int mvs_gru_wta_batch_f32(const float* const* ref, const float* const* src, const float* const* transforms,
                           int views, int view_num, int depth_num, int H, int W, int C, int f1, int f2,
                           int f3, const float* const* params, const float* depth_values, void* workspace,

@@ -84,6 +84,9 @@ SIGNATURES = {
     "mvs_gru_wta_f32": (_i, [_p, _p, _p] + [_i] * 8 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
     "mvs_gru_wta_batch_f32": (_i, [_pp, _pp, _pp] + [_i] * 9 + [_pp, C.POINTER(C.c_float), _p, _sz, _p, _p, _p]),
     "mvs_gru_set_formulation": (_i, [_i]),
+    "mvs_gru_fused_route": (_i, [_i, _i, _i, _i, _sz]),
+    "mvs_set_test_hook": (_i, [_i, _i]),
+    "mvs_get_test_hook": (_i, [_i]),
     "mvs_gru_fused_trace": (_i, [_p, _i]),
     "mvs_gru_prepare": (_i, [_p]),
     "mvs_gru_release": (_i, [_p]),
@@ -92,6 +95,11 @@ SIGNATURES = {
 }
 
 CONV_IMPL = {"auto": 0, "scalar": 1, "mfma": 2, "bf16x3": 3}
+# ids of mvs_set_test_hook (include/mvsnet_hip.h MVS_HOOK_*): the library reads nothing from the environment
+HOOKS = {"cv_tile_rows_log2": 0, "conv_no_span": 1, "conv_no_fuse2": 2, "s2_planes": 3, "gru_one_stream": 4,
+         "gru_producer_threads": 5}
+HOOK_DEFAULTS = {"cv_tile_rows_log2": -1, "conv_no_span": 0, "conv_no_fuse2": 0, "s2_planes": 0, "gru_one_stream": 0,
+                 "gru_producer_threads": 128}
 
 _lib = None
 
@@ -212,3 +220,25 @@ def ptr_array(tensors):
 
 def set_conv_impl(name: str):
     check(load().mvs_set_conv_impl(CONV_IMPL[name]), "mvs_set_conv_impl")
+
+
+def set_test_hook(name: str, value: int):
+    """mvs_set_test_hook by name (tests and measurement tools only; HOOKS)."""
+    check(load().mvs_set_test_hook(HOOKS[name], int(value)), "mvs_set_test_hook(%s, %d)" % (name, value))
+
+
+class test_hooks:
+    """Context manager: sets hooks by name, restores the defaults on exit.  ``with _lib.test_hooks(conv_no_span=1): ...``"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_test_hook(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_test_hook(k, HOOK_DEFAULTS[k])
+        return False

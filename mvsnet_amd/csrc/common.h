@@ -9,6 +9,11 @@
 #define MVS_CHECK_ARG(cond) do { if (!(cond)) return MVS_E_BADARG; } while (0)
 #define MVS_LAUNCH_RET() do { hipError_t e__ = hipGetLastError(); return (int)e__; } while (0)
 
+// test / measurement hooks (mvs_set_test_hook, include/mvsnet_hip.h; defined in regnet.hip).  No getenv anywhere in the library.
+#include <atomic>
+extern std::atomic<int> mvs_hooks[MVS_HOOK_COUNT];
+static inline int mvs_hook(int id) { return mvs_hooks[id].load(std::memory_order_relaxed); }
+
 static inline hipStream_t mvs_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int mvs_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -475,7 +475,7 @@ int launch_c8(const ConvArgs& a0, const FuseArgs& fa, hipStream_t st) {
         // steps), 5 tiles / 16 workgroups fill every slot with ranges of 60 (60 + 3, + 2 across a boundary): 581 -> 565 us,
         // 921 -> 935 depth maps/s on one box.  Ranges 8 planes shorter across a boundary (62 / 54) and a pairing of long with
         // short ranges on a CU measured the same (profiles/r04_pair_span_ab.txt).
-        if (!aff && !getenv("MVS_CONV_NO_SPAN")) {      // (test hook: whole depth chunks, the schedule SPAN replaces)
+        if (!aff && !mvs_hook(MVS_HOOK_CONV_NO_SPAN)) {      // (test hook: whole depth chunks, the schedule SPAN replaces)
             const long long chunk_cost = (((long long)tiles * grid.z + 511) / 512) * (a.planes_per_wg + 3);
             int bg = 0, bm = 0; long long bcost = chunk_cost;
             for (int G = 1; G <= 8; ++G) {

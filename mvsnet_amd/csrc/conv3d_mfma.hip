@@ -567,7 +567,7 @@ int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const
 // 3dconv1_1 (x -> y, 16 -> 16, stride 1) and 3dconv2_0 (x -> y2, 16 -> 32, stride 2) over the same BN + ReLU input in one pass
 int mvs_conv3d_s1s2_16_bn(const float* x, const BnSrc& bn, const float* w, const float* wprep, int D, int H, int W, float* y,
                           double* stats, const float* w2, float* y2, double* stats2, hipStream_t st, int stats_slots) {
-    if (getenv("MVS_CONV_NO_FUSE2")) return MVS_E_SHAPE;      // test hook: the caller then runs the two layers apart (tests/test_gpu_parity.py)
+    if (mvs_hook(MVS_HOOK_CONV_NO_FUSE2)) return MVS_E_SHAPE;      // test hook: the caller then runs the two layers apart (tests/test_gpu_parity.py)
     ConvArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, w, y, stats, D, H, W, 16, 0, 0, 0, 0, bn, BnSrc{}, wprep, nullptr, stats_slots};
     return launch_s1_fuse2(a, Fuse2Args{w2, y2, stats2, stats_slots}, st);
 }

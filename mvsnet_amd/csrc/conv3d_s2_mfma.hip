@@ -259,7 +259,7 @@ int launch_s2(const ConvArgs& a0, int Cout, hipStream_t st) {
     a.planes_per_wg = conv_pick_planes(Do, (long long)tiles * groups, 1);
     // test hook (tests/test_gpu_parity.py::test_stride2_plane_ranges): output planes per workgroup, so that every
     // residue of the 4-way unrolled plane march and every end-of-range case is reachable at small sizes
-    if (const char* e = getenv("MVS_S2_PLANES")) { const int v = atoi(e); if (v >= 1) a.planes_per_wg = v < Do ? v : Do; }
+    if (const int v = mvs_hook(MVS_HOOK_S2_PLANES)) a.planes_per_wg = v < Do ? v : Do;
     dim3 grid(tiles, groups, (Do + a.planes_per_wg - 1) / a.planes_per_wg);
     size_t smem = (size_t)(9 * (CIN / 4) * 48 * 4 + 2 * (2 * TOH + 1) * IW * SlabGeom<CIN>::S) * sizeof(float);
     static bool attr_done = false;

@@ -294,10 +294,9 @@ void launch_sweep(const float* ref, const float* src, const float* transforms, i
     // Q = 2 (8 channels per lane) halves the per-lane bookkeeping per channel but needs 236 VGPRs
     // (2 waves/SIMD instead of 3): measured 0.258 ms vs 0.243 ms at the metric config, so only Q = 1 is instantiated.
     const int lg = C / 4, ppw = 64 / lg, nw = threads / 64;
-    // wave tile: rows x columns of pixels, voted in the kernel from the transforms (ty_log2 = -1); MVS_CV_TILE_ROWS_LOG2 = 0..3 forces
+    // wave tile: rows x columns of pixels, voted in the kernel from the transforms (ty_log2 = -1); the test hook MVS_HOOK_CV_TILE_ROWS_LOG2 = 0..3 forces
     // a shape (tests, measurements).  The grid covers the shape that needs the most workgroups; the others return early.
-    const char* ty_env = getenv("MVS_CV_TILE_ROWS_LOG2");
-    int ty_log2 = ty_env ? atoi(ty_env) : -1;
+    int ty_log2 = mvs_hook(MVS_HOOK_CV_TILE_ROWS_LOG2);
     if (ty_log2 > 3) ty_log2 = 3;
     while (ty_log2 >= 0 && (1 << ty_log2) > ppw) --ty_log2;
     int blocks = 0;
@@ -341,6 +340,8 @@ int mvs_cost_volume_threads_f32(const float* ref, const float* src, const float*
     MVS_CHECK_ARG(ref && src && transforms && cost);
     MVS_CHECK_ARG(view_num >= 2 && depth_total >= 1 && d_begin >= 0 && d_count >= 1 &&
                   d_begin + d_count <= depth_total && H > 0 && W > 0 && C > 0);
+    // whole waves only, within __launch_bounds__(256): the LDS bookkeeping table is sized per wave
+    MVS_CHECK_ARG(threads == 64 || threads == 128 || threads == 192 || threads == 256);
     if (C % 4 != 0) return MVS_E_SHAPE;
     long long total = (long long)H * W * (C / 4);
     dim3 grid(mvs_cdiv(total, 256), d_count);

@@ -843,6 +843,11 @@ wta_finish_views_kernel(const float* max_prob, const float* exp_sum, const float
 }
 }  // namespace
 
+// shape part of the routing decision of mvs_gru_wta*_f32 (exported for the CPU-side routing test; tests/test_abi_and_io.py)
+extern "C" int mvs_gru_fused_route(int C, int f1, int f2, int f3, size_t view_block_bytes) {
+    return C == 32 && f1 == 16 && f2 == 4 && f3 == 2 && view_block_bytes < ((size_t)1 << 31);
+}
+
 extern "C" size_t mvs_gru_workspace_bytes(int H, int W, int C, int f1, int f2, int f3) {
     return carve(nullptr, H, W, C, f1, f2, f3).bytes;
 }
@@ -908,7 +913,10 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
     // wavefront with the hoisted x-part (formulation 1) is still 3-4 % faster (c3, same box: 21.8 against 22.6 ms): a batch of views
     // must give the single view's bits, and from two views per sweep on, and under hipGraph capture (23.4 against 37 ms), the fused
     // sweep is the faster or equal one (profiles/r05_gru_ab_forms.txt).
-    const bool fused = mfma1 && f2 == 4 && f3 == 2 && (form == 0 || form == 3);
+    // The fused kernels address a whole view's workspace block through one buffer resource with 32-bit byte offsets: blocks of
+    // 2 GiB and more (~10.2 KB per pixel: feature maps above ~210 k pixels, e.g. 576 x 384) take the wavefront route, which
+    // addresses every tensor by itself -- decided HERE, before anything is enqueued.
+    const bool fused = mvs_gru_fused_route(C, f1, f2, f3, vstride) && mfma1 && (form == 0 || form == 3);
     if (fused) {
         GruFusedWs fw;
         fw.base = (char*)workspace; fw.x = ws.x;
@@ -926,9 +934,9 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
         // set, and under hipGraph capture, everything stays on the caller's stream.
         hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
         const bool capturing0 = hipStreamIsCapturing(st, &cs0) == hipSuccess && cs0 != hipStreamCaptureStatusNone;
-        GruStreams* pg = (!capturing0 && depth_num > XB && getenv("MVS_GRU_ONE_STREAM") == nullptr) ? gru_find(st) : nullptr;
+        GruStreams* pg = (!capturing0 && depth_num > XB && !mvs_hook(MVS_HOOK_GRU_ONE_STREAM)) ? gru_find(st) : nullptr;
         const hipStream_t sx = pg ? pg->s[2] : st;
-        static const int small_wg = getenv("MVS_GRU_PRODUCER_THREADS") ? atoi(getenv("MVS_GRU_PRODUCER_THREADS")) : 128;      // A/B hook
+        const int small_wg = mvs_hook(MVS_HOOK_GRU_PRODUCER_THREADS);      // A/B hook, validated by mvs_set_test_hook (64 / 128 / 192 / 256)
         auto xhalf = [&](int bidx) -> float* { return pg ? ws.px + (size_t)(bidx & 1) * XB * hw * C : ws.x; };
         auto produce = [&](int bidx, hipStream_t s) -> int {
             const int t0 = bidx * XB, nb = depth_num - t0 < XB ? depth_num - t0 : XB;
@@ -1010,7 +1018,7 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
     // grid, so the ~7 launches per plane, their ~5 us floors and the cross-stream waits are shared by `views` depth maps.
     const int ring = RG * PG;
     const bool wavefront = route[0] && route[1] && route[2] && depth_num > 2 * PG &&
-                           getenv("MVS_GRU_ONE_STREAM") == nullptr;      // test hook (parity of the one-stream sweep), read per sweep
+                           !mvs_hook(MVS_HOOK_GRU_ONE_STREAM);      // test hook (parity of the one-stream sweep), read per sweep
     // Under hipGraph capture the WAVEFRONT formulations go to the caller's stream alone.  Root cause of the round-4 host crash
     // (profiles/r05_capture_wavefront_root_cause.txt): hip::Stream::EndCapture() of the HIP runtime the PyTorch wheel bundles
     // (libamdhip64 7.0.70002, the runtime every Python process of this library runs on) recurses without bound once two captured
@@ -1020,8 +1028,8 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
     // illegal.  The default formulation (gru_fused.hip) has no cross-stream pattern and is captured at full speed.
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-    static const bool capture_wavefront = getenv("MVS_GRU_CAPTURE_WAVEFRONT") != nullptr;      // diagnostic hook (tools/capture_wavefront_lib.py)
-    GruStreams* gs = (wavefront && (!capturing || capture_wavefront)) ? gru_find(st) : nullptr;
+    // (tools/capture_wavefront_repro.hip is the standalone evidence; the library has no switch that re-enables the crashing path)
+    GruStreams* gs = (wavefront && !capturing) ? gru_find(st) : nullptr;
     if (wavefront && !capturing && !gs) {
         // no side streams for this caller stream: this entry point creates none (mvs_gru_prepare does) -- run the sweep on the
         // caller's stream alone (same results, ~1.7x the time at 400 x 300) and say so once.

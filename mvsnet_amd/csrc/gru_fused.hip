@@ -582,487 +582,6 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
 }
 
 
-// ---- the same launch as TWO groups of four waves that share nothing but the weights (round 5, late) --------------------------
-// tools/phase_probe.hip: when the two waves of a SIMD alternate long matrix and long vector phases and meet at a workgroup-wide
-// s_barrier after every phase, a tile costs matrix time + vector time (the barrier keeps re-aligning them: 33.7 k clocks for 432
-// matrix + 1024 vector instructions per wave, lockstep or anti-phase); when each wave only synchronises with waves of OTHER SIMDs
-// the two drift into opposite phases by themselves and the vector time disappears behind the matrix pipe (27.4 k = the pipe alone).
-// gru_fused_kernel above is the first case: eight waves, one tile, a __syncthreads() per tile.  Here waves 0-3 and waves 4-7 are two
-// groups (wave w and w + 4 share a SIMD), each with its own slab, its own tiles and its own barrier (an LDS counter); a physical
-// wave plays the two "virtual" waves w and w + 4 of gru_fused_kernel one after the other -- the same rows, pieces and small jobs,
-// the same arithmetic per pixel -- in two phases per tile: S = stage the tile (the pieces of virtual wave w were requested during
-// the previous tile's matrix phase, those of w + 4 are requested and waited for here, behind the other group's matrix work),
-// M = the two row sweeps and the two small jobs from the group's slab.
-// MEASURED (c3, same box): exact (parity suite, full-size fixtures, batch = single view) and 3 % SLOWER than gru_fused_kernel: 71.6
-// against 69.3 ms per 4-view sweep, 23.65 against 22.66 ms at one view (73.3 / 23.8 before the second half's loads were moved behind
-// the second sweep).  Per-phase clock sums (-DGRU2_TIMERS prints them for one
-// workgroup): the matrix pipe is busy 76 % of a G launch (one-group kernel: 72 %), but a group spends a third of its tile in the S
-// phase and a tenth at its
-// two barriers; the SIMD serves its older wave first, so waves 4-7 run ~1.6x slower than waves 0-3 while both are busy (tiles are
-// dealt to whichever group asks first).  Opt-in (MVS_GRU_TWO_GROUPS=1): kept for the next step, which is a shorter S phase
-// (x pieces straight into LDS, offsets recomputed instead of kept) -- profiles/r05_gru_two_groups.txt.
-template <int PHASE, bool STEADY>
-__global__ void __launch_bounds__(FNT, 1)
-gru_fused2_kernel(FusedArgs a, FusedDepth dv) {
-    constexpr int S = PHASE == 0 ? 56 : 72;
-    constexpr int COUT = PHASE == 0 ? 32 : 16, MT = COUT / 16;
-    constexpr int CQ = 12, WROW = COUT * 4, W1_FLOATS = 9 * CQ * WROW;
-    constexpr int T2 = 9 * 5 * 16, T3 = 9 * 2 * 16;
-    constexpr int WS_FLOATS = PHASE == 0 ? 2 * T2 + T3 + 20 : T2 + T3;
-    constexpr int SLAB = FNPOS * S;
-    constexpr int XA2 = PHASE == 0 ? 32 : 48;
-    constexpr int XA3 = PHASE == 0 ? 48 : 68;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wl = smem;
-    float* wsm = wl + W1_FLOATS;
-    float* slab_all = wsm + WS_FLOATS;               // [2 groups][FNPOS][S]
-    float* mini_all = slab_all + 2 * SLAB;           // C: [2 groups][FNPOS][4] r3*s3 (.xy), then [FNPOS][4] for the stores nobody reads
-    __shared__ __attribute__((aligned(16))) float lnS[12][4], lnT[12][4];
-    __shared__ double red[2][8][8];
-    __shared__ unsigned gcount[2];
-    __shared__ int tctr, gq[2];
-    __builtin_amdgcn_s_setprio(3);
-
-    const int tid = threadIdx.x, lane = tid & 63, pw = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = pw >> 2, wg = pw & 3;            // group, wave inside the group; virtual waves wg and wg + 4
-    const int n = lane & 15, kq = lane >> 4;
-    const int view = blockIdx.x / a.wg_per_view, j = blockIdx.x - view * a.wg_per_view;
-    const size_t vo = (size_t)view * a.vstride;
-    auto vp = [vo](auto* p) { return p ? (decltype(p))((const char*)p + vo) : p; };
-    auto cell_sel = [&](int k, auto f) { return k == 0 ? f(a.cell[0]) : k == 1 ? f(a.cell[1]) : f(a.cell[2]); };
-    const int tiles = a.tiles_h * a.tiles_w;
-    int first, stride, end;
-    if ((a.wg_per_view & 7) == 0) {
-        const int xcd = j & 7, tb = (tiles + 7) >> 3;
-        first = xcd * tb + (j >> 3); stride = a.wg_per_view >> 3; end = min(tiles, (xcd + 1) * tb);
-    } else { first = j; stride = a.wg_per_view; end = tiles; }
-    // The workgroup's tiles first, first + stride, ... : index 0 and 1 go to the two groups, every further index to the group that asks
-    // first (an LDS counter; the waves of a SIMD are served oldest first, so the second group runs ~1.5x slower than the first while
-    // both are busy -- dealt alternately it finished 25 % after the first).  A group knows its tile one tile ahead (the prefetch).
-    const int gfirst = first + grp * stride;
-    float* slab = slab_all + grp * SLAB;
-    float* mini = mini_all + grp * FNPOS * 4;
-    float* trash = mini_all + 2 * FNPOS * 4;
-
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)vp(a.ws), 0, (int)a.vstride, 0x00020000);
-    const bool blend1 = STEADY || a.cell[0].blend;
-    const bool live1 = STEADY || a.cell[0].conv, live2 = STEADY || a.cell[1].conv, live3 = STEADY || a.cell[2].conv;
-    if (tid < 2) gcount[tid] = 0;
-    if (tid == 0) { tctr = 4; gq[0] = 2; gq[1] = 3; }      // indices 0, 1 are in hand, 2, 3 are the groups' first "next" tiles
-
-    // ---- staging pieces of the two virtual waves (k = 0: wave wg, the small piece is s2; k = 1: wave wg + 4, the small piece is s3)
-    const int q8 = lane & 7, q4 = lane & 3;
-    const int spos = min(wg * 64 + lane, FNPOS - 1);
-    int prc[2][6], loff[2][6], lx[2][3], lh[2][2], lg[2][2], lc[2][PHASE == 0 ? 2 : 1], so1[2][PHASE == 0 ? 2 : 1];
-    int lhs[2], lgs[2], lcs[2] = {0, 0}, sos[2] = {0, 0};
-    unsigned ownbits[2] = {0, 0};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int vt = (wg + 4 * k) * 64 + lane;
-        const bool lo = k == 0;
-        const int FS = lo ? 4 : 2;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            int pos;
-            if (i < 3) { int f = vt + FNT * i; if (f >= FNPOS * 8) f -= FNT; pos = f >> 3; loff[k][i] = pos * S + 4 * q8; }
-            else if (i < 5) { int f = vt + FNT * (i - 3); if (f >= FNPOS * 4) f -= FNT; pos = f >> 2; loff[k][i] = pos * S + 32 + 4 * q4; }
-            else { pos = spos; loff[k][i] = pos * S + (PHASE == 0 ? (lo ? 48 : 52) : 64); }
-            const int r = pos / FPW, c = pos - r * FPW;
-            const int ppix = r * a.W + c;
-            prc[k][i] = ((r - 1) & 0xffff) | ((c - 1) << 16);
-            if (r >= 1 && r <= FTH && c >= 1 && c <= FTW) ownbits[k] |= 1u << i;
-            if (i < 3) lx[k][i] = (int)a.x + ppix * 128 + 16 * q8;
-            else if (i < 5) {
-                lh[k][i - 3] = (int)a.cell[0].h + ppix * 64 + 16 * q4;
-                lg[k][i - 3] = (int)a.cell[0].g + ppix * 128 + 16 * q4 + (PHASE == 0 ? 64 : 0);
-                if (PHASE == 0) { lc[k][i - 3] = (int)a.cell[0].c + ppix * 64 + 16 * q4; so1[k][i - 3] = (int)a.cell[0].h_out + ppix * 64 + 16 * q4; }
-            } else {
-                lhs[k] = (int)(lo ? a.cell[1].h : a.cell[2].h) + ppix * (4 * FS);
-                lgs[k] = (int)(lo ? a.cell[1].g : a.cell[2].g) + ppix * (8 * FS) + (PHASE == 0 ? 4 * FS : 0);
-                if (PHASE == 0) { lcs[k] = (int)(lo ? a.cell[1].c : a.cell[2].c) + ppix * (4 * FS); sos[k] = (int)(lo ? a.cell[1].h_out : a.cell[2].h_out) + ppix * (4 * FS); }
-            }
-        }
-    }
-    // two register sets: the pieces of virtual wave wg (requested at the end of the S phase, in flight during the whole M phase) and
-    // those of wg + 4 (requested behind the second sweep of the M phase, when the sweep's accumulators and operand buffers are dead)
-    float4 pre_[2][6], preg_[2][3], prec_[2][PHASE == 0 ? 3 : 1];
-    unsigned inside_[2] = {0, 0};
-    auto load_piece = [&](auto kc, int i, int tile) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        float4 (&pre)[6] = pre_[k]; float4 (&preg)[3] = preg_[k]; float4 (&prec)[PHASE == 0 ? 3 : 1] = prec_[k]; unsigned& inside = inside_[k];
-        constexpr int FS = k == 0 ? 4 : 2;
-        const int tg = tile < end ? tile : 0;
-        const int th = tg / a.tiles_w, h0 = th * FTH, w0 = (tg - th * a.tiles_w) * FTW;
-        const int bp = (h0 - 1) * a.W + (w0 - 1);
-        const int rr = (prc[k][i] << 16) >> 16, cc = prc[k][i] >> 16;
-        const bool in = (unsigned)(h0 + rr) < (unsigned)a.H && (unsigned)(w0 + cc) < (unsigned)a.W;
-        if (i < 3) pre[i] = ld_b128(rs, in ? lx[k][i] + bp * 128 : FBAD);
-        else if (i < 5) {
-            pre[i] = ld_b128(rs, in ? lh[k][i - 3] + bp * 64 : FBAD);
-            preg[i - 3] = ld_b128(rs, in ? lg[k][i - 3] + bp * 128 : FBAD);
-            if (PHASE == 0) prec[i - 3] = ld_b128(rs, in ? lc[k][i - 3] + bp * 64 : FBAD);
-        } else {
-            pre[5] = ld_b128(rs, in ? lhs[k] + bp * (4 * FS) : FBAD);
-            preg[2] = ld_b128(rs, in ? lgs[k] + bp * (8 * FS) : FBAD);
-            if (PHASE == 0) prec[2] = ld_b128(rs, in ? lcs[k] + bp * (4 * FS) : FBAD);
-        }
-        if (PHASE == 0 && i >= 3) inside = in ? inside | (1u << i) : inside & ~(1u << i);
-    };
-    auto blend1ch = [](float h, float g, float c, float ga, float gb, float ca, float cb) __attribute__((always_inline)) -> float {
-        const float A = __builtin_amdgcn_exp2f(fminf(__builtin_fmaf(g, ga, gb), 64.0f));
-        const float ty = __builtin_fmaf(c, ca, cb);
-        const float B = __builtin_amdgcn_exp2f(-fabsf(ty));
-        const float p2 = 1.0f + B;
-        const float rd = __builtin_amdgcn_rcpf((1.0f + A) * p2);
-        const float ynum = copysignf(1.0f - B, ty);
-        return __builtin_fmaf(A, ynum, h * p2) * rd;
-    };
-    auto stage_piece = [&](auto kc, int i, int tile_of) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        constexpr bool lo = k == 0;
-        const float4 (&pre)[6] = pre_[k]; const float4 (&preg)[3] = preg_[k]; const float4 (&prec)[PHASE == 0 ? 3 : 1] = prec_[k]; const unsigned inside = inside_[k];
-        const bool blend_s = STEADY || (lo ? a.cell[1].blend : a.cell[2].blend);
-        float4 v = pre[i];
-        if (i < 3) { *(float4*)(slab + loff[k][i]) = v; return; }
-        const int gi = i < 5 ? i - 3 : 2;
-        const float4 gq = preg[gi];
-        if (PHASE == 0) {
-            const bool bl = i < 5 ? blend1 : blend_s;
-            const float4 cq = prec[gi];
-            const int uq = i < 5 ? q4 : (lo ? 8 : 10), oq = i < 5 ? 4 + q4 : (lo ? 9 : 11);
-            const float4 ua = *(const float4*)lnS[uq], ub = *(const float4*)lnT[uq], ca = *(const float4*)lnS[oq], cb = *(const float4*)lnT[oq];
-            float4 b;
-            b.x = blend1ch(v.x, gq.x, cq.x, ua.x, ub.x, ca.x, cb.x); b.y = blend1ch(v.y, gq.y, cq.y, ua.y, ub.y, ca.y, cb.y);
-            b.z = blend1ch(v.z, gq.z, cq.z, ua.z, ub.z, ca.z, cb.z); b.w = blend1ch(v.w, gq.w, cq.w, ua.w, ub.w, ca.w, cb.w);
-            const bool in = (inside >> i) & 1u;
-            if (STEADY || bl) v = in ? b : make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool own = (STEADY || bl) && tile_of < end && ((ownbits[k] >> i) & 1u) && in;
-            const int th = tile_of / a.tiles_w, h0 = th * FTH, w0 = (tile_of - th * a.tiles_w) * FTW;
-            const int bp = (h0 - 1) * a.W + (w0 - 1);
-            if (i < 5) st_b128(rs, own ? so1[k][i - 3] + bp * 64 : FBAD, v.x, v.y, v.z, v.w);
-            else {
-                st_b128(rs, own && lo ? sos[k] + bp * 16 : FBAD, v.x, v.y, v.z, v.w);
-                st_b64(rs, own && !lo ? sos[k] + bp * 8 : FBAD, v.x, v.y);
-            }
-            *(float4*)(slab + loff[k][i]) = v;
-        } else {
-            const int rq = i < 5 ? q4 : (lo ? 4 : 5);
-            const float4 ra = *(const float4*)lnS[rq], rb = *(const float4*)lnT[rq];
-            float4 rv;
-            rv.x = v.x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.x, ra.x, rb.x)));
-            rv.y = v.y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.y, ra.y, rb.y)));
-            rv.z = v.z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.z, ra.z, rb.z)));
-            rv.w = v.w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(gq.w, ra.w, rb.w)));
-            if (i < 5) { *(float4*)(slab + loff[k][i]) = rv; *(float4*)(slab + loff[k][i] + 16) = v; }
-            else {
-                float* da = lo ? slab + loff[k][5] : mini + 4 * spos;
-                float* db = lo ? slab + loff[k][5] + 4 : trash + 4 * spos;
-                *(float4*)da = rv; *(float4*)db = v;
-            }
-        }
-    };
-    using K0 = std::integral_constant<int, 0>;
-    using K1 = std::integral_constant<int, 1>;
-
-    // ---- prologue (as gru_fused_kernel): LayerNorm affines, first tile's pieces of virtual wave wg, weights ----------------------
-    constexpr int NAFF = PHASE == 0 ? 44 : 22;
-    double ln_s0 = 0.0, ln_s1 = 1.0; float ln_g = 0.f, ln_b = 0.f; int ln_quad = 0, ln_sub = 0, ln_kind = 0; double ln_cnt = 1.0;
-    if (tid < NAFF) {
-        int k, idx;
-        if (PHASE == 0) { k = tid < 32 ? 0 : tid < 40 ? 1 : 2; idx = tid - (k == 0 ? 0 : k == 1 ? 32 : 40); }
-        else { k = tid < 16 ? 0 : tid < 20 ? 1 : 2; idx = tid - (k == 0 ? 0 : k == 1 ? 16 : 20); }
-        const int F = k == 0 ? 16 : k == 1 ? 4 : 2;
-        const int kind = idx / F, f = idx - kind * F;
-        const double* st = vp(cell_sel(k, [](const FusedCell& c_) { return c_.st_in; })) + (PHASE == 0 ? (kind == 0 ? 2 : 4) : 0);
-        const float* gp = kind == 0 ? cell_sel(k, [](const FusedCell& c_) { return c_.ga; }) : cell_sel(k, [](const FusedCell& c_) { return c_.oa; });
-        const float* bp = kind == 0 ? cell_sel(k, [](const FusedCell& c_) { return c_.gb; }) : cell_sel(k, [](const FusedCell& c_) { return c_.ob; });
-        ln_s0 = st[0]; ln_s1 = st[1]; ln_g = gp[f]; ln_b = bp[f];
-        ln_cnt = (double)a.H * a.W * F;
-        if (PHASE == 0) ln_quad = k == 0 ? 4 * kind + (f >> 2) : k == 1 ? 8 + kind : 10 + kind;
-        else ln_quad = k == 0 ? (f >> 2) : k == 1 ? 4 : 5;
-        ln_sub = f & 3; ln_kind = kind;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) load_piece(K0{}, i, gfirst);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) load_piece(K1{}, i, gfirst);
-    constexpr int N4 = W1_FLOATS / 4, NS4 = WS_FLOATS / 4;
-    constexpr int K1N = (N4 + FNT - 1) / FNT, K2N = (NS4 + FNT - 1) / FNT;
-    {
-        const f32x4* s4 = reinterpret_cast<const f32x4*>(a.w1);
-        const f32x4* t4 = reinterpret_cast<const f32x4*>(a.wsmall);
-        f32x4 wt1[K1N], wt2[K2N];
-#pragma unroll
-        for (int k = 0; k < K1N; ++k) wt1[k] = s4[min(tid + FNT * k, N4 - 1)];
-#pragma unroll
-        for (int k = 0; k < K2N; ++k) wt2[k] = t4[min(tid + FNT * k, NS4 - 1)];
-#pragma unroll
-        for (int k = 0; k < K1N; ++k) reinterpret_cast<f32x4*>(wl)[min(tid + FNT * k, N4 - 1)] = wt1[k];
-#pragma unroll
-        for (int k = 0; k < K2N; ++k) reinterpret_cast<f32x4*>(wsm)[min(tid + FNT * k, NS4 - 1)] = wt2[k];
-    }
-    if (tid < NAFF) {
-        const double mean = ln_s0 / ln_cnt;
-        double var = ln_s1 / ln_cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const double inv = (double)ln_g / sqrt(var + 1e-12);
-        const double shift = (double)ln_b - mean * inv;
-        const double L2E = 1.4426950408889634;
-        const double f = (PHASE == 0 && ln_kind == 1) ? 2.0 * L2E : -L2E;
-        lnS[ln_quad][ln_sub] = (float)(inv * f); lnT[ln_quad][ln_sub] = (float)(shift * f);
-    }
-    if (tid >= 64 && tid < 64 + 8) {
-        const int q = PHASE == 0 ? 10 + ((tid - 64) >> 2) : 5, sub = 2 + ((tid - 64) & 1);
-        lnS[q][sub] = 0.f; lnT[q][sub] = 0.f;
-    }
-    const int a_off = (kq * COUT + n) * 4;
-    float bias4[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) bias4[m][k] = a.cell[0].bias[m * 16 + 4 * kq + k];
-    // per virtual wave: cell-1 row, small job (see gru_fused_kernel)
-    int b_off[2], sy1[2], soff[2], srow[2], sy_small[2], small_px[2], swta[2];
-    bool small_live[2], small_b64[2], wta_wave[2];
-    float sbias[2][4];
-    const int scol = lane & 15;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int vw = wg + 4 * k;
-        b_off[k] = (vw * FPW + n) * S + 4 * kq;
-        sy1[k] = (int)a.cell[0].y + ((vw * a.W + n) * COUT + 4 * kq) * 4;
-        const int half = vw & 1;
-        srow[k] = 4 * half + (lane >> 4);
-        soff[k] = (srow[k] * FPW + scol) * S;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sbias[k][e] = 0.f;
-        const float* bp = nullptr; int nb = 0, b0 = 0;
-        if (PHASE == 0) { if (vw < 4) { bp = a.cell[1].bias; b0 = 4 * (vw >> 1); nb = 4; } else if (vw < 6) { bp = a.cell[2].bias; nb = 4; } }
-        else { if (vw < 2) { bp = a.cell[1].bias; nb = 4; } else if (vw < 4) { bp = a.cell[2].bias; nb = 2; } }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nb) sbias[k][e] = bp[b0 + e];
-        sy_small[k] = FBAD; small_px[k] = 0; small_live[k] = false; small_b64[k] = false;
-        if (PHASE == 0) {
-            if (vw < 4) { sy_small[k] = (int)a.cell[1].y + (srow[k] * a.W + scol) * 32 + 16 * (vw >> 1); small_px[k] = 32; small_live[k] = live2; }
-            else if (vw < 6) { sy_small[k] = (int)a.cell[2].y + (srow[k] * a.W + scol) * 16; small_px[k] = 16; small_live[k] = live3; }
-        } else {
-            if (vw < 2) { sy_small[k] = (int)a.cell[1].y + (srow[k] * a.W + scol) * 16; small_px[k] = 16; small_live[k] = live2; }
-            else if (vw < 4) { sy_small[k] = (int)a.cell[2].y + (srow[k] * a.W + scol) * 8; small_px[k] = 8; small_live[k] = live3; small_b64[k] = true; }
-        }
-        wta_wave[k] = PHASE == 0 && vw >= 6 && (STEADY || a.wta);
-        swta[k] = (srow[k] * a.W + scol) * 4;
-    }
-    __syncthreads();                                 // affines, weights and the group counters are in LDS
-
-    unsigned gtarget = 0;
-    auto group_sync = [&]() __attribute__((always_inline)) {      // barrier of the group's four waves: LDS counter + spin
-        gtarget += 4;
-        if (lane == 0) __hip_atomic_fetch_add(&gcount[grp], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(&gcount[grp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < gtarget) __builtin_amdgcn_s_sleep(1);
-    };
-
-    double st_s[MT], st_q[MT], sm_s[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, sm_q[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-#pragma unroll
-    for (int m = 0; m < MT; ++m) { st_s[m] = 0.0; st_q[m] = 0.0; }
-
-#ifdef GRU2_TIMERS
-    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tq0 = clock64(); int ntile = 0;
-#define GRU2_T(i) { const long long t_ = clock64(); tm[i] += t_ - tq0; tq0 = t_; }
-#else
-#define GRU2_T(i)
-#endif
-    int next_idx = 2 + grp;
-    for (int tile = gfirst; tile < end; ) {
-        const int next_tile = first + next_idx * stride;
-        const int th = tile / a.tiles_w, h0 = th * FTH, w0 = (tile - th * a.tiles_w) * FTW;
-        const int tp = h0 * a.W + w0;
-        GRU2_T(7)
-        // ---- S phase: the tile into the group's slab ------------------------------------------------------------------------------
-#pragma unroll
-        for (int i = 0; i < 6; ++i) stage_piece(K0{}, i, tile);
-        GRU2_T(0)
-        // the winner-take-all accumulators of this tile's pixels (virtual waves 6, 7 of G)
-        float wta_mp = 0.f, wta_es = 0.f;
-        const bool svalid1 = h0 + srow[1] < a.H && w0 + scol < a.W;
-        if (PHASE == 0) {
-            const int wo = wta_wave[1] && svalid1 ? swta[1] + tp * 4 : FBAD;
-            wta_mp = ld_b32(rs, wo == FBAD ? FBAD : wo + (int)a.max_prob);
-            wta_es = ld_b32(rs, wo == FBAD ? FBAD : wo + (int)a.exp_sum);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) stage_piece(K1{}, i, tile);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) load_piece(K0{}, i, next_tile);      // in flight during the matrix phase
-        GRU2_T(1)
-        group_sync();
-        GRU2_T(2)
-        if (wg == 0 && lane == 0) gq[grp] = __hip_atomic_fetch_add(&tctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // the tile after the next
-
-        // ---- M phase: two rows of cell 1, two small jobs ------------------------------------------------------------------------
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int vw = wg + 4 * k;
-            f32x4 acc[MT], accx[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) { acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            {
-                constexpr int NG = 27;
-                f32x4 bv[2], av[2][MT];
-                auto load_grp = [&](int g, f32x4& b, f32x4 (&aop)[MT]) __attribute__((always_inline)) {
-                    const int tap = g / 3, s = g % 3;
-                    const int kh = tap / 3, kw = tap % 3;
-                    b = *(const f32x4*)(slab + b_off[k] + (kh * FPW + kw) * S + 16 * s);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) aop[m] = *(const f32x4*)(wl + a_off + m * 64 + (tap * CQ + 4 * s) * WROW);
-                };
-                load_grp(0, bv[0], av[0]);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g + 1 < NG) load_grp(g + 1, bv[(g + 1) & 1], av[(g + 1) & 1]);
-                    const bool xgroup = (g % 3) < 2;
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            if (xgroup) accx[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][jj], bv[g & 1][jj], accx[m], 0, 0, 0);
-                            else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][m][jj], bv[g & 1][jj], acc[m], 0, 0, 0);
-                        }
-                }
-            }
-            {
-                const bool ok1 = live1 && h0 + vw < a.H && w0 + n < a.W;
-                const int o1 = ok1 ? sy1[k] + tp * (COUT * 4) : FBAD;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const f32x4 r = acc[m], rx = accx[m];
-                    const float4 o = make_float4(r[0] + (rx[0] + bias4[m][0]), r[1] + (rx[1] + bias4[m][1]), r[2] + (rx[2] + bias4[m][2]), r[3] + (rx[3] + bias4[m][3]));
-                    st_b128(rs, ok1 ? o1 + m * 64 : FBAD, o.x, o.y, o.z, o.w);
-                    const float ts = (o.x + o.y) + (o.z + o.w), tq = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-                    st_s[m] += ok1 ? (double)ts : 0.0;
-                    st_q[m] += ok1 ? (double)tq : 0.0;
-                }
-            }
-            GRU2_T(3 + k)
-            if (k == 1) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) load_piece(K1{}, i, next_tile);      // the next tile's second half: lands behind job 1, the barrier and stage A
-            }
-            auto job20 = [&](const float* tab) __attribute__((always_inline)) -> f32x4 {
-                f32x4 r4[4] = {(f32x4){sbias[k][0], sbias[k][1], sbias[k][2], sbias[k][3]}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-                const float* ap = tab + (lane & 3) * 4;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const float* bt = slab + soff[k] + ((tap / 3) * FPW + (tap % 3)) * S + XA2;
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {
-                        const f32x4 bq = *(const f32x4*)(bt + 4 * q);
-                        const f32x4 aq = *(const f32x4*)(ap + (tap * 5 + q) * 16);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) r4[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(aq[e], bq[e], r4[e], 0, 0, 0);
-                    }
-                }
-                return (r4[0] + r4[1]) + (r4[2] + r4[3]);
-            };
-            auto job6 = [&](const float* tab) __attribute__((always_inline)) -> f32x4 {
-                f32x4 r4[4] = {(f32x4){sbias[k][0], sbias[k][1], sbias[k][2], sbias[k][3]}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-                const float* ap = tab + (lane & 3) * 4;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int po = ((tap / 3) * FPW + (tap % 3));
-                    const f32x4 b0 = *(const f32x4*)(slab + soff[k] + po * S + XA3);
-                    float2 b1;
-                    if (PHASE == 0) b1 = *(const float2*)(slab + soff[k] + po * S + 52);
-                    else b1 = *(const float2*)(mini + 4 * (srow[k] * FPW + scol + po));
-                    const f32x4 a0 = *(const f32x4*)(ap + (tap * 2) * 16), a1 = *(const f32x4*)(ap + (tap * 2 + 1) * 16);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) r4[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[e], b0[e], r4[e], 0, 0, 0);
-                    r4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[0], b1.x, r4[0], 0, 0, 0);
-                    r4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[1], b1.y, r4[1], 0, 0, 0);
-                }
-                return (r4[0] + r4[1]) + (r4[2] + r4[3]);
-            };
-            f32x4 sr = {0.f, 0.f, 0.f, 0.f};
-            float pr = 0.f;
-            if (PHASE == 0) {
-                if (vw < 4) sr = job20(wsm + (vw >> 1) * T2);
-                else if (vw < 6) sr = job6(wsm + 2 * T2);
-                else {
-                    const float* pwt = wsm + 2 * T2 + T3;
-                    float pacc = pwt[18];
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        const float2 b = *(const float2*)(slab + soff[k] + ((tap / 3) * FPW + (tap % 3)) * S + 52);
-                        pacc += b.x * pwt[tap * 2]; pacc += b.y * pwt[tap * 2 + 1];
-                    }
-                    pr = expf(pacc);
-                }
-            } else {
-                if (vw < 2) sr = job20(wsm);
-                else if (vw < 4) sr = job6(wsm + T2);
-            }
-            {
-                const bool svalid = h0 + srow[k] < a.H && w0 + scol < a.W;
-                const bool sok = small_live[k] && svalid;
-                const int os = sok ? sy_small[k] + tp * small_px[k] : FBAD;
-                st_b128(rs, small_b64[k] ? FBAD : os, sr[0], sr[1], sr[2], sr[3]);
-                if (PHASE == 1) st_b64(rs, small_b64[k] ? os : FBAD, sr[0], sr[1]);
-                const bool pair = PHASE == 0 ? (vw >= 4) : (vw >= 2);
-                const float s01 = sr[0] + sr[1], q01 = __builtin_fmaf(sr[1], sr[1], sr[0] * sr[0]);
-                const float s23 = sr[2] + sr[3], q23 = __builtin_fmaf(sr[3], sr[3], sr[2] * sr[2]);
-                const float s4 = (s01 + sr[2]) + sr[3], q4s = __builtin_fmaf(sr[3], sr[3], __builtin_fmaf(sr[2], sr[2], q01));
-                const float s0 = pair ? s01 : s4, q0 = pair ? q01 : q4s;
-                sm_s[k][0] += sok ? (double)s0 : 0.0; sm_q[k][0] += sok ? (double)q0 : 0.0;
-                sm_s[k][1] += sok && pair ? (double)s23 : 0.0; sm_q[k][1] += sok && pair ? (double)q23 : 0.0;
-                if (PHASE == 0 && k == 1) {
-                    const int wo = wta_wave[1] && svalid ? swta[1] + tp * 4 : FBAD;
-                    const bool better = wo != FBAD && wta_mp < pr;
-                    st_b32(rs, better ? wo + (int)a.max_prob : FBAD, pr);
-                    st_b32(rs, better ? wo + (int)a.depth_image : FBAD, dv.v[view]);
-                    st_b32(rs, wo == FBAD ? FBAD : wo + (int)a.exp_sum, wta_es + pr);
-                }
-            }
-        }
-        GRU2_T(5)
-        group_sync();                                // the group's slab may be overwritten
-        GRU2_T(6)
-#ifdef GRU2_TIMERS
-        ++ntile;
-#endif
-        tile = next_tile;
-        next_idx = __hip_atomic_load(&gq[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-#ifdef GRU2_TIMERS
-    if (a.launch_id == 400 + PHASE && blockIdx.x == 8 && lane == 0)
-        printf("phase %d wave %d (group %d): %d tiles | clocks per tile: stage A %lld, load+stage B %lld, sync1 %lld, sweep0+store %lld, [job0+sweep1+store] %lld, job1 %lld, sync2 %lld, top %lld\n", PHASE, pw, grp, ntile,
-               tm[0] / ntile, tm[1] / ntile, tm[2] / ntile, tm[3] / ntile, tm[4] / ntile, tm[5] / ntile, tm[6] / ntile, tm[7] / ntile);
-#endif
-
-    // ---- LayerNorm sums of this workgroup -> float64 atomics: red[group][virtual wave][0..3 cell 1 | 4..7 the small job]
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const double s = wave_sum_dpp63(st_s[m]), q = wave_sum_dpp63(st_q[m]);
-        if (lane == 63) { red[grp][wg][2 * m] = s; red[grp][wg][2 * m + 1] = q; red[grp][wg + 4][2 * m] = 0.0; red[grp][wg + 4][2 * m + 1] = 0.0; }
-    }
-    if (MT == 1 && lane == 63) { red[grp][wg][2] = 0.0; red[grp][wg][3] = 0.0; red[grp][wg + 4][2] = 0.0; red[grp][wg + 4][3] = 0.0; }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const double s0 = wave_sum_dpp63(sm_s[k][0]), q0 = wave_sum_dpp63(sm_q[k][0]), s1 = wave_sum_dpp63(sm_s[k][1]), q1 = wave_sum_dpp63(sm_q[k][1]);
-        if (lane == 63) { red[grp][wg + 4 * k][4] = s0; red[grp][wg + 4 * k][5] = q0; red[grp][wg + 4 * k][6] = s1; red[grp][wg + 4 * k][7] = q1; }
-    }
-    __syncthreads();
-    auto R = [&](int w, int e) { return red[0][w][e] + red[1][w][e]; };
-    if (PHASE == 0) {
-        if (tid < 4 && live1) { double t = 0.0; for (int w = 0; w < 8; ++w) t += R(w, tid); atomicAdd(&vp(a.cell[0].st_out)[tid], t); }
-        else if (tid >= 4 && tid < 8 && live2) { const int e = tid - 4, w0 = (e >> 1) * 2; atomicAdd(&vp(a.cell[1].st_out)[e], R(w0, 4 + (e & 1)) + R(w0 + 1, 4 + (e & 1))); }
-        else if (tid >= 8 && tid < 12 && live3) { const int e = tid - 8; atomicAdd(&vp(a.cell[2].st_out)[e], R(4, 4 + e) + R(5, 4 + e)); }
-    } else {
-        if (tid < 2 && live1) { double t = 0.0; for (int w = 0; w < 8; ++w) t += R(w, tid); atomicAdd(&vp(a.cell[0].st_out)[4 + tid], t); }
-        else if (tid >= 2 && tid < 4 && live2) { const int e = tid - 2; atomicAdd(&vp(a.cell[1].st_out)[4 + e], R(0, 4 + e) + R(1, 4 + e)); }
-        else if (tid >= 4 && tid < 6 && live3) { const int e = tid - 4; atomicAdd(&vp(a.cell[2].st_out)[4 + e], R(2, 4 + e) + R(3, 4 + e)); }
-    }
-}
-
 // small-cell weight tables: TensorFlow kernel (3,3,CT,CO) -> out[tap][quad][m][4]: weight of input channel 4*quad + e, output
 // channel co0 + m (zero outside either range)
 __global__ void gru_small_table_kernel(const float* __restrict__ w, int CT, int CO, int co0, int nquad, float* __restrict__ out) {
@@ -1079,14 +598,10 @@ int launch_fused2(const FusedArgs& a, const FusedDepth& dv, int grid, size_t sme
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gru_fused_kernel<PHASE, STEADY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)gru_fused2_kernel<PHASE, STEADY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    // the two-group kernel is an experiment (3 % slower than the one-group kernel, see its header): opt-in, read per launch so that
-    // a test can run both in one process
-    if (getenv("MVS_GRU_TWO_GROUPS") != nullptr && !a.trace) gru_fused2_kernel<PHASE, STEADY><<<grid, FNT, smem, st>>>(a, dv);
-    else gru_fused_kernel<PHASE, STEADY><<<grid, FNT, smem, st>>>(a, dv);
+    // (the two-group form of this launch -- exact, 3 % slower -- is profiles/r05_gru_fused_two_groups.patch, not product code)
+    gru_fused_kernel<PHASE, STEADY><<<grid, FNT, smem, st>>>(a, dv);
     return (int)hipGetLastError();
 }
 template <int PHASE>

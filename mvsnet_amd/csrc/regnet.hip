@@ -52,6 +52,26 @@ extern "C" int mvs_set_conv_impl(int impl) {
 }
 extern "C" int mvs_get_conv_impl(void) { return g_conv_impl; }
 
+// test / measurement hooks (include/mvsnet_hip.h): the only switches of the library; nothing is read from the environment
+std::atomic<int> mvs_hooks[MVS_HOOK_COUNT] = {{-1}, {0}, {0}, {0}, {0}, {128}};
+extern "C" int mvs_set_test_hook(int id, int value) {
+    bool ok = false;
+    switch (id) {
+        case MVS_HOOK_CV_TILE_ROWS_LOG2: ok = value >= -1 && value <= 3; break;
+        case MVS_HOOK_CONV_NO_SPAN: case MVS_HOOK_CONV_NO_FUSE2: case MVS_HOOK_GRU_ONE_STREAM: ok = value == 0 || value == 1; break;
+        case MVS_HOOK_S2_PLANES: ok = value >= 0 && value <= 65536; break;
+        case MVS_HOOK_GRU_PRODUCER_THREADS: ok = value == 64 || value == 128 || value == 192 || value == 256; break;
+        default: break;
+    }
+    if (!ok) return MVS_E_BADARG;
+    mvs_hooks[id].store(value, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int mvs_get_test_hook(int id) {
+    if (id < 0 || id >= MVS_HOOK_COUNT) return MVS_E_BADARG;
+    return mvs_hooks[id].load(std::memory_order_relaxed);
+}
+
 extern "C" int mvs_conv3d_f32(const float* x, const float* xs, const float* xb, const float* x2,
                               const float* x2s, const float* x2b, const float* w, int D, int H,
                               int W, int Cin, int Cout, int stride, float* y, double* stats,

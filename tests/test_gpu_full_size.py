@@ -94,18 +94,25 @@ def check_sweep(tag, w, g, depth, prob):
     return d, p
 
 
-@pytest.mark.parametrize("one_stream", [False, True])
-def test_gru_sweep_matches_the_fixture(lib_built, one_stream, monkeypatch):
-    """c3: 256 planes x 3 ConvGRU cells at 400x300, wavefront over HIP streams (default) and the one-stream sweep."""
+@pytest.mark.parametrize("route", ["fused", "fused-one-stream", "wavefront"])
+def test_gru_sweep_matches_the_fixture(lib_built, route):
+    """c3: 256 planes x 3 ConvGRU cells at 400x300 against the float64 fixture -- the default FUSED sweep (gru_fused.hip: two
+    launches per plane; the cost slices come from a side stream of the stream set), the same with everything on the caller's
+    stream (test hook MVS_HOOK_GRU_ONE_STREAM), and the round-4 WAVEFRONT over the stream set (mvs_gru_set_formulation 1)."""
+    from mvsnet_amd import _lib as L
     from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
     w, g = fixture("c3")
     gp = S.make_gru_params("normal", seed=2, in_channels=w.channels, random_affine=True)
     weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
-    if one_stream:
-        monkeypatch.setenv("MVS_GRU_ONE_STREAM", "1")
-    depth, prob = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end,
-                                            weights=weights, features=t(w.features))
-    d, _ = check_sweep("c3 (one_stream=%s)" % one_stream, w, g, depth, prob)
+    L.check(L.load().mvs_gru_set_formulation(1 if route == "wavefront" else 0), "mvs_gru_set_formulation")
+    try:
+        with L.test_hooks(gru_one_stream=1 if route == "fused-one-stream" else 0):
+            depth, prob = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end,
+                                                    weights=weights, features=t(w.features))
+            torch.cuda.synchronize()
+    finally:
+        L.check(L.load().mvs_gru_set_formulation(0), "mvs_gru_set_formulation")
+    d, _ = check_sweep("c3 (%s)" % route, w, g, depth, prob)
     interval = (w.depth_end - w.depth_start) / (w.depth_num - 1)
     idx = np.rint((d - w.depth_start) / interval).astype(np.int64)
     assert idx.min() >= 0 and idx.max() < w.depth_num

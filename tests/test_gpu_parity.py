@@ -9,6 +9,7 @@ import torch
 
 from oracle import mvsnet_oracle as O
 from mvsnet_amd import synthetic as S
+from mvsnet_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -176,9 +177,9 @@ def test_cost_volume_border_bands_are_exact(variant):
 
 
 @pytest.mark.parametrize("C", [4, 8, 16, 32, 64])
-def test_cost_volume_wave_tile_shapes_give_the_same_bits(C, monkeypatch):
+def test_cost_volume_wave_tile_shapes_give_the_same_bits(C):
     """The sweep lays a wave's pixels out as a rows x columns tile voted from the transforms (cost_volume.hip); every shape, forced
-    through MVS_CV_TILE_ROWS_LOG2, and the voted one compute each voxel with the same instructions: bit-identical volumes,
+    through the test hook MVS_HOOK_CV_TILE_ROWS_LOG2 (mvs_set_test_hook), and the voted one compute each voxel with the same instructions: bit-identical volumes,
     ragged image sizes included (tiles hanging over the right and bottom edges)."""
     from mvsnet_amd.homography_warping import homography_transforms
     from mvsnet_amd.model import cost_volume
@@ -188,7 +189,7 @@ def test_cost_volume_wave_tile_shapes_give_the_same_bits(C, monkeypatch):
     feats = rs.standard_normal((w.view_num, H, Wd, C)).astype(np.float32)
     T = homography_transforms(t(w.cams), w.depth_num, w.depth_start, w.depth_interval)
     T = T * t(np.array([1, 1, Wd / w.width, 1, 1, H / w.height, 1, 1], np.float32))      # keep the samples inside the smaller image
-    monkeypatch.delenv("MVS_CV_TILE_ROWS_LOG2", raising=False)
+    L.set_test_hook("cv_tile_rows_log2", -1)
     voted = n(cost_volume(t(feats[0]), t(feats[1:]), T))
     assert np.isfinite(voted).all() and voted.any()
     To = n(T).astype(np.float64)
@@ -196,14 +197,13 @@ def test_cost_volume_wave_tile_shapes_give_the_same_bits(C, monkeypatch):
                                                    for v in range(w.view_num - 1)], w.view_num, np.float64) for d in range(w.depth_num)])
     assert rel_l1(voted, exp) < 1e-5 and (np.abs(voted - exp) > 1e-4).mean() < 2e-3      # tap flips at near-integer samples
     for rows_log2 in range(4):
-        monkeypatch.setenv("MVS_CV_TILE_ROWS_LOG2", str(rows_log2))
-        got = n(cost_volume(t(feats[0]), t(feats[1:]), T))
+        with L.test_hooks(cv_tile_rows_log2=rows_log2):
+            got = n(cost_volume(t(feats[0]), t(feats[1:]), T))
         assert np.array_equal(got, voted), rows_log2
     # a sweep along y instead of x (transposed geometry) votes another shape: same bits as a forced one again
     Tt = T.clone(); Tt[..., [0, 1, 2, 3, 4, 5]] = T[..., [4, 3, 5, 1, 0, 2]]
-    monkeypatch.setenv("MVS_CV_TILE_ROWS_LOG2", "0")
-    forced = n(cost_volume(t(feats[0]), t(feats[1:]), Tt))
-    monkeypatch.delenv("MVS_CV_TILE_ROWS_LOG2")
+    with L.test_hooks(cv_tile_rows_log2=0):
+        forced = n(cost_volume(t(feats[0]), t(feats[1:]), Tt))
     assert np.array_equal(n(cost_volume(t(feats[0]), t(feats[1:]), Tt)), forced)
 
 
@@ -300,22 +300,21 @@ def test_conv3d_matches_oracle(case, impl):
 @pytest.mark.parametrize("planes", [0, 1, 2, 3])
 @pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 16), (32, 64)])
 @pytest.mark.parametrize("depth", [2, 4, 5, 6, 10, 14])
-def test_stride2_plane_ranges(cin, cout, depth, planes, monkeypatch):
+def test_stride2_plane_ranges(cin, cout, depth, planes):
     """Pins the code shape of conv3d_s2_kernel: with a separate path for the last even plane of a
     workgroup's range, hipcc hoisted the staging arithmetic above both paths and gfx950 codegen reused a register
     before it was read (wrong results for Cin = 16 only).  Every residue of the 4-way unrolled plane march
     (T = 2n+1 input planes, n = 1..7), ranges that end inside / at the end of the volume, both input widths and an
-    odd depth, with the range length forced through the MVS_S2_PLANES test hook (0 = the launcher's own choice)."""
+    odd depth, with the range length forced through the test hook MVS_HOOK_S2_PLANES (0 = the launcher's own choice)."""
     from mvsnet_amd.model import conv3d
-    if planes:
-        monkeypatch.setenv("MVS_S2_PLANES", str(planes))
     rs = np.random.RandomState(1000 * cin + 10 * depth + planes)
     H, W = 6, 20
     x = rs.standard_normal((depth, H, W, cin)).astype(np.float32)
     wgt = (rs.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
     sc = (1 + 0.3 * rs.standard_normal(cin)).astype(np.float32); sh = (0.2 * rs.standard_normal(cin)).astype(np.float32)
     stats = torch.zeros((2, cout), dtype=torch.float64, device=DEV)
-    y = n(conv3d(t(x), t(wgt), 2, (t(sc), t(sh)), None, None, stats))
+    with L.test_hooks(s2_planes=planes):
+        y = n(conv3d(t(x), t(wgt), 2, (t(sc), t(sh)), None, None, stats))
     e = O.conv3d_same(np.maximum(x * sc + sh, 0).astype(np.float64), wgt, 2, np.float64)
     assert y.shape == e.shape
     np.testing.assert_allclose(y, e, rtol=1e-4, atol=2e-5)
@@ -440,10 +439,10 @@ def test_regnet_filler_launches_equal_the_layers_apart(shape):
 
 
 @pytest.mark.parametrize("shape", [(192, 128, 160), (104, 48, 64), (40, 24, 48)])
-def test_regnet_span_and_fused_pair_equal_the_plain_schedules(shape, monkeypatch):
+def test_regnet_span_and_fused_pair_equal_the_plain_schedules(shape):
     """The dominant launch's SPAN schedule (conv3d_c8.hip: workgroups own depth ranges that may cross a tile boundary) against the
     whole-chunk schedule it replaced, and the fused 3dconv1_1 + 3dconv2_0 launch (conv3d_mfma.hip, FUSE2) against the two layers
-    apart -- forced through the library's test hooks MVS_CONV_NO_SPAN / MVS_CONV_NO_FUSE2, at the metric size (where SPAN is
+    apart -- forced through the library's test hooks MVS_HOOK_CONV_NO_SPAN / MVS_HOOK_CONV_NO_FUSE2, at the metric size (where SPAN is
     taken) and at sizes whose half-resolution depth (52, 20) is not a multiple of the planes a workgroup marches (short last
     chunk).  Same arithmetic per voxel; the float64 BatchNorm atomics arrive in another order: 2e-5 of the output's scale."""
     from mvsnet_amd.model import RegNetWeights, regnet_us0
@@ -451,17 +450,12 @@ def test_regnet_span_and_fused_pair_equal_the_plain_schedules(shape, monkeypatch
     params = S.make_regnet_params("normal", seed=33, random_affine=True)
     cost = t(np.abs(np.random.RandomState(34).standard_normal((D, H, W, 32))).astype(np.float32))
     wts = RegNetWeights(params, DEV)
-    for k in ("MVS_CONV_NO_SPAN", "MVS_CONV_NO_FUSE2"):
-        monkeypatch.delenv(k, raising=False)
     default = regnet_us0(cost, wts).clone()
     scale = float(default.abs().max())
     assert scale > 0 and bool(torch.isfinite(default).all())
-    for hooks in (("MVS_CONV_NO_SPAN",), ("MVS_CONV_NO_FUSE2",), ("MVS_CONV_NO_SPAN", "MVS_CONV_NO_FUSE2")):
-        for k in hooks:
-            monkeypatch.setenv(k, "1")
-        plain = regnet_us0(cost, wts).clone()
-        for k in hooks:
-            monkeypatch.delenv(k)
+    for hooks in (("conv_no_span",), ("conv_no_fuse2",), ("conv_no_span", "conv_no_fuse2")):
+        with L.test_hooks(**{k: 1 for k in hooks}):
+            plain = regnet_us0(cost, wts).clone()
         assert float((plain - default).abs().max()) <= 2e-5 * scale, hooks
     if D * H * W <= 48 * 40 * 72:
         assert rel_l1(n(default), O.regnet_us0(n(cost), params, np.float64)) < 2e-5
@@ -661,27 +655,6 @@ def test_gru_wta_ragged_image_sizes_match_oracle(hw):
     finally:
         L.check(lib.mvs_gru_set_formulation(0), "mvs_gru_set_formulation")
     assert (n(d1)[0, :, :, 0] == depth).mean() > 0.97
-
-
-def test_gru_two_group_kernel_matches_the_default_sweep(monkeypatch):
-    """gru_fused2_kernel (gru_fused.hip; opt-in through MVS_GRU_TWO_GROUPS, measured 3 % slower than the default): two groups of four
-    waves with their own slabs, tiles dealt to whichever group asks first.  Same arithmetic per pixel; the float64 LayerNorm sums are
-    added in another order: the same planes up to ties, probabilities to 1e-4."""
-    from mvsnet_amd.model import MVSNetWeights, inference_winner_take_all
-    w = S.make_workload("small")
-    gp = S.make_gru_params("normal", seed=9, in_channels=w.channels, random_affine=True)
-    weights = MVSNetWeights.from_numpy("normal", gru=gp, device=DEV)
-    for hw in ((32, 48), (27, 41)):
-        feats = np.ascontiguousarray(w.features[:, :hw[0], :hw[1]])
-        monkeypatch.delenv("MVS_GRU_TWO_GROUPS", raising=False)
-        d0, p0 = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end, weights=weights, features=t(feats))
-        d0, p0 = n(d0).copy(), n(p0).copy()
-        monkeypatch.setenv("MVS_GRU_TWO_GROUPS", "1")
-        d1, p1 = inference_winner_take_all(None, t(w.cams)[None], w.depth_num, w.depth_start, w.depth_end, weights=weights, features=t(feats))
-        monkeypatch.delenv("MVS_GRU_TWO_GROUPS")
-        same = n(d1) == d0
-        assert same.mean() > 0.995, same.mean()
-        np.testing.assert_allclose(n(p1)[same], p0[same], rtol=1e-4)
 
 
 # ---- R10 end to end -------------------------------------------------------------------------------------

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 6): MVS_GRU_ONE_STREAM is now mvs_set_test_hook(MVS_HOOK_GRU_ONE_STREAM); kept as the record of the round-3 bisect
 # Second bisect pass: which single kind of work on a side stream makes the null-stream sweep slow, and what the runtime logs.
 set -o pipefail
 mkdir -p gpurun_out

@@ -1,10 +1,14 @@
 """Runs the recurrent sweep at a workload size and saves depth / prob maps: used to compare the pipelined
-(three streams) and the single-stream sweep (MVS_GRU_ONE_STREAM=1) at full size."""
+(three streams) and the single-stream sweep (`--one-stream`: test hook MVS_HOOK_GRU_ONE_STREAM) at full size."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvsnet_amd import synthetic as S, model as M
 
+if "--one-stream" in sys.argv:
+    sys.argv.remove("--one-stream")
+    from mvsnet_amd import _lib
+    _lib.set_test_hook("gru_one_stream", 1)
 wl = S.make_workload(sys.argv[1] if len(sys.argv) > 2 else "c3")
 out = sys.argv[-1]
 weights = M.MVSNetWeights.from_numpy("normal", gru=S.make_gru_params("normal", random_affine=True), device="cuda")

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 6): MVS_CV_TILE_ROWS_LOG2 is no longer read from the environment; the shape is forced through mvs_set_test_hook(MVS_HOOK_CV_TILE_ROWS_LOG2) -- kept as the record of the round-5 measurement
 # round 5: wave tile shape of the warp + variance sweep (rows = 1, 2, 4, 8 of the wave's 8 pixels): parity tests at every shape, then
 # the whole depth map, same box, three repetitions
 cd "$GRAFT_REPO_ROOT" || exit 1
