@@ -15,37 +15,13 @@
 // live in LDS; v_mfma_f32_16x16x4_f32, exact fp32).  CG = channels per operand read: 16 (ds_read_b128,
 // 4 MFMAs), 8 (b64, 2 MFMAs) or 4 (b32, 1 MFMA) for the 3/4-, 8- and >=16-channel layers.
 // Transposed convolutions (4 small layers) are a VALU gather kernel.
-#include "common.h"
+#include "unet2d_common.h"
 #include <type_traits>
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-// producer GroupNorm of one source, given as raw float64 group sums (or stats == null: identity)
-struct GnSrc {
-    const float* x;           // (V,H,W,C) raw producer output (or the image)
-    const double* stats;      // (V, C/8, 2) [sum, sumsq] per view and group, or null
-    const float* gamma; const float* beta;
-    double count;             // elements per (view, group) = H*W*8
-    int C;                    // channels of this source
-    int relu;                 // ReLU after the affine (conv_gn) or not (deconv_gn, network.py:357)
-};
-
-struct Conv2dArgs {
-    GnSrc a, b;               // b.x == null: single source
-    const float* wprep;       // [cout group][chunk][tap][CK/4][16*MT][4]
-    float* y;                 // (V,Ho,Wo,Cout) raw
-    double* stats;            // (V, Cout/8, 2) or null
-    int V, H, W, Ho, Wo, Cout, pad_h, pad_w;
-};
-
 constexpr int TH = 8, TW = 16;
-// GroupNorm sums are spread over NSLOT partial accumulators per (view, group): a full-resolution layer
-// has ~13 000 workgroups adding into ~10 (view, group) pairs, and that many float64 atomics on one
-// address serialise in L2 (measured: 287 us for a 20 us layer).  Consumers add the slots up.
-constexpr int NSLOT = 32;
+constexpr int NSLOT = GN_NSLOT;
 
 __device__ __forceinline__ void gn_affine4(const GnSrc& s, int view, int c0, float4& sc, float4& sh) {
     sc = make_float4(1.f, 1.f, 1.f, 1.f); sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -450,18 +426,26 @@ void conv2d_tiling(int Cin_total, int Cout, int c1, int& CG, int& MT) {
 
 extern "C" int mvs_gn_stat_slots(void) { return NSLOT; }
 
-extern "C" size_t mvs_conv2d_prepared_floats(int ks, int cin1, int cin2, int cout) {
+static size_t conv2d_plain_floats(int ks, int cin1, int cin2, int cout) {
     int CG, MT; conv2d_tiling(cin1 + cin2, cout, cin1, CG, MT);
     const int cin = cin1 + cin2, cpad = (cin + CG - 1) / CG * CG, ct = 16 * MT;
     return (size_t)((cout + ct - 1) / ct) * (cpad / CG) * ks * ks * (CG / 4) * ct * 4;
+}
+
+extern "C" size_t mvs_conv2d_prepared_floats(int ks, int cin1, int cin2, int cout) {
+    int CG, MT; conv2d_tiling(cin1 + cin2, cout, cin1, CG, MT);
+    const int cin = cin1 + cin2, cpad = (cin + CG - 1) / CG * CG, ct = 16 * MT;
+    return conv2d_plain_floats(ks, cin1, cin2, cout) + ((cin1 % CG) || (cin2 % CG) ? 0 : mvs_conv2d_pair_floats(ks, 1, cin, cout));
 }
 
 extern "C" int mvs_conv2d_prepare_f32(const float* w, int ks, int cin1, int cin2, int cout, float* prepared, void* stream) {
     MVS_CHECK_ARG(w && prepared && (ks == 3 || ks == 5) && cin1 > 0 && cin2 >= 0 && cout > 0);
     int CG, MT; conv2d_tiling(cin1 + cin2, cout, cin1, CG, MT);
     const int cin = cin1 + cin2, cpad = (cin + CG - 1) / CG * CG;
-    const size_t total = mvs_conv2d_prepared_floats(ks, cin1, cin2, cout);
+    const size_t total = conv2d_plain_floats(ks, cin1, cin2, cout);
     conv2d_weight_layout_kernel<<<mvs_cdiv((long long)total, 256), 256, 0, mvs_stream(stream)>>>(w, ks, cin, cout, CG, 16 * MT, cpad, prepared);
+    if (mvs_conv2d_prepared_floats(ks, cin1, cin2, cout) > total)      // 8-cout 3 x 3 layers: the pixel-pair layout of the persistent kernel behind it
+        return mvs_conv2d_pair_prepare(w, cin, cout, CG, prepared + total, mvs_stream(stream));
     MVS_LAUNCH_RET();
 }
 
@@ -480,9 +464,15 @@ extern "C" int mvs_conv2d_gn_f32(const float* x1, const double* stats1, const fl
     p.a = GnSrc{x1, stats1, gamma1, beta1, (double)H * W * 8, c1, relu1};
     p.b = GnSrc{x2, stats2, gamma2, beta2, (double)H * W * 8, c2, relu2};
     p.wprep = prepared; p.y = y; p.stats = stats_out;
+    p.wpair = (stride == 1 && mvs_conv2d_prepared_floats(ks, c1, c2, cout) > conv2d_plain_floats(ks, c1, c2, cout)) ? prepared + conv2d_plain_floats(ks, c1, c2, cout) : nullptr;
     p.V = V; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.Cout = cout;
     p.pad_h = pad_before(H, Ho); p.pad_w = pad_before(W, Wo);
     hipStream_t st = mvs_stream(stream);
+    // persistent form where an instance exists (unet2d_p.hip; the same prepared weights)
+    if (const int inst = mvs_conv2d_p_find(ks, stride, c1 + c2, CG, MT, cout); inst >= 0) {
+        const int rc = mvs_conv2d_p_run(inst, p, st);
+        if (rc != MVS_E_SHAPE) return rc;
+    }
 #define CASE(K, S_, G, M) if (ks == K && stride == S_ && CG == G && MT == M) return launch_conv2d<K, S_, G, M>(p, st);
     CASE(3, 1, 4, 1) CASE(3, 1, 8, 1) CASE(3, 1, 16, 1) CASE(3, 1, 16, 2) CASE(3, 1, 8, 2) CASE(3, 1, 4, 2)
     CASE(3, 2, 4, 1) CASE(3, 2, 8, 1) CASE(3, 2, 16, 1) CASE(3, 2, 16, 2) CASE(3, 2, 8, 2) CASE(3, 2, 4, 2)
@@ -516,7 +506,7 @@ extern "C" int mvs_deconv2d_gn_f32(const float* x, const double* stats, const fl
         Conv2dArgs q;
         q.a = GnSrc{x, stats, gamma, beta, (double)H * W * 8, cin, relu};
         q.b = GnSrc{nullptr, nullptr, nullptr, nullptr, 1.0, 0, 0};
-        q.wprep = prepared; q.y = y; q.stats = stats_out;
+        q.wprep = prepared; q.wpair = nullptr; q.y = y; q.stats = stats_out;
         q.V = V; q.H = H; q.W = W; q.Ho = H; q.Wo = W; q.Cout = cout; q.pad_h = 1; q.pad_w = 1;
         return launch_conv2d<2, 1, 16, 2, true>(q, mvs_stream(stream));
     }

@@ -7,6 +7,8 @@ the glue (north_star) and as the cross-check in tests.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -14,12 +16,24 @@ from . import _lib
 from .feature_net import UNET_LAYERS
 
 
+# The encoder's side branches (mvsnetworks.py:66-84) depend on ONE layer of the stride-2 chain each and are only read again by the
+# decoder: with `side_streams` they run on streams of their own beside the chain 1_0 .. 4_2 -> 5_0 (launch-bound low-resolution
+# layers) instead of in line with it.
+SIDE_BRANCH = {"2dconv0_1": 0, "2dconv0_2": 0, "2dconv1_1": 1, "2dconv1_2": 1,
+               "2dconv2_1": 2, "2dconv2_2": 2, "2dconv3_1": 3, "2dconv3_2": 3}      # branch index; stream = index % side_streams
+
+
 class HipUNetDS2GN:
     """``params`` in TensorFlow variable layouts as for `UNetDS2GN` (conv (k,k,Cin,Cout), transposed
-    conv (k,k,Cout,Cin), GroupNorm gamma/beta)."""
+    conv (k,k,Cout,Cin), GroupNorm gamma/beta).  `side_streams` (0 .. 4): HIP streams beside the caller's for the encoder's
+    side branches (forked from / joined to the caller's stream with events inside every call; 0 = everything in line)."""
 
-    def __init__(self, params, device="cuda"):
+    def __init__(self, params, device="cuda", side_streams=0):
         self.device = torch.device(device)
+        self.side_streams = int(side_streams)
+        self._streams = None
+        # layers whose output is read by a layer of the other kind (chain <-> side branch)
+        self._fork_join = {s_ for name, _k, srcs, *_r in UNET_LAYERS for s_ in srcs if (name in SIDE_BRANCH) != (s_ in SIDE_BRANCH)}
         lib = _lib.load()
         self.slots = lib.mvs_gn_stat_slots()               # partial GroupNorm accumulators per (view, group)
         chans = {"data": 4}                               # the image is padded 3 -> 4 channels
@@ -73,7 +87,8 @@ class HipUNetDS2GN:
             offs[name] = total
             total += V * (cout // 8) * 2 * self.slots
         stats = torch.zeros(total, dtype=torch.float64, device=self.device)
-        self._bufs[key] = (acts, offs, stats, shapes)
+        data = torch.zeros((V, H, W, 4), dtype=torch.float32, device=self.device)      # the image padded 3 -> 4 channels (channel 3 stays 0)
+        self._bufs[key] = (acts, offs, stats, shapes, data)
         return self._bufs[key]
 
     @torch.no_grad()
@@ -84,17 +99,31 @@ class HipUNetDS2GN:
         V, H, W, _ = x.shape
         if H % 16 or W % 16:
             raise ValueError("UNetDS2GN needs image sizes divisible by 16")
-        acts, offs, stats, shapes = self._plan(V, H, W)
+        acts, offs, stats, shapes, data = self._plan(V, H, W)
         stats.zero_()
-        data = torch.zeros((V, H, W, 4), dtype=torch.float32, device=self.device)
         data[..., :3] = x
-        st = _lib.stream_ptr()
+        main = torch.cuda.current_stream(self.device)
+        ns = self.side_streams
+        if ns and self._streams is None:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(ns)]
+        stream_of = lambda name: (self._streams[SIDE_BRANCH[name] % ns] if ns and name in SIDE_BRANCH else main)
+        done = {}                                          # layer -> event, for layers read from another stream
+        if ns:
+            done["data"] = main.record_event()
         src_of = {"data": (data, None, None, None, 0)}    # tensor, stats view, gamma, beta, relu
+        where = {"data": main}
         for name, kind, srcs, k, stride, wd, g, b, cins, cout, wraw in self.layers:
             h, w = shapes[srcs[0]]
             y = acts[name]
             so = stats[offs[name]:offs[name] + V * (cout // 8) * 2 * self.slots] if kind != "c" else None
             a = src_of[srcs[0]]
+            st_ = stream_of(name)
+            for s_ in srcs:                                # producers on another stream: wait for their event
+                if where[s_] is not st_:
+                    if s_ not in done:
+                        done[s_] = where[s_].record_event()
+                    st_.wait_event(done[s_])
+            st = C.c_void_p(st_.cuda_stream)
             if kind == "dg":
                 _lib.check(lib.mvs_deconv2d_gn_f32(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]), cins[0], a[4],
                                                    _lib.ptr(wraw), _lib.ptr(wd), V, h, w, cout, _lib.ptr(y), _lib.ptr(so), st),
@@ -108,4 +137,7 @@ class HipUNetDS2GN:
                            "mvs_conv2d_gn_f32")
             # consumers apply this layer's GroupNorm: ReLU after conv_gn, none after deconv_gn (network.py:357)
             src_of[name] = (y, so, g, b, 1 if kind == "cg" else 0)
+            where[name] = st_
+            if ns and name in self._fork_join:             # read from another stream later: its event is recorded right behind it
+                done[name] = st_.record_event()
         return acts["conv10_2"].clone()

@@ -30,6 +30,12 @@ import numpy as np
 _ATTACHED = {}          # worker side: shared-memory blocks by name
 
 
+class PinnedArray(np.ndarray):
+    """uint8 image whose memory is a pinned (page-locked) torch tensor, kept in `.pinned`: the GPU-owning process uploads it
+    with an asynchronous copy straight from here (HostPool.load_image(pin_device=...))."""
+    pinned = None
+
+
 def _attach(name):
     from multiprocessing import shared_memory
     shm = _ATTACHED.get(name)
@@ -191,9 +197,12 @@ class HostPool:
             self.free = list(range(slots))
             return True
 
-    def load_image(self, path, rescale, width, height, base_image_size, output_scale):
+    def load_image(self, path, rescale, width, height, base_image_size, output_scale, pin_device=None):
         """-> Future of (cropped uint8 (h,w,3), output image, original shape, worker seconds); private arrays, the slot is
-        free again when the future resolves."""
+        free again when the future resolves.  `pin_device` (a CUDA device index): the cropped image is copied out of the slot
+        into PINNED host memory (torch's caching host allocator, on the executor's management thread) and comes back as a
+        PinnedArray -- the caller's host -> device copy then needs no staging copy on its own thread (round 5 copied every image
+        twice: slot -> private array here, private array -> pinned staging buffer on the thread that feeds the GPU)."""
         h_cap = max(height, int(np.ceil(height / base_image_size) * base_image_size)) + base_image_size
         w_cap = max(width, int(np.ceil(width / base_image_size) * base_image_size)) + base_image_size
         need = h_cap * w_cap * 3
@@ -213,7 +222,16 @@ class HostPool:
             try:
                 cs, os_, shape, sec = f.result()
                 n1 = int(np.prod(cs)); n2 = int(np.prod(os_))
-                cr = np.frombuffer(shm.buf, np.uint8, n1, off).reshape(cs).copy()
+                src = np.frombuffer(shm.buf, np.uint8, n1, off).reshape(cs)
+                if pin_device is None:
+                    cr = src.copy()
+                else:
+                    import torch
+                    with torch.cuda.device(pin_device):
+                        tbuf = torch.empty(tuple(cs), dtype=torch.uint8, pin_memory=True)
+                    cr = tbuf.numpy().view(PinnedArray)
+                    cr.pinned = tbuf
+                    np.copyto(cr, src)
                 oi = np.frombuffer(shm.buf, np.uint8, n2, off + n1).reshape(os_).copy()
                 out.set_result((cr, oi, shape, sec))
             except BaseException as e:                 # noqa: BLE001  (delivered to the consumer)

@@ -117,9 +117,10 @@ class SessionLoader:
     come back as LISTS of per-view uint8 arrays (no (N,H,W,3) copy on this thread).  Image sizes (needed for the cluster's
     scale-to-cover factor before anything is decoded, mvs_cluster.py:178-192) come from the files' headers."""
 
-    def __init__(self, gen, pool, limit=192):
+    def __init__(self, gen, pool, limit=192, pin_device=None):
         from collections import OrderedDict
-        self.gen, self.pool, self.limit = gen, pool, limit
+        self.gen, self.pool, self.limit, self.pin_device = gen, pool, limit, pin_device
+        self.cams = {}                               # (session, index, depth range) -> camera: one build per image and call
         self.images = OrderedDict()                  # (session, index, rescale) -> Future of (cropped, output image, shape, seconds)
         self.sizes = {}
         self.load_seconds = 0.0
@@ -145,7 +146,7 @@ class SessionLoader:
             f = self.images.get(key)
             if f is None:
                 f = self.images[key] = self.pool.load_image(c.image_path(i), c.rescale, g.image_width, g.image_height,
-                                                            g.base_image_size, g.output_scale)
+                                                            g.base_image_size, g.output_scale, pin_device=self.pin_device)
                 while len(self.images) > self.limit:
                     self.images.popitem(last=False)
             else:
@@ -162,7 +163,14 @@ class SessionLoader:
                 self._counted.add(key)
                 self.load_seconds += sec
             ins.append(cr); outs.append(oi)
-        full_cams, out_cams = self.gen.cluster_cameras(c, c.cameras(), sizes)
+        cams = []
+        for i in c.indices:                          # a camera is listed by ~view_num clusters: built once (round 5: 5x, on this thread)
+            ck = (c.session_dir, i, c.min_depth, c.max_depth, c.depth_num, c.interval_scale)
+            cam = self.cams.get(ck)
+            if cam is None:
+                cam = self.cams[ck] = c.load_camera(i)
+            cams.append(cam)
+        full_cams, out_cams = self.gen.cluster_cameras(c, cams, sizes)
         return outs, ins, out_cams, full_cams, c.ref_index
 
 
@@ -245,7 +253,7 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     # writer threads below remain as the thin ends of that pipe (they wait for futures and copy events), and as the whole
     # pipe for upstream-format projects and for host_workers = 0.
     pool = host_pool.get_pool(host_workers) if any(type(c_) is Cluster for c_ in mine) else None
-    session_loader = SessionLoader(gen, pool) if pool is not None else None
+    session_loader = SessionLoader(gen, pool, pin_device=device.index) if pool is not None else None
     cpu0 = None
     if timings is not None:
         try:
@@ -294,6 +302,12 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
         alternating pinned staging buffers (asynchronous copy; a buffer is re-filled only after its previous copy's event)."""
         imgs = list(imgs)
         n, shp, dt = len(imgs), imgs[0].shape, imgs[0].dtype
+        pins = [getattr(im, "pinned", None) for im in imgs]
+        if all(p_ is not None for p_ in pins):        # already in pinned memory (host_pool.PinnedArray): no copy on this thread
+            dst = torch.empty((n,) + tuple(shp), dtype=pins[0].dtype, device=device)
+            for j, p_ in enumerate(pins):
+                dst[j].copy_(p_, non_blocking=True)
+            return dst
         st_ = staging.setdefault((shp, dt), [[None, None], [None, None], 0])
         i_ = st_[2]; st_[2] ^= 1
         cap = 0 if st_[0][i_] is None else st_[0][i_].shape[0]
@@ -418,10 +432,14 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     for _ in range(ahead):
         submit_next(it)
     chunk = 8                                         # reference views per tower pass (their new images form one batch)
+    groups_done = 0
     while pending:
         group = []
         t0 = time.perf_counter()
-        while pending and len(group) < chunk:
+        # the first groups are small (2, 4, then `chunk`): the GPU starts after two reference views' images are decoded, not eight
+        cur_chunk = min(chunk, 2 << groups_done)
+        groups_done += 1
+        while pending and len(group) < cur_chunk:
             c, fut = pending.pop(0)
             submit_next(it)
             try:

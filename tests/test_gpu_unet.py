@@ -137,3 +137,68 @@ def test_images_to_depth_end_to_end_matches_oracle(lib_built):
     d = n(depth)[0, :, :, 0]
     assert float(np.mean(np.abs(d - ed) / ed)) < 1e-3          # north-star bar: 1e-3 relative L1
     assert float(np.mean(np.abs(d - ed) / ed)) < 2e-5          # what the kernels actually deliver here
+
+
+@pytest.mark.parametrize("grid", [0, 3, 8])
+@pytest.mark.parametrize("case", [  # V,H,W,C1,C2,Cout[,k,stride]: every instance of the persistent kernel, ragged tile edges, several views per workgroup
+    (3, 40, 72, 16, 0, 16), (2, 36, 100, 8, 8, 8), (3, 24, 40, 32, 0, 32), (5, 20, 36, 16, 16, 16), (2, 44, 68, 8, 0, 8),
+    (4, 8, 16, 16, 0, 16), (1, 50, 34, 32, 0, 32),
+    (3, 40, 72, 16, 0, 32, 3, 2), (2, 52, 68, 8, 0, 16, 5, 2), (3, 36, 44, 16, 0, 32, 5, 2), (2, 30, 42, 16, 0, 32, 3, 2)])
+def test_persistent_conv2d_gn_matches_oracle_and_the_tile_kernel(case, grid, lib_built):
+    """csrc/unet2d_p.hip: persistent workgroups over contiguous tile ranges.  The range length is forced through the test hook
+    MVS_HOOK_UNET_GRID (3 / 8 workgroups: ranges of many tiles that cross view boundaries -- GroupNorm table rebuilt, sums flushed
+    per view -- and a launch where some workgroups get nothing); against the float64 oracle and against the one-tile-per-workgroup
+    kernel (MVS_HOOK_UNET_PERSISTENT = 0; same products, another summation order)."""
+    from mvsnet_amd import _lib as L
+    lib = L.load()
+    V, H, W, C1, C2, Cout = case[:6]
+    k, stride = case[6:] if len(case) > 6 else (3, 1)
+    rs = np.random.RandomState(sum(case) + grid)
+    x1 = rs.standard_normal((V, H, W, C1)).astype(np.float32) + 0.3
+    x2 = (rs.standard_normal((V, H, W, C2)).astype(np.float32) - 0.2) if C2 else None
+    w = (rs.standard_normal((k, k, C1 + C2, Cout)) / np.sqrt(k * k * (C1 + C2))).astype(np.float32)
+    g1 = (1 + 0.3 * rs.standard_normal(C1)).astype(np.float32); b1 = (0.2 * rs.standard_normal(C1)).astype(np.float32)
+    g2 = (1 + 0.3 * rs.standard_normal(max(C2, 1))).astype(np.float32); b2 = (0.2 * rs.standard_normal(max(C2, 1))).astype(np.float32)
+    SL = lib.mvs_gn_stat_slots()
+
+    def sums(x, C):
+        xs = x.reshape(V, -1, C // 8, 8).astype(np.float64)
+        full = np.stack([xs.sum((1, 3)), (xs ** 2).sum((1, 3))], -1)
+        out = np.zeros((V, C // 8, SL, 2))
+        out[:, :, 1] = 0.75 * full; out[:, :, SL - 2] = 0.25 * full
+        return out
+
+    s1, s2 = t(sums(x1, C1)), (t(sums(x2, C2)) if C2 else None)
+    wp = torch.empty(lib.mvs_conv2d_prepared_floats(k, C1, C2, Cout), dtype=torch.float32, device=DEV)
+    tw = t(w)
+    L.check(lib.mvs_conv2d_prepare_f32(L.ptr(tw), k, C1, C2, Cout, L.ptr(wp), L.stream_ptr()), "prepare")
+    tx1, tx2 = t(x1), (t(x2) if C2 else None)
+    tg1, tb1, tg2, tb2 = t(g1), t(b1), t(g2), t(b2)
+
+    Ho, Wo = -(-H // stride), -(-W // stride)
+
+    def run():
+        y = torch.full((V, Ho, Wo, Cout), float("nan"), dtype=torch.float32, device=DEV)
+        so = torch.zeros((V, Cout // 8, SL, 2), dtype=torch.float64, device=DEV)
+        L.check(lib.mvs_conv2d_gn_f32(L.ptr(tx1), L.ptr(s1), L.ptr(tg1), L.ptr(tb1), C1, 1,
+                                      L.ptr(tx2), L.ptr(s2), L.ptr(tg2) if C2 else None, L.ptr(tb2) if C2 else None, C2, 0,
+                                      L.ptr(wp), V, H, W, Cout, k, stride, L.ptr(y), L.ptr(so), L.stream_ptr()), "conv2d")
+        torch.cuda.synchronize()
+        return n(y), n(so).sum(2)
+
+    with L.test_hooks(unet_grid=grid):
+        got, got_s = run()
+    with L.test_hooks(unet_persistent=0):
+        ref, ref_s = run()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(got_s, ref_s, rtol=1e-6, atol=1e-3)
+    for v in range(V):
+        xin = _gn_relu(x1[v], g1, b1, True)
+        if C2:
+            xin = np.concatenate([xin, _gn_relu(x2[v], g2, b2, False)], -1)
+        exp = O.convnd_same(xin, w, stride, np.float64)
+        np.testing.assert_allclose(got[v], exp, rtol=2e-4, atol=2e-4)
+        es = exp.reshape(-1, Cout // 8, 8)
+        np.testing.assert_allclose(got_s[v, :, 0], es.sum((0, 2)), rtol=1e-4, atol=5e-3)
+        np.testing.assert_allclose(got_s[v, :, 1], (es ** 2).sum((0, 2)), rtol=1e-4, atol=5e-3)

@@ -16,7 +16,7 @@ PEAK_TF, HBM_TBS = 157.3, 8.0
 
 
 def is_tower(name):
-    return ("conv2d_gn" in name or "deconv2d_gn" in name or "unet_" in name) and "layout" not in name
+    return ("conv2d_gn" in name or "deconv2d_gn" in name or "conv2d_p_" in name or "unet_" in name) and "layout" not in name
 
 
 def last_pass(rows, per=None):
