@@ -325,6 +325,10 @@ def session_record(dev, kernel_rate, n_images=48, regularization="3DCNN", procs_
                        "decode_resize_crop (worker processes, summed)": 1e3 * tm["load"] / max(n, 1),
                        "main_thread_waiting_for_loaders": 1e3 * tm["wait_load"] / max(n, 1),
                        "main_thread_enqueueing_gpu_work": 1e3 * tm["host_gpu_submit"] / max(n, 1),
+                       # its parts (round 6): upload + tower launches / feature stack / hot-path launches / result hand-over, where the
+                       # last one INCLUDES the wait for a free result slot (8 in flight): time the GPU is behind this thread, not host work
+                       "main_thread_enqueueing_parts": {k_: 1e3 * tm.get(k_, 0.0) / max(n, 1) for k_ in ("submit_towers", "submit_features", "submit_depth", "submit_finish")},
+                       "gpu_busy_fraction_of_wall": (tm["towers"] + tm["hot_path"] + tm["d2h"]) / tm["wall"],
                        "h2d_and_towers (GPU)": 1e3 * tm["towers"] / max(n, 1),
                        "hot_path (GPU)": 1e3 * tm["hot_path"] / max(n, 1),
                        "d2h (GPU, to pinned buffers)": 1e3 * tm["d2h"] / max(n, 1),
@@ -372,12 +376,75 @@ def training_record(dev, iters=5, configs=(("3dcnn_d128_config5", "3DCNN", 128),
             for _ in range(iters):
                 tr.train_step(images, cams, gt, D)
             torch.cuda.synchronize()
-            out[tag] = {"ms_per_step": (time.perf_counter() - t0) / iters * 1e3, "views": N, "image": "%dx%d" % (W, H), "depth_planes": D}
+            ms_step = (time.perf_counter() - t0) / iters * 1e3
+            out[tag] = {"ms_per_step": ms_step, "views": N, "image": "%dx%d" % (W, H), "depth_planes": D}
+            if reg == "3DCNN":
+                out[tag]["roofline"] = training_roofline(tr, images, cams, gt, N, H, W, D, ms_step, iters)
             del tr
             torch.cuda.empty_cache()
     except Exception as e:                                  # informative record: never fail the bench line over it
         out["error"] = repr(e)[:300]
     return out
+
+
+def training_roofline(tr, images, cams, gt, N, H, W, D, ms_step, iters):
+    """Roofline of one training step: algorithmic FLOPs of forward + backward -- the backward of a
+    convolution is a data-gradient and a weight-gradient convolution of the forward's size, so 3x the forward in all (2x for a
+    network's first layer, which needs no data gradient) -- for the hot path and the towers separately, each part timed ALONE
+    in steady state (so the parts need not add up to the step: the step also holds the loss, the optimiser and Python glue),
+    against the fp32 MFMA peak, and which of it runs on kernels of this library."""
+    from mvsnet_amd import backward as B
+    from mvsnet_amd.feature_net import unet_macs
+    from mvsnet_amd.feature_net_train import hip_towers
+    from mvsnet_amd.homography_warping import homography_transforms
+    dev = tr.params.data.device
+    Hf, Wf = H // 4, W // 4
+    hot_fwd = 2.0 * 11448 * D * Hf * Wf                      # SURVEY 8a R5: 11 448 MAC per voxel (warp + variance: ~54 FLOP per voxel-channel, not counted)
+    tow_fwd = 2.0 * unet_macs(H, W) * N
+    res = {"algorithmic_gflop": {"hot_path_forward": hot_fwd / 1e9, "hot_path_forward_backward": 3 * hot_fwd / 1e9,
+                                 "towers_forward": tow_fwd / 1e9, "towers_forward_backward": 3 * tow_fwd / 1e9},
+           "peak_tflops": MFMA_F32_PEAK_TFLOPS}
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+    try:
+        img_t = torch.as_tensor(images).to(dev)
+        unet_p = tr.params.group("unet")
+
+        def towers():
+            for p_ in unet_p.values():
+                for t_ in p_.values():
+                    t_.grad = None
+            hip_towers(img_t, unet_p).sum().backward()
+        ms_tow = timed(towers)
+        feats = hip_towers(img_t, unet_p).detach().requires_grad_(True)
+        t8 = homography_transforms(torch.as_tensor(cams).to(dev), D, float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1]))
+        reg_p = tr.params.group("regnet")
+        g1 = torch.ones(Hf, Wf, device=dev)
+
+        def hot():
+            d, _ = B.plane_sweep_depth(feats, t8, float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1]), reg_p)
+            d.reshape(Hf, Wf).backward(g1)
+        ms_hot = timed(hot)
+        res.update({
+            "hot_path_forward_backward": {"ms": ms_hot, "achieved_tflops": 3 * hot_fwd / ms_hot / 1e9, "frac_of_fp32_mfma_peak": 3 * hot_fwd / ms_hot / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                                          "kernels": "all HIP (csrc/backward.hip, conv3d_wgrad.hip, the forward's MFMA kernels for the data gradients)"},
+            "towers_forward_backward": {"ms": ms_tow, "achieved_tflops": 3 * tow_fwd / ms_tow / 1e9, "frac_of_fp32_mfma_peak": 3 * tow_fwd / ms_tow / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                                        "kernels": "forward + GroupNorm backward + weight gradients of the 16/32-channel layers: HIP (unet2d.hip, conv2d_wgrad.hip); "
+                                                   "data gradients and the other weight gradients: ATen / MIOpen (feature_net_train.py)"},
+            "whole_step": {"ms": ms_step, "achieved_tflops": 3 * (hot_fwd + tow_fwd) / ms_step / 1e9,
+                           "frac_of_fp32_mfma_peak": 3 * (hot_fwd + tow_fwd) / ms_step / 1e9 / MFMA_F32_PEAK_TFLOPS},
+            "share_of_step": {"hot_path": ms_hot / ms_step, "towers": ms_tow / ms_step}})
+    except Exception as e:                                  # informative: the step time above stands
+        res["error"] = repr(e)[:300]
+    return res
 
 
 def gru_production_order(dev, n_views=8, views_per_sweep=4):
@@ -526,21 +593,10 @@ def main():
     def step(i, record):
         plan = plans[i % n_streams]
         with torch.cuda.stream(streams[i % n_streams]):
-            if not record:
-                # the product's entry: homographies -> cost volume -> RegNetUS0 -> soft-argmin as ONE library call
-                plan.run_depth(feats, cams, w.depth_start, w.depth_interval, end, False)
-                return
-            # stage split for `roofline_kernels` (untimed pass): the same launches through the per-stage entries
-            e = [ev() for _ in range(4)]
-            e[0].record()
-            plan.set_cameras(cams, w.depth_start, w.depth_interval, end, False)
-            cost_volume(feats[0], feats[1:], plan.transforms, 0, plan.D, "mem", out=plan.cost)
-            e[1].record()
-            regnet_us0(plan.cost, weights.regnet, plan.workspace, plan.reg)
-            e[2].record()
-            softargmin_prob(plan.reg, w.depth_start, w.depth_interval, False, plan.depth, plan.prob)
-            e[3].record()
-            marks.append(e)
+            # the product's entry: homographies -> cost volume -> RegNetUS0 -> soft-argmin as ONE library call.  (`record`: the
+            # library brackets its three stages with HIP events -- mvs_profile_stages -- for `roofline_kernels`: the split of THIS
+            # path, not of a separate pass through the per-stage Python entries as in rounds 1-5)
+            plan.run_depth(feats, cams, w.depth_start, w.depth_interval, end, False)
 
     torch.cuda.synchronize()
     # untimed: the requested warm-up steps, topped up to 10 launches so that lazy one-off work (code-object
@@ -591,16 +647,17 @@ def main():
     pair_ms, pair_n = ctypes.c_double(0.0), ctypes.c_int(0)
     _lib.check(lib.mvs_profile_dominant_ms(ctypes.byref(pair_ms), ctypes.byref(pair_n)), "mvs_profile_dominant_ms")
     _lib.check(lib.mvs_profile_dominant(0), "mvs_profile_dominant")
-    # stage split (warp / conv stack / soft-argmin) for `roofline_kernels`: a separate, untimed pass -- every
-    # event record costs a few microseconds of device idle time, and only the dominant kernel's bracket has to
-    # live inside the timed region
+    # stage split (warp / conv stack / soft-argmin) for `roofline_kernels`: the SAME library call as the timed region, with the
+    # library's own event brackets between its stages (untimed pass -- every event record costs a microsecond or two of
+    # device idle time, and only the dominant kernel's bracket has to live inside the timed region)
+    stage_ms, stage_n = (ctypes.c_double * 3)(), ctypes.c_int(0)
+    _lib.check(lib.mvs_profile_stages(1), "mvs_profile_stages")
     for i in range(min(args.steps, 20)):
         step(i, True)
     torch.cuda.synchronize()
-    # per-kernel device time from the events recorded inside the timed region
-    t_warp = np.mean([m[0].elapsed_time(m[1]) for m in marks]) * 1e-3     # includes the tiny homography kernel
-    t_conv = np.mean([m[1].elapsed_time(m[2]) for m in marks]) * 1e-3
-    t_soft = np.mean([m[2].elapsed_time(m[3]) for m in marks]) * 1e-3
+    _lib.check(lib.mvs_profile_stages_ms(stage_ms, ctypes.byref(stage_n)), "mvs_profile_stages_ms")
+    _lib.check(lib.mvs_profile_stages(0), "mvs_profile_stages")
+    t_warp, t_conv, t_soft = (max(stage_ms[k], 1e-6) * 1e-3 for k in range(3))      # [0] includes the tiny homography kernel
     warp_bytes, conv_flops, soft_bytes = algorithmic_work(w.view_num, w.depth_num, w.height, w.width,
                                                          w.channels, S.base_filter(args.network_mode))
     depth_np = plan.depth.cpu().numpy()
@@ -707,6 +764,11 @@ def main():
                        "conv_impl": args.conv_impl, "streams_per_gpu": n_streams},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
             "roofline_kernels": kernels,
+            "roofline_stage_rows": {"sum_ms": (t_warp + t_conv + t_soft) * 1e3, "ms_per_step": elapsed / args.steps * 1e3,
+                                    "launches_timed": stage_n.value,
+                                    "source": "the first three rows of roofline_kernels are the library's own HIP-event brackets between the stages of "
+                                              "mvs_depth_from_features_f32 (mvs_profile_stages), i.e. of the timed path; their sum exceeds ms_per_step "
+                                              "by the device idle time of four event records per depth map"},
             "depth_checksum": float(np.float64(depth_np).sum()),
             "per_rank_depth_maps_per_s": {"min": min(rank_rates), "max": max(rank_rates), "ranks": rank_rates},
             "ranks": {"world_size": dist.get_world_size() if dist else 1, "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if dist else None,
@@ -735,6 +797,28 @@ def main():
             for _ in range(3):
                 f = net(imgs)
             torch.cuda.synchronize()
+            if args.extractor == "hip":
+                # the towers alone: N images -> N feature maps, back to back; events on the stream they run on
+                from mvsnet_amd.feature_net import unet_macs
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n_pass = 50
+                t_h = time.perf_counter()
+                e0.record()
+                for _ in range(n_pass):
+                    f = net(imgs)
+                e1.record()
+                t_h = time.perf_counter() - t_h
+                torch.cuda.synchronize()
+                tw_ms = e0.elapsed_time(e1) / n_pass
+                gf = 2.0 * unet_macs(4 * w.height, 4 * w.width) * w.view_num / 1e9
+                out["towers"] = {"workload": "UNetDS2GN, %d images of %dx%d -> %d feature maps of %dx%dx32, one batched pass" %
+                                             (w.view_num, 4 * w.width, 4 * w.height, w.view_num, w.width, w.height),
+                                 "ms_per_pass": tw_ms, "algorithmic_gflop": gf, "achieved_tflops": gf / tw_ms,
+                                 "peak_tflops": 157.3, "frac_of_fp32_mfma_peak": gf / tw_ms / 157.3,
+                                 "host_enqueue_ms_per_pass": t_h / n_pass * 1e3,
+                                 "side_streams": len(getattr(net, "_choice", {}).get((4 * w.height, 4 * w.width), [])),
+                                 "launches_per_pass": 32,
+                                 "kernels": "csrc/unet2d_p.hip (persistent, 13 layers) + csrc/unet2d.hip (one tile per workgroup, 19 layers)"}
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 f = net(imgs)
@@ -770,6 +854,9 @@ def main():
             out["config_c3_gru_4_views"]["per_plane_counters"] = gru_pmc_per_plane()
             out["config_c3_gru_from_images"] = gru_production_order(dev); lap("config_c3_gru_from_images")
             out["session"] = session_record(dev, out["value"]); lap("session")
+            # the per-GPU share of configuration 4 (1 078 reference views over 8 GPUs = ~135 per rank): the same loop over a session
+            # long enough that the pipeline's fill (first decodes) and drain (last file writes) stop dominating the 48-view record
+            out["session_144_views"] = session_record(dev, out["value"], n_images=144, procs_per_gpu=0); lap("session_144_views")
             # configuration 2's image size (1152 x 864 JPEGs: ~3x the host decode work per image; 288 x 216 feature maps)
             out["session_config2_images"] = session_record(dev, out["config_c2"].get("depth_maps_per_s"), n_images=24, procs_per_gpu=0,
                                                            width=1152, height=864); lap("session_config2_images")

@@ -223,6 +223,11 @@ int mvs_profile_dominant_ms(double* avg_ms, int* count);
  * average duration in milliseconds (the fused 3dconv0_1 + 3dconv1_0 pass reports its time under 3dconv0_1 and 0 under
  * 3dconv1_0) and the number of calls sampled.  Every event costs a few microseconds of device idle time: use it
  * outside timed regions; not during hipGraph capture. */
+/* The same for the three stages of mvs_depth_from_features_f32 -- [0] homographies + warp + variance, [1] the RegNetUS0 stack
+ * (its 11 launches), [2] softmax / soft-argmin / probability -- so that bench.py's stage rows describe the timed path itself (one
+ * library call per depth map) and sum to its duration, plus the ~1-2 us of device idle time each event record costs. */
+int mvs_profile_stages(int enable);
+int mvs_profile_stages_ms(double* avg_ms3, int* count);
 int mvs_profile_layers(int enable);
 int mvs_profile_layers_ms(double* avg_ms11, int* count);
 /* Launch plan of the 1/8-resolution chain.  With prepared weights and the metric's channel widths 3dconv2_1 (read only by

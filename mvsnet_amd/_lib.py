@@ -40,6 +40,8 @@ SIGNATURES = {
     "mvs_deconv2d_gn_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "mvs_profile_dominant": (_i, [_i]),
     "mvs_profile_dominant_ms": (_i, [_p, _p]),
+    "mvs_profile_stages": (_i, [_i]),
+    "mvs_profile_stages_ms": (_i, [_p, _p]),
     "mvs_profile_layers": (_i, [_i]),
     "mvs_profile_layers_ms": (_i, [_p, _p]),
     "mvs_bn_finalize_f32": (_i, [_p, _i, C.c_double, _p, _p, _f, _p, _p, _p]),

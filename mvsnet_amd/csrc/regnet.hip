@@ -176,6 +176,33 @@ extern "C" int mvs_profile_layers_ms(double* avg_ms11, int* count) {
     return 0;
 }
 
+// ---- stage timing of mvs_depth_from_features_f32 (bench.py's roofline_kernels: the split of the TIMED path) ------------
+namespace {
+struct StageProfile { bool on = false; hipEvent_t ev[32][4]; int used = 0; int created = 0; } g_sprof;
+}
+extern "C" int mvs_profile_stages(int enable) {
+    g_sprof.on = enable != 0;
+    g_sprof.used = 0;
+    return 0;
+}
+extern "C" int mvs_profile_stages_ms(double* avg_ms3, int* count) {
+    MVS_CHECK_ARG(avg_ms3 && count);
+    for (int l = 0; l < 3; ++l) avg_ms3[l] = 0.0;
+    for (int i = 0; i < g_sprof.used; ++i) {
+        hipError_t e = hipEventSynchronize(g_sprof.ev[i][3]);
+        if (e != hipSuccess) return (int)e;
+        for (int l = 0; l < 3; ++l) {
+            float ms = 0.f;
+            if ((e = hipEventElapsedTime(&ms, g_sprof.ev[i][l], g_sprof.ev[i][l + 1])) != hipSuccess) return (int)e;
+            avg_ms3[l] += ms;
+        }
+    }
+    *count = g_sprof.used;
+    if (g_sprof.used) for (int l = 0; l < 3; ++l) avg_ms3[l] /= g_sprof.used;
+    g_sprof.used = 0;
+    return 0;
+}
+
 // ---- RegNetUS0 -----------------------------------------------------------------------------------
 
 // Share (1/1000) of 3dconv2_1's blocks that ride as filler workgroups in the launches of 3dconv3_0 and 3dconv3_1 (the rest in
@@ -537,12 +564,26 @@ extern "C" int mvs_depth_from_features_f32(const float* features, const float* c
     RegnetWs ws = carve((char*)workspace, depth_num, H, W, C, base);
     if (workspace_bytes < ws.bytes) return MVS_E_WORKSPACE;
     int rc;
+    int sp = -1;                                     // stage event slot of this call (mvs_profile_stages)
+    if (g_sprof.on && g_sprof.used < 32) {
+        sp = g_sprof.used;
+        if (sp >= g_sprof.created) {
+            for (int k = 0; k < 4 && sp >= 0; ++k) if (hipEventCreate(&g_sprof.ev[sp][k]) != hipSuccess) sp = -1;
+            if (sp >= 0) g_sprof.created = sp + 1;
+        }
+        if (sp >= 0) g_sprof.used = sp + 1;
+    }
+    auto mark = [&](int k) -> int { return sp < 0 ? 0 : (int)hipEventRecord(g_sprof.ev[sp][k], mvs_stream(stream)); };
+    if ((rc = mark(0))) return rc;
     // plane homographies -> 8-vectors, and the zero-fill of this depth map's BatchNorm sums, in one launch
     if ((rc = mvs_homography_transforms_zero(cams, view_num, depth_num, depth_start, depth_interval, depth_end, inverse_depth,
                                              transforms, ws.stats, N_BN * MVS_BN_SLOTS_MAX * 2 * 8 * base, mvs_stream(stream)))) return rc;
     if ((rc = mvs_cost_volume_f32(features, features + (size_t)H * W * C, transforms, view_num, depth_num, 0, depth_num,
                                   H, W, C, variant, 0, 0, cost, stream))) return rc;
+    if ((rc = mark(1))) return rc;
     if ((rc = regnet_run(cost, 1, depth_num, H, W, C, base, weights, prepared, gammas, betas, eps, workspace,
                          workspace_bytes, reg, stream, true))) return rc;
-    return mvs_softargmin_prob_f32(reg, depth_num, H, W, depth_start, depth_interval, inverse_depth, depth, prob, stream);
+    if ((rc = mark(2))) return rc;
+    if ((rc = mvs_softargmin_prob_f32(reg, depth_num, H, W, depth_start, depth_interval, inverse_depth, depth, prob, stream))) return rc;
+    return mark(3);
 }

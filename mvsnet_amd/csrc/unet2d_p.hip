@@ -56,7 +56,7 @@ conv2d_p_kernel(Conv2dArgs p, int tiles_h, int tiles_w, int ntiles, int per_cu) 
     constexpr int KL = CG / 4;                      // channels a lane reads per operand read (4: b128, 2: b64)
     constexpr int NH = CIN / CG;                    // operand reads per tap (= weight chunks)
     constexpr int CGQ = CG / 4;
-    static_assert(CG == 16 || CG == 8, "operand read width");
+    static_assert(CG == 16 || CG == 8 || CG == 4, "operand read width");
     static_assert(CIN % CG == 0 && CIN <= 64 && 256 % CQ == 0, "channel tiling");
     constexpr int NWR = (G::W_FLOATS / 4 + 255) / 256;     // weight float4 per thread
     extern __shared__ __attribute__((aligned(16))) float smem_p[];
@@ -216,7 +216,7 @@ conv2d_p_kernel(Conv2dArgs p, int tiles_h, int tiles_w, int ntiles, int per_cu) 
         b_off[v] = PAIR ? (row * IW + ct * 32 + 2 * n) * S + KL * kq : ((row * STRIDE) * IW + (ct * 16 + n) * STRIDE) * S + KL * kq;
     }
     // A rows: [chunk][tap][CG/4][co][4]; this lane supplies ci = KL * kq + j of the chunk
-    const int a_off = (CG == 16) ? (kq * COUT_T + n) * 4 : (((kq >> 1) * COUT_T + n) * 4 + 2 * (kq & 1));
+    const int a_off = (CG == 16) ? (kq * COUT_T + n) * 4 : (CG == 8) ? (((kq >> 1) * COUT_T + n) * 4 + 2 * (kq & 1)) : n * 4 + kq;
     // outputs leave through one buffer resource over y: an out-of-range offset drops the lane's store (no branches around them)
     const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)((size_t)p.V * p.Ho * p.Wo * p.Cout * sizeof(float)), 0x00020000);
     constexpr int OOB = (int)0x80000000;
@@ -267,13 +267,15 @@ conv2d_p_kernel(Conv2dArgs p, int tiles_h, int tiles_w, int ntiles, int per_cu) 
             for (int v = 0; v < V; ++v) {
                 const float* bp = slab_cur + b_off[v] + (kh * IW + kw) * S + CG * h;
                 if (CG == 16) { f32x4 t = *(const f32x4*)bp; bq[buf][v][0] = t[0]; bq[buf][v][1] = t[1]; bq[buf][v][2] = t[2]; bq[buf][v][3] = t[3]; }
-                else { f32x2 t = *(const f32x2*)bp; bq[buf][v][0] = t[0]; bq[buf][v][1] = t[1]; }
+                else if (CG == 8) { f32x2 t = *(const f32x2*)bp; bq[buf][v][0] = t[0]; bq[buf][v][1] = t[1]; }
+                else bq[buf][v][0] = *bp;
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const float* ap = wl + a_off + ((h * NT + tap) * CGQ * COUT_T + m * 16) * 4;
                 if (CG == 16) { f32x4 t = *(const f32x4*)ap; aq[buf][m][0] = t[0]; aq[buf][m][1] = t[1]; aq[buf][m][2] = t[2]; aq[buf][m][3] = t[3]; }
-                else { f32x2 t = *(const f32x2*)ap; aq[buf][m][0] = t[0]; aq[buf][m][1] = t[1]; }
+                else if (CG == 8) { f32x2 t = *(const f32x2*)ap; aq[buf][m][0] = t[0]; aq[buf][m][1] = t[1]; }
+                else aq[buf][m][0] = *ap;
             }
         };
         operands(0, 0);
@@ -363,6 +365,7 @@ int launch_p(const Conv2dArgs& p, hipStream_t st) {
 // instance table: (ks, stride, cin, cg, mt) -> launcher.  CG and MT follow conv2d_tiling (unet2d.hip): the weight layout is shared.
 struct PInst { int ks, stride, cin, cg, mt, cout_max; int (*fn)(const Conv2dArgs&, hipStream_t); };
 const PInst P_TABLE[] = {
+    {3, 1, 4, 4, 1, 8, launch_p<3, 1, 4, 4, 1, 1, 3, true>},       // 2dconv0_1 (the image, 3 + 1 channels)
     {3, 1, 8, 8, 1, 8, launch_p<3, 1, 8, 8, 1, 1, 3, true>},       // 2dconv0_2, 8_2 (8 couts: pixel-pair rows)
     {3, 1, 16, 8, 1, 8, launch_p<3, 1, 16, 8, 1, 1, 2, true>},     // 2dconv8_1 (8 | 8 -> 8)
     {3, 1, 8, 8, 1, 16, launch_p<3, 1, 8, 8, 1, 2, 3>},
@@ -404,7 +407,7 @@ __global__ void conv2d_pair_weight_layout_kernel(const float* __restrict__ w, in
 
 size_t mvs_conv2d_pair_floats(int ks, int stride_unused, int cin, int cout) {
     (void)stride_unused;
-    return (ks == 3 && cout <= 8 && (cin == 8 || cin == 16)) ? (size_t)12 * cin * 16 : 0;
+    return (ks == 3 && cout <= 8 && (cin == 4 || cin == 8 || cin == 16)) ? (size_t)12 * cin * 16 : 0;
 }
 int mvs_conv2d_pair_prepare(const float* w, int cin, int cout, int ck, float* out, hipStream_t st) {
     const int total = 12 * cin * 16;

@@ -37,6 +37,25 @@ UNET_LAYERS = (
 )
 
 
+def unet_macs(H, W, base_filter=8, image_channels=3):
+    """Algorithmic multiply-adds of one UNetDS2GN pass over one H x W image (mvsnetworks.py:53-115): every conv / transposed
+    conv counted with the taps and channels the reference's layers have (a k3 s2 transposed conv touches 9/4 taps per output)."""
+    shape = {"data": (H, W, image_channels)}
+    total = 0.0
+    for name, kind, srcs, k, mult, stride in UNET_LAYERS:
+        h, w, _ = shape[srcs[0]]
+        cin = sum(shape[s_][2] for s_ in srcs)
+        cout = base_filter * mult
+        if kind == "dg":
+            ho, wo = 2 * h, 2 * w
+            total += ho * wo * 2.25 * cin * cout
+        else:
+            ho, wo = -(-h // stride), -(-w // stride)
+            total += ho * wo * k * k * cin * cout
+        shape[name] = (ho, wo, cout)
+    return total
+
+
 def _same_pad(n, k, s):
     out = -(-n // s)
     total = max((out - 1) * s + k - n, 0)

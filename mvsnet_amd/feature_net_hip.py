@@ -25,13 +25,19 @@ SIDE_BRANCH = {"2dconv0_1": 0, "2dconv0_2": 0, "2dconv1_1": 1, "2dconv1_2": 1,
 
 class HipUNetDS2GN:
     """``params`` in TensorFlow variable layouts as for `UNetDS2GN` (conv (k,k,Cin,Cout), transposed
-    conv (k,k,Cout,Cin), GroupNorm gamma/beta).  `side_streams` (0 .. 4): HIP streams beside the caller's for the encoder's
-    side branches (forked from / joined to the caller's stream with events inside every call; 0 = everything in line)."""
+    conv (k,k,Cout,Cin), GroupNorm gamma/beta).  `side_streams`: HIP streams beside the caller's for the encoder's side
+    branches (forked from / joined to the caller's stream with events inside every call): 0 = everything in line, 1 .. 4 = that
+    many, "auto" (default) = decided by MEASUREMENT at the first call of an input shape: two candidate pairs of streams and the
+    in-line pass are timed (three passes each, the only synchronising calls this class makes) and the fastest is kept -- which
+    hardware queue a HIP stream lands on depends on what else the process created, and a side stream that shares the caller's
+    compute pipe makes the pass SLOWER (measured: 1 807 against 1 055 us with one side stream on the wrong pipe, 985 with two on
+    others; tools/pipe_probe.hip, round 3).  Under hipGraph capture an undecided shape runs in line."""
 
-    def __init__(self, params, device="cuda", side_streams=0):
+    def __init__(self, params, device="cuda", side_streams="auto"):
         self.device = torch.device(device)
-        self.side_streams = int(side_streams)
+        self.side_streams = side_streams if side_streams == "auto" else int(side_streams)
         self._streams = None
+        self._choice = {}                                  # (V, H, W) -> list of side streams (possibly empty)
         # layers whose output is read by a layer of the other kind (chain <-> side branch)
         self._fork_join = {s_ for name, _k, srcs, *_r in UNET_LAYERS for s_ in srcs if (name in SIDE_BRANCH) != (s_ in SIDE_BRANCH)}
         lib = _lib.load()
@@ -91,22 +97,52 @@ class HipUNetDS2GN:
         self._bufs[key] = (acts, offs, stats, shapes, data)
         return self._bufs[key]
 
+    def _side_streams_for(self, x):
+        """The side streams of this input shape (see the class docstring)."""
+        key = tuple(x.shape[1:3])                          # per image size: the pipes do not depend on the batch
+        if self.side_streams != "auto":
+            ns = self.side_streams
+            if ns and self._streams is None:
+                self._streams = [torch.cuda.Stream(self.device) for _ in range(ns)]
+            return self._streams[:ns] if ns else []
+        if key in self._choice:
+            return self._choice[key]
+        if torch.cuda.is_current_stream_capturing():
+            return []
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(4)]
+        import time
+        best, best_t = [], None
+        for cand in ([], self._streams[0:2], self._streams[2:4]):
+            self._run(x, cand)                             # warm: plan buffers, first launches
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                self._run(x, cand)
+            torch.cuda.synchronize(self.device)
+            t_ = time.perf_counter() - t0
+            if best_t is None or t_ < 0.97 * best_t:       # a side-stream set has to win by 3 % against what is kept
+                best, best_t = cand, t_
+        self._choice[key] = best
+        return best
+
     @torch.no_grad()
     def __call__(self, images):
         """images (V,H,W,3) channel-last float32 -> features (V,H/4,W/4,C) contiguous."""
-        lib = _lib.load()
         x = images.to(self.device, torch.float32)
-        V, H, W, _ = x.shape
-        if H % 16 or W % 16:
+        if x.shape[1] % 16 or x.shape[2] % 16:
             raise ValueError("UNetDS2GN needs image sizes divisible by 16")
+        return self._run(x, self._side_streams_for(x))
+
+    def _run(self, x, side):
+        lib = _lib.load()
+        V, H, W, _ = x.shape
         acts, offs, stats, shapes, data = self._plan(V, H, W)
         stats.zero_()
         data[..., :3] = x
         main = torch.cuda.current_stream(self.device)
-        ns = self.side_streams
-        if ns and self._streams is None:
-            self._streams = [torch.cuda.Stream(self.device) for _ in range(ns)]
-        stream_of = lambda name: (self._streams[SIDE_BRANCH[name] % ns] if ns and name in SIDE_BRANCH else main)
+        ns = len(side)
+        stream_of = lambda name: (side[SIDE_BRANCH[name] % ns] if ns and name in SIDE_BRANCH else main)
         done = {}                                          # layer -> event, for layers read from another stream
         if ns:
             done["data"] = main.record_event()

@@ -220,7 +220,9 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     if weights is None:
         weights = build_weights(config, device)
     t_wall = time.perf_counter()
-    tm = {"load": 0.0, "wait_load": 0.0, "host_gpu_submit": 0.0, "write": 0.0}
+    tm = {"load": 0.0, "wait_load": 0.0, "host_gpu_submit": 0.0, "write": 0.0,
+          # parts of host_gpu_submit (this thread): image upload + tower launches, feature stack, hot-path launches, result hand-over
+          "submit_towers": 0.0, "submit_features": 0.0, "submit_depth": 0.0, "submit_finish": 0.0}
     tm_lock = threading.Lock()
 
     def timed(name, fn, *a):
@@ -432,14 +434,12 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     for _ in range(ahead):
         submit_next(it)
     chunk = 8                                         # reference views per tower pass (their new images form one batch)
-    groups_done = 0
+    # (round 6 measured a ramp of 2, 4, 8 views for the first groups: no gain -- the worker processes decode a group's images in
+    #  parallel, so the first group of eight is ready as soon as a group of two would be: 555-570 against 567-583 depth maps/s)
     while pending:
         group = []
         t0 = time.perf_counter()
-        # the first groups are small (2, 4, then `chunk`): the GPU starts after two reference views' images are decoded, not eight
-        cur_chunk = min(chunk, 2 << groups_done)
-        groups_done += 1
-        while pending and len(group) < cur_chunk:
+        while pending and len(group) < chunk:
             c, fut = pending.pop(0)
             submit_next(it)
             try:
@@ -453,13 +453,16 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
         m_start = mark()
         prefetch_features(group)
         m_towers = mark()
+        tm["submit_towers"] += time.perf_counter() - t1
         # the group's cameras in ONE upload through pinned staging (a pageable .to(device) per reference view is a blocking
         # copy queued behind the previous view's kernels: it cost this thread ~0.6 ms per view)
         cams_group = to_device([np.asarray(res_[2], dtype=np.float32) for _c, res_ in group])
         first = True
         for gi, (c, (out_images, in_images, out_cams, full_cams, index)) in enumerate(group):
             start = time.time()
+            t_a = time.perf_counter()
             features = features_of(c, in_images)
+            tm["submit_features"] += time.perf_counter() - t_a
             cams = cams_group[gi]
             depth_start = float(out_cams[0, 1, 3, 0])     # predictlib.set_shapes :190-197
             depth_interval = float(out_cams[0, 1, 3, 1])
@@ -480,12 +483,16 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
             else:
                 ref_image = images_to_device(in_images[0:1]) if config.refinement else None
                 m_a = mark()
+                t_b = time.perf_counter()
                 d, p, _ = pl.get_depth_and_prob_map(None, cams[None], depth_start, depth_interval, config, weights,
                                                     depth_num=depth_num, depth_end=depth_end, features=features,
                                                     ref_image=ref_image)
                 m_depth = mark()
+                t_c = time.perf_counter()
+                tm["submit_depth"] += t_c - t_b
                 marks = [m_start if first else None, m_towers if first else None, m_a, m_depth] if timings is not None else None
                 finish(d, p, *rest, marks)
+                tm["submit_finish"] += time.perf_counter() - t_c
                 if marks is not None:
                     ev_marks.append(marks)
             first = False

@@ -10,7 +10,7 @@ sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 from mvsnet_amd import synthetic as S
 from mvsnet_amd.feature_net_hip import HipUNetDS2GN
 dev = torch.device("cuda", 0)
-net = HipUNetDS2GN(S.make_unet_params("normal", seed=3), dev)
+net = HipUNetDS2GN(S.make_unet_params("normal", seed=3), dev, **({"side_streams": int(os.environ["UNET_SIDE"])} if "UNET_SIDE" in os.environ else {}))
 img = torch.randn(5, 512, 640, 3, device=dev)
 for _ in range(int(os.environ.get("UNET_PASSES", "6"))):
     out = net(img)

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 from mvsnet_amd import _lib
 for kv in filter(None, os.environ.get("UNET_HOOKS", "").split(",")):      # e.g. UNET_HOOKS=unet_persistent=0,unet_grid=768
     k, v = kv.split("="); _lib.set_test_hook(k, int(v))
-net = HipUNetDS2GN(S.make_unet_params("normal", seed=3), dev, side_streams=int(os.environ.get("UNET_SIDE", "0")))
+net = HipUNetDS2GN(S.make_unet_params("normal", seed=3), dev, **({"side_streams": int(os.environ["UNET_SIDE"])} if "UNET_SIDE" in os.environ else {}))
 img = torch.randn(5, 512, 640, 3, device=dev)
 for _ in range(6):
     out = net(img)
@@ -39,7 +39,7 @@ for v in names:
     if not f: continue
     rows = [r for r in csv.DictReader(open(f[0])) if ("conv2d_gn" in r["Kernel_Name"] or "conv2d_p_" in r["Kernel_Name"] or "unet_" in r["Kernel_Name"]) and "layout" not in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    per = len(rows) // 6
+    per = 32                                  # launches of one pass (the last one is taken)
     cols[v] = [((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"]) for r in rows[-per:]]
     spans[v] = (max(int(r["End_Timestamp"]) for r in rows[-per:]) - min(int(r["Start_Timestamp"]) for r in rows[-per:])) / 1e3
 print("%-3s %-44s" % ("i", "kernel") + "".join("%10s" % v[-10:] for v in cols))
