@@ -37,7 +37,10 @@ struct PGeom {
     static constexpr int IH = (PTH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     static constexpr int NPOS = IH * IW;
     static constexpr int CQ = CIN / 4;
-    static constexpr int S = CIN + 4;
+#ifndef P_SPAD
+#define P_SPAD 4
+#endif
+    static constexpr int S = CIN + P_SPAD;
     static constexpr int COUT_T = 16 * MT;
     static constexpr int W_FLOATS = NT * CIN * COUT_T;
     static constexpr int NIN = (NPOS * CQ + 255) / 256;
@@ -97,11 +100,14 @@ conv2d_p_kernel(Conv2dArgs p, int tiles_h, int tiles_w, int ntiles, int per_cu) 
         rc[i] = valid ? ((r << 16) | c) : (0x3fff << 16);          // a row no image has: never loaded
         loff[i] = valid ? pos * S + 4 * q : -1;
     }
-    float4 pin[NIN];
-    unsigned okmask = 0;
+    // TWO register sets for patches in flight: tile t+2's is requested at the START of tile t's MFMAs into the set tile t's own
+    // patch came from, while tile t+1's is staged from the other one -- a request has a whole tile (~2 us) to come back
+    // (with one set it could only go out after the last staging piece, half a microsecond before it was needed).
+    float4 pinA[NIN], pinB[NIN];
+    unsigned okA = 0, okB = 0;
     // Branch-free request of a tile's patch: every lane loads -- from its patch position when that lies inside the image, from
     // the tensor's first element otherwise (zeroed when staged) -- so the NIN loads go out back to back.
-    auto fetch = [&](int tile) __attribute__((always_inline)) {
+    auto fetch = [&](int tile, float4 (&pin)[NIN], unsigned& okmask) __attribute__((always_inline)) {
         const int view = tile / tpv, rem = tile - view * tpv;
         const int th = rem / tiles_w, tw = rem - th * tiles_w;
         const int ih0 = th * PTH * STRIDE - p.pad_h, iw0 = tw * TW * STRIDE - p.pad_w;
@@ -110,7 +116,7 @@ conv2d_p_kernel(Conv2dArgs p, int tiles_h, int tiles_w, int ntiles, int per_cu) 
 #pragma unroll
         for (int i = 0; i < NIN; ++i) {
             const int gh = ih0 + (rc[i] >> 16), gw = iw0 + (rc[i] & 0xffff);
-            const bool ok = (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            const bool ok = ((unsigned)gh < (unsigned)p.H) & ((unsigned)gw < (unsigned)p.W);      // (&: no branch around the load)
             const int off = ok ? (gh * p.W + gw) * sC : 0;
             pin[i] = *reinterpret_cast<const float4*>(base + off);
             okmask |= (ok ? 1u : 0u) << i;
@@ -119,7 +125,7 @@ conv2d_p_kernel(Conv2dArgs p, int tiles_h, int tiles_w, int ntiles, int per_cu) 
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     // registers -> LDS, one patch piece: GroupNorm affine (+ReLU) on the way, zeros outside the image (SAME padding of the
     // normalised input); idle lanes of the last round write the spare float4 behind the weights
-    auto stage_piece = [&](int i, float* slab_to) __attribute__((always_inline)) {
+    auto stage_piece = [&](int i, float* slab_to, const float4 (&pin)[NIN], unsigned okmask) __attribute__((always_inline)) {
         float4 v = pin[i];
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
         if (relu_on) { v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w); }
@@ -223,7 +229,7 @@ conv2d_p_kernel(Conv2dArgs p, int tiles_h, int tiles_w, int ntiles, int per_cu) 
 
     // ---- prologue: first patch, the first view's partial sums and the weights requested together
     if (t0 >= t1) return;
-    fetch(t0);
+    fetch(t0, pinA, okA);
     int view = t0 / tpv;
     affine_begin(view);
     {
@@ -239,16 +245,52 @@ conv2d_p_kernel(Conv2dArgs p, int tiles_h, int tiles_w, int ntiles, int per_cu) 
     float* slab_cur = smem_p;                        // holds the tile being multiplied
     float* slab_nxt = smem_p + G::SLAB;              // receives the next tile while that happens
 #pragma unroll
-    for (int i = 0; i < NIN; ++i) stage_piece(i, slab_cur);
+    for (int i = 0; i < NIN; ++i) stage_piece(i, slab_cur, pinA, okA);
     __syncthreads();
-    if (t0 + 1 < t1) fetch(t0 + 1);
+    if (t0 + 1 < t1) fetch(t0 + 1, pinB, okB);
 
     // One barrier per tile.  Everything that is not an MFMA -- writing tile t+1's patch (already in registers) to the other slab,
     // requesting tile t+2's patch -- sits BETWEEN the MFMAs of tile t in program order (sched_barrier keeps it there): an MFMA
     // occupies the matrix pipe for 32 clocks and the wave's issue port for 8, so those instructions issue in its shadow.
     constexpr int NS = NT * NH;                      // (tap, chunk) steps of a tile
-    constexpr int PPS = (NIN + NS - 2) / (NS - 1);   // staging pieces per step (steps 0 .. NS-2; the prefetch sits in the last step)
-    for (int tile = t0; tile < t1; ++tile) {
+    constexpr int PPS = (NIN + NS - 1) / NS;         // staging pieces per step
+    // A finished tile's results stay in registers (accp) and leave during the NEXT tile's MFMAs: raw outputs through buffer stores
+    // (an out-of-range offset drops the lane), sums in float within the tile (fixed order), float64 across tiles; the sums of a
+    // view are flushed when the first tile of another view has been emitted, or at the end.
+    f32x4 accp[MT][V];
+    int p_view = -1, p_oh0 = 0, p_ow0 = 0, sum_view = -1;
+    auto emit_prev = [&]() __attribute__((always_inline)) {
+        if (p_view < 0) return;
+        if (sum_view >= 0 && sum_view != p_view && p.stats) flush(sum_view);
+        sum_view = p_view;
+        float gs[MT], gq[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { gs[m] = 0.f; gq[m] = 0.f; }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            // lane (kq, n) holds GEMM rows 4kq .. 4kq+3 of column n: plain = couts 4kq.. of pixel n; PAIR = couts 4(kq&1).. of pixel 2n + (kq>>1)
+            const int oh = p_oh0 + 2 * wave + v / TWT, ow = PAIR ? p_ow0 + (v % TWT) * 32 + 2 * n + (kq >> 1) : p_ow0 + (v % TWT) * 16 + n;
+            const bool in = oh < p.Ho && ow < p.Wo;
+            const int pix = ((p_view * p.Ho + oh) * p.Wo + ow) * p.Cout;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co = PAIR ? 4 * (kq & 1) : cog * COUT_T + m * 16 + 4 * kq;
+                const bool ok = in && co < p.Cout;
+                const f32x4 r = accp[m][v];
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])},
+                                                       ry, ok ? (pix + co) * 4 : OOB, 0, 0);
+                const float s1 = (r[0] + r[1]) + (r[2] + r[3]), s2 = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                gs[m] += ok ? s1 : 0.f;
+                gq[m] += ok ? s2 : 0.f;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { gsd[m] += (double)gs[m]; gqd[m] += (double)gq[m]; }
+        p_view = -1;
+    };
+    constexpr int SE = NS - 1;                       // the step behind whose MFMAs the previous tile's results leave
+    // one tile: MFMAs out of slab_cur; tile + 1 staged from (pinS, okS) into slab_nxt; tile + 2 requested into (pinF, okF)
+    auto tile_body = [&](int tile, const float4 (&pinS)[NIN], unsigned okS, float4 (&pinF)[NIN], unsigned& okF) __attribute__((always_inline)) {
         const int rem = tile - view * tpv;
         const int th = rem / tiles_w, tw = rem - th * tiles_w;
         const bool have_next = tile + 1 < t1;
@@ -279,6 +321,7 @@ conv2d_p_kernel(Conv2dArgs p, int tiles_h, int tiles_w, int ntiles, int per_cu) 
             }
         };
         operands(0, 0);
+        if (tile + 2 < t1) fetch(tile + 2, pinF, okF);
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             if (s_ + 1 < NS) operands(s_ + 1, (s_ + 1) & 1);
@@ -290,44 +333,29 @@ conv2d_p_kernel(Conv2dArgs p, int tiles_h, int tiles_w, int ntiles, int per_cu) 
                     for (int v = 0; v < V; ++v)
                         acc[m][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[s_ & 1][m][j], bq[s_ & 1][v][j], acc[m][v], 0, 0, 0);
             // in the shadow of this step's MFMAs: one piece of the next tile's patch -> the other slab; last step: next request
-            if (s_ < NS - 1) {
-                if (have_next) {
+            if (have_next) {
 #pragma unroll
-                    for (int i = s_ * PPS; i < (s_ + 1) * PPS && i < NIN; ++i) stage_piece(i, slab_nxt);
-                }
-            } else if (tile + 2 < t1) fetch(tile + 2);
+                for (int i = s_ * PPS; i < (s_ + 1) * PPS && i < NIN; ++i) stage_piece(i, slab_nxt, pinS, okS);
+            }
+            if (s_ == SE) emit_prev();
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- raw outputs (buffer stores: an out-of-range offset drops the lane); sums in float within the tile, float64 across
-        float gs[MT], gq[MT];
+        // this tile's results wait in registers: they are stored in the shadow of the NEXT tile's MFMAs (emit_prev above)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { gs[m] = 0.f; gq[m] = 0.f; }
-        const int oh0 = th * PTH, ow0 = tw * TW;
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            // lane (kq, n) holds GEMM rows 4kq .. 4kq+3 of column n: plain = couts 4kq.. of pixel n; PAIR = couts 4(kq&1).. of pixel 2n + (kq>>1)
-            const int oh = oh0 + 2 * wave + v / TWT, ow = PAIR ? ow0 + (v % TWT) * 32 + 2 * n + (kq >> 1) : ow0 + (v % TWT) * 16 + n;
-            const bool in = oh < p.Ho && ow < p.Wo;
-            const int pix = ((view * p.Ho + oh) * p.Wo + ow) * p.Cout;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int co = PAIR ? 4 * (kq & 1) : cog * COUT_T + m * 16 + 4 * kq;
-                const bool ok = in && co < p.Cout;
-                const f32x4 r = acc[m][v];
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])},
-                                                       ry, ok ? (pix + co) * 4 : OOB, 0, 0);
-                const float s1 = (r[0] + r[1]) + (r[2] + r[3]), s2 = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
-                gs[m] += ok ? s1 : 0.f;
-                gq[m] += ok ? s2 : 0.f;
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) { gsd[m] += (double)gs[m]; gqd[m] += (double)gq[m]; }
-        if (p.stats && (!have_next || nview != view)) flush(view);
+            for (int v = 0; v < V; ++v) accp[m][v] = acc[m][v];
+        p_view = view; p_oh0 = th * PTH; p_ow0 = tw * TW;
         __syncthreads();                             // the other slab is complete, this one is free
         float* t_ = slab_cur; slab_cur = slab_nxt; slab_nxt = t_;
         view = nview;
+    };
+    for (int tile = t0; tile < t1; tile += 2) {
+        tile_body(tile, pinB, okB, pinA, okA);
+        if (tile + 1 < t1) tile_body(tile + 1, pinA, okA, pinB, okB);
     }
+    emit_prev();
+    if (sum_view >= 0 && p.stats) flush(sum_view);
 }
 
 template <int KS, int STRIDE, int CIN, int CG, int MT, int TWT, int WPE = 2, bool PAIR = false>

@@ -42,14 +42,21 @@ h = buf.cpu().numpy(); n = int(h[0]); r = h[1:1 + 32 * n].reshape(n, 32)
 t0 = r[:, 0].min()
 us = lambda t: (t - t0) / 100.0
 print("launch: %d workgroups, event time %.1f us, first entry -> last exit %.1f us" % (n, e0.elapsed_time(e1) * 1e3, us(r[:, 30].max())))
-print("entry: median %.1f us, last %.1f us | prologue (weights, GroupNorm table, first tile staged): median %.1f us after entry" % (
-    np.median(us(r[:, 0])), us(r[:, 0]).max(), np.median(r[:, 1] - r[:, 0]) / 100.0))
-ntile = ((r[:, 2:30].reshape(n, 7, 4)[:, :, 0] > 0).sum(1))
-print("tiles per workgroup (first 7 traced): min %d max %d" % (ntile.min(), ntile.max()))
+print("entry: median %.1f us, last %.1f us | prologue after entry (medians): loads requested + weights written %.2f, GroupNorm table %.2f, first tile staged %.2f us" % (
+    np.median(us(r[:, 0])), us(r[:, 0]).max(), np.median(r[:, 28] - r[:, 0]) / 100.0, np.median(r[:, 29] - r[:, 0]) / 100.0, np.median(r[:, 1] - r[:, 0]) / 100.0))
+hw = r[:, 31] >> 32                        # HW_ID register: CU / SE / XCC fields identify the compute unit
+cu = hw & 0xfff0                           # drop the wave / SIMD bits, keep CU, SH, SE (and what lies above)
+ntile = ((r[:, 2:26].reshape(n, 8, 3)[:, :, 0] > 0).sum(1))
+print("tiles per workgroup (first 8 traced): min %d max %d" % (ntile.min(), ntile.max()))
+import collections
+per_cu = collections.Counter()
+for i in range(n):
+    per_cu[int(hw[i] >> 4)] += int(ntile[i])
+vals = sorted(per_cu.values())
+print("distinct HW_ID (bits 4..) values: %d; tiles per value: min %d median %d max %d" % (len(per_cu), vals[0], vals[len(vals) // 2], vals[-1]))
 for k in range(int(ntile.max())):
     m = ntile > k
-    q = r[m][:, 2 + 4 * k: 6 + 4 * k]
-    print("tile %d (%4d wgs): MFMAs + interleaved staging/prefetch %.2f | stores + sums %.2f | flush + barrier %.2f us (medians); start at %.1f us" % (
-        k, m.sum(), np.median(q[:, 1] - q[:, 0]) / 100.0, np.median(q[:, 2] - q[:, 1]) / 100.0, np.median(q[:, 3] - q[:, 2]) / 100.0,
-        np.median(us(q[:, 0]))))
+    q = r[m][:, 2 + 3 * k: 5 + 3 * k]
+    print("tile %d (%4d wgs): MFMAs with everything in their shadow %.2f | copy + barrier %.2f us (medians); start at %.1f us" % (
+        k, m.sum(), np.median(q[:, 1] - q[:, 0]) / 100.0, np.median(q[:, 2] - q[:, 1]) / 100.0, np.median(us(q[:, 0]))))
 print("exit median %.1f us, last %.1f us" % (np.median(us(r[:, 30])), us(r[:, 30]).max()))
