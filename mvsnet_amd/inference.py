@@ -181,7 +181,7 @@ _PINNED_RESULTS = {}
 
 
 def compute_depth_maps(input_dir, config=None, weights=None, device=None, timings=None, gru_views=4,
-                       feature_cache_limit=256, host_workers=None, **kwargs):
+                       feature_cache_limit=256, host_workers=None, tower_stream=True, **kwargs):
     """mvsnet/inference.py:83-119.  Returns the number of depth maps this rank wrote.
 
     `timings` (a dict) receives the stage breakdown of the run in seconds: wall, load (decode + resize + crop + centre on the
@@ -190,7 +190,9 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     writers, summed over threads).  `gru_views`: reference views per recurrent sweep (mvs_gru_wta_batch_f32) with the GRU
     regulariser.  `host_workers`: worker PROCESSES for image decoding / rescaling and output encoding (host_pool; None = by
     core count, 0 = round 3's loader / writer threads inside this process); `timings` then also receives host_cpu = CPU
-    seconds of this process and its workers."""
+    seconds of this process and its workers.  `tower_stream`: the image uploads and the UNetDS2GN towers of a group of reference
+    views go to a HIP stream of their own and the hot path waits for their event -- this thread runs several views ahead of the
+    GPU, so the (launch-bound) towers of group g + 1 execute beside the hot path of group g instead of in line with it."""
     import threading
     import torch
     from . import predictlib as pl
@@ -335,9 +337,18 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
         feature_cache.fill(((k_, res_[1][v]) for c_, res_ in group for v, k_ in enumerate(keys_of(c_, res_[1]))),
                            lambda imgs: weights.unet(images_to_device(imgs)))
 
+    # the towers' stream (see `tower_stream`); feature maps are allocated there and read on the compute stream: record_stream keeps
+    # the caching allocator from handing a freed map's memory out again while the compute stream may still be reading it
+    t_stream = torch.cuda.Stream(device) if (tower_stream and weights.unet is not None) else None
+
     def features_of(c, in_images):
         """(N,H/4,W/4,C) of one reference view from the per-image cache (pinned for the group by prefetch_features)."""
-        return torch.stack(feature_cache.get(keys_of(c, in_images))).contiguous()
+        maps = feature_cache.get(keys_of(c, in_images))
+        if t_stream is not None:
+            cur = torch.cuda.current_stream(device)
+            for m_ in maps:
+                m_.record_stream(cur)
+        return torch.stack(maps).contiguous()
 
     pinned = _PINNED_RESULTS                          # shape -> free pinned (depth, prob) buffer pairs, re-used across reference views
 
@@ -450,9 +461,17 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
         tm["wait_load"] += t1 - t0
         if not group:
             continue
-        m_start = mark()
-        prefetch_features(group)
-        m_towers = mark()
+        if t_stream is not None:
+            with torch.cuda.stream(t_stream):
+                m_start = mark()
+                prefetch_features(group)
+                m_towers = mark()
+                towers_done = t_stream.record_event()
+            torch.cuda.current_stream(device).wait_event(towers_done)
+        else:
+            m_start = mark()
+            prefetch_features(group)
+            m_towers = mark()
         tm["submit_towers"] += time.perf_counter() - t1
         # the group's cameras in ONE upload through pinned staging (a pageable .to(device) per reference view is a blocking
         # copy queued behind the previous view's kernels: it cost this thread ~0.6 ms per view)
