@@ -465,6 +465,10 @@ int mvs_rmsprop_step_f32(float* w, const float* g, float* ms, float* mom, size_t
  *                 g_beta(c) = sum_v sums(v,0,c), g_gamma(c) = sum_v sums(v,1,c)
  *   relu          1: y = ReLU(gamma*xhat+beta) (conv_gn), 0: no activation (deconv_gn) */
 int mvs_gn_stats_f32(const float* x, int V, size_t hw, int C, double* stats, void* stream);
+/* The same statistics from the sums the tower convolutions already wrote: slots (V, C/8, nslot, 2) float64 partial [sum, sumsq]
+ * per 8-channel group (mvs_conv2d_gn_f32 / mvs_deconv2d_gn_f32, nslot = mvs_gn_stat_slots()) -> stats (V, 2, C), every channel
+ * carrying an eighth of its group's totals (the group moments the kernels below fold from 8 channel sums are then the forward's). */
+int mvs_gn_slots_to_channel_sums_f64(const double* slots, int V, int C, int nslot, double* stats, void* stream);
 int mvs_gn_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
                      int relu, int V, size_t hw, int C, float* y, void* stream);
 int mvs_gn_bwd_reduce_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,

@@ -712,6 +712,27 @@ extern "C" int mvs_adam_step_f32(float* w, const float* g, float* m, float* v, s
     MVS_LAUNCH_RET();
 }
 
+// The inference kernels' GroupNorm sums -- (V, C/8, slots, 2) float64 partial [sum, sumsq] per 8-channel group (csrc/unet2d*.hip) --
+// in the per-channel layout of the kernels above: every channel of a group carries an eighth of the group's totals, so the
+// group moments folded from "the 8 channel sums" are the forward's own.  The training towers need no second pass over the
+// activations for statistics the forward convolution already produced (round 6: 31 launches and 0.6 ms of a 6 ms step).
+__global__ void gn_slots_to_channel_sums_kernel(const double* __restrict__ slots, int V, int C, int nslot, double* __restrict__ stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (v, k, c)
+    if (i >= V * 2 * C) return;
+    const int c = i % C, k = (i / C) & 1, v = i / (2 * C);
+    const double* p = slots + (((size_t)v * (C / GN_CH) + c / GN_CH) * nslot) * 2 + k;
+    double t = 0.0;
+    for (int s_ = 0; s_ < nslot; ++s_) t += p[2 * s_];
+    stats[i] = t * 0.125;
+}
+
+extern "C" int mvs_gn_slots_to_channel_sums_f64(const double* slots, int V, int C, int nslot, double* stats, void* stream) {
+    MVS_CHECK_ARG(slots && stats && V > 0 && C > 0 && nslot > 0);
+    if (C % GN_CH) return MVS_E_SHAPE;
+    gn_slots_to_channel_sums_kernel<<<mvs_cdiv((long long)V * 2 * C, 256), 256, 0, mvs_stream(stream)>>>(slots, V, C, nslot, stats);
+    MVS_LAUNCH_RET();
+}
+
 // GroupNorm entry points: mode selects the pass (see the kernels above).
 static int gn_check(const void* x, int V, size_t hw, int C) {
     if (!x || V <= 0 || hw == 0 || C <= 0) return MVS_E_BADARG;

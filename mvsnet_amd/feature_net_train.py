@@ -58,6 +58,14 @@ class HipTowers(torch.autograd.Function):
             if kind != "c":
                 P[name]["gamma"], P[name]["beta"] = flat[i].detach().contiguous(), flat[i + 1].detach().contiguous(); i += 2
         acts: Dict[str, torch.Tensor] = {}
+        # every layer's GroupNorm sums in ONE zeroed slab (round 6: one fill instead of 31)
+        so_off, so_total = {}, 0
+        for name, kind, _s, _k, mult, _st in UNET_LAYERS:
+            if kind != "c":
+                cout_ = P[name]["w"].shape[2] if kind == "dg" else P[name]["w"].shape[3]
+                so_off[name] = (so_total, V * (cout_ // 8) * 2 * slots)
+                so_total += so_off[name][1]
+        so_slab = torch.zeros(so_total, dtype=torch.float64, device=dev)
         src_of = {"data": (data, None, None, None, 0)}                           # tensor, stats, gamma, beta, relu
         chans = {"data": 4}
         shapes = {"data": (H, W)}
@@ -72,7 +80,7 @@ class HipTowers(torch.autograd.Function):
                 cout = w.shape[3]
                 ho, wo = -(-h // stride), -(-wd_ // stride)
             y = torch.empty((V, ho, wo, cout), dtype=torch.float32, device=dev)
-            so = torch.zeros(V * (cout // 8) * 2 * slots, dtype=torch.float64, device=dev) if kind != "c" else None
+            so = so_slab[so_off[name][0]:so_off[name][0] + so_off[name][1]] if kind != "c" else None
             a = src_of[srcs[0]]
             if kind == "dg":
                 wraw = w.contiguous()
@@ -99,13 +107,13 @@ class HipTowers(torch.autograd.Function):
             acts[name] = y
             chans[name], shapes[name] = cout, (ho, wo)
             src_of[name] = (y, so, P[name].get("gamma"), P[name].get("beta"), 1 if kind == "cg" else 0)
-        ctx.saved = (data, acts, P)
+        ctx.saved = (data, acts, P, {n_: src_of[n_][1] for n_ in so_off}, slots)
         return acts["conv10_2"].clone()
 
     @staticmethod
     def backward(ctx, g_feat):
         lib = _lib.load()
-        data, acts, P = ctx.saved
+        data, acts, P, fwd_sums, slots = ctx.saved
         dev = data.device
         st = _lib.stream_ptr()
         kinds = {name: kind for name, kind, *_ in UNET_LAYERS}
@@ -116,8 +124,10 @@ class HipTowers(torch.autograd.Function):
             if name not in chan_stats:
                 y = acts[name]
                 V, h, w, c = y.shape
-                s = torch.zeros((V, 2, c), dtype=torch.float64, device=dev)
-                _lib.check(lib.mvs_gn_stats_f32(_lib.ptr(y), V, h * w, c, _lib.ptr(s), st), "mvs_gn_stats_f32")
+                # the forward convolution's own sums (no second pass over the activation)
+                s = torch.empty((V, 2, c), dtype=torch.float64, device=dev)
+                _lib.check(lib.mvs_gn_slots_to_channel_sums_f64(_lib.ptr(fwd_sums[name]), V, c, slots, _lib.ptr(s), st),
+                           "mvs_gn_slots_to_channel_sums_f64")
                 chan_stats[name] = s
             return chan_stats[name]
 
@@ -145,6 +155,14 @@ class HipTowers(torch.autograd.Function):
             g_act[name] = g if name not in g_act else g_act[name] + g
 
         grads: Dict[str, Dict[str, torch.Tensor]] = {}
+        # the (V, 2, C) gradient sums of every GroupNorm layer in one zeroed slab
+        bs_off, bs_total = {}, 0
+        for name, kind, *_r in UNET_LAYERS:
+            if kind != "c":
+                V_, _h, _w, c_ = acts[name].shape
+                bs_off[name] = (bs_total, V_ * 2 * c_)
+                bs_total += V_ * 2 * c_
+        bs_slab = torch.zeros(bs_total, dtype=torch.float64, device=dev)
         for name, kind, srcs, k, _mult, stride in reversed(UNET_LAYERS):
             y = acts[name]
             V, ho, wo, cout = y.shape
@@ -153,7 +171,7 @@ class HipTowers(torch.autograd.Function):
                 grads[name] = {}
             else:
                 g_a = g_act.pop(name).contiguous()
-                sums = torch.zeros((V, 2, cout), dtype=torch.float64, device=dev)
+                sums = bs_slab[bs_off[name][0]:bs_off[name][0] + bs_off[name][1]].view(V, 2, cout)
                 relu = 1 if kind == "cg" else 0
                 args = (_lib.ptr(y), _lib.ptr(stats_of(name)), _lib.ptr(P[name]["gamma"]), _lib.ptr(P[name]["beta"]), GN_EPS, relu,
                         _lib.ptr(g_a))

@@ -16,7 +16,7 @@ def step():
     else:
         f = unet_forward(trainable_layers(tr.params.group("unet")), images, hip_group_norm=(mode == "torch+hipgn"))
     f.sum().backward()
-for _ in range(3): step()
+for _ in range(int(os.environ.get("WARM", "3"))): step()
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(10): step()
 torch.cuda.synchronize()
