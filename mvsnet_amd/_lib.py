@@ -165,40 +165,59 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_GRU_PREPARED = {}             # (device index, stream handle) -> number of live users (DepthPlan objects) of the set mvs_gru_prepare made
+import threading
+
+_GRU_LOCK = threading.Lock()   # the table below is touched from garbage-collection finalizers as well
+_GRU_PREPARED = {}             # (device index, stream handle) -> [generation, live users (DepthPlan objects)] of the set mvs_gru_prepare made
+_GRU_NO_SLOT = set()           # (device, stream) keys for which mvs_gru_prepare answered MVS_E_NO_SLOT: not asked again until a set is released
+_GRU_GENERATION = [0]
 MVS_E_NO_SLOT = -5
 
 
 def gru_prepare():
     """mvs_gru_prepare for torch's CURRENT stream of the current device, once per (device, stream): the only call of the
     recurrent path that creates streams / events and synchronises (include/mvsnet_hip.h).  Skipped under hipGraph capture:
-    a captured sweep runs on the capture stream alone and needs no set.  Returns the key to hand to gru_unref() (or None).
-    When all 16 sets of the process are taken (MVS_E_NO_SLOT) it warns once and carries on: the sweep runs without a set."""
+    a captured sweep runs on the capture stream alone and needs no set.  Returns the token to hand to gru_unref() (or None): the
+    key plus the GENERATION of the set, so that a stale token -- its set was released with gru_release() and the stream
+    prepared again by somebody else -- can no longer give the new set away.  When all 16 sets of the process are taken
+    (MVS_E_NO_SLOT) it warns once per (device, stream), remembers the answer and carries on: the sweep runs without a set."""
     key = (torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
     if torch.cuda.is_current_stream_capturing():
         return None
-    if key not in _GRU_PREPARED:
-        rc = load().mvs_gru_prepare(stream_ptr())
-        if rc == MVS_E_NO_SLOT:
-            import warnings
-            warnings.warn("mvsnet_amd: all 16 stream sets of mvs_gru_prepare are in use; the recurrent sweep of this stream runs on the "
-                          "stream alone (drop DepthPlan objects of streams you no longer use, or call _lib.gru_release())", RuntimeWarning)
+    with _GRU_LOCK:
+        if key in _GRU_NO_SLOT:
             return None
-        check(rc, "mvs_gru_prepare")
-        _GRU_PREPARED[key] = 0
-    _GRU_PREPARED[key] += 1
-    return key
+        if key not in _GRU_PREPARED:
+            rc = load().mvs_gru_prepare(stream_ptr())
+            if rc == MVS_E_NO_SLOT:
+                _GRU_NO_SLOT.add(key)
+                import warnings
+                warnings.warn("mvsnet_amd: all 16 stream sets of mvs_gru_prepare are in use; the recurrent sweep of this stream runs on the "
+                              "stream alone (drop DepthPlan objects of streams you no longer use, or call _lib.gru_release())", RuntimeWarning)
+                return None
+            check(rc, "mvs_gru_prepare")
+            _GRU_GENERATION[0] += 1
+            _GRU_PREPARED[key] = [_GRU_GENERATION[0], 0]
+        _GRU_PREPARED[key][1] += 1
+        return key + (_GRU_PREPARED[key][0],)
 
 
-def gru_unref(key):
+def gru_unref(token):
     """One user of the (device, stream) set less; the last one releases it (mvs_gru_release waits for the side streams).  Called by
     DepthPlan.close() / its finalizer: a set must not outlive the stream it was calibrated for (a later stream may receive the
-    same handle on another hardware queue)."""
-    if key is None or key not in _GRU_PREPARED:
+    same handle on another hardware queue).  Tokens of an earlier generation of the key are ignored."""
+    if token is None:
         return
-    _GRU_PREPARED[key] -= 1
-    if _GRU_PREPARED[key] <= 0:
+    key, gen = token[:2], token[2]
+    with _GRU_LOCK:
+        ent = _GRU_PREPARED.get(key)
+        if ent is None or ent[0] != gen:
+            return
+        ent[1] -= 1
+        if ent[1] > 0:
+            return
         del _GRU_PREPARED[key]
+        _GRU_NO_SLOT.clear()                       # a slot is free again: streams that were refused may ask once more
         try:
             with torch.cuda.device(key[0]):
                 load().mvs_gru_release(C.c_void_p(key[1]))
@@ -207,11 +226,14 @@ def gru_unref(key):
 
 
 def gru_release():
-    """mvs_gru_release for torch's current stream, whatever its user count (before the stream object is dropped)."""
+    """mvs_gru_release for torch's current stream, whatever its user count (before the stream object is dropped); tokens handed
+    out for this set become stale."""
     key = (torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
-    if key in _GRU_PREPARED:
-        del _GRU_PREPARED[key]
-        check(load().mvs_gru_release(stream_ptr()), "mvs_gru_release")
+    with _GRU_LOCK:
+        if key in _GRU_PREPARED:
+            del _GRU_PREPARED[key]
+            _GRU_NO_SLOT.clear()
+            check(load().mvs_gru_release(stream_ptr()), "mvs_gru_release")
 
 
 def ptr_array(tensors):

@@ -72,8 +72,10 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 // assumes that the "store of more than 64 bits followed by a VALU write of its data registers" hazard does not exist and
 // schedules such a write right behind the store; on gfx950 it does exist (first build of this file: the x component of a float4
 // store, overwritten by the next instruction, reached memory corrupted for the last lanes of each row of 16 -- run-to-run
-// differences at 16 x 16 pixels; tools/store_hazard_probe.hip reproduces it in isolation, tools/store_hazard_scan.py and
-// tests/test_abi_and_io.py watch every build of the library for it).
+// differences at 16 x 16 pixels; tools/store_hazard_probe.hip reproduces it in isolation).  With soffset = 0 the compiler does
+// insert ONE wait state -- still one short of the two the hardware needs (profiles/r05_store_hazard_probe.txt: 1 584 of 8 M stores
+// corrupted with one) -- so what GUARANTEES the two wait states in every build is the ISA scan, not the compiler:
+// tools/store_hazard_scan.py (both successors of every branch, loop back-edges included) run by tests/test_abi_and_io.py.
 constexpr int FBAD = (int)0x80000000;
 __device__ __forceinline__ float4 ld_b128(__amdgpu_buffer_rsrc_t rsrc, int voff) {
     u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);

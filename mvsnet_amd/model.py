@@ -338,7 +338,8 @@ class DepthPlan:
             self.workspace = torch.empty(nbytes * self.views, device=dev, dtype=torch.uint8)
             # side streams + calibration for the current stream: the one call that synchronises.  The set is shared by the plans of a
             # stream and released with the last of them (close() or garbage collection).
-            self._gru_keys = [_lib.gru_prepare()]
+            tok = _lib.gru_prepare()
+            self._gru_keys = [tok] if tok is not None else []
             self._finalizer = weakref.finalize(self, DepthPlan._drop_sets, self._gru_keys)
         else:
             raise NotImplementedError(regularization)      # predictlib.py:97-98
@@ -349,17 +350,25 @@ class DepthPlan:
             _lib.gru_unref(keys.pop())
 
     def close(self):
-        """Gives the stream sets of the recurrent sweep back (mvs_gru_release when this was their last user)."""
+        """Gives the stream sets of the recurrent sweep back (mvs_gru_release when this was their last user).  The plan stays
+        usable: a later run_gru prepares (a share of) a set again and re-arms the finalizer."""
         if getattr(self, "_finalizer", None) is not None:
             self._finalizer()
+            self._finalizer = None
 
     def _gru_prepare_here(self):
-        """A plan may run on another stream than it was built on: that stream gets (a share of) a set too."""
+        """A plan may run on another stream than it was built on: that stream gets (a share of) a set too.  One token per
+        (device, stream); a stream that was refused a set (MVS_E_NO_SLOT, remembered in _lib) adds nothing."""
         if torch.cuda.is_current_stream_capturing():
             return
         key = (torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))
-        if key not in [k for k in self._gru_keys if k is not None]:
-            self._gru_keys.append(_lib.gru_prepare())
+        if getattr(self, "_finalizer", None) is None:      # after close(): the list is empty and nothing would release what follows
+            self._gru_keys = []
+            self._finalizer = weakref.finalize(self, DepthPlan._drop_sets, self._gru_keys)
+        if key not in [k[:2] for k in self._gru_keys if k is not None]:
+            tok = _lib.gru_prepare()
+            if tok is not None:
+                self._gru_keys.append(tok)
 
     def set_cameras(self, cams, depth_start, depth_interval, depth_end, inverse_depth, view=0):
         lib = _lib.load()

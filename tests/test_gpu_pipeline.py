@@ -233,6 +233,31 @@ def test_gru_sweep_prepare_capture_and_release(lib_built):
         d17, p17 = plans[-1].run_gru(feats, dv)
         torch.cuda.synchronize()
         assert torch.equal(d17, eager_d) and torch.equal(p17, eager_p)                       # no set: the fused sweep
+    #  the refused stream is remembered: running again neither asks mvs_gru_prepare again nor grows the plan's token list
+    n_tok = len(plans[-1]._gru_keys)
+    with torch.cuda.stream(streams[-1]):
+        plans[-1].run_gru(feats, dv)
+        torch.cuda.synchronize()
+    assert len(plans[-1]._gru_keys) == n_tok and all(k_ is not None for k_ in plans[-1]._gru_keys)
+    # a stale token (its set was released with gru_release and the stream prepared again) cannot give the NEW set away
+    with torch.cuda.stream(s):
+        _lib.gru_release()
+        tok_old = _lib.gru_prepare()
+        _lib.gru_release()
+        tok_new = _lib.gru_prepare()
+        assert tok_old[:2] == tok_new[:2] and tok_old[2] != tok_new[2]
+        _lib.gru_unref(tok_old)
+        assert lib.mvs_gru_stream_layout(_lib.stream_ptr(), None, None) == 0                # still prepared
+        _lib.gru_unref(tok_new)
+        assert lib.mvs_gru_stream_layout(_lib.stream_ptr(), None, None) == -4               # the last real user released it
+    # close() re-arms: the plan prepares (a share of) a set again at its next sweep and gives it back at the next close()
+    with torch.cuda.stream(s):
+        plan.close()
+        plan.run_gru(feats, dv)
+        torch.cuda.synchronize()
+        assert lib.mvs_gru_stream_layout(_lib.stream_ptr(), None, None) == 0 and plan._finalizer is not None
+        plan.close()
+        assert lib.mvs_gru_stream_layout(_lib.stream_ptr(), None, None) == -4
     n_before = len(_lib._GRU_PREPARED)
     plans[0].close()                                                                          # gives its set back ...
     assert len(_lib._GRU_PREPARED) == n_before - 1
