@@ -66,7 +66,8 @@ int mvs_get_conv_impl(void);
 #define MVS_HOOK_GRU_PRODUCER_THREADS 5  /* threads per workgroup of the wavefront's producer launches: 64, 128 (default), 192 or 256.  Same bits */
 #define MVS_HOOK_UNET_PERSISTENT       6  /* 1 (default): tower layers with a persistent instance (csrc/unet2d_p.hip) take it; 0: the one-tile-per-workgroup kernels.  Sums differ in the last float64 bits */
 #define MVS_HOOK_UNET_GRID            7  /* >= 1: persistent workgroups per launch (per cout group; capped at the tile count) -- tests reach multi-tile ranges at small sizes, measurements vary the residency; 0 (default) = the launcher's choice */
-#define MVS_HOOK_COUNT                8
+#define MVS_HOOK_FUSE2_PLANES          8  /* even, >= 2: planes per workgroup of the fused 3dconv1_1 + 2_0 launch (measurement); 0 (default) = the launcher's choice.  BatchNorm sums arrive in another order: last bits */
+#define MVS_HOOK_COUNT                9
 int mvs_set_test_hook(int id, int value);
 int mvs_get_test_hook(int id);
 

@@ -489,6 +489,10 @@ int launch_s1_fuse2(const ConvArgs& a0, const Fuse2Args& fa, hipStream_t st) {
         if (cost < best_cost) { best_cost = cost; best = dr; }
     }
     a.planes_per_wg = best;
+    // measurement hook (round 6): an even number of planes per workgroup -- 8 at the metric size = 480 workgroups,
+    // two per CU, two waves per SIMD instead of one: 100.5 against 99.0 us, 968 against 969 depth maps/s
+    // (profiles/r06_fuse2_planes.txt).  The float64 BatchNorm atomics arrive in another order: results differ in the last bits.
+    if (const int hk = mvs_hook(MVS_HOOK_FUSE2_PLANES)) a.planes_per_wg = hk < a.D ? hk : a.D;
     dim3 grid(tiles, 1, (a.D + a.planes_per_wg - 1) / a.planes_per_wg);
     const size_t smem = (size_t)S1Geom<16, 16, 8>::LDS_BYTES + FUSE2_RED_FLOATS * sizeof(float);
     static bool attr_done = false;

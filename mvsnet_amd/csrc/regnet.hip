@@ -53,7 +53,7 @@ extern "C" int mvs_set_conv_impl(int impl) {
 extern "C" int mvs_get_conv_impl(void) { return g_conv_impl; }
 
 // test / measurement hooks (include/mvsnet_hip.h): the only switches of the library; nothing is read from the environment
-std::atomic<int> mvs_hooks[MVS_HOOK_COUNT] = {{-1}, {0}, {0}, {0}, {0}, {128}, {1}, {0}};
+std::atomic<int> mvs_hooks[MVS_HOOK_COUNT] = {{-1}, {0}, {0}, {0}, {0}, {128}, {1}, {0}, {0}};
 extern "C" int mvs_set_test_hook(int id, int value) {
     bool ok = false;
     switch (id) {
@@ -61,6 +61,7 @@ extern "C" int mvs_set_test_hook(int id, int value) {
         case MVS_HOOK_CONV_NO_SPAN: case MVS_HOOK_CONV_NO_FUSE2: case MVS_HOOK_GRU_ONE_STREAM: case MVS_HOOK_UNET_PERSISTENT:
             ok = value == 0 || value == 1; break;
         case MVS_HOOK_UNET_GRID: ok = value >= 0 && value <= 65536; break;
+        case MVS_HOOK_FUSE2_PLANES: ok = value >= 0 && value <= 65536 && (value & 1) == 0; break;
         case MVS_HOOK_S2_PLANES: ok = value >= 0 && value <= 65536; break;
         case MVS_HOOK_GRU_PRODUCER_THREADS: ok = value == 64 || value == 128 || value == 192 || value == 256; break;
         default: break;
