@@ -398,7 +398,7 @@ const PInst P_TABLE[] = {
     {3, 1, 16, 8, 1, 8, launch_p<3, 1, 16, 8, 1, 1, 2, true>},     // 2dconv8_1 (8 | 8 -> 8)
     {3, 1, 8, 8, 1, 16, launch_p<3, 1, 8, 8, 1, 2, 3>},
     {3, 1, 16, 8, 1, 16, launch_p<3, 1, 16, 8, 1, 2>},
-    {3, 1, 16, 16, 1, 16, launch_p<3, 1, 16, 16, 1, 2>},           // 2dconv1_1, 1_2, 7_2, conv9_1, 9_2
+    {3, 1, 16, 16, 1, 16, launch_p<3, 1, 16, 16, 1, 1>},           // 2dconv1_1, 1_2, 7_2, conv9_1, 9_2 (8 x 16 tiles: 12.5 -> 13 per CU instead of 6.25 -> 7; 28.6-29.5 against 30.4-31.9 us)
     {3, 1, 32, 16, 1, 16, launch_p<3, 1, 32, 16, 1, 1>},           // 2dconv7_1 (16 | 16)
     // (measured and NOT routed here, same box: 32 -> 32 at 128 x 160 as <3, 1, 32, 16, 2, 1> 30-32 us against 28 us of the tile kernel
     //  -- 800 tiles of 4.5 us over 256 workgroups quantise 3.1 -> 4; 2dconv2_0 as <3, 2, 16, 16, 2, 1> 25.6 against 24.6 us)
