@@ -67,7 +67,8 @@ int mvs_get_conv_impl(void);
 #define MVS_HOOK_UNET_PERSISTENT       6  /* 1 (default): tower layers with a persistent instance (csrc/unet2d_p.hip) take it; 0: the one-tile-per-workgroup kernels.  Sums differ in the last float64 bits */
 #define MVS_HOOK_UNET_GRID            7  /* >= 1: persistent workgroups per launch (per cout group; capped at the tile count) -- tests reach multi-tile ranges at small sizes, measurements vary the residency; 0 (default) = the launcher's choice */
 #define MVS_HOOK_FUSE2_PLANES          8  /* even, >= 2: planes per workgroup of the fused 3dconv1_1 + 2_0 launch (measurement); 0 (default) = the launcher's choice.  BatchNorm sums arrive in another order: last bits */
-#define MVS_HOOK_COUNT                9
+#define MVS_HOOK_REGNET_SIDE_BRANCH    9  /* 1: RegNetUS0's 3dconv1_1 on a side stream of the caller's stream set (mvs_gru_prepare) beside 3dconv2_0 and the low-resolution chain (measurement; needs a set, no capture); 0 (default): fused with 3dconv2_0 in line */
+#define MVS_HOOK_COUNT                10
 int mvs_set_test_hook(int id, int value);
 int mvs_get_test_hook(int id);
 

@@ -100,9 +100,9 @@ SIGNATURES = {
 CONV_IMPL = {"auto": 0, "scalar": 1, "mfma": 2, "bf16x3": 3}
 # ids of mvs_set_test_hook (include/mvsnet_hip.h MVS_HOOK_*): the library reads nothing from the environment
 HOOKS = {"cv_tile_rows_log2": 0, "conv_no_span": 1, "conv_no_fuse2": 2, "s2_planes": 3, "gru_one_stream": 4,
-         "gru_producer_threads": 5, "unet_persistent": 6, "unet_grid": 7, "fuse2_planes": 8}
+         "gru_producer_threads": 5, "unet_persistent": 6, "unet_grid": 7, "fuse2_planes": 8, "regnet_side_branch": 9}
 HOOK_DEFAULTS = {"cv_tile_rows_log2": -1, "conv_no_span": 0, "conv_no_fuse2": 0, "s2_planes": 0, "gru_one_stream": 0,
-                 "gru_producer_threads": 128, "unet_persistent": 1, "unet_grid": 0, "fuse2_planes": 0}
+                 "gru_producer_threads": 128, "unet_persistent": 1, "unet_grid": 0, "fuse2_planes": 0, "regnet_side_branch": 0}
 
 _lib = None
 

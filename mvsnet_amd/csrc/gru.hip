@@ -843,6 +843,15 @@ wta_finish_views_kernel(const float* max_prob, const float* exp_sum, const float
 }
 }  // namespace
 
+// One side stream (and a fork / join event pair) of the set mvs_gru_prepare made for `caller`, for other users of the library's
+// stream sets (regnet.hip: a branch layer beside the low-resolution chain); false without a set.
+bool mvs_stream_set_side(hipStream_t caller, hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
+    GruStreams* g = gru_find(caller);
+    if (!g) return false;
+    *side = g->s[0]; *fork = g->fork; *join = g->join[0];
+    return true;
+}
+
 // shape part of the routing decision of mvs_gru_wta*_f32 (exported for the CPU-side routing test; tests/test_abi_and_io.py)
 extern "C" int mvs_gru_fused_route(int C, int f1, int f2, int f3, size_t view_block_bytes) {
     return C == 32 && f1 == 16 && f2 == 4 && f3 == 2 && view_block_bytes < ((size_t)1 << 31);

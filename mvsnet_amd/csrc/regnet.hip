@@ -30,6 +30,8 @@ int mvs_deconv3d_mfma_bn(const float* x, const BnSrc& bn, const float* x2, const
                          float* y, double* stats, hipStream_t st, int stats_slots);
 int mvs_conv_weight_layout(const float* w, int kind, int Cin, int Cout, float* out, hipStream_t st);
 
+bool mvs_stream_set_side(hipStream_t caller, hipStream_t* side, hipEvent_t* fork, hipEvent_t* join);      // gru.hip
+
 static int g_conv_impl = MVS_CONV_IMPL_AUTO;
 
 extern "C" int mvs_abi_version(void) { return MVS_ABI_VERSION; }
@@ -53,12 +55,13 @@ extern "C" int mvs_set_conv_impl(int impl) {
 extern "C" int mvs_get_conv_impl(void) { return g_conv_impl; }
 
 // test / measurement hooks (include/mvsnet_hip.h): the only switches of the library; nothing is read from the environment
-std::atomic<int> mvs_hooks[MVS_HOOK_COUNT] = {{-1}, {0}, {0}, {0}, {0}, {128}, {1}, {0}, {0}};
+std::atomic<int> mvs_hooks[MVS_HOOK_COUNT] = {{-1}, {0}, {0}, {0}, {0}, {128}, {1}, {0}, {0}, {0}};
 extern "C" int mvs_set_test_hook(int id, int value) {
     bool ok = false;
     switch (id) {
         case MVS_HOOK_CV_TILE_ROWS_LOG2: ok = value >= -1 && value <= 3; break;
         case MVS_HOOK_CONV_NO_SPAN: case MVS_HOOK_CONV_NO_FUSE2: case MVS_HOOK_GRU_ONE_STREAM: case MVS_HOOK_UNET_PERSISTENT:
+        case MVS_HOOK_REGNET_SIDE_BRANCH:
             ok = value == 0 || value == 1; break;
         case MVS_HOOK_UNET_GRID: ok = value >= 0 && value <= 65536; break;
         case MVS_HOOK_FUSE2_PLANES: ok = value >= 0 && value <= 65536 && (value & 1) == 0; break;
@@ -463,7 +466,28 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
     // 3dconv1_1 (stride 1) and 3dconv2_0 (stride 2) read the same tensor, BN + ReLU of 3dconv1_0: one fused pass when the
     // shape is the one conv3d_mfma.hip builds it for (round 4), as for the two consumers of the cost volume above.
     bool pair2_done = false;
-    if (all_mfma && !(D1 & 1) && !(H1 & 1) && !(W1 & 1)) {
+    // Round 6 experiment (MVS_HOOK_REGNET_SIDE_BRANCH): 3dconv1_1 is only read by 3dconv6_0, three launches of the latency-bound
+    // low-resolution chain later -- on a side stream of the caller's stream set (mvs_gru_prepare) it runs BESIDE 3dconv2_0 and the
+    // chain instead of in front of them; 3dconv2_0 then runs apart from it.  MEASURED: 986.5-987.8 against 982.4-983.7 depth maps/s
+    // (+0.4 %, profiles/r06_regnet_side_branch.txt) -- the chain's launches stretch by nearly what the branch hides, as in round 1.
+    // Stays a measurement hook (an error return between fork and join would leave the side stream un-joined).
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_branch = false;
+    {
+        hipStreamCaptureStatus cs_ = hipStreamCaptureStatusNone;
+        const bool capturing_ = hipStreamIsCapturing(hs, &cs_) == hipSuccess && cs_ != hipStreamCaptureStatusNone;
+        if (mvs_hook(MVS_HOOK_REGNET_SIDE_BRANCH) && all_mfma && batch == 1 && !capturing_ && lp < 0)
+            side_branch = mvs_stream_set_side(hs, &side, &ev_fork, &ev_join);
+    }
+    if (side_branch) {
+        HIP_RUN(hipEventRecord(ev_fork, hs));
+        HIP_RUN(hipStreamWaitEvent(side, ev_fork, 0));
+        RUN(layer(false, L10, -1, L11, D1, H1, W1, 2 * b, 2 * b, 1, side));
+        HIP_RUN(hipEventRecord(ev_join, side));
+        RUN(layer(false, L10, -1, L20, D1, H1, W1, 2 * b, 4 * b, 2, hs));
+        pair2_done = true;
+    }
+    if (!pair2_done && all_mfma && !(D1 & 1) && !(H1 & 1) && !(W1 & 1)) {
         RUN(lp_mark(L11, 0, hs));
         for (int bi = 0; bi < batch; ++bi) {
             const size_t wo = (size_t)bi * ws_floats1;
@@ -512,6 +536,7 @@ static int regnet_run(const float* cost, int batch, int D, int H, int W, int cin
         RUN(layer(true, L31, -1, L40, D3, H3, W3, 8 * b, 4 * b, 2, hs));
     }
     RUN(layer(true, L40, L21, L50, D2, H2, W2, 4 * b, 2 * b, 2, hs));
+    if (side_branch) HIP_RUN(hipStreamWaitEvent(hs, ev_join, 0));      // 3dconv6_0 reads 3dconv1_1
     RUN(layer(true, L50, L11, L60, D1, H1, W1, 2 * b, b, 2, hs));
     // output conv, no BN / ReLU / bias (mvsnetworks.py:158)
     RUN(layer(false, L60, L01, L62, D, H, W, b, 1, 1, hs));
