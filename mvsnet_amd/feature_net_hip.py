@@ -78,9 +78,10 @@ class HipUNetDS2GN:
         self.out_channels = self.layers[-1][9]
         self._bufs = {}
 
-    def _plan(self, V, H, W):
-        """Activation buffers and one float64 slab of GroupNorm sums for a (V, H, W) input."""
-        key = (V, H, W)
+    def _plan(self, V, H, W, slot=0):
+        """Activation buffers and one float64 slab of GroupNorm sums for a (V, H, W) input (`slot`: independent sets of buffers
+        for passes that run concurrently on different streams)."""
+        key = (V, H, W, slot)
         if key in self._bufs:
             return self._bufs[key]
         shapes = {"data": (H, W)}
@@ -134,10 +135,10 @@ class HipUNetDS2GN:
             raise ValueError("UNetDS2GN needs image sizes divisible by 16")
         return self._run(x, self._side_streams_for(x))
 
-    def _run(self, x, side):
+    def _run(self, x, side, slot=0):
         lib = _lib.load()
         V, H, W, _ = x.shape
-        acts, offs, stats, shapes, data = self._plan(V, H, W)
+        acts, offs, stats, shapes, data = self._plan(V, H, W, slot)
         stats.zero_()
         data[..., :3] = x
         main = torch.cuda.current_stream(self.device)
