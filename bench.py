@@ -814,7 +814,7 @@ def main():
             torch.cuda.synchronize()
             if args.extractor == "hip":
                 # the towers alone: N images -> N feature maps, back to back; events on the stream they run on
-                from mvsnet_amd.feature_net import unet_macs
+                from mvsnet_amd.feature_net import unet_layer_work, unet_macs
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 n_pass = 50
                 t_h = time.perf_counter()
@@ -830,6 +830,12 @@ def main():
                                              (w.view_num, 4 * w.width, 4 * w.height, w.view_num, w.width, w.height),
                                  "ms_per_pass": tw_ms, "algorithmic_gflop": gf, "achieved_tflops": gf / tw_ms,
                                  "peak_tflops": 157.3, "frac_of_fp32_mfma_peak": gf / tw_ms / 157.3,
+                                 # 32 layers, each a global barrier (GroupNorm): the floor of the pass is the SUM over layers of the larger
+                                 # of the layer's matrix time and its HBM time (several full-resolution layers are HBM-bound, not MFMA-bound)
+                                 "floor_ms_sum_over_layers_of_max_mfma_hbm": sum(max(2.0 * m_ * w.view_num / 157.3e12, b_ * w.view_num / HBM_PEAK_GBS / 1e9)
+                                                                               for _n, m_, b_ in unet_layer_work(4 * w.height, 4 * w.width)) * 1e3,
+                                 "frac_of_that_floor": sum(max(2.0 * m_ * w.view_num / 157.3e12, b_ * w.view_num / HBM_PEAK_GBS / 1e9)
+                                                           for _n, m_, b_ in unet_layer_work(4 * w.height, 4 * w.width)) * 1e3 / tw_ms,
                                  "host_enqueue_ms_per_pass": t_h / n_pass * 1e3,
                                  "side_streams": len(getattr(net, "_choice", {}).get((4 * w.height, 4 * w.width), [])),
                                  "launches_per_pass": 32,

@@ -56,6 +56,26 @@ def unet_macs(H, W, base_filter=8, image_channels=3):
     return total
 
 
+def unet_layer_work(H, W, base_filter=8, image_channels=3):
+    """Per layer of one UNetDS2GN pass over one H x W image: (name, multiply-adds, algorithmic bytes = every input tensor read
+    once + the output written once, fp32) -- the two rooflines a layer can be priced against."""
+    shape = {"data": (H, W, image_channels)}
+    rows = []
+    for name, kind, srcs, k, mult, stride in UNET_LAYERS:
+        h, w, _ = shape[srcs[0]]
+        cin = sum(shape[s_][2] for s_ in srcs)
+        cout = base_filter * mult
+        if kind == "dg":
+            ho, wo = 2 * h, 2 * w
+            macs = ho * wo * 2.25 * cin * cout
+        else:
+            ho, wo = -(-h // stride), -(-w // stride)
+            macs = ho * wo * k * k * cin * cout
+        shape[name] = (ho, wo, cout)
+        rows.append((name, macs, 4.0 * (h * w * cin + ho * wo * cout)))
+    return rows
+
+
 def _same_pad(n, k, s):
     out = -(-n // s)
     total = max((out - 1) * s + k - n, 0)
