@@ -902,8 +902,10 @@ def main():
             # configuration 2's image size (1152 x 864 JPEGs: ~3x the host decode work per image; 288 x 216 feature maps)
             out["session_config2_images"] = session_record(dev, out["config_c2"].get("depth_maps_per_s"), n_images=24, procs_per_gpu=0,
                                                            width=1152, height=864); lap("session_config2_images")
-            out["session_config2_images_96_views"] = session_record(dev, out["config_c2"].get("depth_maps_per_s"), n_images=96, procs_per_gpu=0,
-                                                                    width=1152, height=864); lap("session_config2_images_96_views")
+            # configuration 4 as one rank sees it: 1 078 reference views of 1152 x 864 over 8 GPUs = 135 per rank (mvsnet/inference.py:105-119
+            # sharded by reference view); on one GPU this IS that rank's work, the 8-GPU number is the driver's to measure
+            out["session_config4_rank_share_135_views"] = session_record(dev, out["config_c2"].get("depth_maps_per_s"), n_images=135, procs_per_gpu=0,
+                                                                         width=1152, height=864); lap("session_config4_rank_share_135_views")
             out["training"] = training_record(dev, configs=(("3dcnn_d192", "3DCNN", 192), ("3dcnn_d128_config5", "3DCNN", 128), ("gru_d192", "GRU", 192))
                                               if args.training_all else (("3dcnn_d128_config5", "3DCNN", 128),)); lap("training")
         if not args.no_cpu_baseline and world == 1:
