@@ -120,6 +120,30 @@ def test_hip_unet_matches_oracle_and_torch(lib_built):
     assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-4
 
 
+@pytest.mark.parametrize("shape,side", [((5, 512, 640), 0), ((5, 512, 640), 2), ((3, 864, 1152), "auto"), ((2, 1200, 1600), 0), ((9, 112, 208), 2)])
+def test_hip_unet_at_the_baseline_image_sizes_matches_the_torch_towers(shape, side, lib_built):
+    """The towers at BASELINE's image sizes (640 x 512 = M / c1, 1152 x 864 = c2 / configuration 4, 1600 x 1200 = c3) and a ragged
+    one (tiles hanging over both edges at every level), in line / with side streams / autotuned: the persistent kernels' 32-bit
+    offsets, tile ranges that span several images and the fork / join of the side branches, against the PyTorch / MIOpen module
+    (an independent implementation of mvsnetworks.py:53-115).  Run twice: the second pass re-uses the plan's buffers and the
+    side-stream decision."""
+    from mvsnet_amd.feature_net import UNetDS2GN
+    from mvsnet_amd.feature_net_hip import HipUNetDS2GN
+    params = S.make_unet_params("normal", seed=3)
+    V, H, W = shape
+    img = torch.randn((V, H, W, 3), generator=torch.Generator().manual_seed(V * H + W)).to(DEV)
+    ref = UNetDS2GN(params, DEV)(img)
+    hip = HipUNetDS2GN(params, DEV, side_streams=side)
+    scale = float(ref.abs().max())
+    for _ in range(2):
+        got = hip(img)
+        torch.cuda.synchronize()
+        assert got.shape == ref.shape == (V, H // 4, W // 4, 32)
+        assert float((got - ref).abs().max()) / scale < 2e-4
+    del ref, got
+    torch.cuda.empty_cache()
+
+
 def test_images_to_depth_end_to_end_matches_oracle(lib_built):
     """The default product path from IMAGES (HIP towers -> warp/variance -> RegNetUS0 -> soft-argmin)
     against the oracle composition, on the interior-stable quantity (depth) at a toy size."""
