@@ -333,6 +333,16 @@ def test_session_pipeline_equals_the_per_reference_view_calls(tmp_path, lib_buil
     for fn in sorted(os.listdir(cfg.output_dir)):
         assert open(os.path.join(cfg.output_dir, fn), "rb").read() == open(os.path.join(cfg0.output_dir, fn), "rb").read(), fn
     assert len(os.listdir(cfg0.output_dir)) == 42
+    # round 6: the uploads + towers of a group run on a stream of their own (the default above); in line they give the same maps
+    cfg1 = pl.InferenceConfig(input_dir=sess, view_num=3, max_d=24, width=128, height=96, base_image_size=8,
+                              regularization=regularization, output_dir=str(tmp_path / "out_inline"))
+    assert compute_depth_maps(sess, cfg1, weights, torch.device("cuda", 0), gru_views=3, tower_stream=False) == 7
+    for fn in sorted(f_ for f_ in os.listdir(cfg.output_dir) if f_.endswith("_init.pfm")):
+        a_, b_ = pp.load_pfm(os.path.join(cfg.output_dir, fn)), pp.load_pfm(os.path.join(cfg1.output_dir, fn))
+        if regularization == "3DCNN":
+            assert float(np.max(np.abs(a_ - b_) / b_)) < 1e-5, fn
+        else:
+            assert float((a_ == b_).mean()) > 0.99, fn
     gen = make_generator(sess, 3, 128, 96, 24, 1.0, 8, mode="inference", output_scale=0.25)
     for c in sorted(gen.clusters, key=lambda c_: c_.ref_index):
         out_images, in_images, out_cams, full_cams, index = gen.prepare(c)          # float32, standardised on the host
