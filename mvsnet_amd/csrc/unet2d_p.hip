@@ -37,10 +37,7 @@ struct PGeom {
     static constexpr int IH = (PTH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     static constexpr int NPOS = IH * IW;
     static constexpr int CQ = CIN / 4;
-#ifndef P_SPAD
-#define P_SPAD 4
-#endif
-    static constexpr int S = CIN + P_SPAD;
+    static constexpr int S = CIN + 4;                   // (+ 8 / + 12 / + 20 measured: profiles/r06_unet_lds_pitch.txt -- the conflict share moves, the time does not)
     static constexpr int COUT_T = 16 * MT;
     static constexpr int W_FLOATS = NT * CIN * COUT_T;
     static constexpr int NIN = (NPOS * CQ + 255) / 256;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6: LDS bank-conflict share and duration of the persistent tower launches for several slab pitches (variants built with
-# tools/build_variant.sh spad<N> unet2d_p.hip -DP_SPAD=<N>: pitch = Cin + N floats).   gpurun -- 'bash tools/r6_unet_spad.sh'
+# tools/build_variant.sh spad<N> unet2d_p.hip after editing `S = CIN + 4` in PGeom to CIN + N: pitch = Cin + N floats).   gpurun -- 'bash tools/r6_unet_spad.sh'
 cat > /tmp/unet_only.py <<'PY'
 import os, sys, torch
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
