@@ -16,8 +16,12 @@
 //   * the GroupNorm (scale, shift) table is built once per (workgroup, view) instead of once per tile;
 //   * the output sums are float within a tile (fixed order), float64 across the tiles of a workgroup and float64 atomics
 //     across workgroups -- once per (workgroup, view).
-// K is the whole Cin in one pass (no chunk loop): the slab pitch Cin + 4 floats keeps the 16-lane ds_read_b128 groups
-// conflict-free (4 * odd).  Weight layout = the one mvs_conv2d_prepare_f32 writes for conv2d_gn_kernel (chunks of CG channels).
+// K is the whole Cin in one pass (no chunk loop); slab pitch Cin + 4 floats (measured LDS conflict share 0.39 of the LDS-active
+// cycles at + 4, 0.13 at + 8, with the same launch time: profiles/r06_unet_lds_pitch.txt).  Weight layout = the one
+// mvs_conv2d_prepare_f32 writes for conv2d_gn_kernel (chunks of CG channels), the pixel-pair layout behind it for PAIR instances.
+// What the final form's trace and timing-only builds say (profiles/r06_unet_persistent_device_trace.txt, r06_unet_persistent_diag.txt):
+// the full-resolution 8-channel layers move ~115 MB in ~30 us (memory system), a 16 -> 16 layer is 26 us with no memory traffic
+// at all (4 us prologue + 3-4 tiles of 2.4 us shared by two workgroups) and 22-25 us without MFMAs, overlapped to ~30.
 #include "unet2d_common.h"
 
 namespace {
