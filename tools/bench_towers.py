@@ -19,5 +19,6 @@ def step():
 for _ in range(int(os.environ.get("WARM", "3"))): step()
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(10): step()
+t1 = time.time()
 torch.cuda.synchronize()
-print({"mode": mode, "towers_fwd_bwd_ms": round((time.time() - t0) / 10 * 1e3, 2)})
+print({"mode": mode, "towers_fwd_bwd_ms": round((time.time() - t0) / 10 * 1e3, 2), "host_enqueue_ms": round((t1 - t0) / 10 * 1e3, 2)})
