@@ -201,6 +201,9 @@ int mvs_regnet_us0_prepared_f32(const float* cost, int D, int H, int W, int cin,
 int mvs_gn_stat_slots(void);
 size_t mvs_conv2d_prepared_floats(int ks, int cin1, int cin2, int cout);
 int mvs_conv2d_prepare_f32(const float* w, int ks, int cin1, int cin2, int cout, float* prepared, void* stream);
+/* Prepared weights of the stride-1 convolution that computes a layer's INPUT gradient, from the layer's forward kernel
+ * w (k,k,cin_fwd,cout_fwd): consumer and buffer size as mvs_conv2d_prepare_f32(ks, cout_fwd, 0, cin_fwd). */
+int mvs_conv2d_prepare_dgrad_f32(const float* w, int ks, int cin_fwd, int cout_fwd, float* prepared, void* stream);
 int mvs_conv2d_gn_f32(const float* x1, const double* stats1, const float* gamma1, const float* beta1, int c1, int relu1,
                       const float* x2, const double* stats2, const float* gamma2, const float* beta2, int c2, int relu2,
                       const float* prepared, int V, int H, int W, int cout, int ks, int stride,
@@ -475,6 +478,8 @@ int mvs_gn_apply_f32(const float* x, const double* stats, const float* gamma, co
                      int relu, int V, size_t hw, int C, float* y, void* stream);
 int mvs_gn_bwd_reduce_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
                           int relu, const float* g, int V, size_t hw, int C, double* sums, void* stream);
+int mvs_gn_bwd_reduce_tot_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
+                              int relu, const float* g, int V, size_t hw, int C, double* sums, double* totals, void* stream);
 int mvs_gn_bwd_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
                          int relu, const float* g, const double* sums, int V, size_t hw, int C, float* dx,
                          void* stream);

@@ -34,6 +34,7 @@ SIGNATURES = {
     "mvs_gn_stat_slots": (_i, []),
     "mvs_conv2d_prepared_floats": (_sz, [_i, _i, _i, _i]),
     "mvs_conv2d_prepare_f32": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "mvs_conv2d_prepare_dgrad_f32": (_i, [_p, _i, _i, _i, _p, _p]),
     "mvs_conv2d_gn_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "mvs_deconv2d_prepared_floats": (_sz, [_i, _i]),
     "mvs_deconv2d_prepare_f32": (_i, [_p, _i, _i, _p, _p]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "mvs_gn_slots_to_channel_sums_f64": (_i, [_p, _i, _i, _i, _p, _p]),
     "mvs_gn_apply_f32": (_i, [_p, _p, _p, _p, _f, _i, _i, _sz, _i, _p, _p]),
     "mvs_gn_bwd_reduce_f32": (_i, [_p, _p, _p, _p, _f, _i, _p, _i, _sz, _i, _p, _p]),
+    "mvs_gn_bwd_reduce_tot_f32": (_i, [_p, _p, _p, _p, _f, _i, _p, _i, _sz, _i, _p, _p, _p]),
     "mvs_gn_bwd_apply_f32": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _i, _sz, _i, _p, _p]),
     "mvs_momentum_step_f32": (_i, [_p, _p, _p, _sz, _f, _f, _f, _p]),
     "mvs_adam_step_f32": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),

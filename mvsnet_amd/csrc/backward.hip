@@ -477,7 +477,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256)
 gn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ g, const double* __restrict__ stats,
                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
-                 size_t hw, int cq, double* __restrict__ out) {
+                 size_t hw, int cq, double* __restrict__ out, double* __restrict__ tot = nullptr) {
     __shared__ float red[256][8];
     const int tid = threadIdx.x, v = blockIdx.y;
     const int c = (tid % cq) * 4, C = cq * 4;
@@ -524,6 +524,7 @@ gn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ g, const
         for (int k = 0; k < 4; ++k) {
             atomicAdd(out + ((size_t)v * 2) * C + c + k, sa[k]);
             atomicAdd(out + ((size_t)v * 2 + 1) * C + c + k, sb[k]);
+            if (tot) { atomicAdd(tot + c + k, sa[k]); atomicAdd(tot + C + c + k, sb[k]); }      // (2, C) over all views: d beta, d gamma
         }
     }
 }
@@ -766,6 +767,16 @@ extern "C" int mvs_gn_bwd_reduce_f32(const float* x, const double* stats, const 
     int rc = gn_check(x, V, hw, C); if (rc) return rc;
     MVS_CHECK_ARG(stats && gamma && beta && g && sums);
     gn_reduce_kernel<1><<<gn_grid(hw, C, V, 128), 256, 0, mvs_stream(stream)>>>(x, g, stats, gamma, beta, eps, relu, hw, C / 4, sums);
+    MVS_LAUNCH_RET();
+}
+
+// The same with the sums over ALL views accumulated beside them: totals (2, C) float64 [d beta, d gamma] (zeroed by the caller) --
+// the parameter gradients without a reduction launch per layer.
+extern "C" int mvs_gn_bwd_reduce_tot_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
+                                         int relu, const float* g, int V, size_t hw, int C, double* sums, double* totals, void* stream) {
+    int rc = gn_check(x, V, hw, C); if (rc) return rc;
+    MVS_CHECK_ARG(stats && gamma && beta && g && sums && totals);
+    gn_reduce_kernel<1><<<gn_grid(hw, C, V, 128), 256, 0, mvs_stream(stream)>>>(x, g, stats, gamma, beta, eps, relu, hw, C / 4, sums, totals);
     MVS_LAUNCH_RET();
 }
 

@@ -282,8 +282,10 @@ conv2d_gn_kernel(Conv2dArgs p) {
 }
 
 // TensorFlow conv2d kernel (k,k,Cin,Cout) -> [cout group][chunk][tap][CK/4][COUT_T][4], zero padded
+// flipT: `w` is the FORWARD kernel (k,k,Cout,Cin) of the layer whose input gradient this convolution computes -- the tap is
+// mirrored and the channel roles swapped while reading (what w.flip(0,1).permute(0,1,3,2).contiguous() materialised before)
 __global__ void conv2d_weight_layout_kernel(const float* __restrict__ w, int KS, int Cin, int Cout, int CK,
-                                            int COUT_T, int CinPad, float* __restrict__ out) {
+                                            int COUT_T, int CinPad, float* __restrict__ out, int flipT) {
     const int nch = CinPad / CK, CQ = CK / 4, groups = (Cout + COUT_T - 1) / COUT_T;
     const long long total = (long long)groups * nch * KS * KS * CQ * COUT_T * 4;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,7 +297,8 @@ __global__ void conv2d_weight_layout_kernel(const float* __restrict__ w, int KS,
     const int tap = r % (KS * KS); r /= (KS * KS);
     const int ch = r % nch; const int g = r / nch;
     const int ci = ch * CK + ciq * 4 + j, cout = g * COUT_T + co;
-    out[i] = (ci < Cin && cout < Cout) ? w[((size_t)tap * Cin + ci) * Cout + cout] : 0.f;
+    if (!(ci < Cin && cout < Cout)) { out[i] = 0.f; return; }
+    out[i] = flipT ? w[((size_t)(KS * KS - 1 - tap) * Cout + cout) * Cin + ci] : w[((size_t)tap * Cin + ci) * Cout + cout];
 }
 
 // TensorFlow conv2d_transpose kernel (3,3,Cout,Cin) -> the stacked 2x2-tap form described at
@@ -443,9 +446,25 @@ extern "C" int mvs_conv2d_prepare_f32(const float* w, int ks, int cin1, int cin2
     int CG, MT; conv2d_tiling(cin1 + cin2, cout, cin1, CG, MT);
     const int cin = cin1 + cin2, cpad = (cin + CG - 1) / CG * CG;
     const size_t total = conv2d_plain_floats(ks, cin1, cin2, cout);
-    conv2d_weight_layout_kernel<<<mvs_cdiv((long long)total, 256), 256, 0, mvs_stream(stream)>>>(w, ks, cin, cout, CG, 16 * MT, cpad, prepared);
+    conv2d_weight_layout_kernel<<<mvs_cdiv((long long)total, 256), 256, 0, mvs_stream(stream)>>>(w, ks, cin, cout, CG, 16 * MT, cpad, prepared, 0);
     if (mvs_conv2d_prepared_floats(ks, cin1, cin2, cout) > total)      // 8-cout 3 x 3 layers: the pixel-pair layout of the persistent kernel behind it
-        return mvs_conv2d_pair_prepare(w, cin, cout, CG, prepared + total, mvs_stream(stream));
+        return mvs_conv2d_pair_prepare(w, cin, cout, CG, prepared + total, mvs_stream(stream), 0);
+    MVS_LAUNCH_RET();
+}
+
+// Prepared weights of the stride-1 convolution that computes a layer's INPUT gradient, straight from the layer's forward kernel
+// w (k,k,cin_fwd,cout_fwd): the gradient convolution maps cout_fwd -> cin_fwd channels with the mirrored, transposed kernel.
+// Same buffer size / consumer as mvs_conv2d_prepare_f32(k, cout_fwd, 0, cin_fwd) (training towers: one launch instead of
+// flip + permute + copy + prepare).
+extern "C" int mvs_conv2d_prepare_dgrad_f32(const float* w, int ks, int cin_fwd, int cout_fwd, float* prepared, void* stream) {
+    MVS_CHECK_ARG(w && prepared && (ks == 3 || ks == 5) && cin_fwd > 0 && cout_fwd > 0);
+    const int cin = cout_fwd, cout = cin_fwd;            // roles in the gradient convolution
+    int CG, MT; conv2d_tiling(cin, cout, cin, CG, MT);
+    const int cpad = (cin + CG - 1) / CG * CG;
+    const size_t total = conv2d_plain_floats(ks, cin, 0, cout);
+    conv2d_weight_layout_kernel<<<mvs_cdiv((long long)total, 256), 256, 0, mvs_stream(stream)>>>(w, ks, cin, cout, CG, 16 * MT, cpad, prepared, 1);
+    if (mvs_conv2d_prepared_floats(ks, cin, 0, cout) > total)
+        return mvs_conv2d_pair_prepare(w, cin, cout, CG, prepared + total, mvs_stream(stream), 1);
     MVS_LAUNCH_RET();
 }
 

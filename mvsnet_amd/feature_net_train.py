@@ -22,6 +22,7 @@ from . import _lib
 from .feature_net import UNET_LAYERS, _same_pad
 
 GN_EPS = 1e-5
+_SHAPE_ONLY = {}          # (shape, device) -> uninitialised tensor handed to ATen where only the weight's shape matters
 
 
 def _cl(t):
@@ -162,7 +163,14 @@ class HipTowers(torch.autograd.Function):
                 V_, _h, _w, c_ = acts[name].shape
                 bs_off[name] = (bs_total, V_ * 2 * c_)
                 bs_total += V_ * 2 * c_
-        bs_slab = torch.zeros(bs_total, dtype=torch.float64, device=dev)
+        # ... followed by their totals over the views, (2, C) per layer: [d beta, d gamma] (one conversion for all layers at the end)
+        ps_off, ps_total = {}, 0
+        for name, kind, *_r in UNET_LAYERS:
+            if kind != "c":
+                ps_off[name] = (ps_total, acts[name].shape[3])
+                ps_total += 2 * acts[name].shape[3]
+        zero_slab = torch.zeros(bs_total + ps_total, dtype=torch.float64, device=dev)
+        bs_slab, ps_slab = zero_slab[:bs_total], zero_slab[bs_total:]
         for name, kind, srcs, k, _mult, stride in reversed(UNET_LAYERS):
             y = acts[name]
             V, ho, wo, cout = y.shape
@@ -175,11 +183,11 @@ class HipTowers(torch.autograd.Function):
                 relu = 1 if kind == "cg" else 0
                 args = (_lib.ptr(y), _lib.ptr(stats_of(name)), _lib.ptr(P[name]["gamma"]), _lib.ptr(P[name]["beta"]), GN_EPS, relu,
                         _lib.ptr(g_a))
-                _lib.check(lib.mvs_gn_bwd_reduce_f32(*args, V, ho * wo, cout, _lib.ptr(sums), st), "mvs_gn_bwd_reduce_f32")
+                tot = ps_slab[ps_off[name][0]:ps_off[name][0] + 2 * cout]
+                _lib.check(lib.mvs_gn_bwd_reduce_tot_f32(*args, V, ho * wo, cout, _lib.ptr(sums), _lib.ptr(tot), st), "mvs_gn_bwd_reduce_tot_f32")
                 g_y = torch.empty_like(y)
                 _lib.check(lib.mvs_gn_bwd_apply_f32(*args, _lib.ptr(sums), V, ho * wo, cout, _lib.ptr(g_y), st), "mvs_gn_bwd_apply_f32")
-                tot = sums.sum(0).to(torch.float32)
-                grads[name] = {"gamma": tot[1], "beta": tot[0]}
+                grads[name] = {}                           # gamma / beta: views of the converted totals, after the loop
             # convolution backward on the materialised normalised inputs.  Weight gradient: ATen / MIOpen.  Input
             # gradient: the forward HIP kernels -- a stride-1 convolution's is the convolution with the flipped,
             # transposed kernel, a stride-2 convolution's IS the transposed convolution with the same kernel array
@@ -189,12 +197,18 @@ class HipTowers(torch.autograd.Function):
             w_tf = P[name]["w"]
             if srcs == ("data",):
                 w_tf = torch.cat([w_tf, torch.zeros(w_tf.shape[:2] + (1, cout), device=dev)], dim=2)
-            w_t = w_tf.permute(3, 2, 0, 1).contiguous()            # conv (Cout,Cin,k,k); transposed conv (Cin,Cout,k,k)
             xin, gy = _cl(x), _cl(g_y)
             cin_tot = x.shape[3]
             need_gx = srcs != ("data",)
             g_x = None
             hip_gx = need_gx and k == 3 and cin_tot % 8 == 0
+            if need_gx and not hip_gx:
+                w_t = w_tf.permute(3, 2, 0, 1).contiguous()        # conv (Cout,Cin,k,k); transposed conv (Cin,Cout,k,k)
+            else:                                                  # ATen computes the weight gradient only: it needs the kernel's SHAPE, not its values
+                shp = (w_tf.shape[3], w_tf.shape[2], w_tf.shape[0], w_tf.shape[1])
+                w_t = _SHAPE_ONLY.get((shp, dev))
+                if w_t is None:
+                    w_t = _SHAPE_ONLY[(shp, dev)] = torch.empty(shp, dtype=torch.float32, device=dev)
             if hip_gx:
                 gxt = torch.empty((V, x.shape[1], x.shape[2], cin_tot), dtype=torch.float32, device=dev)
                 if kind == "dg":                                       # conv stride 2 with the same array (3,3,Cout,Cin)
@@ -204,10 +218,10 @@ class HipTowers(torch.autograd.Function):
                     _lib.check(lib.mvs_conv2d_gn_f32(_lib.ptr(g_y), None, None, None, cout, 0, None, None, None, None, 0, 0,
                                                      _lib.ptr(prep), V, ho, wo, cin_tot, 3, 2, _lib.ptr(gxt), None, st),
                                "mvs_conv2d_gn_f32")
-                elif stride == 1:                                       # conv with flip(w)^T: (3,3,Cout,Cin)
-                    wc = w_tf.flip(0, 1).permute(0, 1, 3, 2).contiguous()
+                elif stride == 1:                                       # conv with flip(w)^T (3,3,Cout,Cin), laid out straight from w
+                    wc = w_tf.contiguous()
                     prep = torch.empty(lib.mvs_conv2d_prepared_floats(3, cout, 0, cin_tot), dtype=torch.float32, device=dev)
-                    _lib.check(lib.mvs_conv2d_prepare_f32(_lib.ptr(wc), 3, cout, 0, cin_tot, _lib.ptr(prep), st), "mvs_conv2d_prepare_f32")
+                    _lib.check(lib.mvs_conv2d_prepare_dgrad_f32(_lib.ptr(wc), 3, cin_tot, cout, _lib.ptr(prep), st), "mvs_conv2d_prepare_dgrad_f32")
                     _lib.check(lib.mvs_conv2d_gn_f32(_lib.ptr(g_y), None, None, None, cout, 0, None, None, None, None, 0, 0,
                                                      _lib.ptr(prep), V, ho, wo, cin_tot, 3, 1, _lib.ptr(gxt), None, st),
                                "mvs_conv2d_gn_f32")
@@ -254,6 +268,9 @@ class HipTowers(torch.autograd.Function):
                     add_grad(s_name, g_x[..., c0:c0 + c])
                     c0 += c
         ctx.saved = None
+        ps32 = ps_slab.to(torch.float32)
+        for name, (o_, c_) in ps_off.items():
+            grads[name]["beta"], grads[name]["gamma"] = ps32[o_:o_ + c_], ps32[o_ + c_:o_ + 2 * c_]
         flat = []
         for name, kind, *_ in UNET_LAYERS:
             flat.append(grads[name]["w"])
