@@ -76,27 +76,36 @@ class HipUNetDS2GN:
             self.layers.append((name, kind, srcs, k, stride, wd, g, b, cins, cout, wraw))
         torch.cuda.synchronize(self.device)
         self.out_channels = self.layers[-1][9]
-        self._bufs = {}
+        self._bufs, self._retired = {}, []
 
     def _plan(self, V, H, W, slot=0):
         """Activation buffers and one float64 slab of GroupNorm sums for a (V, H, W) input (`slot`: independent sets of buffers
-        for passes that run concurrently on different streams)."""
-        key = (V, H, W, slot)
-        if key in self._bufs:
-            return self._bufs[key]
-        shapes = {"data": (H, W)}
-        acts, offs, total = {}, {}, 0
-        for name, kind, srcs, k, stride, _w, _g, _b, _cins, cout, _wr in self.layers:
-            h, w = shapes[srcs[0]]
-            ho, wo = (2 * h, 2 * w) if kind == "dg" else (-(-h // stride), -(-w // stride))
-            shapes[name] = (ho, wo)
-            acts[name] = torch.empty((V, ho, wo, cout), dtype=torch.float32, device=self.device)
-            offs[name] = total
-            total += V * (cout // 8) * 2 * self.slots
-        stats = torch.zeros(total, dtype=torch.float64, device=self.device)
-        data = torch.zeros((V, H, W, 4), dtype=torch.float32, device=self.device)      # the image padded 3 -> 4 channels (channel 3 stays 0)
-        self._bufs[key] = (acts, offs, stats, shapes, data)
-        return self._bufs[key]
+        for passes that run concurrently on different streams).  One set per image size, sized for the largest V seen so far:
+        a smaller batch uses the leading V views of every buffer (V is the outermost dimension of all of them), so a session
+        whose groups bring 1 .. 16 new images allocates once or twice, not once per distinct V."""
+        key = (H, W, slot)
+        held = self._bufs.get(key)
+        if held is None or held[0] < V:
+            shapes = {"data": (H, W)}
+            acts, offs, total = {}, {}, 0
+            for name, kind, srcs, k, stride, _w, _g, _b, _cins, cout, _wr in self.layers:
+                h, w = shapes[srcs[0]]
+                ho, wo = (2 * h, 2 * w) if kind == "dg" else (-(-h // stride), -(-w // stride))
+                shapes[name] = (ho, wo)
+                acts[name] = torch.empty((V, ho, wo, cout), dtype=torch.float32, device=self.device)
+                offs[name] = total
+                total += V * (cout // 8) * 2 * self.slots
+            stats = torch.zeros(total, dtype=torch.float64, device=self.device)
+            data = torch.zeros((V, H, W, 4), dtype=torch.float32, device=self.device)  # the image padded 3 -> 4 channels (channel 3 stays 0)
+            if held is not None:                            # a pass on another stream may still be reading the smaller set: keep it
+                self._retired.append(held)
+            held = self._bufs[key] = (V, acts, offs, stats, shapes, data, {})
+        cap, acts, offs, stats, shapes, data, views = held
+        if cap != V:
+            if V not in views:
+                views[V] = ({n_: a[:V] for n_, a in acts.items()}, data[:V])
+            acts, data = views[V]
+        return acts, offs, stats, shapes, data
 
     def _side_streams_for(self, x):
         """The side streams of this input shape (see the class docstring)."""

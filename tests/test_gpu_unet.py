@@ -144,6 +144,22 @@ def test_hip_unet_at_the_baseline_image_sizes_matches_the_torch_towers(shape, si
     torch.cuda.empty_cache()
 
 
+def test_hip_unet_batches_of_different_sizes_share_one_set_of_buffers(lib_built):
+    """A session's groups bring 1 .. 16 new images: one set of plan buffers per image size, sized for the largest batch seen
+    (a smaller one uses the leading views, a larger one re-allocates once); every batch size gives what a fresh network gives
+    on the same images (to the rounding of the float64 GroupNorm sums, whose order of addition depends on the tile ranges)."""
+    from mvsnet_amd.feature_net_hip import HipUNetDS2GN
+    params = S.make_unet_params("normal", seed=3)
+    img = torch.randn((7, 96, 128, 3), generator=torch.Generator().manual_seed(11)).to(DEV)
+    hip = HipUNetDS2GN(params, DEV, side_streams=2)
+    full = HipUNetDS2GN(params, DEV, side_streams=0)(img)
+    for V in (5, 3, 7, 1, 5):                              # 5 allocates, 3 slices, 7 grows (the set of 5 is retired), 1 and 5 slice
+        got = hip(img[:V])
+        torch.cuda.synchronize()
+        assert float((got - full[:V]).abs().max()) / float(full.abs().max()) < 1e-6, V
+    assert len(hip._bufs) == 1 and len(hip._retired) == 1 and hip._bufs[(96, 128, 0)][0] == 7
+
+
 def test_images_to_depth_end_to_end_matches_oracle(lib_built):
     """The default product path from IMAGES (HIP towers -> warp/variance -> RegNetUS0 -> soft-argmin)
     against the oracle composition, on the interior-stable quantity (depth) at a toy size."""
