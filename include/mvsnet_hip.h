@@ -214,6 +214,17 @@ int mvs_deconv2d_gn_f32(const float* x, const double* stats, const float* gamma,
                         const float* w, const float* prepared, int V, int H, int W, int cout, float* y,
                         double* stats_out, void* stream);
 
+/* The towers' input side: per-image, per-channel standardisation of decoded uint8 images on the device, replacing the host
+ * call mvs_data_generation/utils.py:33-38 center_image (applied per image by cluster_generator before the graph sees it):
+ *   images     (V, H, W, 3) uint8, 4-byte aligned, H*W a multiple of 4
+ *   out4       (V, H, W, 4) float32, 16-byte aligned: (x - mean_c) / (sqrt(var_c) + 1e-8) per image and channel, channel 3 = 0
+ *              (the layout mvs_conv2d_gn_f32 reads the image in: 3 channels padded to 4)
+ *   workspace  mvs_center_images_workspace_bytes(V) bytes (zeroed by the call): exact uint64 sums and sums of squares
+ * mean and biased variance come from exact integer totals in float64; the output expression is evaluated in float32 as the
+ * reference's.  MVS_E_SHAPE for sizes / alignments outside the above. */
+size_t mvs_center_images_workspace_bytes(int V);
+int mvs_center_images_u8_f32(const uint8_t* images, int V, int H, int W, float* out4, void* workspace, void* stream);
+
 /* Live timing of the dominant kernel for bench.py's `roofline` object: while enabled, every
  * mvs_regnet_us0_*_f32 call brackets its first launch (the fused 3dconv0_1 + 3dconv1_0 pass over the
  * cost volume, conv3d_c8_kernel) with HIP events on the caller's stream (up to 64 calls).

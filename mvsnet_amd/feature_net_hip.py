@@ -97,15 +97,16 @@ class HipUNetDS2GN:
                 total += V * (cout // 8) * 2 * self.slots
             stats = torch.zeros(total, dtype=torch.float64, device=self.device)
             data = torch.zeros((V, H, W, 4), dtype=torch.float32, device=self.device)  # the image padded 3 -> 4 channels (channel 3 stays 0)
+            csum = torch.empty(_lib.load().mvs_center_images_workspace_bytes(V) // 8, dtype=torch.int64, device=self.device)
             if held is not None:                            # a pass on another stream may still be reading the smaller set: keep it
                 self._retired.append(held)
-            held = self._bufs[key] = (V, acts, offs, stats, shapes, data, {})
-        cap, acts, offs, stats, shapes, data, views = held
+            held = self._bufs[key] = (V, acts, offs, stats, shapes, data, {}, csum)
+        cap, acts, offs, stats, shapes, data, views, csum = held
         if cap != V:
             if V not in views:
                 views[V] = ({n_: a[:V] for n_, a in acts.items()}, data[:V])
             acts, data = views[V]
-        return acts, offs, stats, shapes, data
+        return acts, offs, stats, shapes, data, csum
 
     def _side_streams_for(self, x):
         """The side streams of this input shape (see the class docstring)."""
@@ -138,8 +139,11 @@ class HipUNetDS2GN:
 
     @torch.no_grad()
     def __call__(self, images):
-        """images (V,H,W,3) channel-last float32 -> features (V,H/4,W/4,C) contiguous."""
-        x = images.to(self.device, torch.float32)
+        """images (V,H,W,3) channel-last -> features (V,H/4,W/4,C) contiguous.  float32: the centred images as the reference's
+        graph takes them; uint8: the DECODED images, standardised per image and channel on the device on their way into the
+        first layer's input (mvs_center_images_u8_f32 = mvs_data_generation/utils.py:33-38; a session uploads a quarter of the
+        bytes and no float copy of the batch exists outside the plan's buffers)."""
+        x = images.to(self.device) if images.dtype == torch.uint8 else images.to(self.device, torch.float32)
         if x.shape[1] % 16 or x.shape[2] % 16:
             raise ValueError("UNetDS2GN needs image sizes divisible by 16")
         return self._run(x, self._side_streams_for(x))
@@ -147,9 +151,14 @@ class HipUNetDS2GN:
     def _run(self, x, side, slot=0):
         lib = _lib.load()
         V, H, W, _ = x.shape
-        acts, offs, stats, shapes, data = self._plan(V, H, W, slot)
+        acts, offs, stats, shapes, data, csum = self._plan(V, H, W, slot)
         stats.zero_()
-        data[..., :3] = x
+        if x.dtype == torch.uint8:
+            x = x.contiguous()
+            _lib.check(lib.mvs_center_images_u8_f32(_lib.ptr(x), V, H, W, _lib.ptr(data), _lib.ptr(csum), _lib.stream_ptr()),
+                       "mvs_center_images_u8_f32")
+        else:
+            data[..., :3] = x
         main = torch.cuda.current_stream(self.device)
         ns = len(side)
         stream_of = lambda name: (side[SIDE_BRANCH[name] % ns] if ns and name in SIDE_BRANCH else main)

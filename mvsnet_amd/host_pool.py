@@ -126,10 +126,14 @@ class HostPool:
         #    unguarded main script again: a second copy of the application, GPU work included; and failing outright when the
         #    parent runs from stdin or an embedded interpreter).  The workers only ever call functions of this module, so they
         #    are started with an EMPTY __main__: nothing of the application is imported there.
-        # ProcessPoolExecutor starts its workers ON DEMAND (Python 3.9+: one per submit while no worker is idle), so the window in
-        # which the parent's environment / __main__ are swapped stays open until all `workers` processes exist: every warm-up task
-        # holds its worker for a moment, and the loop runs until the executor's own process table is full (a fast
-        # first task used to let later workers start outside the window, with the GPU visible and the real __main__).
+        # ProcessPoolExecutor starts its workers ON DEMAND (Python 3.9+: one per submit while no worker is idle, inside submit()
+        # itself), so the window in which the parent's environment / __main__ are swapped has to cover the submits that start
+        # them -- and nothing else: the constructor does NOT wait for the workers to come up (interpreter start + imports,
+        # ~0.3 s, used to be half of a one-scan process's first pass); the session's first tasks queue behind the warm-up
+        # tasks while the parent goes on with its own one-offs.  Should fewer than `workers` processes exist after the submits
+        # (a worker came up and went idle in between: not seen, but nothing forbids it), the warm-up tasks are waited for and a
+        # round of holding ones is submitted until the executor's own process table is full (a fast first task used
+        # to let later workers start outside the window, with the GPU visible and the real __main__).
         import sys
         import types
         hide = {"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "", "MVS_HOST_WORKER": "1"}
@@ -138,14 +142,19 @@ class HostPool:
         real_main = sys.modules.get("__main__")
         sys.modules["__main__"] = types.ModuleType("__main__")
         try:
-            futs = []
-            for _ in range(8):                               # normally one round
-                futs += [self.ex.submit(_warm, 0.2) for _ in range(self.workers)]
+            futs = [self.ex.submit(_warm) for _ in range(self.workers)]
+            for _ in range(8):                               # normally not entered
+                if len(getattr(self.ex, "_processes", None) or {}) >= self.workers or not hasattr(self.ex, "_processes"):
+                    break
                 for f in futs:
                     f.result()
-                if len(getattr(self.ex, "_processes", {}) or {}) >= self.workers:
-                    break
+                futs = [self.ex.submit(_warm, 0.2) for _ in range(self.workers)]
             procs = getattr(self.ex, "_processes", None)
+            if not procs:                                    # an executor without a process table: ask the workers
+                for _ in range(8):
+                    futs += [self.ex.submit(_warm, 0.2) for _ in range(self.workers)]
+                    if len(set(f.result() for f in futs)) >= self.workers:
+                        break
             self.pids = sorted(procs.keys()) if procs else sorted(set(f.result() for f in futs))
         finally:
             if real_main is not None:

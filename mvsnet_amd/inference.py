@@ -55,8 +55,10 @@ def build_weights(config, device, weights_path=None, model_dir=None, ckpt_step=N
 
 def center_images_device(u8):
     """mvs_data_generation/utils.py:33-38 (per-image, per-channel standardisation) on the device: (n,H,W,3) uint8 ->
-    float32 (x - mean) / (sqrt(var) + 1e-8) with the moments accumulated in float64 (the reference's numpy float32
-    reductions agree with them to ~1e-7 relative)."""
+    float32 (x - mean) / (sqrt(var) + 1e-8) with the moments accumulated in float64.  PyTorch restatement of
+    mvs_center_images_u8_f32 (csrc/center_images.hip, which the HIP towers call themselves when they are given uint8): used for the
+    torch extractor and as the bit-for-bit cross-check in tests.  (The reference's numpy float32 reductions keep running sums
+    over the leading axes: ~1e-3 relative away from the exact moments at 640 x 512; tests/test_gpu_unet.py.)"""
     import torch
     x = u8.to(torch.float32)
     # float64 ACCUMULATION of float32 terms that are exact (grey levels and their squares are integers below 2^16): the sums are
@@ -66,6 +68,24 @@ def center_images_device(u8):
     mean = x.sum(dim=(1, 2), keepdim=True, dtype=torch.float64) / n
     var = ((x * x).sum(dim=(1, 2), keepdim=True, dtype=torch.float64) / n - mean * mean).clamp_(min=0.0)
     return ((x - mean.float()) / (var.sqrt().float() + 0.00000001)).contiguous()
+
+
+_DEVICE_WARM = set()
+
+
+def warm_device_one_offs(device):
+    """Once per process and device: the torch kernels of the upload path (the reductions and elementwise kernels of
+    `center_images_device`, a copy, a stack) are launched on a 16 x 16 image so that their code objects load -- ~0.4 s of
+    first-use cost on this stack -- WHILE the worker processes decode the session's first images, not after they have arrived
+    (tools/r6_first_pass.py: a one-scan process's first pass)."""
+    import torch
+    if device in _DEVICE_WARM:
+        return
+    _DEVICE_WARM.add(device)
+    z = torch.zeros((2, 16, 16, 3), dtype=torch.uint8, device=device)
+    f = center_images_device(z)
+    torch.stack([f[0], f[1]]).clone()
+    torch.cuda.Event(enable_timing=True).record()
 
 
 class FeatureCache:
@@ -327,9 +347,13 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
         ev = torch.cuda.Event(); ev.record(); st_[1][i_] = ev
         return t_
 
+    towers_take_u8 = type(weights.unet).__name__ == "HipUNetDS2GN"      # standardises uint8 input in the library
+
     def images_to_device(imgs):
         t_ = to_device(imgs)
-        return center_images_device(t_) if t_.dtype == torch.uint8 else t_.to(torch.float32)
+        if t_.dtype == torch.uint8:
+            return t_ if towers_take_u8 else center_images_device(t_)
+        return t_.to(torch.float32)
 
     def prefetch_features(group):
         """The images of these reference views that the cache misses go through the towers as ONE batch (a tower pass is ~31
@@ -444,6 +468,7 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     it = iter(mine)
     for _ in range(ahead):
         submit_next(it)
+    warm_device_one_offs(device)
     chunk = 8                                         # reference views per tower pass (their new images form one batch)
     # (round 6 measured a ramp of 2, 4, 8 views for the first groups: no gain -- the worker processes decode a group's images in
     #  parallel, so the first group of eight is ready as soon as a group of two would be: 555-570 against 567-583 depth maps/s)

@@ -656,6 +656,18 @@ def unet_ds2gn(image, params, dtype=np.float32):
     return layers["conv10_2"]
 
 
+def standardise_image(image, dtype=np.float32):
+    """The towers' input (mvs_data_generation/utils.py:33-38, applied per image by the cluster generators): every channel of ONE
+    decoded image minus its mean over the image, over (its biased standard deviation + 1e-8).  dtype float32 follows the
+    reference to the letter (numpy's float32 reductions -- over the two leading axes numpy keeps RUNNING float32 sums, so at
+    640 x 512 and above the reference's own moments are only good to ~1e-3 relative and depend on the numpy build); float64
+    gives the exact moments the HIP path forms from integer sums (the two agree to ~2e-6 on a 64 x 80 image)."""
+    x = np.asarray(image).astype(dtype)
+    spread = np.sqrt(np.var(x, axis=(0, 1), keepdims=True))
+    centre = np.mean(x, axis=(0, 1), keepdims=True)
+    return (x - centre) / (spread + dtype(0.00000001))
+
+
 # --------------------------------------------------------------------------------------
 # 8f row f3  depth refinement (model.py:753-811, mvsnetworks.py:178-193,261-324)
 # --------------------------------------------------------------------------------------

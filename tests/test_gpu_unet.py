@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import mvsnet_oracle as O
-from mvsnet_amd import synthetic as S
+from mvsnet_amd import _lib, synthetic as S
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -158,6 +158,65 @@ def test_hip_unet_batches_of_different_sizes_share_one_set_of_buffers(lib_built)
         torch.cuda.synchronize()
         assert float((got - full[:V]).abs().max()) / float(full.abs().max()) < 1e-6, V
     assert len(hip._bufs) == 1 and len(hip._retired) == 1 and hip._bufs[(96, 128, 0)][0] == 7
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 80), (2, 512, 640), (1, 1200, 1600), (2, 6, 10), (5, 2, 2)])
+def test_center_images_matches_the_oracle_and_the_torch_restatement(shape, lib_built):
+    """mvs_center_images_u8_f32 (the towers' input side, utils.py:33-38): against the oracle with exact float64 moments
+    (2e-6 absolute on outputs of a few units), BIT FOR BIT against the PyTorch restatement the session used before (same exact
+    sums, same float64 -> float32 roundings, IEEE division), and against the oracle to the letter of the reference -- numpy
+    float32 reductions over the two LEADING axes, which numpy accumulates as running float32 sums (no pairwise splitting there):
+    accurate to 2e-5 on an image of a few thousand pixels, but only to ~1e-3 at 640 x 512 and above (measured: variance off by
+    2.5e-4 .. 7e-4 relative on uniform noise, more on low-contrast channels; it also depends on the numpy build's SIMD width).
+    The device path keeps the exact moments; the bound asserted for the large images is that distance, not a kernel tolerance.
+    One channel of the last image is constant (variance 0 -> zeros)."""
+    from mvsnet_amd.inference import center_images_device
+    lib = _lib.load()
+    V, H, W = shape
+    rs = np.random.RandomState(H + W)
+    u8 = (rs.rand(V, H, W, 3) * rs.choice([30, 255], (V, 1, 1, 3))).astype(np.uint8)
+    u8[-1, ..., 1] = 77
+    d = t(u8)
+    out = torch.full((V, H, W, 4), 9.0, device=DEV)
+    ws = torch.empty(lib.mvs_center_images_workspace_bytes(V) // 8, dtype=torch.int64, device=DEV)
+    _lib.check(lib.mvs_center_images_u8_f32(_lib.ptr(d), V, H, W, _lib.ptr(out), _lib.ptr(ws), _lib.stream_ptr()), "center")
+    got = n(out)
+    assert np.all(got[..., 3] == 0) and np.all(got[-1, ..., 1] == 0)
+    assert torch.equal(out[..., :3], center_images_device(d))
+    for v in range(V):
+        np.testing.assert_allclose(got[v, ..., :3], O.standardise_image(u8[v], np.float64), rtol=0, atol=2e-6)
+        letter = O.standardise_image(u8[v])
+        if H * W > 8192 and v == V - 1:                    # the constant channel to the letter: rounding noise of the running mean over
+            letter[..., 1] = 0                             # a ~1e-5 "deviation" (measured: 1.0013 everywhere at 640 x 512), not a value
+        np.testing.assert_allclose(got[v, ..., :3], letter, rtol=0, atol=2e-5 if H * W <= 8192 else 5e-3)
+
+
+def test_center_images_refuses_what_its_packets_cannot_address(lib_built):
+    """MVS_E_SHAPE (-2) / MVS_E_BADARG (-1) before anything is launched."""
+    lib = _lib.load()
+    d = torch.zeros(64, dtype=torch.uint8, device=DEV)
+    out = torch.zeros(64, device=DEV)
+    ws = torch.zeros(6, dtype=torch.int64, device=DEV)
+    bad = lambda *a: lib.mvs_center_images_u8_f32(*a, _lib.stream_ptr())
+    assert bad(_lib.ptr(d), 1, 3, 3, _lib.ptr(out), _lib.ptr(ws)) == -2           # 9 pixels: not whole 4-pixel packets
+    assert bad(_lib.ptr(d[1:]), 1, 2, 2, _lib.ptr(out), _lib.ptr(ws)) == -2       # images not 4-byte aligned
+    assert bad(_lib.ptr(d), 1, 2, 2, _lib.ptr(out[1:]), _lib.ptr(ws)) == -2       # output not 16-byte aligned
+    assert bad(None, 1, 2, 2, _lib.ptr(out), _lib.ptr(ws)) == -1
+    assert bad(_lib.ptr(d), 0, 2, 2, _lib.ptr(out), _lib.ptr(ws)) == -1
+
+
+def test_hip_unet_takes_decoded_uint8_images(lib_built):
+    """uint8 in = float32 in of the same images standardised by the PyTorch restatement (the same first-layer input, bit for
+    bit; what remains is the order of the GroupNorm atomics), in line and under the autotuned side streams."""
+    from mvsnet_amd.feature_net_hip import HipUNetDS2GN
+    from mvsnet_amd.inference import center_images_device
+    params = S.make_unet_params("normal", seed=3)
+    u8 = torch.randint(0, 256, (3, 96, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).to(DEV)
+    for side in (0, "auto"):
+        hip = HipUNetDS2GN(params, DEV, side_streams=side)
+        want = hip(center_images_device(u8))
+        got = hip(u8)
+        assert float((got - want).abs().max()) / float(want.abs().max()) < 1e-6
 
 
 def test_images_to_depth_end_to_end_matches_oracle(lib_built):
