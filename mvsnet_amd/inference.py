@@ -73,17 +73,17 @@ def center_images_device(u8):
 _DEVICE_WARM = set()
 
 
-def warm_device_one_offs(device):
-    """Once per process and device: the torch kernels of the upload path (the reductions and elementwise kernels of
-    `center_images_device`, a copy, a stack) are launched on a 16 x 16 image so that their code objects load -- ~0.4 s of
-    first-use cost on this stack -- WHILE the worker processes decode the session's first images, not after they have arrived
-    (tools/r6_first_pass.py: a one-scan process's first pass)."""
+def warm_device_one_offs(device, centre):
+    """Once per process and device: the torch kernels of the session's glue (a stack, a copy; with `centre` -- the torch
+    extractor -- the reductions and elementwise kernels of `center_images_device`) are launched on a 16 x 16 image so that their
+    code objects load -- 40-100 ms of first-use cost each on this stack -- WHILE the worker processes decode the session's
+    first images, not after they have arrived (tools/r6_first_pass.py: a one-scan process's first pass)."""
     import torch
-    if device in _DEVICE_WARM:
+    if (device, centre) in _DEVICE_WARM:
         return
-    _DEVICE_WARM.add(device)
+    _DEVICE_WARM.add((device, centre))
     z = torch.zeros((2, 16, 16, 3), dtype=torch.uint8, device=device)
-    f = center_images_device(z)
+    f = center_images_device(z) if centre else z.to(torch.float32)
     torch.stack([f[0], f[1]]).clone()
     torch.cuda.Event(enable_timing=True).record()
 
@@ -468,7 +468,7 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
     it = iter(mine)
     for _ in range(ahead):
         submit_next(it)
-    warm_device_one_offs(device)
+    warm_device_one_offs(device, centre=not towers_take_u8)
     chunk = 8                                         # reference views per tower pass (their new images form one batch)
     # (round 6 measured a ramp of 2, 4, 8 views for the first groups: no gain -- the worker processes decode a group's images in
     #  parallel, so the first group of eight is ready as soon as a group of two would be: 555-570 against 567-583 depth maps/s)
