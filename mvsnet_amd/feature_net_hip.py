@@ -33,6 +33,8 @@ class HipUNetDS2GN:
     compute pipe makes the pass SLOWER (measured: 1 807 against 1 055 us with one side stream on the wrong pipe, 985 with two on
     others; tools/pipe_probe.hip, round 3).  Under hipGraph capture an undecided shape runs in line."""
 
+    takes_uint8 = True                                     # __call__ standardises decoded uint8 images itself
+
     def __init__(self, params, device="cuda", side_streams="auto"):
         self.device = torch.device(device)
         self.side_streams = side_streams if side_streams == "auto" else int(side_streams)

@@ -40,7 +40,8 @@ def flatten_unet_params(params) -> List[torch.Tensor]:
 
 
 class HipTowers(torch.autograd.Function):
-    """images (V,H,W,3) + the tower variables in TensorFlow layouts -> features (V,H/4,W/4,32)."""
+    """images (V,H,W,3) float32 (centred) or uint8 (as decoded; standardised here) + the tower variables in TensorFlow layouts
+    -> features (V,H/4,W/4,32)."""
 
     @staticmethod
     def forward(ctx, images, *flat):
@@ -51,8 +52,14 @@ class HipTowers(torch.autograd.Function):
             raise ValueError("UNetDS2GN needs image sizes divisible by 16")
         slots = lib.mvs_gn_stat_slots()
         st = _lib.stream_ptr()
-        data = torch.zeros((V, H, W, 4), dtype=torch.float32, device=dev)       # image padded 3 -> 4 channels
-        data[..., :3] = images.detach()
+        if images.dtype == torch.uint8:                                          # decoded images: standardised into the padded layout
+            data = torch.empty((V, H, W, 4), dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.mvs_center_images_workspace_bytes(V) // 8, dtype=torch.int64, device=dev)
+            _lib.check(lib.mvs_center_images_u8_f32(_lib.ptr(images.contiguous()), V, H, W, _lib.ptr(data), _lib.ptr(ws), st),
+                       "mvs_center_images_u8_f32")
+        else:
+            data = torch.zeros((V, H, W, 4), dtype=torch.float32, device=dev)   # image padded 3 -> 4 channels
+            data[..., :3] = images.detach()
         P, i = {}, 0
         for name, kind, *_ in UNET_LAYERS:
             P[name] = {"w": flat[i].detach()}; i += 1

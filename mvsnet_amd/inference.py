@@ -347,7 +347,7 @@ def compute_depth_maps(input_dir, config=None, weights=None, device=None, timing
         ev = torch.cuda.Event(); ev.record(); st_[1][i_] = ev
         return t_
 
-    towers_take_u8 = type(weights.unet).__name__ == "HipUNetDS2GN"      # standardises uint8 input in the library
+    towers_take_u8 = bool(getattr(weights.unet, "takes_uint8", False))    # HipUNetDS2GN standardises uint8 input in the library
 
     def images_to_device(imgs):
         t_ = to_device(imgs)

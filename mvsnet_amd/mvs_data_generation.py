@@ -261,8 +261,10 @@ class ClusterGenerator:
         else:
             self.load_clusters(data_dir, self.clusters)
 
-    def prepare_training(self, c):
-        """cluster_generator.py:171-196"""
+    def prepare_training(self, c, center=True):
+        """cluster_generator.py:171-196.  center=False: the images come back as the cropped uint8 BGR stack and the caller
+        standardises them (on the device: `Trainer.loss` takes uint8 -- a quarter of the bytes through the loader's pipe and
+        the upload, no float32 reductions on the loader)."""
         images, cams = c.images(), c.cameras()
         depth = c.masked_reference_depth()
         if depth is None:
@@ -270,7 +272,7 @@ class ClusterGenerator:
         images, cams, depth = scale_mvs_input(images, cams, scale=c.rescale, depth_image=depth[:, :, 0])
         images, cams, depth = crop_mvs_input(images, cams, self.image_width, self.image_height,
                                              self.base_image_size, depth)
-        images = np.stack([center_image(i) for i in images], axis=0)
+        images = np.stack([center_image(i) if center else np.ascontiguousarray(i) for i in images], axis=0)
         depth = depth.astype(np.float32)
         rescaled = scale_image(depth, self.output_scale, "nearest")[:, :, None]
         cams = np.stack([scale_camera(cam, self.output_scale) for cam in cams], axis=0)
@@ -468,3 +470,91 @@ def make_generator(data_dir, *args, **kwargs):
     if os.path.isfile(os.path.join(data_dir, "pair.txt")):
         return PairClusterGenerator(data_dir, *args, **kwargs)
     raise FileNotFoundError("%s holds neither covisibility.json nor pair.txt" % data_dir)
+
+
+# ------------------------------------------------------------------------------------------------
+# training input pipeline (train.py:189-247: tf.data from_generator + parallel_interleave + prefetch)
+# ------------------------------------------------------------------------------------------------
+
+_WORKER_GENERATORS = {}                # in a worker process: constructor arguments -> (generator, {(session, ref view): cluster})
+
+
+def _training_task(gen_args, ident, center):
+    """Runs in a host-pool worker: `prepare_training` of the cluster `ident` = (session directory, reference view) of the
+    generator described by `gen_args` (built once per worker; its cluster list is the parent's -- same directory listing,
+    same seed -- but clusters are looked up by identity, not by position)."""
+    hit = _WORKER_GENERATORS.get(gen_args)
+    if hit is None:
+        gen = ClusterGenerator(**dict(gen_args))
+        hit = _WORKER_GENERATORS[gen_args] = (gen, {(c.session_dir, c.ref_index): c for c in gen.clusters})
+    gen, by_ident = hit
+    return gen.prepare_training(by_ident[ident], center=center)
+
+
+class TrainingPrefetcher:
+    """Training batches prepared AHEAD of the optimisation step, in order.
+
+    The reference feeds its towers from `tf.data`: generators interleaved over parallel threads with prefetching
+    (train.py:208-247), so decoding, resizing and cropping of the next clusters overlap the current step.  Here the clusters
+    of `order` (indices into `gen.clusters`) are prepared by the host pool's worker PROCESSES (`host_pool.get_pool`; the
+    thread that launches the kernels is the bottleneck of a step and shares no GIL with them), `ahead` clusters in flight,
+    and handed out in `order`.  `workers` = 0: a pool of threads in this process; "inline": nothing ahead, every cluster is
+    prepared on the calling thread when it is asked for (one generator, no prefetch).  A cluster that fails to load
+    (OSError / ValueError / KeyError, cluster_generator.py:217-220) is skipped, or raised when `strict` (several ranks:
+    a skipped step would leave the gradient all-reduce without its peer).  Iterating yields (position in `order`, batch) with
+    batch = (images, cams, depth (H/4,W/4,1), full depth (H,W,1)); `center=False` leaves the images uint8 for the device."""
+
+    def __init__(self, gen, gen_args, order, workers=None, ahead=None, center=True, strict=False):
+        from . import host_pool
+        self.gen, self.gen_args = gen, tuple(sorted(gen_args.items()))
+        self.order = list(order)
+        self.center, self.strict = bool(center), bool(strict)
+        self.inline = workers == "inline"
+        self.pool = None if self.inline else host_pool.get_pool(workers)
+        self.threads = None
+        if self.pool is None and not self.inline:
+            from concurrent.futures import ThreadPoolExecutor
+            self.threads = ThreadPoolExecutor(max_workers=4)
+        n = self.pool.workers if self.pool is not None else 4
+        self.ahead = max(1, int(ahead) if ahead is not None else 2 * n)       # prefetch_input_elements = 2 x generators (:243)
+
+    def _submit(self, ci):
+        c = self.gen.clusters[ci]
+        if self.pool is not None:
+            return self.pool.ex.submit(_training_task, self.gen_args, (c.session_dir, c.ref_index), self.center)
+        return self.threads.submit(self.gen.prepare_training, c, self.center)
+
+    def __iter__(self):
+        import collections
+        if self.inline:
+            for pos, ci in enumerate(self.order):
+                try:
+                    batch = self.gen.prepare_training(self.gen.clusters[ci], self.center)
+                except (OSError, ValueError, KeyError):
+                    if self.strict:
+                        raise
+                    continue
+                yield pos, batch
+            return
+        pending = collections.deque()
+        it = iter(enumerate(self.order))
+        for pos, ci in it:
+            pending.append((pos, self._submit(ci)))
+            if len(pending) >= self.ahead:
+                break
+        while pending:
+            pos, fut = pending.popleft()
+            for nxt, ci in it:
+                pending.append((nxt, self._submit(ci)))
+                break
+            try:
+                batch = fut.result()
+            except (OSError, ValueError, KeyError):
+                if self.strict:
+                    raise
+                continue
+            yield pos, batch
+
+    def close(self):
+        if self.threads is not None:
+            self.threads.shutdown(wait=False)

@@ -203,17 +203,27 @@ class Trainer:
     def loss(self, images, cams, depth_image, depth_num, full_depth=None, sync="self"):
         """images (N,H,W,3), cams (N,2,4,4) at the output scale, depth_image (H/4,W/4,1) GT.  Returns
         (loss, less_one, less_three, depth_map) exactly as get_loss (train.py:307-353), batch 1.
+        `images`: float32 = centred as the reference's generator hands them out; uint8 = the cropped images as decoded
+        (TrainingPrefetcher(center=False)): standardised per image and channel on the device (utils.py:33-38; by the HIP towers
+        themselves, mvs_center_images_u8_f32).
         `sync`: the cross-replica BatchNorm reducer; "self" = the trainer's own (None unless --sync_bn)."""
         sync = self.sync if sync == "self" else sync
         from .backward import plane_sweep_depth
-        images = torch.as_tensor(images, dtype=torch.float32, device=self.device)
+        images = torch.as_tensor(images, device=self.device)
+        raw = images if images.dtype == torch.uint8 else None
+        hip_towers_path = self.device.type == "cuda" and self.network_mode == "normal"
+        if raw is None:
+            images = images.to(torch.float32)
+        elif not (hip_towers_path and not self.refinement):   # somebody needs the float images: the ATen towers, the refinement's guide
+            from .inference import center_images_device
+            images = center_images_device(raw)
         cams_t = torch.as_tensor(cams, dtype=torch.float32, device=self.device)
         gt = torch.as_tensor(depth_image, dtype=torch.float32, device=self.device)[None]
         depth_start, depth_interval = float(cams[0][1][3][0]), float(cams[0][1][3][1])
         depth_end = float(cams[0][1][3][3])
-        if self.device.type == "cuda" and self.network_mode == "normal":
+        if hip_towers_path:
             from .feature_net_train import hip_towers       # HIP forward / GroupNorm backward, ATen convolution backward
-            feats = hip_towers(images, self.params.group("unet"))
+            feats = hip_towers(raw if raw is not None else images, self.params.group("unet"))
         else:                                               # narrower towers (channel counts below the HIP kernels' tiling)
             feats = unet_forward(trainable_layers(self.params.group("unet")), images,
                                  hip_group_norm=self.device.type == "cuda")
@@ -389,6 +399,9 @@ def build_parser():
     a("--loss_type", default="power"); a("--alpha", type=float, default=0.25); a("--beta", type=float, default=0.0)
     a("--eta", type=float, default=0.02); a("--no_grad_loss", action="store_true")
     a("--seed", type=int, default=0)
+    a("--loader_workers", type=int, default=None,
+      help="worker processes that prepare the next clusters while the GPU trains (default: the host's share; 0 = threads)")
+    a("--no_prefetch", action="store_true", help="prepare every cluster on the training thread, as one generator would")
     a("--sync_bn", action="store_true", help="BatchNorm statistics over all replicas (not in the reference)")
     return p
 
@@ -409,25 +422,27 @@ def train(args):
     if args.ckpt_step:
         ck = tf_checkpoint.ckpt_path(args.model_load_dir or args.model_dir, args.regularization, args.network_mode)
         tr.restore(tf_checkpoint.model_path(ck, args.ckpt_step))
-    mk = lambda mode: ClusterGenerator(args.train_data_root, args.view_num, args.width, args.height, args.max_d,
-                                       args.interval_scale, args.base_image_size, mode=mode,
-                                       output_scale=args.sample_scale, sessions_frac=args.dataset_fraction,
-                                       seed=args.seed, flip_cams=args.regularization == "GRU")     # train.py:194-196
+    gen_args = lambda mode: dict(data_dir=args.train_data_root, view_num=args.view_num, image_width=args.width,
+                                 image_height=args.height, depth_num=args.max_d, interval_scale=args.interval_scale,
+                                 base_image_size=args.base_image_size, mode=mode, output_scale=args.sample_scale,
+                                 sessions_frac=args.dataset_fraction, seed=args.seed,
+                                 flip_cams=args.regularization == "GRU")                            # train.py:194-196
+    mk = lambda mode: ClusterGenerator(**gen_args(mode))
     train_gen, val_gen = mk("train"), mk("val")
     mine = shard_indices(len(train_gen.clusters), rank, world)
     steps = len(mine) if args.max_steps_per_epoch is None else min(len(mine), args.max_steps_per_epoch)
     if world > 1:                                   # every rank must take the same number of steps
         t = torch.tensor([steps], device="cuda"); torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
         steps = int(t.item())
+    from .mvs_data_generation import TrainingPrefetcher
+    # the input pipeline (train.py:208-247): the next clusters are decoded / resized / cropped by worker processes while this
+    # thread launches the step; the images travel as uint8 and are standardised on the device (Trainer.loss).  A cluster that
+    # fails to load is skipped -- except with several ranks, where a skipped step would desynchronise the all-reduce
+    feed = TrainingPrefetcher(train_gen, gen_args("train"), mine[:steps], workers="inline" if args.no_prefetch else args.loader_workers,
+                              center=False, strict=world > 1)
     for epoch in range(args.epoch):
-        for step, ci in enumerate(mine[:steps]):
-            t0 = time.time()
-            try:
-                images, cams, depth, _full = train_gen.prepare_training(train_gen.clusters[ci])
-            except (OSError, ValueError, KeyError):
-                if world > 1:
-                    raise                              # a skipped step would desynchronise the all-reduce
-                continue
+        t0 = time.time()
+        for step, (images, cams, depth, _full) in feed:
             loss, l1, l3 = tr.train_step(images, cams, depth, args.max_d, _full)
             if args.regularization == "GRU":           # the same cluster with the sweep reversed (cluster_generator.py:303-304)
                 from .mvs_data_generation import flip_cams
@@ -458,6 +473,8 @@ def train(args):
                     m = np.mean(np.asarray(vals), axis=0)
                     print("VAL STEP COMPLETED. Average loss: %g, Average less one: %g, Average less three: %g"
                           % (m[0], m[1], m[2]), flush=True)
+            t0 = time.time()                           # sec/step: from the end of one step to the end of the next
+    feed.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -50,6 +50,45 @@ def test_generator_train_and_val_modes(tmp_path):
         G.ClusterGenerator(str(tmp_path), mode="bogus")
 
 
+@pytest.mark.parametrize("workers", [2, 0, "inline"])
+def test_training_prefetcher_hands_out_the_generators_batches_in_order(tmp_path, workers):
+    """The input pipeline of the training loop (train.py:208-247: tf.data from_generator + parallel_interleave + prefetch):
+    worker processes (2), threads (0) or the calling thread ("inline") prepare the clusters; what comes out is what
+    `prepare_training` gives on this thread, in the order asked for -- centred float32, or uint8 for the device
+    (center=False: the cropped images before utils.py:33-38).  A cluster whose ground truth is missing is skipped
+    (cluster_generator.py:217-220), or raised when `strict` (several ranks)."""
+    from mvsnet_amd import mvs_data_generation as G
+    for k, nm in enumerate(("a", "b")):
+        s = make_session(str(tmp_path / "train" / nm), seed=k)
+        add_depths(s, seed=k)
+    args = dict(data_dir=str(tmp_path), view_num=3, image_width=64, image_height=48, depth_num=16, base_image_size=8,
+                mode="train", seed=3)
+    gen = G.ClusterGenerator(**args)
+    order = [4, 0, 5, 2, 1, 3, 0]
+    for center in (True, False):
+        feed = G.TrainingPrefetcher(gen, args, order, workers=workers, ahead=3, center=center)
+        got = list(feed)
+        feed.close()
+        assert [p_ for p_, _b in got] == list(range(len(order)))
+        for (p_, batch), ci in zip(got, order):
+            want = gen.prepare_training(gen.clusters[ci], center=center)
+            assert len(batch) == 4 and all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(batch, want))
+        assert got[0][1][0].dtype == (np.float32 if center else np.uint8)
+    # uint8 + the device's standardisation = the centred batch (float64 moments against numpy's float32: 2e-5 at this size)
+    u8 = gen.prepare_training(gen.clusters[0], center=False)[0]
+    f32 = gen.prepare_training(gen.clusters[0])[0]
+    x = u8.astype(np.float64)
+    np.testing.assert_allclose((x - x.mean((1, 2), keepdims=True)) / (x.std((1, 2), keepdims=True) + 1e-8), f32, atol=2e-5)
+    # a cluster without ground truth
+    c = gen.clusters[order[2]]
+    os.remove(c.depth_path(c.ref_index))
+    feed = G.TrainingPrefetcher(gen, args, order, workers=workers, ahead=2)
+    assert [p_ for p_, _b in feed] == [0, 1, 3, 4, 5, 6]
+    feed.close()
+    with pytest.raises(OSError):
+        list(G.TrainingPrefetcher(gen, args, order, workers=workers, ahead=2, strict=True))
+
+
 def test_schedule_and_initialisers():
     from mvsnet_amd import train as T
     from mvsnet_amd.synthetic import make_regnet_params
