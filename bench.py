@@ -393,6 +393,42 @@ def training_record(dev, iters=5, configs=(("3dcnn_d128_config5", "3DCNN", 128),
     return out
 
 
+def training_from_disk_record(steps=30, n_images=16, src=(1600, 1200)):
+    """SURVEY 8f f4, the loop AROUND the step: `python -m mvsnet_amd.train` on an on-disk dataset in the reference's layout,
+    images stored at DTU's 1600 x 1200 and decoded / rescaled / cropped to configuration 5's 640 x 480 by the generator
+    (mvs_cluster.py:178-192), D = 128: seconds per step as the loop prints them, with the input pipeline (the next clusters
+    prepared by worker processes, uint8 upload, standardisation on the device: the reference's tf.data parallel_interleave +
+    prefetch, train.py:208-247) and with one generator on the training thread."""
+    import contextlib, io, re, tempfile
+    out = {"images_stored_at": "%dx%d" % src, "trained_at": "3 views x 640x480, D = 128", "steps_per_run": steps}
+    try:
+        from PIL import Image
+        from mvsnet_amd import synthetic as S, train as T
+        root = tempfile.mkdtemp()
+        for mode in ("train", "val"):
+            sdir = os.path.join(root, mode, "s0")
+            S.write_session(sdir, n_images=n_images if mode == "train" else 4, height=src[1], width=src[0], view_num=3, depth_num=128)
+            os.makedirs(os.path.join(sdir, "depths"))
+            rs = np.random.RandomState(0)
+            for i in range(n_images if mode == "train" else 4):
+                d = (S.PIVOT_DEPTH + 20.0 * rs.standard_normal((src[1], src[0]))).clip(1, 65535).astype(np.uint16)
+                Image.fromarray(d).save(os.path.join(sdir, "depths", "%d.png" % i))
+        for tag, extra in (("warm-up", []), ("input_pipeline", []), ("one_generator_on_the_training_thread", ["--no_prefetch"])):
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                T.main(["--train_data_root", root, "--model_dir", os.path.join(root, "model"), "--network_mode", "normal",
+                        "--view_num", "3", "--max_d", "128", "--width", "640", "--height", "480", "--epoch", "4",
+                        "--max_steps_per_epoch", str(steps // 4 + 1), "--snapshot", "1000000", "--train_steps_per_val", "1000000"] + extra)
+            per = [float(x) for x in re.findall(r"\(([0-9.]+) sec/step\)", buf.getvalue())]
+            if tag != "warm-up":
+                out[tag] = {"median_ms_per_step": 1e3 * float(np.median(per[len(per) // 3:])), "steps": len(per)}
+        import shutil
+        shutil.rmtree(root, ignore_errors=True)
+    except (Exception, SystemExit) as e:                    # informative record: never fail the bench line over it
+        out["error"] = repr(e)[:300]
+    return out
+
+
 def training_roofline(tr, images, cams, gt, N, H, W, D, ms_step, iters):
     """Roofline of one training step: algorithmic FLOPs of forward + backward -- the backward of a
     convolution is a data-gradient and a weight-gradient convolution of the forward's size, so 3x the forward in all (2x for a
@@ -914,6 +950,7 @@ def main():
                                                                          width=1152, height=864); lap("session_config4_rank_share_135_views")
             out["training"] = training_record(dev, configs=(("3dcnn_d192", "3DCNN", 192), ("3dcnn_d128_config5", "3DCNN", 128), ("gru_d192", "GRU", 192))
                                               if args.training_all else (("3dcnn_d128_config5", "3DCNN", 128),)); lap("training")
+            out["training_from_disk"] = training_from_disk_record(); lap("training_from_disk")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, rp, args.cpu_budget, depth_np)
             if args.workload == "M":       # configs[0]: the configuration BASELINE.json defines AS the CPU run (N=3, D=32, 160x128 features)
