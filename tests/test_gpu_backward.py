@@ -254,6 +254,27 @@ def test_trainer_reduces_the_loss_on_one_batch(optimizer):
     assert float(tr.params.grad.abs().max()) == 0.0                        # zeroed after the update
 
 
+@pytest.mark.parametrize("mode,refinement", [("normal", False), ("normal", True), ("lite", False)])
+def test_trainer_takes_decoded_uint8_images(mode, refinement):
+    """The training loop's input pipeline hands the cropped images over as uint8 (TrainingPrefetcher(center=False)):
+    loss and gradients are those of the same images standardised beforehand -- by the HIP towers' own launch pair
+    (mvs_center_images_u8_f32, "normal") or by its PyTorch restatement in front of the ATen towers ("lite") and of the
+    refinement's guide image."""
+    from mvsnet_amd import train as T
+    from mvsnet_amd.inference import center_images_device
+    _images, cams, gt, D = _train_batch()
+    u8 = torch.randint(0, 256, _images.shape, dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    full = np.repeat(np.repeat(gt, 4, axis=0), 4, axis=1) if refinement else None
+    out = []
+    for images in (center_images_device(u8.to(DEV)), u8.numpy()):
+        tr = T.Trainer(mode, DEV, seed=0, refinement=refinement)
+        loss, l1, l3, _d = tr.loss(images, cams, gt, D, full)
+        loss.backward()
+        out.append((float(loss.detach()), tr.params.grad.clone()))
+    assert abs(out[0][0] - out[1][0]) <= 1e-5 * abs(out[0][0])
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 1e-4 * float(out[0][1].abs().max())
+
+
 def test_trainer_checkpoint_round_trip(tmp_path):
     from mvsnet_amd import train as T
     from mvsnet_amd import tf_checkpoint
