@@ -43,9 +43,23 @@ def benchmark_depth_maps(input_dir, config, weights, device, losses, less_ones, 
                          output_scale=config.sample_scale,
                          max_clusters_per_session=config.max_clusters_per_session)
     done = 0
-    for c in gen.clusters:
+    # the next clusters are decoded / resized on loader threads while this one is on the GPU (the reference feeds one cluster per
+    # sess.run, test.py:121-135; preparing five images takes 20-50 x as long as their depth map here)
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    loaders, ahead = ThreadPoolExecutor(max_workers=4), deque()
+    todo = iter(gen.clusters)
+    for c in todo:
+        ahead.append((c, loaders.submit(gen.prepare, c)))
+        if len(ahead) >= 6:
+            break
+    while ahead:
+        c, fut = ahead.popleft()
+        for nxt in todo:
+            ahead.append((nxt, loaders.submit(gen.prepare, nxt)))
+            break
         try:
-            out_images, in_images, out_cams, full_cams, index, full_depth = gen.prepare(c)
+            out_images, in_images, out_cams, full_cams, index, full_depth = fut.result()
         except Exception as e:
             logger.warning("skipping cluster %s/%d: %s", c.session_dir, c.ref_index, e)
             continue
@@ -67,6 +81,7 @@ def benchmark_depth_maps(input_dir, config, weights, device, losses, less_ones, 
             out_dir = pl.setup_output_dir(input_dir, config.output_dir)
             pl.write_output_slice(out_dir, d.cpu().numpy(), p.cpu().numpy(), out_images[0], out_cams[0], index)
         done += 1
+    loaders.shutdown(wait=False)
     return done
 
 

@@ -463,12 +463,11 @@ def train(args):
                 print("Saving model to", tr.save(args.model_dir, args.regularization), flush=True)
             if rank == 0 and (step + 1) % args.train_steps_per_val == 0:
                 vals = []
-                for k, vc in enumerate(val_gen.clusters[:args.val_batch_size]):
-                    try:
-                        vi, vcam, vd, _vf = val_gen.prepare_training(vc)
-                    except (OSError, ValueError, KeyError):
-                        continue
+                val_feed = TrainingPrefetcher(val_gen, gen_args("val"), range(min(len(val_gen.clusters), args.val_batch_size)),
+                                              workers="inline" if args.no_prefetch else args.loader_workers, center=False)
+                for _k, (vi, vcam, vd, _vf) in val_feed:   # the other ranks wait in their next all-reduce meanwhile: same pipeline
                     vals.append([float(x) for x in tr.validate_step(vi, vcam, vd, args.max_d, _vf)])
+                val_feed.close()
                 if vals:
                     m = np.mean(np.asarray(vals), axis=0)
                     print("VAL STEP COMPLETED. Average loss: %g, Average less one: %g, Average less three: %g"
