@@ -460,11 +460,8 @@ def training_roofline(tr, images, cams, gt, N, H, W, D, ms_step, iters):
         img_t = torch.as_tensor(images).to(dev)
         unet_p = tr.params.group("unet")
 
-        def towers():
-            for p_ in unet_p.values():
-                for t_ in p_.values():
-                    t_.grad = None
-            hip_towers(img_t, unet_p).sum().backward()
+        def towers():                                          # as the step runs them: parameter gradients added into the flat buffer
+            hip_towers(img_t, unet_p, accumulate_into_grads=True).sum().backward()
         ms_tow = timed(towers)
         feats = hip_towers(img_t, unet_p).detach().requires_grad_(True)
         t8 = homography_transforms(torch.as_tensor(cams).to(dev), D, float(cams[0, 1, 3, 0]), float(cams[0, 1, 3, 1]))

@@ -477,8 +477,10 @@ int mvs_rmsprop_step_f32(float* w, const float* g, float* ms, float* mom, size_t
  *   x, y, g, dx   (V, hw, C) channel-last, C a multiple of 8
  *   stats         (V, 2, C) float64 per-channel [sum, sum of squares] of x, zeroed by the caller before
  *                 mvs_gn_stats_f32 (group moments are folded from a group's 8 channel sums where needed)
- *   sums          (V, 2, C) float64 [sum gz, sum gz*xhat], zeroed by the caller before mvs_gn_bwd_reduce_f32;
- *                 g_beta(c) = sum_v sums(v,0,c), g_gamma(c) = sum_v sums(v,1,c)
+ *   sums          mvs_gn_bwd_sums_doubles(V, C) float64 = mvs_gn_bwd_sum_slots() copies of (V, 2, C) [sum gz, sum gz*xhat],
+ *                 zeroed by the caller before mvs_gn_bwd_reduce_f32: the workgroups spread their float64 atomics over the
+ *                 copies (atomics on one address are performed one after the other), mvs_gn_bwd_apply_f32 adds them up;
+ *                 g_beta(c) = sum over slots and views of sums(s,v,0,c), g_gamma(c) likewise of sums(s,v,1,c)
  *   relu          1: y = ReLU(gamma*xhat+beta) (conv_gn), 0: no activation (deconv_gn) */
 int mvs_gn_stats_f32(const float* x, int V, size_t hw, int C, double* stats, void* stream);
 /* The same statistics from the sums the tower convolutions already wrote: slots (V, C/8, nslot, 2) float64 partial [sum, sumsq]
@@ -487,13 +489,18 @@ int mvs_gn_stats_f32(const float* x, int V, size_t hw, int C, double* stats, voi
 int mvs_gn_slots_to_channel_sums_f64(const double* slots, int V, int C, int nslot, double* stats, void* stream);
 int mvs_gn_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
                      int relu, int V, size_t hw, int C, float* y, void* stream);
+int mvs_gn_bwd_sum_slots(void);
+size_t mvs_gn_bwd_sums_doubles(int V, int C);
 int mvs_gn_bwd_reduce_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
                           int relu, const float* g, int V, size_t hw, int C, double* sums, void* stream);
-int mvs_gn_bwd_reduce_tot_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
-                              int relu, const float* g, int V, size_t hw, int C, double* sums, double* totals, void* stream);
 int mvs_gn_bwd_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
                          int relu, const float* g, const double* sums, int V, size_t hw, int C, float* dx,
                          void* stream);
+/* ... with g_beta / g_gamma ADDED to totals (2, C) float64 by the launch's first workgroup (the parameter gradients without a
+ * reduction launch per layer); C <= 128. */
+int mvs_gn_bwd_apply_tot_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
+                             int relu, const float* g, const double* sums, double* totals, int V, size_t hw, int C, float* dx,
+                             void* stream);
 /* The other two optimisers of setup_optimizer (train.py:248-271): tf.train.MomentumOptimizer
  * (accum = momentum*accum + g; w -= lr*accum) and tf.train.AdamOptimizer (lr_t = lr*sqrt(1-beta2^t)/
  * (1-beta1^t) formed by the caller; w -= lr_t*m/(sqrt(v)+eps)). */
@@ -501,6 +508,17 @@ int mvs_momentum_step_f32(float* w, const float* g, float* accum, size_t n, floa
                           float grad_scale, void* stream);
 int mvs_adam_step_f32(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float beta1,
                       float beta2, float eps, float grad_scale, void* stream);
+
+/* Many small tensors in one launch (the end of the towers' backward, replacing a permute-copy and an autograd accumulation
+ * launch per parameter -- average_gradients' inputs, train.py:155-187, land in the flat gradient buffer directly):
+ *   mvs_transpose_add_many_f32   job i: dst_i (KK, keep, B) += src_i (B, A, KK) with the axes reversed, rows a >= keep dropped
+ *                                (ATen's (Cout, Cin, k, k) weight gradient into TensorFlow's (k, k, Cin, Cout) variable);
+ *                                dims = n x 4 host ints [B, A, KK, keep], src / dst host arrays of n device pointers
+ *   mvs_add_f64_many_f32         job i: dst_i[0..counts_i) += (float)src_i[..]  (GroupNorm gamma / beta gradients accumulated
+ *                                in float64 by mvs_gn_bwd_apply_tot_f32)
+ * Any n (the jobs travel in the kernel arguments, 48 / 96 per launch). */
+int mvs_transpose_add_many_f32(int n, const float* const* src, float* const* dst, const int* dims, void* stream);
+int mvs_add_f64_many_f32(int n, const double* const* src, float* const* dst, const int* counts, void* stream);
 
 /* Training of the recurrent regulariser (inference_prob_recurrent, mvsnet/model.py:505-599; ConvGRUCell,
  * mvsnet/convgru.py:82-122): the plane-sequential part of back-propagation through time of ONE cell over all D

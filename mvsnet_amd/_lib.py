@@ -74,13 +74,17 @@ SIGNATURES = {
     "mvs_cost_volume_bwd_gather_f32": (_i, [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _sz, _p, _p, _p]),
     "mvs_rmsprop_step_f32": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),
     "mvs_gn_stats_f32": (_i, [_p, _i, _sz, _i, _p, _p]),
+    "mvs_transpose_add_many_f32": (_i, [_i, _p, _p, _p, _p]),
+    "mvs_add_f64_many_f32": (_i, [_i, _p, _p, _p, _p]),
     "mvs_center_images_workspace_bytes": (_sz, [_i]),
     "mvs_center_images_u8_f32": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "mvs_gn_bwd_sums_doubles": (_sz, [_i, _i]),
     "mvs_gn_slots_to_channel_sums_f64": (_i, [_p, _i, _i, _i, _p, _p]),
     "mvs_gn_apply_f32": (_i, [_p, _p, _p, _p, _f, _i, _i, _sz, _i, _p, _p]),
     "mvs_gn_bwd_reduce_f32": (_i, [_p, _p, _p, _p, _f, _i, _p, _i, _sz, _i, _p, _p]),
-    "mvs_gn_bwd_reduce_tot_f32": (_i, [_p, _p, _p, _p, _f, _i, _p, _i, _sz, _i, _p, _p, _p]),
     "mvs_gn_bwd_apply_f32": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _i, _sz, _i, _p, _p]),
+    "mvs_gn_bwd_apply_tot_f32": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p, _i, _sz, _i, _p, _p]),
+    "mvs_gn_bwd_sum_slots": (_i, []),
     "mvs_momentum_step_f32": (_i, [_p, _p, _p, _sz, _f, _f, _f, _p]),
     "mvs_adam_step_f32": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),
     "mvs_gru_train_slots": (_i, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libmvsnet_hip.so")
 SOURCES = ["homography.hip", "cost_volume.hip", "conv3d_scalar.hip", "conv3d_mfma.hip", "conv3d_s2_mfma.hip",
            "deconv3d_mfma.hip", "deconv3d_c8.hip", "conv3d_os.hip", "conv3d_out.hip", "conv3d_bf16x3.hip", "conv3d_c8.hip",
-           "regnet.hip", "softargmin.hip", "gru.hip", "gru_mfma.hip", "gru_fused.hip", "unet2d.hip", "unet2d_p.hip", "center_images.hip",
+           "regnet.hip", "softargmin.hip", "gru.hip", "gru_mfma.hip", "gru_fused.hip", "unet2d.hip", "unet2d_p.hip", "center_images.hip", "multi_tensor.hip",
            "backward.hip", "conv3d_wgrad.hip", "conv3d_c1.hip", "conv3d_k8.hip", "gru_train.hip", "conv2d_wgrad.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

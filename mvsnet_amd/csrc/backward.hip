@@ -471,14 +471,15 @@ cvb_fold_kernel(const float* __restrict__ part, int rows, size_t n4, float* __re
 // x (V, HW, C) channel-last; stats (V, 2, C) float64 per-channel [sum, sumsq] (group moments are folded from
 // the 8 channel sums of a group wherever they are needed); sums (V, 2, C) float64 [sum gz, sum gz*xhat].
 constexpr int GN_CH = 8;
+constexpr int GN_BWD_SLOTS = 8;        // copies of the backward sums the workgroups spread their float64 atomics over
 
 // mode 0: stats += [x, x^2];  mode 1: sums += [gz, gz*xhat], gz = g * [gamma*xhat+beta > 0] (when relu)
 template <int MODE>
 __global__ void __launch_bounds__(256)
 gn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ g, const double* __restrict__ stats,
                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
-                 size_t hw, int cq, double* __restrict__ out, double* __restrict__ tot = nullptr) {
-    __shared__ float red[256][8];
+                 size_t hw, int cq, double* __restrict__ out) {
+    __shared__ float red[4 * 32][8];                       // [wave][channel quad <= 32][sum, weighted sum]
     const int tid = threadIdx.x, v = blockIdx.y;
     const int c = (tid % cq) * 4, C = cq * 4;
     const size_t n4 = hw * cq;
@@ -495,14 +496,12 @@ gn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ g, const
         for (int k = 0; k < 4; ++k) { ga[k] = gamma[c + k]; be[k] = beta[c + k]; }
     }
     float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n4; i += (size_t)gridDim.x * 256) {
-        const float4 xx = ld4(xv + 4 * i);
+    auto fold = [&](const float4 xx, const float4 g4) {
         const float vv[4] = {xx.x, xx.y, xx.z, xx.w};
         if (MODE == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { a[k] += vv[k]; b[k] += vv[k] * vv[k]; }
         } else {
-            const float4 g4 = ld4(gv + 4 * i);
             const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -511,20 +510,48 @@ gn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ g, const
                 a[k] += gz; b[k] += gz * xh;
             }
         }
-    }
+    };
+    // four elements per trip, their loads issued together: with one per trip a full-resolution layer was ~19 dependent trips of
+    // two loads per thread on 384 workgroups -- latency-bound at 38 us per launch on average (round 6's trace of the training step)
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + tid;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 xx[4], g4[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { red[tid][k] = a[k]; red[tid][4 + k] = b[k]; }
+        for (int u = 0; u < 4; ++u) {
+            xx[u] = ld4(xv + 4 * (i + u * stride));
+            g4[u] = MODE ? ld4(gv + 4 * (i + u * stride)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fold(xx[u], g4[u]);
+    }
+    for (; i < n4; i += stride) fold(ld4(xv + 4 * i), MODE ? ld4(gv + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f));
+    // lanes l, l + cq, l + 2 cq, ... of a wave hold the same channel quad (cq divides 64): butterfly over the offsets >= cq, then
+    // the four waves' rows through LDS (with 8 channels the old tree had TWO threads walk 128 rows each: +5 us per launch)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int o = 32; o >= cq; o >>= 1) { a[k] += __shfl_xor(a[k], o, 64); b[k] += __shfl_xor(b[k], o, 64); }
+    if ((tid & 63) < cq) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[(tid >> 6) * 32 + (tid & 63)][k] = a[k]; red[(tid >> 6) * 32 + (tid & 63)][4 + k] = b[k]; }
+    }
     __syncthreads();
     if (tid < cq) {
         double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
-        for (int j = tid; j < 256; j += cq)
+        for (int w = 0; w < 4; ++w)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { sa[k] += red[j][k]; sb[k] += red[j][4 + k]; }
+            for (int k = 0; k < 4; ++k) { sa[k] += red[w * 32 + tid][k]; sb[k] += red[w * 32 + tid][4 + k]; }
+        // MODE 1: the partial sums go to one of GN_BWD_SLOTS copies of `out`, which the apply pass adds up as it reads them.
+        // Atomics on ONE address are performed one after the other by the L2, ~40 ns each (tools/r6_gn_reduce_probe.py: a
+        // launch of 384 workgroups cost 15 us more than one of 128 whatever the tensor's size): round 6 first let every
+        // workgroup add to per-layer totals as well, then take a ticket so that the last one would fold -- either way 384
+        // serialised atomics, 30-52 us per launch in the training step against 5-23 us for the element-wise pass over the
+        // same tensors.  No cross-workgroup step is left here: 16 atomics per address and slot.
+        double* dst = out + (MODE ? (size_t)(blockIdx.x % GN_BWD_SLOTS) * gridDim.y * 2 * C : 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            atomicAdd(out + ((size_t)v * 2) * C + c + k, sa[k]);
-            atomicAdd(out + ((size_t)v * 2 + 1) * C + c + k, sb[k]);
-            if (tot) { atomicAdd(tot + c + k, sa[k]); atomicAdd(tot + C + c + k, sb[k]); }      // (2, C) over all views: d beta, d gamma
+            atomicAdd(dst + ((size_t)v * 2) * C + c + k, sa[k]);
+            atomicAdd(dst + ((size_t)v * 2 + 1) * C + c + k, sb[k]);
         }
     }
 }
@@ -534,17 +561,40 @@ template <int MODE>
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ g, const double* __restrict__ stats,
                 const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
-                float eps, int relu, size_t hw, int cq, float* __restrict__ out) {
+                float eps, int relu, size_t hw, int cq, float* __restrict__ out, double* __restrict__ tot = nullptr) {
     const int tid = threadIdx.x, v = blockIdx.y;
     const int c = (tid % cq) * 4, C = cq * 4;
     const size_t n4 = hw * cq;
     const int c0 = c & ~(GN_CH - 1);
+    const size_t plane = (size_t)gridDim.y * 2 * C;       // one slot of the backward sums: (V, 2, C)
+    if (MODE && tot && blockIdx.x == 0 && blockIdx.y == 0) {
+        // (2, C) over all views and slots: d beta, d gamma -- one workgroup, one thread per (statistic, channel); C <= 128
+        if (tid < 2 * C) {
+            double acc = 0.0;
+            for (unsigned vv = 0; vv < gridDim.y; ++vv)
+#pragma unroll
+                for (int sl = 0; sl < GN_BWD_SLOTS; ++sl) acc += sums[sl * plane + (size_t)vv * 2 * C + tid];
+            tot[tid] += acc;
+        }
+    }
+    // the slots of this view's backward sums, added up ONCE per workgroup (one thread per (statistic, channel), C <= 128), not by
+    // every thread for its own group (128 float64 loads per thread: the pass took 37 instead of 15 us on a 240 x 320 x 16 layer)
+    __shared__ double folded[2 * 128];
+    if (MODE) {
+        if (tid < 2 * C) {
+            double acc = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < GN_BWD_SLOTS; ++sl) acc += sums[sl * plane + (size_t)v * 2 * C + tid];
+            folded[tid] = acc;
+        }
+        __syncthreads();
+    }
     double s = 0.0, q = 0.0, ta = 0.0, tb = 0.0;
     for (int k = 0; k < GN_CH; ++k) {
         s += stats[((size_t)v * 2) * C + c0 + k]; q += stats[((size_t)v * 2 + 1) * C + c0 + k];
         if (MODE) {
-            ta += (double)gamma[c0 + k] * sums[((size_t)v * 2) * C + c0 + k];
-            tb += (double)gamma[c0 + k] * sums[((size_t)v * 2 + 1) * C + c0 + k];
+            ta += (double)gamma[c0 + k] * folded[c0 + k];
+            tb += (double)gamma[c0 + k] * folded[C + c0 + k];
         }
     }
     const double nn = (double)hw * GN_CH, mu = s / nn;
@@ -737,9 +787,14 @@ extern "C" int mvs_gn_slots_to_channel_sums_f64(const double* slots, int V, int 
 // GroupNorm entry points: mode selects the pass (see the kernels above).
 static int gn_check(const void* x, int V, size_t hw, int C) {
     if (!x || V <= 0 || hw == 0 || C <= 0) return MVS_E_BADARG;
-    if (C % GN_CH || 256 % (C / 4)) return MVS_E_SHAPE;
+    if (C % GN_CH || 256 % (C / 4) || C > 128) return MVS_E_SHAPE;     // a wave's lanes cover whole rows of C / 4 quads; LDS rows for <= 32 quads
     return 0;
 }
+// Workgroups per view of the reductions (each ends with float64 atomics on shared cache lines: see GN_BWD_SLOTS).
+#ifndef GN_REDUCE_BLOCKS
+#define GN_REDUCE_BLOCKS 128
+#endif
+
 static dim3 gn_grid(size_t hw, int C, int V, int cap) {
     size_t b = (hw * (size_t)(C / 4) + 255) / 256;
     return dim3((unsigned)(b < (size_t)cap ? (b ? b : 1) : cap), V);
@@ -748,7 +803,7 @@ static dim3 gn_grid(size_t hw, int C, int V, int cap) {
 extern "C" int mvs_gn_stats_f32(const float* x, int V, size_t hw, int C, double* stats, void* stream) {
     int rc = gn_check(x, V, hw, C); if (rc) return rc;
     MVS_CHECK_ARG(stats);
-    gn_reduce_kernel<0><<<gn_grid(hw, C, V, 128), 256, 0, mvs_stream(stream)>>>(x, nullptr, nullptr, nullptr, nullptr, 0.f, 0,
+    gn_reduce_kernel<0><<<gn_grid(hw, C, V, GN_REDUCE_BLOCKS), 256, 0, mvs_stream(stream)>>>(x, nullptr, nullptr, nullptr, nullptr, 0.f, 0,
                                                                                 hw, C / 4, stats);
     MVS_LAUNCH_RET();
 }
@@ -762,21 +817,18 @@ extern "C" int mvs_gn_apply_f32(const float* x, const double* stats, const float
     MVS_LAUNCH_RET();
 }
 
+// `sums`: mvs_gn_bwd_sums_doubles(V, C) float64, zeroed by the caller: mvs_gn_bwd_sum_slots() copies of (V, 2, C) that the
+// workgroups spread their atomics over; the apply pass (and whoever wants d gamma / d beta) adds the copies up.
+extern "C" int mvs_gn_bwd_sum_slots(void) { return GN_BWD_SLOTS; }
+extern "C" size_t mvs_gn_bwd_sums_doubles(int V, int C) {
+    return (V > 0 && C > 0) ? (size_t)GN_BWD_SLOTS * V * 2 * C : 0;
+}
+
 extern "C" int mvs_gn_bwd_reduce_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
                                      int relu, const float* g, int V, size_t hw, int C, double* sums, void* stream) {
     int rc = gn_check(x, V, hw, C); if (rc) return rc;
     MVS_CHECK_ARG(stats && gamma && beta && g && sums);
-    gn_reduce_kernel<1><<<gn_grid(hw, C, V, 128), 256, 0, mvs_stream(stream)>>>(x, g, stats, gamma, beta, eps, relu, hw, C / 4, sums);
-    MVS_LAUNCH_RET();
-}
-
-// The same with the sums over ALL views accumulated beside them: totals (2, C) float64 [d beta, d gamma] (zeroed by the caller) --
-// the parameter gradients without a reduction launch per layer.
-extern "C" int mvs_gn_bwd_reduce_tot_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
-                                         int relu, const float* g, int V, size_t hw, int C, double* sums, double* totals, void* stream) {
-    int rc = gn_check(x, V, hw, C); if (rc) return rc;
-    MVS_CHECK_ARG(stats && gamma && beta && g && sums && totals);
-    gn_reduce_kernel<1><<<gn_grid(hw, C, V, 128), 256, 0, mvs_stream(stream)>>>(x, g, stats, gamma, beta, eps, relu, hw, C / 4, sums, totals);
+    gn_reduce_kernel<1><<<gn_grid(hw, C, V, GN_REDUCE_BLOCKS), 256, 0, mvs_stream(stream)>>>(x, g, stats, gamma, beta, eps, relu, hw, C / 4, sums);
     MVS_LAUNCH_RET();
 }
 
@@ -787,6 +839,18 @@ extern "C" int mvs_gn_bwd_apply_f32(const float* x, const double* stats, const f
     MVS_CHECK_ARG(stats && gamma && beta && g && sums && dx);
     gn_apply_kernel<1><<<gn_grid(hw, C, V, 2048), 256, 0, mvs_stream(stream)>>>(x, g, stats, sums, gamma, beta, eps, relu,
                                                                                 hw, C / 4, dx);
+    MVS_LAUNCH_RET();
+}
+
+// The same, and the sums over ALL views and slots ADDED to totals (2, C) float64 [d beta, d gamma] by the first workgroup: the
+// parameter gradients without a reduction launch per layer.  C <= 128.
+extern "C" int mvs_gn_bwd_apply_tot_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
+                                        int relu, const float* g, const double* sums, double* totals, int V, size_t hw, int C,
+                                        float* dx, void* stream) {
+    int rc = gn_check(x, V, hw, C); if (rc) return rc;
+    MVS_CHECK_ARG(stats && gamma && beta && g && sums && totals && dx);
+    gn_apply_kernel<1><<<gn_grid(hw, C, V, 2048), 256, 0, mvs_stream(stream)>>>(x, g, stats, sums, gamma, beta, eps, relu,
+                                                                                hw, C / 4, dx, totals);
     MVS_LAUNCH_RET();
 }
 

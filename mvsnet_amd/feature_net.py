@@ -149,7 +149,7 @@ class HipGroupNorm(torch.autograd.Function):
         eps, relu = ctx.cfg
         V, C, H, W = x.shape
         g = g.contiguous(memory_format=torch.channels_last)
-        sums = torch.zeros((V, 2, C), device=x.device, dtype=torch.float64)
+        sums = torch.zeros(lib.mvs_gn_bwd_sums_doubles(V, C), device=x.device, dtype=torch.float64)   # (slots, V, 2, C)
         dx = torch.empty_like(x)
         xp, gp = _lib.ptr(x.permute(0, 2, 3, 1)), _lib.ptr(g.permute(0, 2, 3, 1))
         _lib.check(lib.mvs_gn_bwd_reduce_f32(xp, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, relu, gp, V, H * W, C,
@@ -157,7 +157,7 @@ class HipGroupNorm(torch.autograd.Function):
         _lib.check(lib.mvs_gn_bwd_apply_f32(xp, _lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), eps, relu, gp, _lib.ptr(sums),
                                             V, H * W, C, _lib.ptr(dx.permute(0, 2, 3, 1)), _lib.stream_ptr()),
                    "mvs_gn_bwd_apply_f32")
-        tot = sums.sum(0).to(torch.float32)
+        tot = sums.view(-1, 2, C).sum(0).to(torch.float32)
         return dx, tot[1], tot[0], None, None
 
 

@@ -44,8 +44,12 @@ class HipTowers(torch.autograd.Function):
     -> features (V,H/4,W/4,32)."""
 
     @staticmethod
-    def forward(ctx, images, *flat):
+    def forward(ctx, images, into, *flat):
+        """`into`: None, or one tensor per entry of `flat` (the variables' slices of a flat gradient buffer): the backward then
+        ACCUMULATES the parameter gradients there itself -- two launches for all 94 of them -- and hands autograd nothing
+        (otherwise: a permute-copy per kernel and an accumulation launch per variable, ~190 launches)."""
         lib = _lib.load()
+        ctx.into = into
         dev = images.device
         V, H, W, _ = images.shape
         if H % 16 or W % 16:
@@ -169,8 +173,8 @@ class HipTowers(torch.autograd.Function):
             if kind != "c":
                 V_, _h, _w, c_ = acts[name].shape
                 bs_off[name] = (bs_total, V_ * 2 * c_)
-                bs_total += V_ * 2 * c_
-        # ... followed by their totals over the views, (2, C) per layer: [d beta, d gamma] (one conversion for all layers at the end)
+                bs_total += lib.mvs_gn_bwd_sums_doubles(V_, c_)             # (slots, V, 2, C): added up by the apply pass
+        # ... followed by their totals over the views, (2, C) per layer: [d beta, d gamma]
         ps_off, ps_total = {}, 0
         for name, kind, *_r in UNET_LAYERS:
             if kind != "c":
@@ -186,14 +190,15 @@ class HipTowers(torch.autograd.Function):
                 grads[name] = {}
             else:
                 g_a = g_act.pop(name).contiguous()
-                sums = bs_slab[bs_off[name][0]:bs_off[name][0] + bs_off[name][1]].view(V, 2, cout)
+                sums = bs_slab[bs_off[name][0]:]                           # this layer's (slots, V, 2, C) start here
                 relu = 1 if kind == "cg" else 0
                 args = (_lib.ptr(y), _lib.ptr(stats_of(name)), _lib.ptr(P[name]["gamma"]), _lib.ptr(P[name]["beta"]), GN_EPS, relu,
                         _lib.ptr(g_a))
                 tot = ps_slab[ps_off[name][0]:ps_off[name][0] + 2 * cout]
-                _lib.check(lib.mvs_gn_bwd_reduce_tot_f32(*args, V, ho * wo, cout, _lib.ptr(sums), _lib.ptr(tot), st), "mvs_gn_bwd_reduce_tot_f32")
+                _lib.check(lib.mvs_gn_bwd_reduce_f32(*args, V, ho * wo, cout, _lib.ptr(sums), st), "mvs_gn_bwd_reduce_f32")
                 g_y = torch.empty_like(y)
-                _lib.check(lib.mvs_gn_bwd_apply_f32(*args, _lib.ptr(sums), V, ho * wo, cout, _lib.ptr(g_y), st), "mvs_gn_bwd_apply_f32")
+                _lib.check(lib.mvs_gn_bwd_apply_tot_f32(*args, _lib.ptr(sums), _lib.ptr(tot), V, ho * wo, cout, _lib.ptr(g_y), st),
+                           "mvs_gn_bwd_apply_tot_f32")
                 grads[name] = {}                           # gamma / beta: views of the converted totals, after the loop
             # convolution backward on the materialised normalised inputs.  Weight gradient: ATen / MIOpen.  Input
             # gradient: the forward HIP kernels -- a stride-1 convolution's is the convolution with the flipped,
@@ -263,10 +268,13 @@ class HipTowers(torch.autograd.Function):
                         gx_a = gx_a[:, :, ph[0]:ph[0] + x.shape[1], pw[0]:pw[0] + x.shape[2]]
             if mask[0]:
                 g_x = gx_a
-            g_wtf = g_w.permute(2, 3, 1, 0)                           # back to the TensorFlow layout
-            if srcs == ("data",):
-                g_wtf = g_wtf[:, :, :3]
-            grads[name]["w"] = g_wtf.contiguous()
+            if ctx.into is not None:                                   # transposed into the flat buffer after the loop
+                grads[name]["w_aten"] = g_w.contiguous()
+            else:
+                g_wtf = g_w.permute(2, 3, 1, 0)                       # back to the TensorFlow layout
+                if srcs == ("data",):
+                    g_wtf = g_wtf[:, :, :3]
+                grads[name]["w"] = g_wtf.contiguous()
             if g_x is not None:
                 g_x = g_x.permute(0, 2, 3, 1)                         # (V,H,W,Cin) view
                 c0 = 0
@@ -275,6 +283,30 @@ class HipTowers(torch.autograd.Function):
                     add_grad(s_name, g_x[..., c0:c0 + c])
                     c0 += c
         ctx.saved = None
+        if ctx.into is not None:
+            import ctypes as C
+            slot, i = {}, 0
+            for name, kind, *_ in UNET_LAYERS:
+                slot[name] = i
+                i += 1 if kind == "c" else 3
+            src, dst, dims = [], [], []
+            for name, _kind, srcs, k, *_ in UNET_LAYERS:
+                gw = grads[name]["w_aten"]                            # (B, A, k, k) -> (k, k, A [:3 for the image], B)
+                src.append(gw.data_ptr()); dst.append(ctx.into[slot[name]].data_ptr())
+                dims += [gw.shape[0], gw.shape[1], k * k, 3 if srcs == ("data",) else gw.shape[1]]
+            n = len(src)
+            _lib.check(lib.mvs_transpose_add_many_f32(n, (C.c_void_p * n)(*src), (C.c_void_p * n)(*dst), (C.c_int * (4 * n))(*dims), st),
+                       "mvs_transpose_add_many_f32")
+            src, dst, cnt = [], [], []
+            base = ps_slab.data_ptr()
+            for name, (o_, c_) in ps_off.items():                     # [d beta (C), d gamma (C)] float64 per layer
+                src += [base + 8 * (o_ + c_), base + 8 * o_]
+                dst += [ctx.into[slot[name] + 1].data_ptr(), ctx.into[slot[name] + 2].data_ptr()]
+                cnt += [c_, c_]
+            n = len(src)
+            _lib.check(lib.mvs_add_f64_many_f32(n, (C.c_void_p * n)(*src), (C.c_void_p * n)(*dst), (C.c_int * n)(*cnt), st),
+                       "mvs_add_f64_many_f32")
+            return (None, None) + (None,) * len(ctx.into)
         ps32 = ps_slab.to(torch.float32)
         for name, (o_, c_) in ps_off.items():
             grads[name]["beta"], grads[name]["gamma"] = ps32[o_:o_ + c_], ps32[o_ + c_:o_ + 2 * c_]
@@ -283,9 +315,19 @@ class HipTowers(torch.autograd.Function):
             flat.append(grads[name]["w"])
             if kind != "c":
                 flat += [grads[name]["gamma"], grads[name]["beta"]]
-        return (None,) + tuple(flat)
+        return (None, None) + tuple(flat)
 
 
-def hip_towers(images, params):
-    """images (V,H,W,3) device tensor, params[name] = {'w','gamma','beta'} leaves in TF layouts -> (V,H/4,W/4,32)."""
-    return HipTowers.apply(images, *flatten_unet_params(params))
+def hip_towers(images, params, accumulate_into_grads=False):
+    """images (V,H,W,3) device tensor, params[name] = {'w','gamma','beta'} leaves in TF layouts -> (V,H/4,W/4,32).
+    `accumulate_into_grads`: the leaves carry pre-allocated contiguous `.grad` tensors (train.FlatParameters: views of one flat
+    buffer) and the backward adds the parameter gradients into them itself (see HipTowers.forward); autograd then sees no
+    gradient for them -- for callers that read `.grad` afterwards, not for torch.autograd.grad."""
+    flat = flatten_unet_params(params)
+    into = None
+    if accumulate_into_grads:
+        into = [p.grad for p in flat]
+        if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.device != images.device or g.shape != p.shape
+               for g, p in zip(into, flat)):
+            raise ValueError("accumulate_into_grads needs a contiguous float32 .grad of the variable's shape on every leaf")
+    return HipTowers.apply(images, into, *flat)

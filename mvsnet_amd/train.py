@@ -223,7 +223,9 @@ class Trainer:
         depth_end = float(cams[0][1][3][3])
         if hip_towers_path:
             from .feature_net_train import hip_towers       # HIP forward / GroupNorm backward, ATen convolution backward
-            feats = hip_towers(raw if raw is not None else images, self.params.group("unet"))
+            # the towers' backward adds its 94 parameter gradients into the flat buffer itself (two launches, no autograd accumulation)
+            feats = hip_towers(raw if raw is not None else images, self.params.group("unet"),
+                               accumulate_into_grads=torch.is_grad_enabled())
         else:                                               # narrower towers (channel counts below the HIP kernels' tiling)
             feats = unet_forward(trainable_layers(self.params.group("unet")), images,
                                  hip_group_norm=self.device.type == "cuda")

@@ -440,6 +440,32 @@ def test_hip_towers_match_the_torch_towers_forward_and_backward():
     print("worst tower gradient rel-L1:", worst)
 
 
+def test_hip_towers_accumulate_their_parameter_gradients_into_the_flat_buffer():
+    """`accumulate_into_grads` (the trainer's mode): the backward adds all 94 parameter gradients into the leaves' pre-allocated
+    `.grad` slices itself (mvs_transpose_add_many_f32 for ATen's (Cout,Cin,k,k) kernels, mvs_add_f64_many_f32 for the float64
+    gamma / beta sums) -- the same values autograd accumulates from the returned tensors, added to what the buffer held."""
+    from mvsnet_amd import train as T
+    from mvsnet_amd.feature_net_train import hip_towers
+    images = t(S.make_images(2, 32, 48, seed=4))
+    g = t(np.random.RandomState(1).randn(2, 8, 12, 32).astype(np.float32))
+    out = []
+    for into in (False, True):
+        tr = T.Trainer("normal", DEV, seed=0)
+        tr.params.grad.fill_(0.25)                                          # ADDED to, not overwritten
+        f = hip_towers(images, tr.params.group("unet"), accumulate_into_grads=into)
+        (f * g).sum().backward()
+        out.append(tr.params.grad.clone())
+    assert float((out[0] - 0.25).abs().max()) > 0
+    # (two backward passes differ in the last bits by themselves: float64 atomics of the GroupNorm sums, MIOpen's weight gradients)
+    assert float((out[0] - out[1]).abs().max()) <= 1e-5 * float(out[0].abs().max())
+    grp = T.Trainer("normal", DEV, seed=0).params.group("unet")
+    from mvsnet_amd.feature_net import UNET_LAYERS
+    first = UNET_LAYERS[0][0]                                               # the layer that reads the image: (3, 3, 3, 8)
+    leaf = torch.zeros(3, 3, 3, 8, device=DEV, requires_grad=True)          # a leaf without .grad
+    with pytest.raises(ValueError):
+        hip_towers(images, {**grp, first: {**grp[first], "w": leaf}}, accumulate_into_grads=True)
+
+
 def test_train_cli_runs_on_a_synthetic_dataset(tmp_path, capsys):
     """python -m mvsnet_amd.train end to end (train.py:412-535): train/ + val/ session folders -> generator ->
     trainer -> TensorFlow-format checkpoint, two steps."""

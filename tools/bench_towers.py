@@ -12,7 +12,7 @@ from mvsnet_amd.feature_net_train import hip_towers
 mode = sys.argv[1] if len(sys.argv) > 1 else "hip"
 def step():
     if mode == "hip":
-        f = hip_towers(images, tr.params.group("unet"))
+        f = hip_towers(images, tr.params.group("unet"), accumulate_into_grads=os.environ.get("INTO", "1") == "1")
     else:
         f = unet_forward(trainable_layers(tr.params.group("unet")), images, hip_group_norm=(mode == "torch+hipgn"))
     f.sum().backward()
