@@ -208,6 +208,13 @@ int mvs_conv2d_gn_f32(const float* x1, const double* stats1, const float* gamma1
                       const float* x2, const double* stats2, const float* gamma2, const float* beta2, int c2, int relu2,
                       const float* prepared, int V, int H, int W, int cout, int ks, int stride,
                       float* y, double* stats_out, void* stream);
+/* n weight preparations in one launch (the training towers: every layer's forward and input-gradient kernel once per step).
+ * Job i: kind 0 = mvs_conv2d_prepare_f32(w, ks, c1, c2, cout) with cin_src channels actually in `w` (the image layer: c1 = 4,
+ * cin_src = 3, the fourth laid out as zeros; otherwise c1 + c2); kind 1 = mvs_conv2d_prepare_dgrad_f32(w, ks, cin_fwd = c1,
+ * cout_fwd = cout); kind 2 = mvs_deconv2d_prepare_f32(w, cin = c1, cout); into prepared[i], sized as for the single calls.
+ * All array arguments are host arrays of n entries. */
+int mvs_unet_prepare_many_f32(int n, const int* kind, const float* const* w, const int* ks, const int* c1, const int* c2,
+                              const int* cin_src, const int* cout, float* const* prepared, void* stream);
 size_t mvs_deconv2d_prepared_floats(int cin, int cout);
 int mvs_deconv2d_prepare_f32(const float* w, int cin, int cout, float* prepared, void* stream);
 int mvs_deconv2d_gn_f32(const float* x, const double* stats, const float* gamma, const float* beta, int cin, int relu,

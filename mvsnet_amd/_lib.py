@@ -74,6 +74,7 @@ SIGNATURES = {
     "mvs_cost_volume_bwd_gather_f32": (_i, [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _sz, _p, _p, _p]),
     "mvs_rmsprop_step_f32": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _p]),
     "mvs_gn_stats_f32": (_i, [_p, _i, _sz, _i, _p, _p]),
+    "mvs_unet_prepare_many_f32": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mvs_transpose_add_many_f32": (_i, [_i, _p, _p, _p, _p]),
     "mvs_add_f64_many_f32": (_i, [_i, _p, _p, _p, _p]),
     "mvs_center_images_workspace_bytes": (_sz, [_i]),

@@ -284,12 +284,10 @@ conv2d_gn_kernel(Conv2dArgs p) {
 // TensorFlow conv2d kernel (k,k,Cin,Cout) -> [cout group][chunk][tap][CK/4][COUT_T][4], zero padded
 // flipT: `w` is the FORWARD kernel (k,k,Cout,Cin) of the layer whose input gradient this convolution computes -- the tap is
 // mirrored and the channel roles swapped while reading (what w.flip(0,1).permute(0,1,3,2).contiguous() materialised before)
-__global__ void conv2d_weight_layout_kernel(const float* __restrict__ w, int KS, int Cin, int Cout, int CK,
-                                            int COUT_T, int CinPad, float* __restrict__ out, int flipT) {
-    const int nch = CinPad / CK, CQ = CK / 4, groups = (Cout + COUT_T - 1) / COUT_T;
-    const long long total = (long long)groups * nch * KS * KS * CQ * COUT_T * 4;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+// (`CinSrc`: channels `w` really has -- the image layer's kernel (k,k,3,Cout) is laid out for 4 channels, the fourth zero)
+__device__ __forceinline__ float conv2d_layout_value(const float* __restrict__ w, int KS, int Cin, int CinSrc, int Cout, int CK,
+                                                     int COUT_T, int CinPad, int flipT, long long i) {
+    const int nch = CinPad / CK, CQ = CK / 4;
     long long r = i;
     const int j = r & 3; r >>= 2;
     const int co = r % COUT_T; r /= COUT_T;
@@ -297,18 +295,23 @@ __global__ void conv2d_weight_layout_kernel(const float* __restrict__ w, int KS,
     const int tap = r % (KS * KS); r /= (KS * KS);
     const int ch = r % nch; const int g = r / nch;
     const int ci = ch * CK + ciq * 4 + j, cout = g * COUT_T + co;
-    if (!(ci < Cin && cout < Cout)) { out[i] = 0.f; return; }
-    out[i] = flipT ? w[((size_t)(KS * KS - 1 - tap) * Cout + cout) * Cin + ci] : w[((size_t)tap * Cin + ci) * Cout + cout];
+    if (!(ci < Cin && ci < CinSrc && cout < Cout)) return 0.f;
+    return flipT ? w[((size_t)(KS * KS - 1 - tap) * Cout + cout) * CinSrc + ci] : w[((size_t)tap * CinSrc + ci) * Cout + cout];
+}
+
+__global__ void conv2d_weight_layout_kernel(const float* __restrict__ w, int KS, int Cin, int Cout, int CK,
+                                            int COUT_T, int CinPad, float* __restrict__ out, int flipT) {
+    const int nch = CinPad / CK, CQ = CK / 4, groups = (Cout + COUT_T - 1) / COUT_T;
+    const long long total = (long long)groups * nch * KS * KS * CQ * COUT_T * 4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    out[i] = conv2d_layout_value(w, KS, Cin, Cin, Cout, CK, COUT_T, CinPad, flipT, i);
 }
 
 // TensorFlow conv2d_transpose kernel (3,3,Cout,Cin) -> the stacked 2x2-tap form described at
 // conv2d_gn_kernel: [group][chunk][tap 2x2][CK/4][COUT_T][4], rows = (class, cout)
-__global__ void deconv2d_weight_layout_kernel(const float* __restrict__ w, int Cin, int Cout, int CK, int COUT_T,
-                                              float* __restrict__ out) {
-    const int nch = Cin / CK, CQ = CK / 4, rows = 4 * Cout, groups = (rows + COUT_T - 1) / COUT_T;
-    const long long total = (long long)groups * nch * 4 * CQ * COUT_T * 4;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+__device__ __forceinline__ float deconv2d_layout_value(const float* __restrict__ w, int Cin, int Cout, int CK, int COUT_T, long long i) {
+    const int nch = Cin / CK, CQ = CK / 4, rows = 4 * Cout;
     long long r = i;
     const int j = r & 3; r >>= 2;
     const int co = r % COUT_T; r /= COUT_T;
@@ -324,7 +327,29 @@ __global__ void deconv2d_weight_layout_kernel(const float* __restrict__ w, int C
         const int kh = ph ? (dh ? -1 : 1) : (dh ? 2 : 0), kw = pw ? (dw ? -1 : 1) : (dw ? 2 : 0);
         if (kh >= 0 && kw >= 0) v = w[((size_t)(kh * 3 + kw) * Cout + c) * Cin + ci];
     }
-    out[i] = v;
+    return v;
+}
+
+__global__ void deconv2d_weight_layout_kernel(const float* __restrict__ w, int Cin, int Cout, int CK, int COUT_T,
+                                              float* __restrict__ out) {
+    const int nch = Cin / CK, CQ = CK / 4, rows = 4 * Cout, groups = (rows + COUT_T - 1) / COUT_T;
+    const long long total = (long long)groups * nch * 4 * CQ * COUT_T * 4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    out[i] = deconv2d_layout_value(w, Cin, Cout, CK, COUT_T, i);
+}
+
+// Many kernels in one launch (the training towers lay out every layer's forward AND input-gradient kernel once per step: ~60
+// launches of a step the launching thread bounds); the jobs ride in the kernel arguments, blockIdx.y = job.
+constexpr int PREP_MAX = 56;
+struct PrepJob { const float* w; float* out; long long total; int deconv, KS, Cin, CinSrc, Cout, CK, COUT_T, CinPad, flipT; };
+struct PrepJobs { PrepJob j[PREP_MAX]; };
+
+__global__ __launch_bounds__(256) void weight_layout_many_kernel(PrepJobs jobs) {
+    const PrepJob J = jobs.j[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < J.total; i += (long long)gridDim.x * 256)
+        J.out[i] = J.deconv ? deconv2d_layout_value(J.w, J.Cin, J.Cout, J.CK, J.COUT_T, i)
+                            : conv2d_layout_value(J.w, J.KS, J.Cin, J.CinSrc, J.Cout, J.CK, J.COUT_T, J.CinPad, J.flipT, i);
 }
 
 // ---- transposed convolution k3 s2 SAME (out = 2n, cropped at the end), bias-free, VALU gather --------------
@@ -511,6 +536,59 @@ extern "C" int mvs_deconv2d_prepare_f32(const float* w, int cin, int cout, float
     const size_t total = mvs_deconv2d_prepared_floats(cin, cout);
     if (!total) return MVS_E_SHAPE;
     deconv2d_weight_layout_kernel<<<mvs_cdiv((long long)total, 256), 256, 0, mvs_stream(stream)>>>(w, cin, cout, 16, 32, prepared);
+    MVS_LAUNCH_RET();
+}
+
+// n preparations in ONE launch (+ one small launch per 8-cout 3 x 3 layer for its pixel-pair layout).  Job i:
+//   kind 0  mvs_conv2d_prepare_f32(w, ks, c1, c2, cout) -- with cin_src channels in `w` (the image layer: c1 = 4, cin_src = 3;
+//           otherwise c1 + c2)
+//   kind 1  mvs_conv2d_prepare_dgrad_f32(w, ks, cin_fwd = c1, cout_fwd = cout)
+//   kind 2  mvs_deconv2d_prepare_f32(w, cin = c1, cout)
+// into prepared[i] (sized by the matching *_prepared_floats).
+extern "C" int mvs_unet_prepare_many_f32(int n, const int* kind, const float* const* w, const int* ks, const int* c1, const int* c2,
+                                         const int* cin_src, const int* cout, float* const* prepared, void* stream) {
+    MVS_CHECK_ARG(n > 0 && kind && w && ks && c1 && c2 && cin_src && cout && prepared);
+    for (int i = 0; i < n; ++i) {
+        MVS_CHECK_ARG(w[i] && prepared[i] && c1[i] > 0 && c2[i] >= 0 && cout[i] > 0 && kind[i] >= 0 && kind[i] <= 2);
+        if (kind[i] != 2) MVS_CHECK_ARG(ks[i] == 3 || ks[i] == 5);
+        else if (!mvs_deconv2d_prepared_floats(c1[i], cout[i])) return MVS_E_SHAPE;
+        if (kind[i] == 0) MVS_CHECK_ARG(cin_src[i] > 0 && cin_src[i] <= c1[i] + c2[i]);
+    }
+    hipStream_t st = mvs_stream(stream);
+    for (int first = 0; first < n; first += PREP_MAX) {
+        const int m = n - first < PREP_MAX ? n - first : PREP_MAX;
+        PrepJobs jobs;
+        long long largest = 1;
+        for (int k = 0; k < m; ++k) {
+            const int i = first + k;
+            PrepJob& J = jobs.j[k];
+            J.w = w[i]; J.out = prepared[i];
+            if (kind[i] == 2) {
+                J.deconv = 1; J.KS = 3; J.Cin = c1[i]; J.CinSrc = c1[i]; J.Cout = cout[i]; J.CK = 16; J.COUT_T = 32; J.CinPad = c1[i]; J.flipT = 0;
+                J.total = (long long)mvs_deconv2d_prepared_floats(c1[i], cout[i]);
+            } else {
+                const int cin = kind[i] == 1 ? cout[i] : c1[i] + c2[i], co = kind[i] == 1 ? c1[i] : cout[i];      // roles in THIS convolution
+                int CG, MT; conv2d_tiling(cin, co, kind[i] == 1 ? cin : c1[i], CG, MT);
+                J.deconv = 0; J.KS = ks[i]; J.Cin = cin; J.CinSrc = kind[i] == 0 ? cin_src[i] : cin; J.Cout = co; J.CK = CG; J.COUT_T = 16 * MT;
+                J.CinPad = (cin + CG - 1) / CG * CG; J.flipT = kind[i] == 1;
+                J.total = (long long)(kind[i] == 1 ? conv2d_plain_floats(ks[i], cin, 0, co) : conv2d_plain_floats(ks[i], c1[i], c2[i], co));
+            }
+            if (J.total > largest) largest = J.total;
+        }
+        const int gx = (int)((largest + 2047) / 2048 < 32 ? (largest + 2047) / 2048 : 32);
+        hipLaunchKernelGGL(weight_layout_many_kernel, dim3(gx, m), dim3(256), 0, st, jobs);
+    }
+    for (int i = 0; i < n; ++i) {                          // the pixel-pair layouts behind the plain ones
+        if (kind[i] == 2) continue;
+        const int cin = kind[i] == 1 ? cout[i] : c1[i] + c2[i], co = kind[i] == 1 ? c1[i] : cout[i];
+        const int a1 = kind[i] == 1 ? cin : c1[i], a2 = kind[i] == 1 ? 0 : c2[i];
+        const size_t plain = conv2d_plain_floats(ks[i], a1, a2, co);
+        if (mvs_conv2d_prepared_floats(ks[i], a1, a2, co) > plain) {
+            int CG, MT; conv2d_tiling(cin, co, a1, CG, MT);
+            int rc = mvs_conv2d_pair_prepare(w[i], cin, co, CG, prepared[i] + plain, st, kind[i] == 1, kind[i] == 0 ? cin_src[i] : cin);
+            if (rc) return rc;
+        }
+    }
     MVS_LAUNCH_RET();
 }
 

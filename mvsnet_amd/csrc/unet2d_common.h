@@ -34,5 +34,5 @@ constexpr int GN_NSLOT = 32;
 int mvs_conv2d_p_find(int ks, int stride, int cin, int cg, int mt, int cout);
 // 3 x 3 layers with at most 8 output channels carry a second, pixel-pair weight layout behind the plain one in the prepared buffer
 size_t mvs_conv2d_pair_floats(int ks, int stride, int cin, int cout);
-int mvs_conv2d_pair_prepare(const float* w, int cin, int cout, int ck, float* out, hipStream_t st, int flipT);
+int mvs_conv2d_pair_prepare(const float* w, int cin, int cout, int ck, float* out, hipStream_t st, int flipT, int cin_src = 0);
 int mvs_conv2d_p_run(int inst, const Conv2dArgs& p, hipStream_t st);

@@ -419,7 +419,8 @@ int mvs_conv2d_p_find(int ks, int stride, int cin, int cg, int mt, int cout) {  
 }
 
 // pixel-pair weight layout (PAIR instances): [chunk][step = kh * 4 + j][CG/4][16 rows = (dx, co)][4], zero where no tap applies
-__global__ void conv2d_pair_weight_layout_kernel(const float* __restrict__ w, int Cin, int Cout, int CK, float* __restrict__ out, int flipT) {
+// (`CinSrc`: channels `w` really has: the image layer's (3,3,3,Cout) kernel is laid out for 4 channels, the fourth zero)
+__global__ void conv2d_pair_weight_layout_kernel(const float* __restrict__ w, int Cin, int Cout, int CK, float* __restrict__ out, int flipT, int CinSrc) {
     const int nch = Cin / CK, CQ = CK / 4;
     const int total = nch * 12 * CQ * 16 * 4;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -431,18 +432,18 @@ __global__ void conv2d_pair_weight_layout_kernel(const float* __restrict__ w, in
     const int step = r % 12; const int ch = r / 12;
     const int kh = step / 4, j = step - 4 * kh, dx = row >> 3, co = row & 7, kw = j - dx;
     const int ci = ch * CK + ciq * 4 + e;
-    if (!(kw >= 0 && kw < 3 && co < Cout && ci < Cin)) { out[i] = 0.f; return; }
+    if (!(kw >= 0 && kw < 3 && co < Cout && ci < Cin && ci < CinSrc)) { out[i] = 0.f; return; }
     // flipT: w is the forward kernel (3,3,Cout,Cin) of the layer whose input gradient this convolution computes (mirrored tap, swapped roles)
-    out[i] = flipT ? w[((size_t)(8 - (kh * 3 + kw)) * Cout + co) * Cin + ci] : w[((size_t)(kh * 3 + kw) * Cin + ci) * Cout + co];
+    out[i] = flipT ? w[((size_t)(8 - (kh * 3 + kw)) * Cout + co) * CinSrc + ci] : w[((size_t)(kh * 3 + kw) * CinSrc + ci) * Cout + co];
 }
 
 size_t mvs_conv2d_pair_floats(int ks, int stride_unused, int cin, int cout) {
     (void)stride_unused;
     return (ks == 3 && cout <= 8 && (cin == 4 || cin == 8 || cin == 16)) ? (size_t)12 * cin * 16 : 0;
 }
-int mvs_conv2d_pair_prepare(const float* w, int cin, int cout, int ck, float* out, hipStream_t st, int flipT) {
+int mvs_conv2d_pair_prepare(const float* w, int cin, int cout, int ck, float* out, hipStream_t st, int flipT, int cin_src) {
     const int total = 12 * cin * 16;
-    conv2d_pair_weight_layout_kernel<<<(total + 255) / 256, 256, 0, st>>>(w, cin, cout, ck, out, flipT);
+    conv2d_pair_weight_layout_kernel<<<(total + 255) / 256, 256, 0, st>>>(w, cin, cout, ck, out, flipT, cin_src > 0 ? cin_src : cin);
     return (int)hipGetLastError();
 }
 

@@ -39,6 +39,71 @@ def flatten_unet_params(params) -> List[torch.Tensor]:
     return flat
 
 
+_WEIGHT_PLANS = {}        # (device, ((layer, address, shape), ...)) -> _WeightPlan
+
+
+class _WeightPlan:
+    """Every layer's kernel in the layouts the convolution kernels read -- for the forward pass AND for the input-gradient
+    convolution of the backward pass -- laid out by ONE launch per step (`mvs_unet_prepare_many_f32`; ~60 launches before).
+    Built once per set of variables (their addresses: the trainer's leaves are views of one flat buffer) and kept: the
+    prepared copies live in one slab that every step overwrites in stream order, the job table is a handful of ctypes
+    arrays.  (A forward pass whose backward has not run yet shares the slab with any later forward pass over the same
+    variables: same values unless the variables were updated in between.)"""
+
+    def __init__(self, weights, dev):
+        import ctypes as C
+        lib = _lib.load()
+        chans, jobs = {"data": 4}, []                       # jobs: (key, kind, w, ks, c1, c2, cin_src, cout, floats)
+        for name, kind, srcs, k, _mult, stride in UNET_LAYERS:
+            w = weights[name]
+            cins = [chans[s_] for s_ in srcs]
+            cin_tot = sum(cins)
+            if kind == "dg":
+                cout = w.shape[2]
+                n = lib.mvs_deconv2d_prepared_floats(cins[0], cout)
+                if n:
+                    jobs.append((("fwd", name), 2, w, 3, cins[0], 0, cins[0], cout, n))
+            else:
+                cout = w.shape[3]
+                c1, c2 = cins[0], (cins[1] if len(cins) > 1 else 0)
+                jobs.append((("fwd", name), 0, w, k, c1, c2, w.shape[2], cout, lib.mvs_conv2d_prepared_floats(k, c1, c2, cout)))
+            chans[name] = cout
+            # the input gradient on the forward kernels (HipTowers.backward): 3 x 3 layers that are not fed by the image
+            if srcs != ("data",) and k == 3 and cin_tot % 8 == 0:
+                if kind == "dg":                            # conv stride 2 with the same array (3,3,Cout,Cin)
+                    jobs.append((("bwd", name), 0, w, 3, cout, 0, cout, cin_tot, lib.mvs_conv2d_prepared_floats(3, cout, 0, cin_tot)))
+                elif stride == 1:                           # conv with the mirrored, transposed kernel
+                    jobs.append((("bwd", name), 1, w, 3, cin_tot, 0, cin_tot, cout, lib.mvs_conv2d_prepared_floats(3, cout, 0, cin_tot)))
+                else:                                       # transposed conv with the same array (3,3,Cin,Cout)
+                    n = lib.mvs_deconv2d_prepared_floats(cout, cin_tot)
+                    if n:
+                        jobs.append((("bwd", name), 2, w, 3, cout, 0, cout, cin_tot, n))
+        total = sum((j[8] + 63) // 64 * 64 for j in jobs)
+        self.slab = torch.empty(total, dtype=torch.float32, device=dev)
+        self.prepared, off = {}, 0
+        for j in jobs:
+            self.prepared[j[0]] = self.slab[off:off + j[8]]
+            off += (j[8] + 63) // 64 * 64
+        n = self.n = len(jobs)
+        ints = lambda col: (C.c_int * n)(*[j[col] for j in jobs])
+        self.args = (ints(1), (C.c_void_p * n)(*[j[2].data_ptr() for j in jobs]), ints(3), ints(4), ints(5), ints(6), ints(7),
+                     (C.c_void_p * n)(*[self.prepared[j[0]].data_ptr() for j in jobs]))
+        self.keep = [j[2] for j in jobs]                    # the addresses in the table stay valid
+
+    def run(self, st):
+        _lib.check(_lib.load().mvs_unet_prepare_many_f32(self.n, *self.args, st), "mvs_unet_prepare_many_f32")
+
+
+def _weight_plan(weights, dev):
+    key = (str(dev), tuple((n_, w.data_ptr(), tuple(w.shape)) for n_, w in weights.items()))
+    plan = _WEIGHT_PLANS.get(key)
+    if plan is None:
+        if len(_WEIGHT_PLANS) > 8:                          # trainers come and go in tests: do not collect their slabs
+            _WEIGHT_PLANS.clear()
+        plan = _WEIGHT_PLANS[key] = _WeightPlan(weights, dev)
+    return plan
+
+
 class HipTowers(torch.autograd.Function):
     """images (V,H,W,3) float32 (centred) or uint8 (as decoded; standardised here) + the tower variables in TensorFlow layouts
     -> features (V,H/4,W/4,32)."""
@@ -66,9 +131,11 @@ class HipTowers(torch.autograd.Function):
             data[..., :3] = images.detach()
         P, i = {}, 0
         for name, kind, *_ in UNET_LAYERS:
-            P[name] = {"w": flat[i].detach()}; i += 1
+            P[name] = {"w": flat[i].detach().contiguous()}; i += 1
             if kind != "c":
                 P[name]["gamma"], P[name]["beta"] = flat[i].detach().contiguous(), flat[i + 1].detach().contiguous(); i += 2
+        plan = _weight_plan({n_: P[n_]["w"] for n_ in P}, dev)
+        plan.run(st)                                                             # all forward + input-gradient layouts: one launch
         acts: Dict[str, torch.Tensor] = {}
         # every layer's GroupNorm sums in ONE zeroed slab (round 6: one fill instead of 31)
         so_off, so_total = {}, 0
@@ -94,23 +161,13 @@ class HipTowers(torch.autograd.Function):
             y = torch.empty((V, ho, wo, cout), dtype=torch.float32, device=dev)
             so = so_slab[so_off[name][0]:so_off[name][0] + so_off[name][1]] if kind != "c" else None
             a = src_of[srcs[0]]
+            prep = plan.prepared.get(("fwd", name))
             if kind == "dg":
-                wraw = w.contiguous()
-                n = lib.mvs_deconv2d_prepared_floats(cins[0], cout)
-                prep = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
-                if n:
-                    _lib.check(lib.mvs_deconv2d_prepare_f32(_lib.ptr(wraw), cins[0], cout, _lib.ptr(prep), st), "mvs_deconv2d_prepare_f32")
                 _lib.check(lib.mvs_deconv2d_gn_f32(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]), cins[0], a[4],
-                                                   _lib.ptr(wraw), _lib.ptr(prep) if n else None, V, h, wd_, cout, _lib.ptr(y),
+                                                   _lib.ptr(w), _lib.ptr(prep), V, h, wd_, cout, _lib.ptr(y),
                                                    _lib.ptr(so), st), "mvs_deconv2d_gn_f32")
             else:
-                wt = w
-                if srcs == ("data",):                                            # zero kernel for the padding channel
-                    wt = torch.cat([w, torch.zeros(w.shape[:2] + (1, cout), device=dev)], dim=2)
-                wt = wt.contiguous()
                 c1, c2 = cins[0], (cins[1] if len(cins) > 1 else 0)
-                prep = torch.empty(lib.mvs_conv2d_prepared_floats(k, c1, c2, cout), dtype=torch.float32, device=dev)
-                _lib.check(lib.mvs_conv2d_prepare_f32(_lib.ptr(wt), k, c1, c2, cout, _lib.ptr(prep), st), "mvs_conv2d_prepare_f32")
                 b = src_of[srcs[1]] if len(srcs) > 1 else (None, None, None, None, 0)
                 _lib.check(lib.mvs_conv2d_gn_f32(_lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]), c1, a[4],
                                                  _lib.ptr(b[0]), _lib.ptr(b[1]), _lib.ptr(b[2]), _lib.ptr(b[3]), c2, b[4],
@@ -119,13 +176,13 @@ class HipTowers(torch.autograd.Function):
             acts[name] = y
             chans[name], shapes[name] = cout, (ho, wo)
             src_of[name] = (y, so, P[name].get("gamma"), P[name].get("beta"), 1 if kind == "cg" else 0)
-        ctx.saved = (data, acts, P, {n_: src_of[n_][1] for n_ in so_off}, slots)
+        ctx.saved = (data, acts, P, {n_: src_of[n_][1] for n_ in so_off}, slots, plan)
         return acts["conv10_2"].clone()
 
     @staticmethod
     def backward(ctx, g_feat):
         lib = _lib.load()
-        data, acts, P, fwd_sums, slots = ctx.saved
+        data, acts, P, fwd_sums, slots, plan = ctx.saved
         dev = data.device
         st = _lib.stream_ptr()
         kinds = {name: kind for name, kind, *_ in UNET_LAYERS}
@@ -207,43 +264,27 @@ class HipTowers(torch.autograd.Function):
             xs = [normalised(s) for s in srcs]
             x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=3)
             w_tf = P[name]["w"]
-            if srcs == ("data",):
-                w_tf = torch.cat([w_tf, torch.zeros(w_tf.shape[:2] + (1, cout), device=dev)], dim=2)
             xin, gy = _cl(x), _cl(g_y)
-            cin_tot = x.shape[3]
+            cin_tot = x.shape[3]                                       # 4 for the image layers (their kernels have 3 input channels)
             need_gx = srcs != ("data",)
             g_x = None
             hip_gx = need_gx and k == 3 and cin_tot % 8 == 0
             if need_gx and not hip_gx:
                 w_t = w_tf.permute(3, 2, 0, 1).contiguous()        # conv (Cout,Cin,k,k); transposed conv (Cin,Cout,k,k)
             else:                                                  # ATen computes the weight gradient only: it needs the kernel's SHAPE, not its values
-                shp = (w_tf.shape[3], w_tf.shape[2], w_tf.shape[0], w_tf.shape[1])
+                shp = (w_tf.shape[3], cin_tot if kind != "dg" else w_tf.shape[2], w_tf.shape[0], w_tf.shape[1])
                 w_t = _SHAPE_ONLY.get((shp, dev))
                 if w_t is None:
                     w_t = _SHAPE_ONLY[(shp, dev)] = torch.empty(shp, dtype=torch.float32, device=dev)
             if hip_gx:
                 gxt = torch.empty((V, x.shape[1], x.shape[2], cin_tot), dtype=torch.float32, device=dev)
-                if kind == "dg":                                       # conv stride 2 with the same array (3,3,Cout,Cin)
-                    wc = w_tf.contiguous()
-                    prep = torch.empty(lib.mvs_conv2d_prepared_floats(3, cout, 0, cin_tot), dtype=torch.float32, device=dev)
-                    _lib.check(lib.mvs_conv2d_prepare_f32(_lib.ptr(wc), 3, cout, 0, cin_tot, _lib.ptr(prep), st), "mvs_conv2d_prepare_f32")
+                prep = plan.prepared.get(("bwd", name))
+                if kind == "dg" or stride == 1:                        # a convolution over g_y: stride 2 with the same array / stride 1 with the mirrored one
                     _lib.check(lib.mvs_conv2d_gn_f32(_lib.ptr(g_y), None, None, None, cout, 0, None, None, None, None, 0, 0,
-                                                     _lib.ptr(prep), V, ho, wo, cin_tot, 3, 2, _lib.ptr(gxt), None, st),
-                               "mvs_conv2d_gn_f32")
-                elif stride == 1:                                       # conv with flip(w)^T (3,3,Cout,Cin), laid out straight from w
-                    wc = w_tf.contiguous()
-                    prep = torch.empty(lib.mvs_conv2d_prepared_floats(3, cout, 0, cin_tot), dtype=torch.float32, device=dev)
-                    _lib.check(lib.mvs_conv2d_prepare_dgrad_f32(_lib.ptr(wc), 3, cin_tot, cout, _lib.ptr(prep), st), "mvs_conv2d_prepare_dgrad_f32")
-                    _lib.check(lib.mvs_conv2d_gn_f32(_lib.ptr(g_y), None, None, None, cout, 0, None, None, None, None, 0, 0,
-                                                     _lib.ptr(prep), V, ho, wo, cin_tot, 3, 1, _lib.ptr(gxt), None, st),
+                                                     _lib.ptr(prep), V, ho, wo, cin_tot, 3, 2 if kind == "dg" else 1, _lib.ptr(gxt), None, st),
                                "mvs_conv2d_gn_f32")
                 else:                                                   # transposed conv with the same array (3,3,Cin,Cout)
-                    wc = w_tf.contiguous()
-                    n = lib.mvs_deconv2d_prepared_floats(cout, cin_tot)
-                    prep = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
-                    if n:
-                        _lib.check(lib.mvs_deconv2d_prepare_f32(_lib.ptr(wc), cout, cin_tot, _lib.ptr(prep), st), "mvs_deconv2d_prepare_f32")
-                    _lib.check(lib.mvs_deconv2d_gn_f32(_lib.ptr(g_y), None, None, None, cout, 0, _lib.ptr(wc), _lib.ptr(prep) if n else None,
+                    _lib.check(lib.mvs_deconv2d_gn_f32(_lib.ptr(g_y), None, None, None, cout, 0, _lib.ptr(w_tf), _lib.ptr(prep),
                                                        V, ho, wo, cin_tot, _lib.ptr(gxt), None, st), "mvs_deconv2d_gn_f32")
                 g_x = _cl(gxt)
             mask = [need_gx and not hip_gx, True, False]
