@@ -494,6 +494,10 @@ int mvs_gn_stats_f32(const float* x, int V, size_t hw, int C, double* stats, voi
  * per 8-channel group (mvs_conv2d_gn_f32 / mvs_deconv2d_gn_f32, nslot = mvs_gn_stat_slots()) -> stats (V, 2, C), every channel
  * carrying an eighth of its group's totals (the group moments the kernels below fold from 8 channel sums are then the forward's). */
 int mvs_gn_slots_to_channel_sums_f64(const double* slots, int V, int C, int nslot, double* stats, void* stream);
+/* ... for n layers in one launch: layer i's slots start slot_off[i] float64 behind `slots`, its (V, 2, C[i]) statistics
+ * stat_off[i] behind `stats` (host arrays of n entries). */
+int mvs_gn_slots_to_channel_sums_many_f64(int n, const double* slots, const long long* slot_off, const int* C, int V, int nslot,
+                                          double* stats, const long long* stat_off, void* stream);
 int mvs_gn_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta, float eps,
                      int relu, int V, size_t hw, int C, float* y, void* stream);
 int mvs_gn_bwd_sum_slots(void);
@@ -526,6 +530,9 @@ int mvs_adam_step_f32(float* w, const float* g, float* m, float* v, size_t n, fl
  * Any n (the jobs travel in the kernel arguments, 48 / 96 per launch). */
 int mvs_transpose_add_many_f32(int n, const float* const* src, float* const* dst, const int* dims, void* stream);
 int mvs_add_f64_many_f32(int n, const double* const* src, float* const* dst, const int* counts, void* stream);
+/*   mvs_add_many_f32             job i: dst_i[0..counts_i) += src_i[..] (the regulariser's parameter gradients, already in the
+ *                                variables' layouts, into the flat gradient buffer) */
+int mvs_add_many_f32(int n, const float* const* src, float* const* dst, const long long* counts, void* stream);
 
 /* Training of the recurrent regulariser (inference_prob_recurrent, mvsnet/model.py:505-599; ConvGRUCell,
  * mvsnet/convgru.py:82-122): the plane-sequential part of back-propagation through time of ONE cell over all D

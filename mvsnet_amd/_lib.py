@@ -77,8 +77,10 @@ SIGNATURES = {
     "mvs_unet_prepare_many_f32": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mvs_transpose_add_many_f32": (_i, [_i, _p, _p, _p, _p]),
     "mvs_add_f64_many_f32": (_i, [_i, _p, _p, _p, _p]),
+    "mvs_add_many_f32": (_i, [_i, _p, _p, _p, _p]),
     "mvs_center_images_workspace_bytes": (_sz, [_i]),
     "mvs_center_images_u8_f32": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "mvs_gn_slots_to_channel_sums_many_f64": (_i, [_i, _p, _p, _p, _i, _i, _p, _p, _p]),
     "mvs_gn_bwd_sums_doubles": (_sz, [_i, _i]),
     "mvs_gn_slots_to_channel_sums_f64": (_i, [_p, _i, _i, _i, _p, _p]),
     "mvs_gn_apply_f32": (_i, [_p, _p, _p, _p, _f, _i, _i, _sz, _i, _p, _p]),

@@ -336,8 +336,11 @@ class PlaneSweepDepth(torch.autograd.Function):
     (it is an input channel of the refinement network, model.py:753-811); its bucket indices do not."""
 
     @staticmethod
-    def forward(ctx, features, transforms, depth_start, depth_interval, inverse_depth, sync, *flat):
+    def forward(ctx, features, transforms, depth_start, depth_interval, inverse_depth, sync, into, *flat):
+        """`into`: None, or one tensor per entry of `flat` (the variables' slices of a flat gradient buffer): the backward then adds
+        the parameter gradients there itself -- one launch for all of them (mvs_add_many_f32) -- and hands autograd nothing."""
         from .model import softargmin_prob
+        ctx.into = into
         p = unflatten_params([t.detach() for t in flat])
         features = features.detach().contiguous()
         cost = cost_volume(features[0], features[1:], transforms, variant="eager")      # model.py:330-332
@@ -361,10 +364,26 @@ class PlaneSweepDepth(torch.autograd.Function):
             if n in BN_LAYERS:
                 flat += [G[n]["gamma"], G[n]["beta"]]
         ctx.saved = None
-        return (g_feat, None, None, None, None, None) + tuple(flat)
+        if ctx.into is not None:
+            import ctypes as C
+            flat = [g.contiguous() for g in flat]
+            n = len(flat)
+            _lib.check(_lib.load().mvs_add_many_f32(n, (C.c_void_p * n)(*[g.data_ptr() for g in flat]),
+                                                    (C.c_void_p * n)(*[t.data_ptr() for t in ctx.into]),
+                                                    (C.c_longlong * n)(*[g.numel() for g in flat]), _lib.stream_ptr()), "mvs_add_many_f32")
+            return (g_feat, None, None, None, None, None, None) + (None,) * n
+        return (g_feat, None, None, None, None, None, None) + tuple(flat)
 
 
-def plane_sweep_depth(features, transforms, depth_start, depth_interval, params, inverse_depth=False, sync=None):
-    """`sync`: a SyncBN for cross-replica BatchNorm statistics under torch.distributed (default: per-replica)."""
-    return PlaneSweepDepth.apply(features, transforms, depth_start, depth_interval, inverse_depth, sync,
-                                 *flatten_params(params))
+def plane_sweep_depth(features, transforms, depth_start, depth_interval, params, inverse_depth=False, sync=None,
+                      accumulate_into_grads=False):
+    """`sync`: a SyncBN for cross-replica BatchNorm statistics under torch.distributed (default: per-replica).
+    `accumulate_into_grads`: the leaves carry pre-allocated contiguous `.grad` tensors (train.FlatParameters) and the backward adds
+    the parameter gradients into them itself, in one launch; autograd then sees no gradient for them."""
+    flat = flatten_params(params)
+    into = None
+    if accumulate_into_grads:
+        into = [p.grad for p in flat]
+        if any(g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != p.shape for g, p in zip(into, flat)):
+            raise ValueError("accumulate_into_grads needs a contiguous float32 .grad of the variable's shape on every leaf")
+    return PlaneSweepDepth.apply(features, transforms, depth_start, depth_interval, inverse_depth, sync, into, *flat)

@@ -784,6 +784,46 @@ extern "C" int mvs_gn_slots_to_channel_sums_f64(const double* slots, int V, int 
     MVS_LAUNCH_RET();
 }
 
+// All layers of a tower in one launch: layer i's slots start `slot_off[i]` float64 behind `slots`, its (V, 2, C_i) statistics
+// `stat_off[i]` behind `stats` (the jobs ride in the kernel arguments; blockIdx.y = layer).
+constexpr int GN_MANY_MAX = 64;
+struct GnManyJobs { long long slot_off[GN_MANY_MAX], stat_off[GN_MANY_MAX]; int C[GN_MANY_MAX]; };
+
+__global__ void gn_slots_to_channel_sums_many_kernel(const double* __restrict__ slots, int V, int nslot, double* __restrict__ stats,
+                                                     GnManyJobs jobs) {
+    const int C = jobs.C[blockIdx.y];
+    const double* sl = slots + jobs.slot_off[blockIdx.y];
+    double* out = stats + jobs.stat_off[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V * 2 * C; i += gridDim.x * blockDim.x) {
+        const int c = i % C, k = (i / C) & 1, v = i / (2 * C);
+        const double* p = sl + (((size_t)v * (C / GN_CH) + c / GN_CH) * nslot) * 2 + k;
+        double t = 0.0;
+        for (int s_ = 0; s_ < nslot; ++s_) t += p[2 * s_];
+        out[i] = t * 0.125;
+    }
+}
+
+extern "C" int mvs_gn_slots_to_channel_sums_many_f64(int n, const double* slots, const long long* slot_off, const int* C, int V,
+                                                     int nslot, double* stats, const long long* stat_off, void* stream) {
+    MVS_CHECK_ARG(n > 0 && slots && slot_off && C && stats && stat_off && V > 0 && nslot > 0);
+    for (int i = 0; i < n; ++i) {
+        MVS_CHECK_ARG(C[i] > 0 && slot_off[i] >= 0 && stat_off[i] >= 0);
+        if (C[i] % GN_CH) return MVS_E_SHAPE;
+    }
+    for (int first = 0; first < n; first += GN_MANY_MAX) {
+        const int m = n - first < GN_MANY_MAX ? n - first : GN_MANY_MAX;
+        GnManyJobs jobs;
+        int cmax = 1;
+        for (int k = 0; k < m; ++k) {
+            jobs.slot_off[k] = slot_off[first + k]; jobs.stat_off[k] = stat_off[first + k]; jobs.C[k] = C[first + k];
+            if (C[first + k] > cmax) cmax = C[first + k];
+        }
+        hipLaunchKernelGGL(gn_slots_to_channel_sums_many_kernel, dim3(mvs_cdiv((long long)V * 2 * cmax, 256), m), dim3(256), 0,
+                           mvs_stream(stream), slots, V, nslot, stats, jobs);
+    }
+    MVS_LAUNCH_RET();
+}
+
 // GroupNorm entry points: mode selects the pass (see the kernels above).
 static int gn_check(const void* x, int V, size_t hw, int C) {
     if (!x || V <= 0 || hw == 0 || C <= 0) return MVS_E_BADARG;

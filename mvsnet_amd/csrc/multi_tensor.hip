@@ -32,6 +32,15 @@ __global__ __launch_bounds__(128) void add_f64_kernel(AddJobs jobs) {
     for (int i = threadIdx.x; i < J.n; i += 128) J.dst[i] += (float)J.src[i];
 }
 
+constexpr int ADDF_MAX = 96;
+struct AddFJob { const float* src; float* dst; long long n; };
+struct AddFJobs { AddFJob j[ADDF_MAX]; };
+
+__global__ __launch_bounds__(256) void add_f32_kernel(AddFJobs jobs) {
+    const AddFJob J = jobs.j[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < J.n; i += (long long)gridDim.x * 256) J.dst[i] += J.src[i];
+}
+
 }  // namespace
 
 extern "C" int mvs_transpose_add_many_f32(int n, const float* const* src, float* const* dst, const int* dims, void* stream) {
@@ -63,6 +72,23 @@ extern "C" int mvs_add_f64_many_f32(int n, const double* const* src, float* cons
         AddJobs jobs;
         for (int i = 0; i < m; ++i) jobs.j[i] = {src[first + i], dst[first + i], counts[first + i]};
         hipLaunchKernelGGL(add_f64_kernel, dim3(m), dim3(128), 0, mvs_stream(stream), jobs);
+    }
+    MVS_LAUNCH_RET();
+}
+
+extern "C" int mvs_add_many_f32(int n, const float* const* src, float* const* dst, const long long* counts, void* stream) {
+    MVS_CHECK_ARG(n > 0 && src && dst && counts);
+    for (int i = 0; i < n; ++i) MVS_CHECK_ARG(src[i] && dst[i] && counts[i] > 0);
+    for (int first = 0; first < n; first += ADDF_MAX) {
+        const int m = n - first < ADDF_MAX ? n - first : ADDF_MAX;
+        AddFJobs jobs;
+        long long largest = 1;
+        for (int i = 0; i < m; ++i) {
+            jobs.j[i] = {src[first + i], dst[first + i], counts[first + i]};
+            if (counts[first + i] > largest) largest = counts[first + i];
+        }
+        const int gx = (int)((largest + 2047) / 2048 < 32 ? (largest + 2047) / 2048 : 32);
+        hipLaunchKernelGGL(add_f32_kernel, dim3(gx, m), dim3(256), 0, mvs_stream(stream), jobs);
     }
     MVS_LAUNCH_RET();
 }

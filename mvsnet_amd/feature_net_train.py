@@ -22,6 +22,7 @@ from . import _lib
 from .feature_net import UNET_LAYERS, _same_pad
 
 GN_EPS = 1e-5
+_conv_bwd = torch.ops.aten.convolution_backward      # MIOpen's weight gradients (and the two 5x5 layers' input gradients)
 _SHAPE_ONLY = {}          # (shape, device) -> uninitialised tensor handed to ATen where only the weight's shape matters
 
 
@@ -40,6 +41,7 @@ def flatten_unet_params(params) -> List[torch.Tensor]:
 
 
 _WEIGHT_PLANS = {}        # (device, ((layer, address, shape), ...)) -> _WeightPlan
+_STATS_TABLES = {}        # (views, slots, layer offsets) -> the job table of mvs_gn_slots_to_channel_sums_many_f64
 
 
 class _WeightPlan:
@@ -176,29 +178,37 @@ class HipTowers(torch.autograd.Function):
             acts[name] = y
             chans[name], shapes[name] = cout, (ho, wo)
             src_of[name] = (y, so, P[name].get("gamma"), P[name].get("beta"), 1 if kind == "cg" else 0)
-        ctx.saved = (data, acts, P, {n_: src_of[n_][1] for n_ in so_off}, slots, plan)
+        # per-channel (V, 2, C) float64 sums of every raw output, from the slot sums the convolutions wrote (no second pass over
+        # the activations): all layers in one launch, for the backward's GroupNorm kernels
+        key = (V, slots, tuple(so_off[n_] for n_ in so_off))
+        tab = _STATS_TABLES.get(key)
+        if tab is None:
+            import ctypes as C
+            names = list(so_off)
+            couts = [chans[n_] for n_ in names]
+            cs_off, tot_ = [], 0
+            for c_ in couts:
+                cs_off.append(tot_); tot_ += V * 2 * c_
+            n = len(names)
+            tab = _STATS_TABLES[key] = (n, (C.c_longlong * n)(*[so_off[n_][0] for n_ in names]), (C.c_int * n)(*couts),
+                                        (C.c_longlong * n)(*cs_off), tot_, dict(zip(names, zip(cs_off, couts))))
+        n, slot_off_a, c_a, stat_off_a, cs_total, cs_where = tab
+        cs_slab = torch.empty(cs_total, dtype=torch.float64, device=dev)
+        _lib.check(lib.mvs_gn_slots_to_channel_sums_many_f64(n, _lib.ptr(so_slab), slot_off_a, c_a, V, slots, _lib.ptr(cs_slab), stat_off_a, st),
+                   "mvs_gn_slots_to_channel_sums_many_f64")
+        chan_stats = {n_: cs_slab[o_:o_ + V * 2 * c_].view(V, 2, c_) for n_, (o_, c_) in cs_where.items()}
+        ctx.saved = (data, acts, P, chan_stats, plan)
         return acts["conv10_2"].clone()
 
     @staticmethod
     def backward(ctx, g_feat):
         lib = _lib.load()
-        data, acts, P, fwd_sums, slots, plan = ctx.saved
+        data, acts, P, chan_stats, plan = ctx.saved
         dev = data.device
         st = _lib.stream_ptr()
         kinds = {name: kind for name, kind, *_ in UNET_LAYERS}
 
-        chan_stats: Dict[str, torch.Tensor] = {}                                # per-channel (V,2,C) float64 sums of raw y
-
-        def stats_of(name):
-            if name not in chan_stats:
-                y = acts[name]
-                V, h, w, c = y.shape
-                # the forward convolution's own sums (no second pass over the activation)
-                s = torch.empty((V, 2, c), dtype=torch.float64, device=dev)
-                _lib.check(lib.mvs_gn_slots_to_channel_sums_f64(_lib.ptr(fwd_sums[name]), V, c, slots, _lib.ptr(s), st),
-                           "mvs_gn_slots_to_channel_sums_f64")
-                chan_stats[name] = s
-            return chan_stats[name]
+        stats_of = chan_stats.__getitem__                                        # per-channel (V,2,C) float64 sums of raw y (forward)
 
         norm_cache: Dict[str, torch.Tensor] = {}
 
@@ -294,16 +304,16 @@ class HipTowers(torch.autograd.Function):
                 pb_w = _same_pad(n_w * stride, k, stride)[0]
                 full_h, full_w = stride * (n_h - 1) + k, stride * (n_w - 1) + k
                 gfull = F.pad(gy, (pb_w, full_w - pb_w - wo, pb_h, full_h - pb_h - ho))
-                gx_a, g_w, _ = torch.ops.aten.convolution_backward(gfull, xin, w_t, None, [stride, stride], [0, 0], [1, 1], True,
+                gx_a, g_w, _ = _conv_bwd(gfull, xin, w_t, None, [stride, stride], [0, 0], [1, 1], True,
                                                                    [0, 0], 1, mask)
             else:
                 ph, pw = _same_pad(x.shape[1], k, stride), _same_pad(x.shape[2], k, stride)
                 if ph[0] == ph[1] and pw[0] == pw[1]:
-                    gx_a, g_w, _ = torch.ops.aten.convolution_backward(gy, xin, w_t, None, [stride, stride], [ph[0], pw[0]], [1, 1],
+                    gx_a, g_w, _ = _conv_bwd(gy, xin, w_t, None, [stride, stride], [ph[0], pw[0]], [1, 1],
                                                                        False, [0, 0], 1, mask)
                 else:
                     xp = F.pad(xin, (pw[0], pw[1], ph[0], ph[1]))
-                    gx_a, g_w, _ = torch.ops.aten.convolution_backward(gy, xp, w_t, None, [stride, stride], [0, 0], [1, 1], False,
+                    gx_a, g_w, _ = _conv_bwd(gy, xp, w_t, None, [stride, stride], [0, 0], [1, 1], False,
                                                                        [0, 0], 1, mask)
                     if mask[0]:
                         gx_a = gx_a[:, :, ph[0]:ph[0] + x.shape[1], pw[0]:pw[0] + x.shape[2]]

@@ -238,7 +238,7 @@ class Trainer:
         if feats.shape[-1] < 32:
             feats = torch.nn.functional.pad(feats, (0, 32 - feats.shape[-1]))      # padded channels: zero cost, zero gradient
         depth, _prob = plane_sweep_depth(feats, transforms, depth_start, depth_interval, self.params.group("regnet"),
-                                         sync=sync)
+                                         sync=sync, accumulate_into_grads=torch.is_grad_enabled())
         est = depth[None, :, :, None]
         ds = torch.tensor([depth_start], device=self.device)
         de = torch.tensor([depth_end], device=self.device)

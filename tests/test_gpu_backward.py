@@ -466,6 +466,28 @@ def test_hip_towers_accumulate_their_parameter_gradients_into_the_flat_buffer():
         hip_towers(images, {**grp, first: {**grp[first], "w": leaf}}, accumulate_into_grads=True)
 
 
+def test_plane_sweep_depth_accumulates_its_parameter_gradients_into_the_flat_buffer():
+    """`accumulate_into_grads` of the hot path's autograd node (the trainer's mode): one mvs_add_many_f32 launch adds every
+    RegNetUS0 gradient into the leaves' `.grad` slices -- the values autograd accumulates from the returned tensors."""
+    from mvsnet_amd import backward as B, train as T
+    from mvsnet_amd.homography_warping import homography_transforms
+    w = S.make_workload("toy")
+    feats = t(w.features[:3])
+    cams = S.make_cams(3, w.height, w.width, w.depth_num)
+    t8 = homography_transforms(t(cams), w.depth_num, w.depth_start, w.depth_interval)
+    out = []
+    for into in (False, True):
+        tr = T.Trainer("normal", DEV, seed=0)
+        tr.params.grad.fill_(0.5)
+        f = feats.clone().requires_grad_(True)
+        depth, _p = B.plane_sweep_depth(f, t8, w.depth_start, w.depth_interval, tr.params.group("regnet"), accumulate_into_grads=into)
+        depth.sum().backward()
+        out.append((tr.params.grad.clone(), f.grad.clone()))
+    assert float((out[0][0] - 0.5).abs().max()) > 0
+    assert float((out[0][0] - out[1][0]).abs().max()) <= 1e-5 * float(out[0][0].abs().max())
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 1e-5 * float(out[0][1].abs().max())
+
+
 def test_train_cli_runs_on_a_synthetic_dataset(tmp_path, capsys):
     """python -m mvsnet_amd.train end to end (train.py:412-535): train/ + val/ session folders -> generator ->
     trainer -> TensorFlow-format checkpoint, two steps."""
