@@ -81,14 +81,18 @@ class SyncBN:
         return t
 
 
-def bn_relu_bwd(y, stats, affine, gamma, g1, g2=None, eps=BN_EPSILON, sync: Optional[SyncBN] = None):
+def bn_relu_bwd(y, stats, affine, gamma, g1, g2=None, eps=BN_EPSILON, sync: Optional[SyncBN] = None, sums=None):
     """BatchNorm(batch statistics)+ReLU backward (network.py:492-509).  Returns (g_y, g_gamma, g_beta).
-    `stats` are the sums the forward normalised with (global ones under `sync`)."""
+    `stats` are the sums the forward normalised with (global ones under `sync`).  `sums`: a ZEROED float64 buffer of
+    mvs_bn_bwd_sum_slots() * 2 * C entries to use (regnet_backward hands out pieces of one slab: one fill for all layers)."""
     lib = _lib.load()
     Cn = y.shape[-1]
     vox = y.numel() // Cn
     world = sync.world if sync is not None else 1
-    sums = torch.zeros((lib.mvs_bn_bwd_sum_slots(), 2, Cn), device=y.device, dtype=torch.float64)
+    if sums is None:
+        sums = torch.zeros((lib.mvs_bn_bwd_sum_slots(), 2, Cn), device=y.device, dtype=torch.float64)
+    else:
+        sums = sums.view(lib.mvs_bn_bwd_sum_slots(), 2, Cn)
     s, t = affine
     _lib.check(lib.mvs_bn_bwd_reduce_f32(_lib.ptr(y), _lib.ptr(stats), float(vox * world), float(eps), _lib.ptr(s), _lib.ptr(t),
                                          _lib.ptr(g1), _lib.ptr(g2), vox, Cn, _lib.ptr(sums), _lib.stream_ptr()),
@@ -201,10 +205,18 @@ def regnet_forward_train(cost, p: Dict[str, Dict[str, torch.Tensor]], sync: Opti
     dev = cost.device
     y, st, aff = {}, {}, {}
     world = sync.world if sync is not None else 1
+    # every layer's (2, Cout) float64 BatchNorm sums from ONE zeroed slab (round 6: one fill instead of eleven)
+    slab = torch.zeros(sum(2 * max(v["w"].shape[3], v["w"].shape[4]) for v in p.values()), device=dev, dtype=torch.float64)
+    used = [0]
+
+    def zeros2(cout):
+        o = used[0]
+        used[0] += 2 * cout
+        return slab[o:o + 2 * cout].view(2, cout)
 
     def layer(name, x, stride=1, x_aff=None, skip=None, skip_aff=None, transpose=False):
         cout = p[name]["w"].shape[3] if transpose else p[name]["w"].shape[4]
-        s = torch.zeros((2, cout), device=dev, dtype=torch.float64)
+        s = zeros2(cout)
         out = conv3d(x, p[name]["w"], stride, x_aff, skip, skip_aff, s, transpose)
         if world > 1:
             sync.all_reduce(s)
@@ -213,8 +225,7 @@ def regnet_forward_train(cost, p: Dict[str, Dict[str, torch.Tensor]], sync: Opti
 
     if cost.shape[3] == 32 and p["3dconv0_1"]["w"].shape[4] == 8 and not (cost.shape[0] | cost.shape[1] | cost.shape[2]) & 1:
         # both consumers of the cost volume in one pass over it (mvs_conv3d_pair_f32)
-        s01 = torch.zeros((2, 8), device=dev, dtype=torch.float64)
-        s10 = torch.zeros((2, 16), device=dev, dtype=torch.float64)
+        s01, s10 = zeros2(8), zeros2(16)
         y["3dconv0_1"], y["3dconv1_0"] = conv3d_pair(cost, p["3dconv0_1"]["w"], p["3dconv1_0"]["w"], s01, s10)
         for nm, s in (("3dconv0_1", s01), ("3dconv1_0", s10)):
             if world > 1:
@@ -246,9 +257,15 @@ def regnet_backward(saved, p, g_reg):
     cost, y, st, aff, sync = saved
     G: Dict[str, Dict[str, torch.Tensor]] = {}
     g_reg = g_reg.contiguous()[..., None]
+    nsl = _lib.load().mvs_bn_bwd_sum_slots()
+    slab = torch.zeros(nsl * sum(2 * y[n_].shape[-1] for n_ in st), device=g_reg.device, dtype=torch.float64)
+    used = [0]
 
     def bn_bwd(name, g1, g2=None):
-        g_y, gg, gb = bn_relu_bwd(y[name], st[name], aff[name], p[name]["gamma"], g1, g2, sync=sync)
+        n_ = nsl * 2 * y[name].shape[-1]
+        sums = slab[used[0]:used[0] + n_]
+        used[0] += n_
+        g_y, gg, gb = bn_relu_bwd(y[name], st[name], aff[name], p[name]["gamma"], g1, g2, sync=sync, sums=sums)
         G[name] = {"gamma": gg, "beta": gb}
         return g_y
 
