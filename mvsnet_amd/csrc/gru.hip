@@ -48,6 +48,9 @@ struct GruFusedWs {
     float *w1g, *w1c, *wsg, *wsc;
 };
 constexpr int GRU_FUSED_RING = 64;       // LayerNorm-sum rows of the fused sweep: plane p uses row p % 64
+constexpr int GRU_FUSED_SLOTS = 8;       // copies of a row the workgroups spread their float64 atomics over (gru_fused.hip)
+constexpr int GRU_FUSED_SLOT_STRIDE = 32;                  // doubles between copies: every copy on cache lines of its own (18 used)
+constexpr int GRU_FUSED_ROW = GRU_FUSED_SLOT_STRIDE * GRU_FUSED_SLOTS;      // doubles per row: [slot][cell][6]
 int mvs_gru_fused_prepare_weights(const float* const* params, const GruFusedWs& ws, hipStream_t st);
 int mvs_gru_fused_step(const GruFusedWs& ws, const float* const* params, int t, int depth_num, const float* x_t, int H, int W,
                        int views, size_t vstride, const float* depth_values, hipStream_t st);
@@ -624,7 +627,7 @@ struct GruWs {
     float *px, *wx, *wgh, *woh;        // hoisted x-part of cell 1: (2, XB, H, W, 3*f1) and its prepared weights
     float *wfg, *wfo;                  // cell 1 unhoisted: prepared weights of the full 48-channel convolutions
     float *wsg, *wsc;                  // fused sweep: small-cell tables of the gates / output launch (gru_fused.hip)
-    double* fstats;                    // fused sweep: GRU_FUSED_RING planes x 3 cells x 6 LayerNorm sums
+    double* fstats;                    // fused sweep: GRU_FUSED_RING planes x GRU_FUSED_SLOTS copies x 3 cells x 6 LayerNorm sums
     double* stats;     // per plane of a batch: 3 cells x (gates: 2 groups x 2, out: 1 x 2) = 3 x 6 doubles
     size_t bytes;
 };
@@ -662,7 +665,7 @@ GruWs carve(char* base, int H, int W, int C, int f1, int f2, int f3) {
     w.wfg = take((size_t)9 * (C + f1) * 2 * f1); w.wfo = take((size_t)9 * (C + f1) * f1);
     w.stats = (double*)(base ? base + off : nullptr); off += align256((size_t)(SB + 1) * XB * 18 * 8);   // SB + 1 batches deep
     w.wsg = take(2 * 720 + 288 + 20); w.wsc = take(720 + 288);
-    w.fstats = (double*)(base ? base + off : nullptr); off += align256((size_t)GRU_FUSED_RING * 18 * 8);
+    w.fstats = (double*)(base ? base + off : nullptr); off += align256((size_t)GRU_FUSED_RING * GRU_FUSED_ROW * 8);
     w.bytes = off;
     return w;
 }
@@ -935,7 +938,7 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
         if ((rc = mvs_gru1_full_weights(params[0], params[6], C, f1, ws.wfg, ws.wfo, st))) return rc;
         if ((rc = mvs_gru_fused_prepare_weights(params, fw, st))) return rc;
         for (int k = 0; k < 3; ++k) if ((rc = zero(ws.h[k][1], hw * F[k]))) return rc;      // s(-1) = 0 lives in S[k][1]; S[k][0] zeroed above
-        if ((rc = zero((float*)ws.fstats, (size_t)GRU_FUSED_RING * 18 * 2))) return rc;
+        if ((rc = zero((float*)ws.fstats, (size_t)GRU_FUSED_RING * GRU_FUSED_ROW * 2))) return rc;
         // The -variance cost slices (model.py:680-693,698) come in batches of XB planes from one depth-sweep launch per view.  With a
         // stream set (mvs_gru_prepare) the producer runs ONE BATCH AHEAD on the set's low-priority stream, into the other half of
         // a two-batch buffer (the px tensor of the wavefront formulations, unused here): its waves fill the issue slots the
@@ -983,7 +986,7 @@ extern "C" int mvs_gru_wta_batch_f32(const float* const* ref, const float* const
                         }
                     }
                     // LayerNorm-sum rows of planes t + XB .. t + 2 XB - 1 (their previous users, planes 64 earlier, are long done)
-                    if (t > 0 && (rc = zero((float*)(ws.fstats + (size_t)((t + XB) % GRU_FUSED_RING) * 18), (size_t)XB * 18 * 2))) return rc;
+                    if (t > 0 && (rc = zero((float*)(ws.fstats + (size_t)((t + XB) % GRU_FUSED_RING) * GRU_FUSED_ROW), (size_t)XB * GRU_FUSED_ROW * 2))) return rc;
                 }
                 const int tx = t < depth_num ? t : depth_num - 1;
                 if ((rc = mvs_gru_fused_step(fw, params, t, depth_num, xhalf(tx / XB) + (size_t)(tx % XB) * hw * C, H, W, views, vstride, depth_values, st))) return rc;

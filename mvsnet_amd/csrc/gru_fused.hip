@@ -37,6 +37,13 @@ namespace {
 constexpr int FMAXV = 8;                 // reference views per launch (mvs_gru_wta_batch_f32)
 constexpr int FNT = 512, FTH = 8, FTW = 16, FPW = FTW + 2, FNPOS = (FTH + 2) * FPW;      // 180 staged positions per tile
 
+// Copies of a plane's LayerNorm sums: every workgroup of a launch adds its partial sums with float64 atomics, and atomics on one
+// cache line are performed one after the other by the L2 -- 256 workgroups x 3 cells on the same 144 bytes were 6 us of every
+// plane (round 6: a build without these atomics ran the c3 sweep in 20.87 instead of 22.41 ms; tools/r6_gru_nostat_diag.patch).
+// A workgroup adds to copy blockIdx.x % 8 (256 bytes apart: other lines); the next launch's prologue adds the copies up.
+constexpr int GRU_FUSED_SLOTS = 8;
+constexpr int GRU_FUSED_SLOT_STRIDE = 32;
+
 struct FusedCell {
     // byte offsets inside the view's workspace block (every activation tensor of the sweep lives in it)
     unsigned h;             // G: the state BEFORE the blend (entered plane p-1), or the state itself when !blend;  C: the state s(p-1)
@@ -44,8 +51,8 @@ struct FusedCell {
     unsigned g;             // G: raw gate convolution of plane p-1 (update half read);  C: of plane p (reset half read)   (H,W,2F)
     unsigned h_out;         // G: receives s(p-1) on the tile's own pixels
     unsigned y;             // the output: G raw gates of plane p (H,W,2F);  C raw candidate of plane p (H,W,F)
-    const double* st_in;    // 6 doubles [reset s,q | update s,q | candidate s,q]: G of plane p-1, C of plane p (view 0's block)
-    double* st_out;         // 6 doubles of plane p: G adds [0..3], C adds [4..5]
+    const double* st_in;    // 6 doubles [reset s,q | update s,q | candidate s,q] in each of GRU_FUSED_SLOTS copies, GRU_FUSED_SLOT_STRIDE doubles apart: G of plane p-1, C of plane p (view 0's block)
+    double* st_out;         // 6 doubles of plane p (x copies): G adds [0..3], C adds [4..5]
     const float* bias;
     const float *ga, *gb, *oa, *ob;      // G: update gamma / beta, candidate gamma / beta;  C: reset gamma / beta (ga, gb)
     int conv, blend;        // this cell's convolution is live (its plane exists) / the blend of plane p-1 is formed on load
@@ -308,7 +315,10 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         const double* st = vp(cell_sel(k, [](const FusedCell& c_) { return c_.st_in; })) + (PHASE == 0 ? (kind == 0 ? 2 : 4) : 0);
         const float* gp = kind == 0 ? cell_sel(k, [](const FusedCell& c_) { return c_.ga; }) : cell_sel(k, [](const FusedCell& c_) { return c_.oa; });
         const float* bp = kind == 0 ? cell_sel(k, [](const FusedCell& c_) { return c_.gb; }) : cell_sel(k, [](const FusedCell& c_) { return c_.ob; });
-        ln_s0 = st[0]; ln_s1 = st[1]; ln_g = gp[f]; ln_b = bp[f];
+        ln_s0 = 0.0; ln_s1 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < GRU_FUSED_SLOTS; ++sl) { ln_s0 += st[GRU_FUSED_SLOT_STRIDE * sl]; ln_s1 += st[GRU_FUSED_SLOT_STRIDE * sl + 1]; }
+        ln_g = gp[f]; ln_b = bp[f];
         ln_cnt = (double)a.H * a.W * F;
         if (PHASE == 0) ln_quad = k == 0 ? 4 * kind + (f >> 2) : k == 1 ? 8 + kind : 10 + kind;
         else ln_quad = k == 0 ? (f >> 2) : k == 1 ? 4 : 5;
@@ -563,15 +573,16 @@ gru_fused_kernel(FusedArgs a, FusedDepth dv) {
         if (lane == 63) { red[wave][4] = s0; red[wave][5] = q0; red[wave][6] = s1; red[wave][7] = q1; }
     }
     __syncthreads();
+    const int so = GRU_FUSED_SLOT_STRIDE * (blockIdx.x % GRU_FUSED_SLOTS);      // this workgroup's copy of the row
     if (PHASE == 0) {
         // cell 1: [0..3] = reset s,q | update s,q.  cell 2: reset = waves 0,1 ; update = waves 2,3.  cell 3: waves 4,5 (both groups)
-        if (tid < 4 && live1) { double t = 0.0; for (int w = 0; w < 8; ++w) t += red[w][tid]; atomicAdd(&vp(a.cell[0].st_out)[tid], t); }
-        else if (tid >= 4 && tid < 8 && live2) { const int e = tid - 4, w0 = (e >> 1) * 2; atomicAdd(&vp(a.cell[1].st_out)[e], red[w0][4 + (e & 1)] + red[w0 + 1][4 + (e & 1)]); }
-        else if (tid >= 8 && tid < 12 && live3) { const int e = tid - 8; atomicAdd(&vp(a.cell[2].st_out)[e], red[4][4 + e] + red[5][4 + e]); }
+        if (tid < 4 && live1) { double t = 0.0; for (int w = 0; w < 8; ++w) t += red[w][tid]; atomicAdd(&vp(a.cell[0].st_out)[so + tid], t); }
+        else if (tid >= 4 && tid < 8 && live2) { const int e = tid - 4, w0 = (e >> 1) * 2; atomicAdd(&vp(a.cell[1].st_out)[so + e], red[w0][4 + (e & 1)] + red[w0 + 1][4 + (e & 1)]); }
+        else if (tid >= 8 && tid < 12 && live3) { const int e = tid - 8; atomicAdd(&vp(a.cell[2].st_out)[so + e], red[4][4 + e] + red[5][4 + e]); }
     } else {
-        if (tid < 2 && live1) { double t = 0.0; for (int w = 0; w < 8; ++w) t += red[w][tid]; atomicAdd(&vp(a.cell[0].st_out)[4 + tid], t); }
-        else if (tid >= 2 && tid < 4 && live2) { const int e = tid - 2; atomicAdd(&vp(a.cell[1].st_out)[4 + e], red[0][4 + e] + red[1][4 + e]); }
-        else if (tid >= 4 && tid < 6 && live3) { const int e = tid - 4; atomicAdd(&vp(a.cell[2].st_out)[4 + e], red[2][4 + e] + red[3][4 + e]); }
+        if (tid < 2 && live1) { double t = 0.0; for (int w = 0; w < 8; ++w) t += red[w][tid]; atomicAdd(&vp(a.cell[0].st_out)[so + 4 + tid], t); }
+        else if (tid >= 2 && tid < 4 && live2) { const int e = tid - 2; atomicAdd(&vp(a.cell[1].st_out)[so + 4 + e], red[0][4 + e] + red[1][4 + e]); }
+        else if (tid >= 4 && tid < 6 && live3) { const int e = tid - 4; atomicAdd(&vp(a.cell[2].st_out)[so + 4 + e], red[2][4 + e] + red[3][4 + e]); }
     }
     if (a.trace && tid == 0) {
         const long long slot = (long long)atomicAdd((unsigned long long*)a.trace, 1ULL);
@@ -628,7 +639,7 @@ int launch_fused(const FusedArgs& a0, const FusedDepth& dv, int views, bool stea
 
 // ---- host side of the fused sweep (called from mvs_gru_wta_batch_f32, gru.hip) -------------------------------------------
 // Workspace of one view as the fused sweep sees it (carved by gru.hip): S[k][2] state ping-pong, G[k][2] gate ping-pong, Cb[k]
-// candidate, stats (a ring of planes x 3 cells x 6 doubles), x (a batch of XB cost slices).
+// candidate, stats (a ring of planes x GRU_FUSED_SLOTS copies x 3 cells x 6 doubles), x (a batch of XB cost slices).
 struct GruFusedWs {
     char* base;                              // view 0's workspace block (everything below lies inside it)
     float* x; float* S[3][2]; float* G[3][2]; float* Cb[3]; double* stats;
@@ -636,6 +647,7 @@ struct GruFusedWs {
     float *w1g, *w1c, *wsg, *wsc;            // prepared weights (shared by the views; view 0's block)
 };
 constexpr int GRU_FUSED_RING = 64;           // LayerNorm-sum rows: plane p uses row p % 64 (gru.hip zeroes them a batch ahead)
+constexpr int GRU_FUSED_ROW = GRU_FUSED_SLOT_STRIDE * GRU_FUSED_SLOTS;      // doubles per row: [slot][cell][6] (the same constants as in gru.hip)
 
 namespace {
 __global__ void gru_prob_table_kernel(const float* __restrict__ pw, const float* __restrict__ pb, float* __restrict__ out) {
@@ -684,16 +696,16 @@ int mvs_gru_fused_step(const GruFusedWs& ws, const float* const* params, int t, 
         // s(q) lives in S[k][q & 1] (s(-1) = 0 in S[k][1]); G forms s(p-1) from s(p-2)
         gc.h = off(blend ? ws.S[k][p & 1] : ws.S[k][(p - 1) & 1]);
         gc.c = off(ws.Cb[k]); gc.g = off(ws.G[k][(p - 1) & 1]);
-        gc.st_in = ws.stats + ((size_t)(pm % GRU_FUSED_RING) * 3 + k) * 6;
+        gc.st_in = ws.stats + (size_t)(pm % GRU_FUSED_RING) * GRU_FUSED_ROW + k * 6;
         gc.h_out = off(ws.S[k][(p - 1) & 1]);
         gc.y = off(ws.G[k][p & 1]);
-        gc.st_out = ws.stats + ((size_t)(pc % GRU_FUSED_RING) * 3 + k) * 6;
+        gc.st_out = ws.stats + (size_t)(pc % GRU_FUSED_RING) * GRU_FUSED_ROW + k * 6;
         gc.bias = pp[1]; gc.ga = pp[4]; gc.gb = pp[5]; gc.oa = pp[8]; gc.ob = pp[9];
         gc.conv = conv; gc.blend = blend;
         FusedCell& cc = c.cell[k];
         cc.h = off(ws.S[k][(p - 1) & 1]); cc.c = 0; cc.g = off(ws.G[k][p & 1]);
-        cc.st_in = ws.stats + ((size_t)(pc % GRU_FUSED_RING) * 3 + k) * 6;
-        cc.h_out = 0; cc.y = off(ws.Cb[k]); cc.st_out = ws.stats + ((size_t)(pc % GRU_FUSED_RING) * 3 + k) * 6;
+        cc.st_in = ws.stats + (size_t)(pc % GRU_FUSED_RING) * GRU_FUSED_ROW + k * 6;
+        cc.h_out = 0; cc.y = off(ws.Cb[k]); cc.st_out = ws.stats + (size_t)(pc % GRU_FUSED_RING) * GRU_FUSED_ROW + k * 6;
         cc.bias = pp[7]; cc.ga = pp[2]; cc.gb = pp[3]; cc.oa = pp[2]; cc.ob = pp[3];
         cc.conv = conv; cc.blend = 0;
     }
