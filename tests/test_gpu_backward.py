@@ -488,6 +488,96 @@ def test_plane_sweep_depth_accumulates_its_parameter_gradients_into_the_flat_buf
     assert float((out[0][1] - out[1][1]).abs().max()) <= 1e-5 * float(out[0][1].abs().max())
 
 
+def test_many_tensor_launches_match_numpy_beyond_one_table():
+    """csrc/multi_tensor.hip: the jobs ride in the kernel arguments, 48 / 96 / 96 per launch -- more jobs than one table holds,
+    ragged sizes, a dropped padding channel; results ADDED to what the destinations held (integers: exact)."""
+    import ctypes as C
+    from mvsnet_amd import _lib as L
+    lib = L.load()
+    rs = np.random.RandomState(7)
+    vp = lambda ts: (C.c_void_p * len(ts))(*[x.data_ptr() for x in ts])
+    # (B, A, k, k) -> (k, k, keep, B)
+    shapes = [(rs.randint(1, 9), rs.randint(1, 7), int(rs.choice([1, 9, 25]))) for _ in range(101)]
+    src = [t(rs.randint(-9, 9, (b, a, kk)).astype(np.float32)) for b, a, kk in shapes]
+    keep = [max(1, a - (i % 3 == 0)) for i, (_b, a, _kk) in enumerate(shapes)]
+    dst0 = [rs.randint(-9, 9, (kk, kp, b)).astype(np.float32) for (b, _a, kk), kp in zip(shapes, keep)]
+    dst = [t(d) for d in dst0]
+    dims = (C.c_int * (4 * len(src)))(*[v for (b, a, kk), kp in zip(shapes, keep) for v in (b, a, kk, kp)])
+    L.check(lib.mvs_transpose_add_many_f32(len(src), vp(src), vp(dst), dims, L.stream_ptr()), "transpose_add_many")
+    for s_, d_, d0, kp in zip(src, dst, dst0, keep):
+        assert np.array_equal(n(d_), d0 + n(s_).transpose(2, 1, 0)[:, :kp, :])
+    # float64 -> float32 rows, float32 -> float32 tensors
+    cnt = [int(rs.randint(1, 300)) for _ in range(197)]
+    s64 = [torch.as_tensor(rs.randint(-99, 99, c_).astype(np.float64)).to(DEV) for c_ in cnt]
+    d0 = [rs.randint(-9, 9, c_).astype(np.float32) for c_ in cnt]
+    d = [t(x) for x in d0]
+    L.check(lib.mvs_add_f64_many_f32(len(cnt), vp(s64), vp(d), (C.c_int * len(cnt))(*cnt), L.stream_ptr()), "add_f64_many")
+    assert all(np.array_equal(n(a_), b_ + n(c_).astype(np.float32)) for a_, b_, c_ in zip(d, d0, s64))
+    cnt = [int(rs.randint(1, 5000)) for _ in range(120)]
+    s32 = [t(rs.randint(-99, 99, c_).astype(np.float32)) for c_ in cnt]
+    d0 = [rs.randint(-9, 9, c_).astype(np.float32) for c_ in cnt]
+    d = [t(x) for x in d0]
+    L.check(lib.mvs_add_many_f32(len(cnt), vp(s32), vp(d), (C.c_longlong * len(cnt))(*cnt), L.stream_ptr()), "add_many")
+    assert all(np.array_equal(n(a_), b_ + n(c_)) for a_, b_, c_ in zip(d, d0, s32))
+    assert lib.mvs_add_many_f32(0, vp(s32), vp(d), (C.c_longlong * 1)(1), L.stream_ptr()) == -1       # MVS_E_BADARG
+
+
+def test_prepare_many_equals_the_single_preparations():
+    """mvs_unet_prepare_many_f32 / mvs_gn_slots_to_channel_sums_many_f64 against their one-at-a-time forms, bit for bit: every
+    kind (forward conv with one / two sources, the 3-channel image kernels laid out for 4, 5 x 5, input-gradient form, transposed
+    conv), more jobs than one table holds."""
+    import ctypes as C
+    from mvsnet_amd import _lib as L
+    lib = L.load()
+    rs = np.random.RandomState(3)
+    st = L.stream_ptr()
+    jobs = []                                                   # (kind, w, ks, c1, c2, cin_src, cout, single-call reference)
+    def conv(ks, c1, c2, cout, cin_src=None):
+        src_c = cin_src or (c1 + c2)
+        w = t(rs.randn(ks, ks, src_c, cout).astype(np.float32))
+        ref = torch.full((lib.mvs_conv2d_prepared_floats(ks, c1, c2, cout),), 7.0, device=DEV)
+        wp = w if src_c == c1 + c2 else torch.cat([w, torch.zeros(ks, ks, c1 + c2 - src_c, cout, device=DEV)], 2).contiguous()
+        L.check(lib.mvs_conv2d_prepare_f32(L.ptr(wp), ks, c1, c2, cout, L.ptr(ref), st), "single")
+        jobs.append((0, w, ks, c1, c2, src_c, cout, ref))
+    def dgrad(ks, cin_fwd, cout_fwd):
+        w = t(rs.randn(ks, ks, cin_fwd, cout_fwd).astype(np.float32))
+        ref = torch.full((lib.mvs_conv2d_prepared_floats(ks, cout_fwd, 0, cin_fwd),), 7.0, device=DEV)
+        L.check(lib.mvs_conv2d_prepare_dgrad_f32(L.ptr(w), ks, cin_fwd, cout_fwd, L.ptr(ref), st), "single")
+        jobs.append((1, w, ks, cin_fwd, 0, cin_fwd, cout_fwd, ref))
+    def deconv(cin, cout):
+        w = t(rs.randn(3, 3, cout, cin).astype(np.float32))
+        ref = torch.full((lib.mvs_deconv2d_prepared_floats(cin, cout),), 7.0, device=DEV)
+        L.check(lib.mvs_deconv2d_prepare_f32(L.ptr(w), cin, cout, L.ptr(ref), st), "single")
+        jobs.append((2, w, 3, cin, 0, cin, cout, ref))
+    for _ in range(9):
+        conv(3, 4, 0, 8, 3); conv(3, 4, 0, 16, 3); conv(3, 8, 0, 8); conv(3, 16, 16, 16); conv(5, 8, 0, 16); conv(3, 64, 64, 64); conv(3, 32, 0, 32)
+        dgrad(3, 8, 8); dgrad(3, 16, 8); dgrad(3, 32, 16); deconv(16, 8); deconv(128, 64)
+    k = len(jobs)
+    assert k > 56
+    out = [torch.full_like(j[7], -3.0) for j in jobs]
+    ints = lambda col: (C.c_int * k)(*[j[col] for j in jobs])
+    vp = lambda ts: (C.c_void_p * k)(*[x.data_ptr() for x in ts])
+    L.check(lib.mvs_unet_prepare_many_f32(k, ints(0), vp([j[1] for j in jobs]), ints(2), ints(3), ints(4), ints(5), ints(6), vp(out), st),
+               "mvs_unet_prepare_many_f32")
+    for j, o in zip(jobs, out):
+        assert torch.equal(o, j[7]), j[:7:2]
+    # GroupNorm statistics of many layers
+    V, nslot = 3, lib.mvs_gn_stat_slots()
+    Cs = [int(rs.choice([8, 16, 32, 64, 128])) for _ in range(70)]
+    slot_off, stat_off, a, b = [], [], 0, 0
+    for c_ in Cs:
+        slot_off.append(a); stat_off.append(b)
+        a += V * (c_ // 8) * nslot * 2; b += V * 2 * c_
+    slots = torch.as_tensor(rs.randn(a)).to(DEV)
+    got = torch.zeros(b, dtype=torch.float64, device=DEV)
+    L.check(lib.mvs_gn_slots_to_channel_sums_many_f64(len(Cs), L.ptr(slots), (C.c_longlong * len(Cs))(*slot_off), (C.c_int * len(Cs))(*Cs),
+                                                         V, nslot, L.ptr(got), (C.c_longlong * len(Cs))(*stat_off), st), "many")
+    for c_, so, to in zip(Cs, slot_off, stat_off):
+        ref = torch.zeros(V * 2 * c_, dtype=torch.float64, device=DEV)
+        L.check(lib.mvs_gn_slots_to_channel_sums_f64(L.ptr(slots[so:]), V, c_, nslot, L.ptr(ref), st), "single")
+        assert torch.equal(got[to:to + V * 2 * c_], ref)
+
+
 def test_train_cli_runs_on_a_synthetic_dataset(tmp_path, capsys):
     """python -m mvsnet_amd.train end to end (train.py:412-535): train/ + val/ session folders -> generator ->
     trainer -> TensorFlow-format checkpoint, two steps."""
