@@ -385,7 +385,7 @@ def training_record(dev, iters=5, configs=(("3dcnn_d128_config5", "3DCNN", 128),
             out[tag] = {"ms_per_step": ms_step, "views": N, "image": "%dx%d" % (W, H), "depth_planes": D}
             if reg == "3DCNN":
                 out[tag]["roofline"] = training_roofline(tr, images_np, cams, gt, N, H, W, D, ms_step, iters)
-                out[tag]["inputs"] = "images and ground truth resident on the device (uploaded once); the step is host-bound: enqueue time = step time"
+                out[tag]["inputs"] = "images and ground truth resident on the device (uploaded once); the launching thread and the GPU bound the step together (541 launches, 9.2 ms of kernel time per step: profiles/r06_train_step_kernels_after.txt)"
             del tr
             torch.cuda.empty_cache()
     except Exception as e:                                  # informative record: never fail the bench line over it
